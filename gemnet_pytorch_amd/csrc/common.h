@@ -1,0 +1,43 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) GemNet kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gemnet_hip.h"
+
+#define GN_WAVE 64
+
+#define GN_LAUNCH_CHECK()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+static inline int gn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ScaledSiLU and its derivatives (reference: gemnet/model/layers/base_layers.py:51-58,
+// y = silu(x)/0.6).  s = sigmoid(x):
+//   f   = x s / 0.6
+//   f'  = s (1 + x (1-s)) / 0.6
+//   f'' = s (1-s) (2 + x (1-2s)) / 0.6
+//   f'''= s (1-s) (3 (1-2s) + x (1 - 6s + 6s^2)) / 0.6
+#define GN_INV_06 1.6666666666666667f
+
+__device__ __forceinline__ float gn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float gn_ssilu(float x) { return x * gn_sigmoid(x) * GN_INV_06; }
+
+__device__ __forceinline__ float gn_dssilu(float x) {
+  float s = gn_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s)) * GN_INV_06;
+}
+
+__device__ __forceinline__ float gn_d2ssilu(float x) {
+  float s = gn_sigmoid(x);
+  return s * (1.0f - s) * (2.0f + x * (1.0f - 2.0f * s)) * GN_INV_06;
+}
+
+__device__ __forceinline__ float gn_d3ssilu(float x) {
+  float s = gn_sigmoid(x);
+  return s * (1.0f - s) * (3.0f * (1.0f - 2.0f * s) + x * (1.0f - 6.0f * s + 6.0f * s * s)) * GN_INV_06;
+}

@@ -1,0 +1,114 @@
+/* gemnet_hip.h — C ABI of the MI355X-native (gfx950) GemNet hot path.
+ *
+ * The reference (TUM-DAML/gemnet_pytorch) is 100 % Python and has no FFI: the boundary its
+ * callers see is the Python class gemnet.model.gemnet.GemNet (gemnet/model/gemnet.py:21).
+ * This header is the seam UNDER that class: one exported symbol family per hot-path row of
+ * SURVEY.md §8(a).  Each declaration cites the reference code it replaces (file:line under
+ * /root/reference).  INTEGRATION.md shows the ctypes stub a maintainer of the reference
+ * would add to bind these.
+ *
+ * Conventions
+ *   - plain C ABI, no torch / C++ types; device pointers are raw `void*`/typed pointers,
+ *     sizes are explicit `int`/`int64_t`, indices are int32 on the device.
+ *   - caller-owned buffers: no entry point allocates, frees or synchronises.
+ *   - every launch goes to the explicit `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 on success, otherwise a hipError_t code (gn_error_string()).
+ *   - re-entrant, no global mutable state; safe to call from the autograd worker thread.
+ *   - all floating tensors are fp32, row-major, contiguous unless a leading dimension is given.
+ */
+#ifndef GEMNET_HIP_H
+#define GEMNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int gn_abi_version(void);
+const char* gn_error_string(int code);
+
+/* ---- dense contractions (P11: base_layers.py:44-48 Dense.forward = nn.Linear + ScaledSiLU,
+ *      :84-89 ResidualLayer; embedding_block.py:60-75 concat-Dense) on f32 MFMA ------------
+ *   acc[m][n] = sum_k opA(A)[m][k] * opB(B)[k][n]
+ *     opA(A)[m][k] = trans_a ? A[k*lda+m] : A[m*lda+k]
+ *     opB(B)[k][n] = trans_b ? B[k*ldb+n] : B[n*ldb+k]       (trans_b=0: B is a torch Linear weight (N,K))
+ *     if a_dact_pre: opA(A)[m][k] *= d/dz ssilu(a_dact_pre[same index as A])   (backward through the activation)
+ *   z = acc + (gadd1 ? gadd1[gidx1[m]*ldg+n] : 0) + (gadd2 ? gadd2[gidx2[m]*ldg+n] : 0)
+ *   if pre_out: pre_out[m*ldc+n] = z
+ *   y = act ? ssilu(z) : z ;  ssilu(z) = z*sigmoid(z)/0.6   (base_layers.py:51-58)
+ *   if mul: y *= mul[m*ldmul+n]
+ *   y *= alpha
+ *   if res: y = (y + res[m*ldres+n]) * beta
+ *   C[m*ldc+n] = y
+ */
+typedef struct {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int trans_a, trans_b;
+  const float* a_dact_pre;
+  int act;
+  float* pre_out;
+  const float* mul; int ldmul;
+  float alpha;
+  const float* res; int ldres;
+  float beta;
+  const float* gadd1; const int32_t* gidx1;
+  const float* gadd2; const int32_t* gidx2;
+  int ldg;
+} gn_gemm_args;
+int gn_gemm_f32(const gn_gemm_args* args, void* stream);
+
+/* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
+ * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */
+int gn_bmm_f32(const float* A, const float* B, float* C, int batch, int m, int n, int k,
+               int trans_a, int trans_b, void* stream);
+
+/* ---- row gather / segmented sum (P2/P3/P10: `x[id3_expand_ba]` interaction_block.py:678,
+ *      `x[id4_expand_*]` :543,:548, `x_ac[id_swap]` :693, h[id] embedding_block.py:70-71 and
+ *      torch_scatter.scatter(..., reduce="add") atom_update_block.py:67,172, gemnet.py:580) -- */
+int gn_gather_rows_f32(const float* x, const int32_t* idx, float* y, int64_t T, int C, void* stream);
+/* x[n,:] = sum_{k in [seg_off[n], seg_off[n+1])} y[perm ? perm[k] : k, :]   (deterministic, no atomics) */
+int gn_segsum_rows_f32(const float* y, const int32_t* perm, const int32_t* seg_off, float* x,
+                       int64_t N, int C, void* stream);
+
+/* ---- bilinear aggregation, CSR-segmented (P4: efficient.py:159-189 without the zero-padded
+ *      (E,Kmax,C) tensors; SURVEY.md Appendix D kernels K1 and its two adjoints) -----------
+ * r(t) = reduce edge of triplet/quadruplet t (sorted ascending, seg_off[e]..seg_off[e+1]),
+ * g(t) = expand row.  S = num_spherical (7) or num_spherical^2 (49).  C = channels (<=128). */
+/* Sm[e,s,c] = sum_{t in seg(e)} Y[t,s] * x[g(t),c] */
+int gn_bil_reduce_f32(const float* Y, const float* x, const int32_t* expand_idx,
+                      const int32_t* seg_off, float* Sm, int64_t E, int S, int C, void* stream);
+/* dx[j,c] = sum_{k in segT(j)} sum_s Y[t,s] * dSm[r(t),s,c],  t = permT[k]   (j < J rows of x) */
+int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32_t* reduce_idx,
+                        const int32_t* permT, const int32_t* segT_off, float* dx,
+                        int64_t J, int S, int C, void* stream);
+/* dY[t,s] = sum_c dSm[r(t),s,c] * x[g(t),c] */
+int gn_bil_dot_f32(const float* dSm, const float* x, const int32_t* expand_idx,
+                   const int32_t* seg_off, float* dY, int64_t E, int S, int C, void* stream);
+
+/* ---- basis functions (P6-P8; closed forms of SURVEY.md Appendix A, evaluated in f64 in-kernel) */
+/* out[e,n] = d^kd/dd^kd d^kf/df_n^kf [ u(d/c) sqrt(2/c) sin(f_n d/c)/d ]   (basis_layers.py:45-49);
+ * (kd,kf) in {(0,0),(1,0),(2,0),(0,1),(1,1)} */
+int gn_bessel_rbf_f32(const float* d, const float* freq, float* out, int64_t E, int R,
+                      float cutoff, int p, int kd, int kf, void* stream);
+/* out[e,l,n] = d^kd/dd^kd [ u(d/c) c^-1.5 N_ln j_l(z_ln d/c) ], kd in {0,1,2}
+ * (basis_layers.py:121-128,241-250; z (S,R) f32 roots and nrm (S,R) f64 normalisers are host tables) */
+int gn_sph_radial_f32(const float* d, const float* z, const double* nrm, float* out, int64_t E,
+                      int S, int R, float cutoff, int p, int kd, void* stream);
+/* out[t,l] = d^k/dtheta^k Y_l0(theta), l < S, k in {0,1,2}   (basis_layers.py:130-131 with zero_m_only) */
+int gn_ylm0_f32(const float* theta, float* out, int64_t T, int S, int k, void* stream);
+/* out[q,j] = d^kt/dtheta^kt d^kp/dphi^kp Y_j(theta,phi), j < S*S in the reference order
+ * (m = 0,+1..+l,-l..-1 per l; basis_layers.py:269), kt+kp <= 2 */
+int gn_ylm_f32(const float* theta, const float* phi, float* out, int64_t Q, int S, int kt, int kp,
+               void* stream);
+
+/* ---- pointwise -------------------------------------------------------------------------
+ * out[i] = d^k/dx^k ssilu(x[i]), k in {0,1,2,3}   (base_layers.py:51-58) */
+int gn_ssilu_f32(const float* x, float* out, int64_t n, int k, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEMNET_HIP_H */

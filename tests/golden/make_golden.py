@@ -1,0 +1,295 @@
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box never sees the
+reference.  Only data (inputs + the reference's outputs) is written; weights are NOT
+stored — they come from the builder-owned deterministic generator
+`oracle.gemnet_oracle.make_params(cfg, seed)` and are pushed into the reference model
+with load_state_dict.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Oracle-side shims (never shipped as product):
+  torch_scatter.scatter -> index_add based;  numba.njit -> identity;  np.math -> math.
+"""
+import math
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def install_shims():
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter(src, index, dim=0, dim_size=None, reduce="add"):
+        assert dim == 0
+        dim_size = int(index.max()) + 1 if dim_size is None else int(dim_size)
+        out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+        out = out.index_add(0, index, src)
+        if reduce == "mean":
+            cnt = torch.zeros(dim_size, dtype=src.dtype).index_add(
+                0, index, torch.ones(index.shape[0], dtype=src.dtype)).clamp(min=1)
+            out = out / cnt.view((-1,) + (1,) * (src.dim() - 1))
+        return out
+
+    ts.scatter = scatter
+    sys.modules["torch_scatter"] = ts
+    nb = types.ModuleType("numba")
+
+    def njit(*a, **k):
+        if len(a) == 1 and callable(a[0]):
+            return a[0]
+        return lambda f: f
+
+    nb.njit = njit
+    sys.modules["numba"] = nb
+    np.math = math
+    sys.path.insert(0, REF)
+
+
+install_shims()
+from gemnet.model.gemnet import GemNet  # noqa: E402  (the reference)
+from gemnet.model.layers import basis_utils as ref_bu  # noqa: E402
+from gemnet.model.layers.basis_layers import (BesselBasisLayer, SphericalBasisLayer,  # noqa: E402
+                                              TensorBasisLayer)
+from gemnet.training.data_container import DataContainer  # noqa: E402
+
+from gemnet_pytorch_amd.synthetic import make_dataset, make_molecule  # noqa: E402
+from oracle import gemnet_oracle as GO  # noqa: E402
+
+SCALE_FILE = os.path.join(REF, "scaling_factors.json")
+
+
+def cfg_small(triplets_only, num_blocks=1):
+    return dict(num_spherical=7, num_radial=6, num_blocks=num_blocks, emb_size_atom=64,
+                emb_size_edge=64, emb_size_trip=32, emb_size_quad=32, emb_size_rbf=16,
+                emb_size_cbf=16, emb_size_sbf=32, emb_size_bil_quad=32, emb_size_bil_trip=32,
+                num_before_skip=1, num_after_skip=1, num_concat=1, num_atom=2,
+                triplets_only=triplets_only)
+
+
+def cfg_full(triplets_only, num_blocks=2):
+    return dict(num_spherical=7, num_radial=6, num_blocks=num_blocks, emb_size_atom=128,
+                emb_size_edge=128, emb_size_trip=64, emb_size_quad=32, emb_size_rbf=16,
+                emb_size_cbf=16, emb_size_sbf=32, emb_size_bil_quad=32, emb_size_bil_trip=64,
+                num_before_skip=1, num_after_skip=1, num_concat=1, num_atom=2,
+                triplets_only=triplets_only)
+
+
+# ------------------------------------------------------------------------------- G1 basis
+def golden_basis():
+    out = {}
+    out["jn_zeros"] = ref_bu.Jn_zeros(7, 6)
+    z = out["jn_zeros"]
+    out["normalizer"] = np.array(
+        [[1 / np.sqrt(0.5 * ref_bu.Jn(z[l, i], l + 1) ** 2) for i in range(6)] for l in range(7)])
+    out["prefactor"] = np.array(
+        [[ref_bu.sph_harm_prefactor(l, m) if m <= l else 0.0 for m in range(7)] for l in range(7)])
+    rs = np.random.RandomState(7)
+    d = torch.tensor(np.concatenate([np.linspace(0.9, 5.0, 40), rs.uniform(0.9, 5.2, 24)]),
+                     dtype=torch.float64)
+    d10 = torch.tensor(np.concatenate([np.linspace(0.9, 10.0, 40), rs.uniform(0.9, 10.3, 24)]),
+                       dtype=torch.float64)
+    theta = torch.tensor(np.concatenate([np.linspace(1e-3, np.pi - 1e-3, 40),
+                                         rs.uniform(0, np.pi, 24)]), dtype=torch.float64)
+    phi = torch.tensor(np.concatenate([np.linspace(1e-3, np.pi - 1e-3, 40)[::-1].copy(),
+                                       rs.uniform(0, np.pi, 24)]), dtype=torch.float64)
+    out.update(d=d.numpy(), d10=d10.numpy(), theta=theta.numpy(), phi=phi.numpy())
+    n = d.shape[0]
+    idx = torch.arange(n)
+    zeros = torch.zeros(n, dtype=torch.long)
+
+    bes = BesselBasisLayer(6, cutoff=5.0).double()
+    freq = bes.frequencies.detach().clone()
+    out["freq"] = freq.numpy()
+    dd = d.clone().requires_grad_(True)
+    y = bes(dd)
+    out["bessel_rbf"] = y.detach().numpy()
+    g = torch.stack([torch.autograd.grad(y[:, k].sum(), dd, retain_graph=True)[0] for k in range(6)], 1)
+    out["bessel_rbf_dd"] = g.numpy()
+
+    for name, cutoff, dist in (("c5", 5.0, d), ("c10", 10.0, d10)):
+        lay = SphericalBasisLayer(7, 6, cutoff=cutoff, efficient=False).double()
+        dd = dist.clone().requires_grad_(True)
+        th = theta.clone().requires_grad_(True)
+        o = lay(dd, th, idx, None)  # (n, 42) = rbf_env[l,n] * Y_l0
+        out[f"cbf_{name}"] = o.detach().numpy()
+        # separate factors: efficient branch returns (S,E,R) radial and padded sph
+        lay_e = SphericalBasisLayer(7, 6, cutoff=cutoff, efficient=True).double()
+        rad, sph2 = lay_e(dd, th, idx, zeros)
+        out[f"radial_{name}"] = rad.detach().permute(1, 0, 2).numpy()  # (n,S,R)
+        out[f"y_l0"] = sph2.detach()[:, 0, :].numpy()
+        gr = torch.stack([torch.autograd.grad(rad[l, :, k].sum(), dd, retain_graph=True)[0]
+                          for l in range(7) for k in range(6)], 1)
+        out[f"radial_{name}_dd"] = gr.reshape(n, 7, 6).numpy()
+        gy = torch.stack([torch.autograd.grad(sph2[:, 0, l].sum(), th, retain_graph=True,
+                                              allow_unused=True)[0] if l > 0 else torch.zeros(n, dtype=torch.float64)
+                          for l in range(7)], 1)
+        out["y_l0_dtheta"] = gy.numpy()
+
+    ten = TensorBasisLayer(7, 6, cutoff=5.0, efficient=True).double()
+    th = theta.clone().requires_grad_(True)
+    ph = phi.clone().requires_grad_(True)
+    rad, sph2 = ten(d, th, ph, idx, zeros)
+    out["radial_tensor_c5"] = rad.permute(1, 0, 2).numpy()  # (n,49,6)
+    Y = sph2[:, 0, :]
+    out["y_lm"] = Y.detach().numpy()
+    out["y_lm_dtheta"] = torch.stack(
+        [torch.autograd.grad(Y[:, k].sum(), th, retain_graph=True, allow_unused=True)[0]
+         if k > 0 else torch.zeros(n, dtype=torch.float64) for k in range(49)], 1).numpy()
+    gphi = []
+    for k in range(49):
+        g = torch.autograd.grad(Y[:, k].sum(), ph, retain_graph=True, allow_unused=True)[0]
+        gphi.append(torch.zeros(n, dtype=torch.float64) if g is None else g)
+    out["y_lm_dphi"] = torch.stack(gphi, 1).numpy()
+    np.savez_compressed(os.path.join(HERE, "basis.npz"), **out)
+    print("basis.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------ G2 indices
+class _MemContainer(DataContainer):
+    """The reference DataContainer fed from memory instead of an npz path."""
+
+    def __init__(self, data, cutoff, int_cutoff, triplets_only):
+        self._data = data
+        super().__init__("<memory>", cutoff, int_cutoff, triplets_only=triplets_only)
+
+    def _load_npz(self, path, keys):
+        for k in keys:
+            if k in self._data:
+                setattr(self, k, self._data[k])
+
+
+def special_molecules():
+    mols = []
+    # two atoms within cutoff; two atoms beyond the cutoff (no edge)
+    mols.append(("pair", np.array([[0, 0, 0], [1.2, 0, 0]], np.float32)))
+    mols.append(("noedge", np.array([[0, 0, 0], [7.5, 0, 0]], np.float32)))
+    # linear (collinear triplets -> the 1e-9 clamp of gemnet.py:309)
+    mols.append(("linear", np.array([[0, 0, 0], [1.1, 0, 0], [2.2, 0, 0], [3.3, 0, 0]], np.float32)))
+    # one pair exactly at the cutoff (<=), one just beyond in float32
+    mols.append(("atcut", np.array([[0, 0, 0], [5.0, 0, 0], [0, 3.0, 0], [5.0000005, 3.0, 0.0],
+                                    [2.5, 1.5, 1.0]], np.float32)))
+    for n, seed in ((3, 11), (5, 12), (8, 13), (12, 14), (14, 15)):
+        mols.append((f"rand{n}", make_molecule(n, seed, box=max(3.0, 0.42 * n))["R"]))
+    return mols
+
+
+def run_container(Rlist, triplets_only, cutoff=5.0, int_cutoff=10.0):
+    N = np.array([len(r) for r in Rlist], dtype=np.int32)
+    R = np.concatenate(Rlist).astype(np.float32)
+    Z = np.ones(len(R), np.int32)
+    data = dict(N=N, Z=Z, R=R, E=np.zeros(len(N), np.float32), F=np.zeros_like(R))
+    dc = _MemContainer(data, cutoff, int_cutoff, triplets_only)
+    batch = dc[list(range(len(N)))]
+    return R, N, {k: batch[k].numpy() for k in dc.index_keys}
+
+
+def golden_indices():
+    out = {}
+    mols = special_molecules()
+    names = []
+    for name, R in mols:
+        for to in (True, False):
+            Rc, N, idx = run_container([R], to)
+            tag = f"{name}.{'T' if to else 'Q'}"
+            out[f"{tag}.R"] = Rc
+            out[f"{tag}.N"] = N
+            for k, v in idx.items():
+                out[f"{tag}.{k}"] = v.astype(np.int32)
+        names.append(name)
+    # a batch of three molecules (block-diagonal offsets, _bmat_fast :115-151)
+    batch = [mols[6][1], mols[4][1], mols[7][1]]
+    for to in (True, False):
+        Rc, N, idx = run_container(batch, to)
+        tag = f"batch3.{'T' if to else 'Q'}"
+        out[f"{tag}.R"], out[f"{tag}.N"] = Rc, N
+        for k, v in idx.items():
+            out[f"{tag}.{k}"] = v.astype(np.int32)
+    names.append("batch3")
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "indices.npz"), **out)
+    print("indices.npz", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------- G4 model
+def run_model(cfg, seed, Rlist, Zlist, tag, out, with_grads):
+    to = cfg["triplets_only"]
+    N = np.array([len(r) for r in Rlist], dtype=np.int32)
+    R = np.concatenate(Rlist).astype(np.float32)
+    Z = np.concatenate(Zlist).astype(np.int32)
+    rs = np.random.RandomState(seed + 99)
+    Et = rs.standard_normal(len(N)).astype(np.float32)
+    Ft = rs.standard_normal(R.shape).astype(np.float32)
+    dc = _MemContainer(dict(N=N, Z=Z, R=R, E=Et, F=Ft), 5.0, 10.0, to)
+    batch = dc[list(range(len(N)))]
+    sf = GO.load_scale_factors(SCALE_FILE)
+    params = GO.make_params(cfg, seed, sf, dtype=torch.float64)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).double()
+    missing = model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
+    inputs = {k: v for k, v in batch.items() if k not in ("E", "F")}
+    inputs["R"] = inputs["R"].double()
+    model.train()
+    E, F = model(inputs)
+    out[f"{tag}.seed"] = np.array(seed)
+    out[f"{tag}.cfg"] = np.array(repr(cfg))
+    out[f"{tag}.Z"], out[f"{tag}.R"], out[f"{tag}.N"] = Z, R, N
+    out[f"{tag}.Et"], out[f"{tag}.Ft"] = Et, Ft
+    for k in dc.index_keys:
+        out[f"{tag}.{k}"] = batch[k].numpy().astype(np.int32)
+    out[f"{tag}.E"] = E.detach().numpy()
+    out[f"{tag}.F"] = F.detach().numpy()
+    if with_grads:
+        loss = GO.training_loss(E, F, batch["E"].double(), batch["F"].double())
+        out[f"{tag}.loss"] = loss.detach().numpy()
+        loss.backward()
+        names, norms = [], []
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                norms.append(float(p.grad.norm()))
+        out[f"{tag}.grad_names"] = np.array(names)
+        out[f"{tag}.grad_norms"] = np.array(norms)
+        # full gradients of three representative parameters
+        for n in ("rbf_basis.frequencies", "mlp_cbf3.weight", "int_blocks.0.trip_interaction.mlp_cbf.weight",
+                  "int_blocks.0.dense_ca.weight"):
+            out[f"{tag}.grad.{n}"] = dict(model.named_parameters())[n].grad.numpy()
+    print(tag, "E", E.detach().numpy().ravel()[:3], "|F|max", float(F.abs().max()),
+          {k: int(batch[k].shape[0]) for k in ("id_a", "id3_reduce_ca")})
+
+
+def golden_models():
+    out = {}
+    m12 = make_molecule(12, 1000 * 1 + 0)
+    # config 1: GemNet-T, 1 block, emb 64, single 12-atom molecule
+    run_model(cfg_small(True), 1, [m12["R"]], [m12["Z"]], "t1", out, with_grads=True)
+    # GemNet-Q, 1 block, emb 64, same molecule
+    run_model(cfg_small(False), 2, [m12["R"]], [m12["Z"]], "q1", out, with_grads=True)
+    # GemNet-T full width, 2 blocks, batch of 2 (12 + 9 atoms)
+    m9 = make_molecule(9, 77, box=4.5)
+    run_model(cfg_full(True, 2), 3, [m12["R"], m9["R"]], [m12["Z"], m9["Z"]], "t2", out, with_grads=True)
+    # GemNet-Q full width, 2 blocks, batch of 2
+    run_model(cfg_full(False, 2), 4, [m12["R"], m9["R"]], [m12["Z"], m9["Z"]], "q2", out, with_grads=False)
+    # GemNet-T full (4 blocks) on one 32-atom COLL-shaped molecule
+    m32 = make_molecule(32, 2000)
+    run_model(cfg_full(True, 4), 5, [m32["R"]], [m32["Z"]], "t4", out, with_grads=False)
+    np.savez_compressed(os.path.join(HERE, "model.npz"), **out)
+    print("model.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["basis", "indices", "models"]
+    if "basis" in which:
+        golden_basis()
+    if "indices" in which:
+        golden_indices()
+    if "models" in which:
+        golden_models()
