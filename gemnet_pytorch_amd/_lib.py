@@ -1,0 +1,97 @@
+"""ctypes binding of the C-ABI HIP library (include/gemnet_hip.h).
+
+There is deliberately NO fallback: if ``csrc/libgemnet_hip.so`` is missing or a call fails the
+product path raises.  PyTorch is used only for device memory and streams: every entry point
+receives raw device pointers + sizes + ``torch.cuda.current_stream()``.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgemnet_hip.so")
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class GemmArgs(ctypes.Structure):
+    """Mirror of `gn_gemm_args` (include/gemnet_hip.h)."""
+    _fields_ = [
+        ("A", _vp), ("B", _vp), ("C", _vp),
+        ("M", _i), ("N", _i), ("K", _i),
+        ("lda", _i), ("ldb", _i), ("ldc", _i),
+        ("trans_a", _i), ("trans_b", _i),
+        ("a_dact_pre", _vp),
+        ("act", _i),
+        ("pre_out", _vp),
+        ("mul", _vp), ("ldmul", _i),
+        ("alpha", _f),
+        ("res", _vp), ("ldres", _i),
+        ("beta", _f),
+        ("gadd1", _vp), ("gidx1", _vp),
+        ("gadd2", _vp), ("gidx2", _vp),
+        ("ldg", _i),
+    ]
+
+
+# name -> argtypes; every function returns int (0 = ok)
+SIGNATURES = {
+    "gn_gemm_f32": [ctypes.POINTER(GemmArgs), _vp],
+    "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
+    "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "gn_bil_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bil_reduce_t_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bil_dot_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bessel_rbf_f32": [_vp, _vp, _vp, _i64, _i, _f, _i, _i, _i, _vp],
+    "gn_sph_radial_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _i, _vp],
+    "gn_ylm0_f32": [_vp, _vp, _i64, _i, _i, _vp],
+    "gn_ylm_f32": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "gn_ssilu_f32": [_vp, _vp, _i64, _i, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.gn_abi_version.restype = _i
+    lib.gn_error_string.restype = ctypes.c_char_p
+    lib.gn_error_string.argtypes = [_i]
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().gn_error_string(code)
+        raise RuntimeError(f"{what} failed: hip error {code} ({msg.decode() if msg else '?'})")
+
+
+def stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "gemnet_pytorch_amd ops run only on a HIP device (MI355X); got a CPU tensor. "
+                "There is no CPU fallback — use the oracle in tests if you need a CPU result.")

@@ -1,0 +1,119 @@
+// Basis functions of GemNet in closed form, with the analytic derivatives force training needs.
+//
+// The reference builds these formulas symbolically with sympy at constructor time (17-59 s) and
+// evaluates them as ~50 lambdified Python closures, one ATen launch per elementary op
+// (gemnet/model/layers/basis_layers.py:45-49,119-131,239-270; basis_utils.py:47-80,174-253).
+// Here one kernel per basis family evaluates value or d/d^2 derivative directly; arithmetic is
+// done in f64 in-kernel (E*42 resp. T*7 values: negligible cost) so the f32 results are
+// correctly rounded even where the reference's expanded sympy form cancels catastrophically
+// (small z*d/c, SURVEY.md Appendix A "numerical-stability finding").
+#include "common.h"
+#include "basis_math.h"
+
+namespace {
+
+__global__ void bessel_rbf_kernel(const float* __restrict__ dist, const float* __restrict__ freq,
+                                  float* __restrict__ out, int64_t E, int R, double cutoff, int p,
+                                  int kd, int kf) {
+  const int64_t n = E * R;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / R;
+    const int r = (int)(i - e * R);
+    out[i] = (float)bessel_rbf_eval((double)dist[e], (double)freq[r], cutoff, p, kd, kf);
+  }
+}
+
+__global__ void sph_radial_kernel(const float* __restrict__ dist, const float* __restrict__ z,
+                                  const double* __restrict__ nrm, float* __restrict__ out,
+                                  int64_t E, int S, int R, double cutoff, int p, int kd) {
+  const int SR = S * R;
+  const int64_t n = E * SR;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / SR;
+    const int lr = (int)(i - e * SR);
+    out[i] = (float)sph_radial_eval((double)dist[e], (double)z[lr], nrm[lr], lr / R, cutoff, p, kd);
+  }
+}
+
+__global__ void ylm0_kernel(const float* __restrict__ theta, float* __restrict__ out, int64_t T,
+                            int S, int k) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < T;
+       t += (int64_t)gridDim.x * blockDim.x)
+    ylm0_row((double)theta[t], S, k, out + t * S);
+}
+
+constexpr int YL_MAX = 7;
+__global__ void ylm_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                           float* __restrict__ out, int64_t Q, int S, int kt, int kp) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q;
+       q += (int64_t)gridDim.x * blockDim.x)
+    ylm_row((double)theta[q], (double)phi[q], S, kt, kp, out + q * (int64_t)S * S);
+}
+
+__global__ void ssilu_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int k) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    out[i] = k == 0 ? gn_ssilu(v) : (k == 1 ? gn_dssilu(v) : (k == 2 ? gn_d2ssilu(v) : gn_d3ssilu(v)));
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int gn_bessel_rbf_f32(const float* d, const float* freq, float* out, int64_t E, int R,
+                                 float cutoff, int p, int kd, int kf, void* stream) {
+  if (E <= 0) return 0;
+  if (kd < 0 || kf < 0 || kf > 1 || kd + kf > 2 || p < 2) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bessel_rbf_kernel, dim3(grid_for(E * R)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d, freq, out, E, R, (double)cutoff, p, kd, kf);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_sph_radial_f32(const float* d, const float* z, const double* nrm, float* out,
+                                 int64_t E, int S, int R, float cutoff, int p, int kd, void* stream) {
+  if (E <= 0) return 0;
+  if (kd < 0 || kd > 2 || p < 2 || S > YL_MAX + 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sph_radial_kernel, dim3(grid_for(E * S * R)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d, z, nrm, out, E, S, R, (double)cutoff, p, kd);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_ylm0_f32(const float* theta, float* out, int64_t T, int S, int k, void* stream) {
+  if (T <= 0) return 0;
+  if (k < 0 || k > 2) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(ylm0_kernel, dim3(grid_for(T)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     theta, out, T, S, k);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_ylm_f32(const float* theta, const float* phi, float* out, int64_t Q, int S, int kt,
+                          int kp, void* stream) {
+  if (Q <= 0) return 0;
+  if (kt < 0 || kp < 0 || kt + kp > 2) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(ylm_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     theta, phi, out, Q, S, kt, kp);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_ssilu_f32(const float* x, float* out, int64_t n, int k, void* stream) {
+  if (n <= 0) return 0;
+  if (k < 0 || k > 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(ssilu_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, out, n, k);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_abi_version(void) { return 1; }
+extern "C" const char* gn_error_string(int code) { return hipGetErrorString((hipError_t)code); }

@@ -1,0 +1,190 @@
+// Pure math of the GemNet basis functions, shared by the HIP kernels (basis.hip) and by the
+// host-side unit-test shim (tests/host_math_shim.cpp, compiled with g++): every function here is
+// GN_HD so the formulas can be checked against the reference goldens without a GPU.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#if defined(__HIPCC__)
+#define GN_HD __host__ __device__ __forceinline__
+#else
+#define GN_HD inline
+#endif
+
+struct Env3 { double u, u1, u2; };  // envelope value, d/dd, d2/dd2
+
+// u(x) = 1 + a x^p + b x^(p+1) + c x^(p+2) for x < 1 else 0, x = d / cutoff  (envelope.py:14-29)
+GN_HD Env3 envelope(double x, int p, double inv_c) {
+  Env3 r = {0.0, 0.0, 0.0};
+  if (x < 1.0) {
+    const double a = -(p + 1) * (p + 2) / 2.0, b = (double)p * (p + 2), c = -p * (p + 1) / 2.0;
+    const double xp2 = pow(x, (double)(p - 2));  // p >= 2 in all GemNet configs (p = 5)
+    const double xp1 = xp2 * x, xp = xp1 * x, xq = xp * x, xr = xq * x;
+    r.u = 1.0 + a * xp + b * xq + c * xr;
+    r.u1 = (a * p * xp1 + b * (p + 1) * xp + c * (p + 2) * xq) * inv_c;
+    r.u2 = (a * p * (p - 1) * xp2 + b * (p + 1) * p * xp1 + c * (p + 2) * (p + 1) * xp) * inv_c * inv_c;
+  }
+  return r;
+}
+
+// spherical Bessel j_l(y) for l = 0..L (L <= 7), stable: series for y < l, upward recurrence else
+GN_HD double sph_jl_series(int l, double y) {
+  double dfact = 1.0;
+  for (int i = 1; i <= 2 * l + 1; i += 2) dfact *= i;
+  const double q = -0.5 * y * y;
+  double term = 1.0, acc = 1.0;
+  for (int k = 1; k < 30; ++k) {
+    term *= q / (k * (2.0 * l + 2.0 * k + 1.0));
+    acc += term;
+  }
+  return pow(y, (double)l) / dfact * acc;
+}
+
+GN_HD double sph_jl(int l, double y, double sn, double cs) {
+  if (l > 0 && y < (double)l) return sph_jl_series(l, y);
+  const double iy = 1.0 / y;
+  double jm = sn * iy;  // j0
+  if (l == 0) return jm;
+  double j = sn * iy * iy - cs * iy;  // j1
+  for (int k = 1; k < l; ++k) {
+    const double jn = (2 * k + 1) * iy * j - jm;
+    jm = j;
+    j = jn;
+  }
+  return j;
+}
+
+GN_HD double ylm_prefactor(int l, int m) {
+  // sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!)   (basis_utils.py:83-104), m >= 0
+  double r = (2.0 * l + 1.0) / (4.0 * 3.14159265358979323846);
+  for (int k = l - m + 1; k <= l + m; ++k) r /= k;
+  return sqrt(r);
+}
+
+// second-order jet in theta
+struct Jet { double v, d1, d2; };
+GN_HD Jet jmul(const Jet& a, const Jet& b) {
+  return {a.v * b.v, a.d1 * b.v + a.v * b.d1, a.d2 * b.v + 2.0 * a.d1 * b.d1 + a.v * b.d2};
+}
+GN_HD Jet jscale(const Jet& a, double s) { return {a.v * s, a.d1 * s, a.d2 * s}; }
+GN_HD Jet jsub(const Jet& a, const Jet& b) { return {a.v - b.v, a.d1 - b.d1, a.d2 - b.d2}; }
+
+
+// d^kd/dd^kd d^kf/df^kf [ u(d/c) sqrt(2/c) sin(f d/c) / d ]    (basis_layers.py:45-49)
+GN_HD double bessel_rbf_eval(double d, double f, double cutoff, int p, int kd, int kf) {
+  const double inv_c = 1.0 / cutoff;
+  const double A = sqrt(2.0 * inv_c);
+  const double w = f * inv_c;
+  const Env3 u = envelope(d * inv_c, p, inv_c);
+  double sn, cs;
+  sincos(w * d, &sn, &cs);
+  const double id = 1.0 / d;
+  double v;
+  if (kf == 0) {
+    const double h = sn * id;
+    const double h1 = w * cs * id - sn * id * id;
+    if (kd == 0) v = u.u * h;
+    else if (kd == 1) v = u.u1 * h + u.u * h1;
+    else {
+      const double h2 = -w * w * sn * id - 2.0 * w * cs * id * id + 2.0 * sn * id * id * id;
+      v = u.u2 * h + 2.0 * u.u1 * h1 + u.u * h2;
+    }
+  } else {  // d/df: dh/df = cos(wd)/c, dh'/df = -w sin(wd)/c
+    if (kd == 0) v = u.u * cs * inv_c;
+    else v = (u.u1 * cs - u.u * w * sn) * inv_c;
+  }
+  return A * v;
+}
+
+// d^kd/dd^kd [ u(d/c) c^-1.5 N j_l(z d/c) ]    (basis_layers.py:121-128; basis_utils.py:47-80)
+GN_HD double sph_radial_eval(double d, double z, double nrm, int l, double cutoff, int p, int kd) {
+  const double inv_c = 1.0 / cutoff;
+  const double a = z * inv_c;  // y = a d
+  const double y = a * d;
+  const Env3 u = envelope(d * inv_c, p, inv_c);
+  double sn, cs;
+  sincos(y, &sn, &cs);
+  const double jl = sph_jl(l, y, sn, cs);
+  double v;
+  if (kd == 0) {
+    v = u.u * jl;
+  } else {
+    // j_l' = j_{l-1} - (l+1)/y j_l  (l >= 1);  j_0' = -j_1
+    const double j1 = (l == 0) ? -sph_jl(1, y, sn, cs) : sph_jl(l - 1, y, sn, cs) - (l + 1) / y * jl;
+    const double J1 = a * j1;
+    if (kd == 1) {
+      v = u.u1 * jl + u.u * J1;
+    } else {
+      // y^2 j'' + 2 y j' + (y^2 - l(l+1)) j = 0
+      const double j2 = -2.0 / y * j1 - (1.0 - l * (l + 1) / (y * y)) * jl;
+      v = u.u2 * jl + 2.0 * u.u1 * J1 + u.u * a * a * j2;
+    }
+  }
+  return v * nrm * inv_c * sqrt(inv_c);
+}
+
+// out[l] = d^k/dtheta^k [ N_l0 P_l(cos theta) ], l < S    (zero_m_only branch, basis_utils.py:221-222)
+GN_HD void ylm0_row(double theta, int S, int k, float* out) {
+  double sn, c;
+  sincos(theta, &sn, &c);
+  // P_l = ((2l-1) c P_{l-1} - (l-1) P_{l-2})/l,  P'_l = P'_{l-2} + (2l-1) P_{l-1},
+  // P''_l = P''_{l-2} + (2l-1) P'_{l-1}
+  double P0 = 1.0, P1 = c, D0 = 0.0, D1 = 1.0, H0 = 0.0, H1 = 0.0;
+  for (int l = 0; l < S; ++l) {
+    double P, D, H;
+    if (l == 0) { P = P0; D = D0; H = H0; }
+    else if (l == 1) { P = P1; D = D1; H = H1; }
+    else {
+      P = ((2 * l - 1) * c * P1 - (l - 1) * P0) / l;
+      D = D0 + (2 * l - 1) * P1;
+      H = H0 + (2 * l - 1) * D1;
+      P0 = P1; P1 = P; D0 = D1; D1 = D; H0 = H1; H1 = H;
+    }
+    double v;
+    if (k == 0) v = P;
+    else if (k == 1) v = -sn * D;
+    else v = sn * sn * H - c * D;
+    out[l] = (float)(ylm_prefactor(l, 0) * v);
+  }
+}
+
+// out[j] = d^kt/dtheta^kt d^kp/dphi^kp Y_j(theta, phi), j < S*S; per degree l the slots hold
+// m = 0, +1..+l, -l..-1 (negative list indices at basis_utils.py:237).
+// Y_l,+m = sqrt2 N_lm Q_l^m cos(m phi), Y_l,-m = sqrt2 N_lm Q_l^m sin(m phi), Q_l^m = phase-free
+// associated Legendre in (cos theta, sin theta)  (basis_utils.py:137-159,226-243).
+GN_HD void ylm_row(double theta, double ph, int S, int kt, int kp, float* o) {
+  double sn, cs;
+  sincos(theta, &sn, &cs);
+  const Jet js = {sn, cs, -sn};
+  const Jet jc = {cs, -sn, -cs};
+  Jet qmm = {1.0, 0.0, 0.0};
+  for (int m = 0; m < S; ++m) {
+    if (m > 0) qmm = jscale(jmul(js, qmm), (double)(2 * m - 1));
+    double fc, fs;  // phi factors of +m (cos) and -m (sin), kp-th derivative
+    {
+      double smp, cmp;
+      sincos(m * ph, &smp, &cmp);
+      if (kp == 0) { fc = cmp; fs = smp; }
+      else if (kp == 1) { fc = -m * smp; fs = m * cmp; }
+      else { fc = -(double)m * m * cmp; fs = -(double)m * m * smp; }
+    }
+    Jet qa = qmm;              // q[l-1][m]
+    Jet qb = {0.0, 0.0, 0.0};  // q[l-2][m]
+    for (int l = m; l < S; ++l) {
+      Jet ql;
+      if (l == m) ql = qmm;
+      else if (l == m + 1) ql = jscale(jmul(jc, qa), (double)(2 * m + 1));
+      else ql = jscale(jsub(jscale(jmul(jc, qa), (double)(2 * l - 1)), jscale(qb, (double)(l + m - 1))),
+                       1.0 / (l - m));
+      if (l > m) { qb = qa; qa = ql; }
+      const double tv = (kt == 0) ? ql.v : (kt == 1 ? ql.d1 : ql.d2);
+      const int base = l * l;  // first slot of degree l
+      if (m == 0) {
+        o[base] = (float)(kp == 0 ? ylm_prefactor(l, 0) * tv : 0.0);
+      } else {
+        const double pf = 1.4142135623730951 * ylm_prefactor(l, m) * tv;
+        o[base + m] = (float)(pf * fc);              // +m
+        o[base + 2 * l + 1 - m] = (float)(pf * fs);  // -m
+      }
+    }
+  }
+}

@@ -1,0 +1,160 @@
+// CSR-segmented bilinear aggregation (kernel K1 and its two adjoints).
+//
+// The reference (gemnet/model/layers/efficient.py:159-189) scatters the (T,C) gathered edge
+// embeddings into a zero-padded (E,Kmax,C) tensor, does the same with the harmonics
+// (basis_layers.py:153-159) and multiplies them with bmm.  Triplets/quadruplets arrive already
+// sorted by their reduce edge (data_container.py:324-328,369-375), so here a group of C lanes
+// owns one reduce edge, walks its contiguous segment and keeps the S partial sums in registers:
+// no padding, no zero-fill, no atomics, each output written exactly once.
+#include "common.h"
+
+namespace {
+
+// Sm[e,s,c] = sum_{t in seg(e)} Y[t,s] * x[g(t),c]
+template <int S>
+__global__ __launch_bounds__(256) void bil_reduce_kernel(const float* __restrict__ Y,
+                                                         const float* __restrict__ x,
+                                                         const int32_t* __restrict__ expand_idx,
+                                                         const int32_t* __restrict__ seg_off,
+                                                         float* __restrict__ Sm, int64_t E, int C) {
+  const int epb = blockDim.x / C;
+  const int el = threadIdx.x / C;
+  const int c = threadIdx.x - el * C;
+  const int64_t e = (int64_t)blockIdx.x * epb + el;
+  if (el >= epb || e >= E) return;
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  float acc[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) acc[s] = 0.f;
+  for (int t = t0; t < t1; ++t) {
+    const float xv = x[(int64_t)expand_idx[t] * C + c];
+    const float* __restrict__ y = Y + (int64_t)t * S;
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = fmaf(y[s], xv, acc[s]);
+  }
+  float* __restrict__ o = Sm + e * S * C + c;
+#pragma unroll
+  for (int s = 0; s < S; ++s) o[(int64_t)s * C] = acc[s];
+}
+
+// dx[j,c] = sum_{k in segT(j)} sum_s Y[t,s] * dSm[r(t),s,c],  t = permT[k]
+template <int S>
+__global__ __launch_bounds__(256) void bil_reduce_t_kernel(const float* __restrict__ Y,
+                                                           const float* __restrict__ dSm,
+                                                           const int32_t* __restrict__ reduce_idx,
+                                                           const int32_t* __restrict__ permT,
+                                                           const int32_t* __restrict__ segT_off,
+                                                           float* __restrict__ dx, int64_t J, int C) {
+  const int rpb = blockDim.x / C;
+  const int rl = threadIdx.x / C;
+  const int c = threadIdx.x - rl * C;
+  const int64_t j = (int64_t)blockIdx.x * rpb + rl;
+  if (rl >= rpb || j >= J) return;
+  const int k0 = segT_off[j], k1 = segT_off[j + 1];
+  float acc = 0.f;
+  for (int k = k0; k < k1; ++k) {
+    const int t = permT[k];
+    const float* __restrict__ y = Y + (int64_t)t * S;
+    const float* __restrict__ d = dSm + (int64_t)reduce_idx[t] * S * C + c;
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc = fmaf(y[s], d[(int64_t)s * C], acc);
+  }
+  dx[j * C + c] = acc;
+}
+
+// dY[t,s] = sum_c dSm[r(t),s,c] * x[g(t),c]; one block per reduce edge, dSm[e] staged in LDS
+// with row stride C+4 (lanes of different s hit different 16-B slots; same s broadcasts).
+__global__ __launch_bounds__(256) void bil_dot_kernel(const float* __restrict__ dSm,
+                                                      const float* __restrict__ x,
+                                                      const int32_t* __restrict__ expand_idx,
+                                                      const int32_t* __restrict__ seg_off,
+                                                      float* __restrict__ dY, int S, int C, int vec) {
+  extern __shared__ __attribute__((aligned(16))) float dS[];
+  const int64_t e = blockIdx.x;
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  if (t1 <= t0) return;
+  const int ld = C + 4;
+  const float* __restrict__ src = dSm + e * S * C;
+  for (int i = threadIdx.x; i < S * C; i += blockDim.x) {
+    const int s = i / C;
+    dS[s * ld + (i - s * C)] = src[i];
+  }
+  __syncthreads();
+  const int n = (t1 - t0) * S;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    const int tt = p / S;
+    const int s = p - tt * S;
+    const int t = t0 + tt;
+    const float* __restrict__ xr = x + (int64_t)expand_idx[t] * C;
+    const float* dr = dS + s * ld;
+    float acc = 0.f;
+    if (vec) {
+      for (int c = 0; c < C; c += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(dr + c);
+        const float4 b = *reinterpret_cast<const float4*>(xr + c);
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+        acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+      }
+    } else {
+      for (int c = 0; c < C; ++c) acc = fmaf(dr[c], xr[c], acc);
+    }
+    dY[(int64_t)t * S + s] = acc;
+  }
+}
+
+inline bool ok_channels(int C) { return C > 0 && C <= 256 && (256 % C) == 0; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int gn_bil_reduce_f32(const float* Y, const float* x, const int32_t* expand_idx,
+                                 const int32_t* seg_off, float* Sm, int64_t E, int S, int C,
+                                 void* stream) {
+  if (E <= 0) return 0;
+  if (!ok_channels(C)) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int epb = 256 / C;
+  dim3 grid(gn_cdiv(E, epb)), block(256);
+  if (S == 7) {
+    hipLaunchKernelGGL(bil_reduce_kernel<7>, grid, block, 0, st, Y, x, expand_idx, seg_off, Sm, E, C);
+  } else if (S == 49) {
+    hipLaunchKernelGGL(bil_reduce_kernel<49>, grid, block, 0, st, Y, x, expand_idx, seg_off, Sm, E, C);
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32_t* reduce_idx,
+                                   const int32_t* permT, const int32_t* segT_off, float* dx,
+                                   int64_t J, int S, int C, void* stream) {
+  if (J <= 0) return 0;
+  if (!ok_channels(C)) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpb = 256 / C;
+  dim3 grid(gn_cdiv(J, rpb)), block(256);
+  if (S == 7) {
+    hipLaunchKernelGGL(bil_reduce_t_kernel<7>, grid, block, 0, st, Y, dSm, reduce_idx, permT, segT_off, dx, J, C);
+  } else if (S == 49) {
+    hipLaunchKernelGGL(bil_reduce_t_kernel<49>, grid, block, 0, st, Y, dSm, reduce_idx, permT, segT_off, dx, J, C);
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_dot_f32(const float* dSm, const float* x, const int32_t* expand_idx,
+                              const int32_t* seg_off, float* dY, int64_t E, int S, int C,
+                              void* stream) {
+  if (E <= 0) return 0;
+  if (S <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+  const size_t smem = (size_t)S * (C + 4) * sizeof(float);
+  if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
+  const int vec = (C % 4 == 0) && aligned16(x);
+  hipLaunchKernelGGL(bil_dot_kernel, dim3((unsigned)E), dim3(S <= 7 ? 128 : 256), smem,
+                     static_cast<hipStream_t>(stream), dSm, x, expand_idx, seg_off, dY, S, C, vec);
+  GN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,140 @@
+"""Device-side index plans: int32 copies of the reference's index arrays plus the CSR groupings
+(offsets + permutation) that make every gather's adjoint an atomic-free segmented sum.
+
+The reference hands `GemNet.forward` a dict of int64 tensors (data_container.py:33-56,505-516)
+whose triplet/quadruplet arrays are sorted by reduce edge (:324-328,:369-375); `Kidx3/Kidx4`
+(position inside the segment) exist only to build zero-padded tensors and are not needed here.
+SURVEY.md Appendix D lists the transpose groupings the backward passes need.
+"""
+import torch
+
+
+def _seg_offsets_sorted(sorted_idx: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """offsets[r] = first position with value >= r  (no host sync)."""
+    bounds = torch.arange(n_rows + 1, device=sorted_idx.device, dtype=sorted_idx.dtype)
+    return torch.searchsorted(sorted_idx.contiguous(), bounds).to(torch.int32)
+
+
+class RowIndex:
+    """A row-index array `idx` (T,) into a matrix with `n_rows` rows.
+
+    idx32        int32 copy used by the gather kernels
+    perm/seg_off CSR by destination row for the adjoint (perm is None when idx is sorted)
+    inverse      for permutations (id_swap): adjoint is a gather with the inverse permutation
+    """
+
+    def __init__(self, idx: torch.Tensor, n_rows: int, is_sorted: bool = False, inverse=None):
+        self.idx64 = idx
+        self.idx32 = idx.to(torch.int32).contiguous()
+        self.n_rows = int(n_rows)
+        self.size = int(idx.shape[0])
+        self.is_sorted = is_sorted
+        self.inverse = inverse
+        self._csr = None
+
+    @property
+    def csr(self):
+        if self._csr is None:
+            if self.is_sorted:
+                self._csr = (None, _seg_offsets_sorted(self.idx64, self.n_rows))
+            else:
+                perm = torch.argsort(self.idx64, stable=True)
+                seg = _seg_offsets_sorted(self.idx64[perm], self.n_rows)
+                self._csr = (perm.to(torch.int32).contiguous(), seg)
+        return self._csr
+
+
+class SegmentPlan:
+    """Triplets (or quadruplets) t with reduce row r(t) (sorted) and expand row g(t)."""
+
+    def __init__(self, reduce_idx: torch.Tensor, expand_idx: torch.Tensor, n_reduce: int, n_expand: int):
+        self.reduce = RowIndex(reduce_idx, n_reduce, is_sorted=True)
+        self.expand = RowIndex(expand_idx, n_expand)
+        self.size = int(reduce_idx.shape[0])
+        self.n_reduce = int(n_reduce)
+        self.n_expand = int(n_expand)
+
+    @property
+    def seg_off(self):
+        return self.reduce.csr[1]
+
+
+class GraphPlan:
+    """All index plans of one batch.  Built once per batch (`GraphPlan.from_inputs`), cached in the
+    inputs dict under the key "_plan" so repeated forwards (MD, benchmarks, graph replay) reuse it."""
+
+    def __init__(self, inputs: dict, triplets_only: bool):
+        Z = inputs["Z"]
+        dev = Z.device
+        self.n_atoms = int(Z.shape[0])
+        id_a, id_c = inputs["id_a"], inputs["id_c"]
+        self.n_edges = int(id_a.shape[0])
+        if "N" in inputs:
+            self.n_mol = int(inputs["N"].shape[0])
+        else:  # reference semantics (gemnet.py:578) — costs a host sync
+            self.n_mol = int(inputs["batch_seg"].max().item()) + 1 if self.n_atoms else 0
+        self.id_a = RowIndex(id_a, self.n_atoms)
+        self.id_c = RowIndex(id_c, self.n_atoms)
+        swap = inputs["id_swap"]
+        self.id_swap = RowIndex(swap, self.n_edges)
+        self.id_swap.inverse = self.id_swap  # id_swap is an involution (data_container.py:303-308)
+        self.batch_seg = RowIndex(inputs["batch_seg"], self.n_mol, is_sorted=True)
+        self.trip = SegmentPlan(inputs["id3_reduce_ca"], inputs["id3_expand_ba"], self.n_edges, self.n_edges)
+        # atom triples of each triplet for the angle c<-a->b (gemnet.py:442-444)
+        r, x = inputs["id3_reduce_ca"], inputs["id3_expand_ba"]
+        self.t_c, self.t_a, self.t_b = id_c[r], id_a[r], id_c[x]
+        self.t_c, self.t_a, self.t_b = (RowIndex(v, self.n_atoms) for v in (self.t_c, self.t_a, self.t_b))
+        self.z_rows = RowIndex(Z - 1, 93)
+        self.id_undir = RowIndex(inputs["id_undir"], self.n_edges // 2)
+        if "N" in inputs:
+            self.atoms_per_mol = inputs["N"].to(torch.float32)
+        else:
+            self.atoms_per_mol = torch.bincount(inputs["batch_seg"], minlength=self.n_mol).to(torch.float32)
+        self.triplets_only = triplets_only
+        if not triplets_only:
+            i_a, i_b = inputs["id4_int_a"], inputs["id4_int_b"]
+            self.n_int = int(i_a.shape[0])
+            self.int_a, self.int_b = RowIndex(i_a, self.n_atoms), RowIndex(i_b, self.n_atoms)
+            red_ca, exp_db = inputs["id4_reduce_intm_ca"], inputs["id4_expand_intm_db"]
+            red_ab, exp_ab = inputs["id4_reduce_intm_ab"], inputs["id4_expand_intm_ab"]
+            self.n_intm = int(exp_db.shape[0])
+            self.intm_db = RowIndex(exp_db, self.n_edges)
+            self.intm_ab = RowIndex(exp_ab, self.n_int, is_sorted=True)
+            self.quad = SegmentPlan(inputs["id4_reduce_ca"], inputs["id4_expand_abd"], self.n_edges, self.n_intm)
+            A = self.n_atoms
+            self.quad_geom = {
+                # a - b <- d per intermediate triplet (gemnet.py:385-388)
+                "a_of_exp": RowIndex(i_a[exp_ab], A), "b_of_exp": RowIndex(i_b[exp_ab], A),
+                "d_of_exp": RowIndex(id_c[exp_db], A),
+                # c -> a <- b per intermediate triplet (gemnet.py:399-402)
+                "c_of_red": RowIndex(id_c[red_ca], A), "a_of_red": RowIndex(id_a[red_ca], A),
+                "b_of_red": RowIndex(i_b[red_ab], A),
+                "reduce_cab": RowIndex(inputs["id4_reduce_cab"], self.n_intm),
+            }
+        self.device = dev
+
+    @staticmethod
+    def from_inputs(inputs: dict, triplets_only: bool) -> "GraphPlan":
+        plan = inputs.get("_plan")
+        if plan is None or plan.triplets_only != triplets_only or plan.device != inputs["Z"].device:
+            plan = GraphPlan(inputs, triplets_only)
+            inputs["_plan"] = plan
+        return plan
+
+    def row_indices(self):
+        out = [self.id_a, self.id_c, self.batch_seg, self.trip.reduce, self.trip.expand,
+               self.t_c, self.t_a, self.t_b, self.z_rows, self.id_undir]
+        if not self.triplets_only:
+            out += [self.int_a, self.int_b, self.intm_db, self.intm_ab, self.quad.reduce, self.quad.expand]
+            out += list(self.quad_geom.values())
+        return out
+
+    def warm(self):
+        """Materialise every lazily-built CSR (call before hipGraph capture)."""
+        for ri in self.row_indices():
+            ri.csr
+        return self
+
+    def to(self, *args, **kwargs):
+        """Trainer.dict2device (trainer.py:313-318) calls .to(device) on every dict value."""
+        return self

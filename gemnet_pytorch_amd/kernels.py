@@ -1,0 +1,195 @@
+"""Thin launchers: torch tensors in, torch tensors out, one C-ABI call each (include/gemnet_hip.h).
+
+PyTorch only provides device memory and the current stream here.  No fallbacks: CPU tensors or a
+missing library raise.  (tests/cpu_kernels.py monkeypatches these launchers with CPU
+restatements to exercise the autograd/model logic on machines without a GPU; that emulation
+lives under tests/ and is never imported by the product.)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check, ptr, require_device, stream
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f"HIP path is fp32; got {t.dtype}")
+    return t.contiguous()
+
+
+def _rowmajor(t):
+    """2-D fp32 operand with unit inner stride (row slices of a weight are passed in place)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"HIP path is fp32; got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError("2-D operand expected")
+    if t.shape[0] > 0 and t.shape[1] > 0 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
+def _rowsize(t):
+    c = 1
+    for s in t.shape[1:]:
+        c *= int(s)
+    return c
+
+def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_out=False,
+             mul=None, alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None):
+    """C = epilogue(opA(A) @ opB(B)); see gn_gemm_f32 in include/gemnet_hip.h.
+    trans_b=False means B is a torch Linear weight (N, K).  Returns C or (C, pre)."""
+    require_device(A, B)
+    A, B = _rowmajor(A), _rowmajor(B)
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    N, Kb = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm shape mismatch: {tuple(A.shape)} ta={trans_a} x {tuple(B.shape)} tb={trans_b}")
+    C = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    pre = torch.empty_like(C) if pre_out else None
+    a = GemmArgs()
+    a.A, a.B, a.C = ptr(A), ptr(B), ptr(C)
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldb, a.ldc = A.stride(0), B.stride(0), N
+    a.trans_a, a.trans_b = int(trans_a), int(trans_b)
+    if a_dact_pre is not None:
+        a_dact_pre = _f32c(a_dact_pre)
+        A = _f32c(A)
+        assert a_dact_pre.shape == A.shape
+        a.A, a.lda = ptr(A), A.stride(0)
+    a.a_dact_pre = ptr(a_dact_pre)
+    a.act = int(act)
+    a.pre_out = ptr(pre)
+    if mul is not None:
+        mul = _f32c(mul)
+        assert mul.shape == C.shape
+    a.mul, a.ldmul = ptr(mul), N
+    a.alpha = float(alpha)
+    if res is not None:
+        res = _f32c(res)
+        assert res.shape == C.shape
+    a.res, a.ldres = ptr(res), N
+    a.beta = float(beta)
+    if gadd1 is not None:
+        gadd1 = _f32c(gadd1)
+        assert gadd1.shape[1] == N and gidx1.dtype == torch.int32 and gidx1.shape[0] == M
+    if gadd2 is not None:
+        gadd2 = _f32c(gadd2)
+        assert gadd2.shape[1] == N and gidx2.dtype == torch.int32 and gidx2.shape[0] == M
+    a.gadd1, a.gidx1 = ptr(gadd1), ptr(gidx1)
+    a.gadd2, a.gidx2 = ptr(gadd2), ptr(gidx2)
+    a.ldg = N
+    check(_lib.load().gn_gemm_f32(ctypes.byref(a), stream()), "gn_gemm_f32")
+    return (C, pre) if pre_out else C
+
+
+
+def gather(x, idx32):
+    require_device(x, idx32)
+    x = _f32c(x)
+    y = torch.empty((idx32.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    check(_lib.load().gn_gather_rows_f32(ptr(x), ptr(idx32), ptr(y), idx32.shape[0], _rowsize(x), stream()),
+          "gn_gather_rows_f32")
+    return y
+
+
+def segsum(y, perm, seg_off, n_rows):
+    require_device(y, seg_off)
+    y = _f32c(y)
+    x = torch.empty((n_rows,) + tuple(y.shape[1:]), device=y.device, dtype=torch.float32)
+    check(_lib.load().gn_segsum_rows_f32(ptr(y), ptr(perm), ptr(seg_off), ptr(x), n_rows, _rowsize(y), stream()),
+          "gn_segsum_rows_f32")
+    return x
+
+
+def bmm(A, B, ta, tb):
+    """(A^T if ta else A) @ (B^T if tb else B), batched over dim 0."""
+    require_device(A, B)
+    A, B = _f32c(A), _f32c(B)
+    b = A.shape[0]
+    m, k = (A.shape[2], A.shape[1]) if ta else (A.shape[1], A.shape[2])
+    n = B.shape[1] if tb else B.shape[2]
+    C = torch.empty((b, m, n), device=A.device, dtype=torch.float32)
+    check(_lib.load().gn_bmm_f32(ptr(A), ptr(B), ptr(C), b, m, n, k, int(ta), int(tb), stream()), "gn_bmm_f32")
+    return C
+
+
+def ssilu(x, k):
+    require_device(x)
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    check(_lib.load().gn_ssilu_f32(ptr(x), ptr(out), x.numel(), k, stream()), "gn_ssilu_f32")
+    return out
+
+
+def bil_reduce(Y, x, sp):
+    """Sm[e,s,c] = sum_{t in seg(e)} Y[t,s] x[g(t),c]."""
+    require_device(Y, x)
+    Y, x = _f32c(Y), _f32c(x)
+    S, C = Y.shape[1], x.shape[1]
+    Sm = torch.empty((sp.n_reduce, S, C), device=x.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_reduce_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(Sm),
+                                        sp.n_reduce, S, C, stream()), "gn_bil_reduce_f32")
+    return Sm
+
+
+def bil_reduce_t(Y, D, sp):
+    """dx[j,c] = sum_{t: g(t)=j} sum_s Y[t,s] D[r(t),s,c]."""
+    require_device(Y, D)
+    Y, D = _f32c(Y), _f32c(D)
+    S, C = Y.shape[1], D.shape[2]
+    permT, segT = sp.expand.csr
+    dx = torch.empty((sp.n_expand, C), device=Y.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_reduce_t_f32(ptr(Y), ptr(D), ptr(sp.reduce.idx32), ptr(permT), ptr(segT),
+                                          ptr(dx), sp.n_expand, S, C, stream()), "gn_bil_reduce_t_f32")
+    return dx
+
+
+def bil_dot(D, x, sp):
+    """dY[t,s] = sum_c D[r(t),s,c] x[g(t),c]."""
+    require_device(D, x)
+    D, x = _f32c(D), _f32c(x)
+    S, C = D.shape[1], x.shape[1]
+    dY = torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_dot_f32(ptr(D), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(dY),
+                                     sp.n_reduce, S, C, stream()), "gn_bil_dot_f32")
+    return dY
+
+
+def bessel_rbf(d, freq, cutoff, p, kd, kf):
+    require_device(d, freq)
+    d, freq = _f32c(d), _f32c(freq)
+    out = torch.empty((d.shape[0], freq.shape[0]), device=d.device, dtype=torch.float32)
+    check(_lib.load().gn_bessel_rbf_f32(ptr(d), ptr(freq), ptr(out), d.shape[0], freq.shape[0],
+                                        cutoff, p, kd, kf, stream()), "gn_bessel_rbf_f32")
+    return out
+
+
+def sph_radial(d, z, nrm, cutoff, p, kd):
+    """z (S,R) float32 roots, nrm (S,R) float64 normalisers (device tensors)."""
+    require_device(d, z, nrm)
+    d = _f32c(d)
+    assert z.dtype == torch.float32 and nrm.dtype == torch.float64 and z.is_contiguous() and nrm.is_contiguous()
+    S, R = z.shape
+    out = torch.empty((d.shape[0], S, R), device=d.device, dtype=torch.float32)
+    check(_lib.load().gn_sph_radial_f32(ptr(d), ptr(z), ptr(nrm), ptr(out), d.shape[0], S, R,
+                                        cutoff, p, kd, stream()), "gn_sph_radial_f32")
+    return out
+
+
+def ylm0(theta, S, k):
+    require_device(theta)
+    theta = _f32c(theta)
+    out = torch.empty((theta.shape[0], S), device=theta.device, dtype=torch.float32)
+    check(_lib.load().gn_ylm0_f32(ptr(theta), ptr(out), theta.shape[0], S, k, stream()), "gn_ylm0_f32")
+    return out
+
+
+def ylm(theta, phi, S, kt, kp):
+    require_device(theta, phi)
+    theta, phi = _f32c(theta), _f32c(phi)
+    out = torch.empty((theta.shape[0], S * S), device=theta.device, dtype=torch.float32)
+    check(_lib.load().gn_ylm_f32(ptr(theta), ptr(phi), ptr(out), theta.shape[0], S, kt, kp, stream()),
+          "gn_ylm_f32")
+    return out

@@ -1,0 +1,258 @@
+"""`GemNet` — drop-in for the reference's `gemnet.model.gemnet.GemNet` (gemnet/model/gemnet.py:21-790)
+with the InteractionBlock hot path running on hand-written gfx950 HIP kernels.
+
+Kept verbatim from the reference: constructor signature (:82-113), `forward(inputs) -> (E, F)`
+(:453-615) including the `inputs["R"].requires_grad` toggling (:494,:613), `predict` (:780-784),
+`load_weights`/`save_weights` (:786-790), attribute names the trainer reaches into
+(`mlp_rbf3/.mlp_cbf3/.mlp_rbf_h/.mlp_rbf4/.mlp_cbf4/.mlp_sbf4/.mlp_rbf_out`, `num_blocks`,
+`triplets_only`, `direct_forces`, trainer.py:263-278,417) and the state_dict key set.
+
+Different by design: no zero-padded (E,Kmax,.) tensors, no `Kidx` host syncs, no sympy at
+construction (closed-form basis kernels), no torch_scatter (CSR segmented sums), the concat-Dense
+split into atom-side and edge-side GEMMs.  fp32 on a HIP device only; CPU tensors raise.
+
+Force graph policy: the reference always builds the force with `create_graph=True`.  Here the
+second-order graph is built when it can be used — `self.training and torch.is_grad_enabled()` —
+or when `self.force_graph` is set to True/False explicitly.
+"""
+import torch
+
+from .. import ops
+from ..graph import GraphPlan, RowIndex
+from .layers import (AtomEmbedding, BesselBasisLayer, Dense, EdgeEmbedding,
+                     EfficientInteractionDownProjection, InteractionBlock,
+                     InteractionBlockTripletsOnly, OutputBlock, SphericalBasisLayer, TensorBasisLayer)
+from .scaling import AutomaticFit
+
+
+class GemNet(torch.nn.Module):
+    def __init__(
+        self,
+        num_spherical: int,
+        num_radial: int,
+        num_blocks: int,
+        emb_size_atom: int,
+        emb_size_edge: int,
+        emb_size_trip: int,
+        emb_size_quad: int,
+        emb_size_rbf: int,
+        emb_size_cbf: int,
+        emb_size_sbf: int,
+        emb_size_bil_quad: int,
+        emb_size_bil_trip: int,
+        num_before_skip: int,
+        num_after_skip: int,
+        num_concat: int,
+        num_atom: int,
+        triplets_only: bool,
+        num_targets: int = 1,
+        direct_forces: bool = False,
+        cutoff: float = 5.0,
+        int_cutoff: float = 10.0,
+        envelope_exponent: int = 5,
+        extensive=True,
+        forces_coupled: bool = False,
+        output_init="HeOrthogonal",
+        activation: str = "swish",
+        scale_file=None,
+        name="gemnet",
+        **kwargs,
+    ):
+        super().__init__()
+        assert num_blocks > 0
+        self.num_targets = num_targets
+        self.num_blocks = num_blocks
+        self.extensive = extensive
+        self.forces_coupled = forces_coupled
+        self.direct_forces = direct_forces
+        self.triplets_only = triplets_only
+        self.num_spherical = num_spherical
+        self.force_graph = None  # None: auto (training & grad enabled); True/False: forced
+
+        AutomaticFit.reset()
+
+        self.rbf_basis = BesselBasisLayer(num_radial, cutoff=cutoff, envelope_exponent=envelope_exponent)
+        if not triplets_only:
+            self.cbf_basis = SphericalBasisLayer(num_spherical, num_radial, cutoff=int_cutoff,
+                                                 envelope_exponent=envelope_exponent, efficient=False)
+            self.sbf_basis = TensorBasisLayer(num_spherical, num_radial, cutoff=cutoff,
+                                              envelope_exponent=envelope_exponent, efficient=True)
+        self.cbf_basis3 = SphericalBasisLayer(num_spherical, num_radial, cutoff=cutoff,
+                                              envelope_exponent=envelope_exponent, efficient=True)
+
+        # shared down projections (gemnet.py:158-204)
+        if not triplets_only:
+            self.mlp_rbf4 = Dense(num_radial, emb_size_rbf, activation=None, bias=False)
+            self.mlp_cbf4 = Dense(num_radial * num_spherical, emb_size_cbf, activation=None, bias=False)
+            self.mlp_sbf4 = EfficientInteractionDownProjection(num_spherical ** 2, num_radial, emb_size_sbf)
+        self.mlp_rbf3 = Dense(num_radial, emb_size_rbf, activation=None, bias=False)
+        self.mlp_cbf3 = EfficientInteractionDownProjection(num_spherical, num_radial, emb_size_cbf)
+        self.mlp_rbf_h = Dense(num_radial, emb_size_rbf, activation=None, bias=False)
+        self.mlp_rbf_out = Dense(num_radial, emb_size_rbf, activation=None, bias=False)
+
+        self.atom_emb = AtomEmbedding(emb_size_atom)
+        self.edge_emb = EdgeEmbedding(emb_size_atom, num_radial, emb_size_edge, activation=activation)
+
+        block_cls = InteractionBlockTripletsOnly if triplets_only else InteractionBlock
+        int_blocks = []
+        for i in range(num_blocks):
+            kw = dict(emb_size_atom=emb_size_atom, emb_size_edge=emb_size_edge, emb_size_trip=emb_size_trip,
+                      emb_size_quad=emb_size_quad, emb_size_rbf=emb_size_rbf, emb_size_cbf=emb_size_cbf,
+                      emb_size_bil_trip=emb_size_bil_trip, num_before_skip=num_before_skip,
+                      num_after_skip=num_after_skip, num_concat=num_concat, num_atom=num_atom,
+                      activation=activation, scale_file=scale_file, name=f"IntBlock_{i+1}")
+            if not triplets_only:
+                kw.update(emb_size_sbf=emb_size_sbf, emb_size_bil_quad=emb_size_bil_quad)
+            int_blocks.append(block_cls(**kw))
+        out_blocks = [
+            OutputBlock(emb_size_atom=emb_size_atom, emb_size_edge=emb_size_edge, emb_size_rbf=emb_size_rbf,
+                        nHidden=num_atom, num_targets=num_targets, activation=activation,
+                        output_init=output_init, direct_forces=direct_forces, scale_file=scale_file,
+                        name=f"OutBlock_{i}")
+            for i in range(num_blocks + 1)
+        ]
+        self.out_blocks = torch.nn.ModuleList(out_blocks)
+        self.int_blocks = torch.nn.ModuleList(int_blocks)
+
+    # -------------------------------------------------------------------------- geometry (P9)
+    @staticmethod
+    def calculate_interatomic_vectors(R, id_s, id_t):
+        """id_s / id_t: RowIndex of the source / target atoms (gemnet.py:261-286)."""
+        V_st = ops.gather_rows(R, id_t) - ops.gather_rows(R, id_s)
+        D_st = torch.sqrt(torch.sum(V_st ** 2, dim=1))
+        return D_st, V_st / D_st[..., None]
+
+    @staticmethod
+    def calculate_neighbor_angles(R_ac, R_ab):
+        """atan2(max(|u x v|, 1e-9), u.v)  (gemnet.py:288-311)."""
+        x = torch.sum(R_ac * R_ab, dim=1)
+        y = torch.linalg.cross(R_ac, R_ab, dim=-1).norm(dim=-1)
+        y = torch.clamp(y, min=1e-9)
+        return torch.atan2(y, x)
+
+    @staticmethod
+    def vector_rejection(R_ab, P_n):
+        a_x_b = torch.sum(R_ab * P_n, dim=-1)
+        b_x_b = torch.sum(P_n * P_n, dim=-1)
+        return R_ab - (a_x_b / b_x_b)[:, None] * P_n
+
+    @staticmethod
+    def calculate_angles3(R, plan):
+        """(gemnet.py:420-451) angle c<-a->b of every triplet."""
+        Ra = ops.gather_rows(R, plan.t_a)
+        R_ac = ops.gather_rows(R, plan.t_c) - Ra
+        R_ab = ops.gather_rows(R, plan.t_b) - Ra
+        return GemNet.calculate_neighbor_angles(R_ac, R_ab)
+
+    @staticmethod
+    def calculate_angles(R, plan):
+        """Quadruplet angles (gemnet.py:334-418): Phi_cab (Q,), Phi_abd (I,), Theta_cabd (Q,)."""
+        q = plan.quad_geom
+        Ra = ops.gather_rows(R, q["a_of_exp"])
+        Rb = ops.gather_rows(R, q["b_of_exp"])
+        Rd = ops.gather_rows(R, q["d_of_exp"])
+        R_ba, R_bd = Ra - Rb, Rd - Rb
+        angle_abd = GemNet.calculate_neighbor_angles(R_ba, R_bd)
+        R_bd_proj = ops.gather_rows(GemNet.vector_rejection(R_bd, R_ba), plan.quad.expand)
+
+        Rc = ops.gather_rows(R, q["c_of_red"])
+        Ra2 = ops.gather_rows(R, q["a_of_red"])
+        Rb2 = ops.gather_rows(R, q["b_of_red"])
+        R_ac, R_ab = Rc - Ra2, Rb2 - Ra2
+        angle_cab = ops.gather_rows(GemNet.calculate_neighbor_angles(R_ab, R_ac)[:, None], q["reduce_cab"])[:, 0]
+        R_ac_proj = ops.gather_rows(GemNet.vector_rejection(R_ac, R_ab), q["reduce_cab"])
+        angle_cabd = GemNet.calculate_neighbor_angles(R_ac_proj, R_bd_proj)
+        return angle_cab, angle_abd, angle_cabd
+
+    # ---------------------------------------------------------------------------------- forward
+    def _energy(self, R, plan):
+        T = self.triplets_only
+        D_ca, V_ca = self.calculate_interatomic_vectors(R, plan.id_c, plan.id_a)
+        if not T:
+            D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
+            Phi_cab, Phi_abd, Theta_cabd = self.calculate_angles(R, plan)
+            cbf4 = self.cbf_basis(D_ab, Phi_abd, plan.intm_ab)           # (I, S*R)
+            sbf4 = self.sbf_basis(D_ca, Phi_cab, Theta_cabd)              # ((E,S,R), (Q,S^2))
+        rbf = self.rbf_basis(D_ca)
+        Angles3 = self.calculate_angles3(R, plan)
+        rad3, sph3 = self.cbf_basis3(D_ca, Angles3)
+
+        h = self.atom_emb(plan.z_rows)
+        m = self.edge_emb(h, rbf, plan.id_c, plan.id_a)
+
+        if not T:
+            rbf4 = self.mlp_rbf4(rbf)
+            cbf4 = self.mlp_cbf4(cbf4)
+            sbf4 = (self.mlp_sbf4(sbf4[0]), sbf4[1])
+        else:
+            rbf4 = cbf4 = sbf4 = None
+        rbf3 = self.mlp_rbf3(rbf)
+        cbf3 = (self.mlp_cbf3(rad3), sph3)
+        rbf_h = self.mlp_rbf_h(rbf)
+        rbf_out = self.mlp_rbf_out(rbf)
+
+        E_a, F_ca = self.out_blocks[0](h, m, rbf_out, plan.id_a)
+        for i in range(self.num_blocks):
+            h, m = self.int_blocks[i](h=h, m=m, rbf4=rbf4, cbf4=cbf4, sbf4=sbf4, rbf3=rbf3, cbf3=cbf3,
+                                      rbf_h=rbf_h, plan=plan)
+            E, F = self.out_blocks[i + 1](h, m, rbf_out, plan.id_a)
+            F_ca = F_ca + F
+            E_a = E_a + E
+
+        E_mol = ops.segsum_rows(E_a, plan.batch_seg)                      # (nMolecules, num_targets)
+        if not self.extensive:
+            E_mol = E_mol / plan.atoms_per_mol.clamp(min=1)[:, None]
+        return E_mol, F_ca, V_ca
+
+    def forward(self, inputs):
+        R = inputs["R"]
+        self._check_inputs(R)
+        plan = GraphPlan.from_inputs(inputs, self.triplets_only)
+        if not self.direct_forces:
+            inputs["R"].requires_grad = True
+
+        E_mol, F_ca, V_ca = self._energy(R, plan)
+
+        if self.direct_forces:
+            if self.forces_coupled:  # enforce |F_ac| = |F_ca| (gemnet.py:588-592)
+                F_ca = ops.segsum_rows(F_ca, plan.id_undir) * 0.5
+                F_ca = ops.gather_rows(F_ca, plan.id_undir)
+            F_ji = F_ca[:, :, None] * V_ca[:, None, :]
+            F_j = ops.segsum_rows(F_ji, plan.id_a)                         # (nAtoms, num_targets, 3)
+        else:
+            graph = self.force_graph
+            if graph is None:
+                graph = self.training and torch.is_grad_enabled()
+            with ops.param_grads(False):  # only dE/dR is needed here
+                if self.num_targets > 1:
+                    F_j = torch.stack(
+                        [-torch.autograd.grad(E_mol[:, i].sum(), R, create_graph=graph, retain_graph=True)[0]
+                         for i in range(self.num_targets)], dim=1)
+                else:
+                    F_j = -torch.autograd.grad(E_mol.sum(), R, create_graph=graph)[0]
+            inputs["R"].requires_grad = False
+        return E_mol, F_j
+
+    @staticmethod
+    def _check_inputs(R):
+        if not R.is_cuda:
+            raise RuntimeError("gemnet_pytorch_amd.GemNet runs on a HIP device only (no CPU fallback); "
+                               "move the model and the batch to 'cuda'.")
+        if R.dtype != torch.float32:
+            raise TypeError("gemnet_pytorch_amd.GemNet computes in fp32; got R of dtype %s" % R.dtype)
+
+    # ----------------------------------------------------------------------------------- misc
+    def predict(self, inputs):
+        E, F = self(inputs)
+        return E.detach().cpu(), F.detach().cpu()
+
+    def load_weights(self, path):
+        self.load_state_dict(torch.load(path))
+
+    def save_weights(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_tfmodel(self, path):
+        raise NotImplementedError(
+            "TensorFlow checkpoint import (gemnet.py:617-778) is out of scope: TensorFlow is not "
+            "available in this environment (SURVEY.md §2 row 10).")

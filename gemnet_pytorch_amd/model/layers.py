@@ -1,0 +1,449 @@
+"""Layer modules of the MI355X-native GemNet.
+
+Module/parameter NAMES mirror the reference so `state_dict()` has the reference's key set
+(including the aliased duplicates `Dense.weight` == `Dense.linear.weight`
+and `OutputBlock.seq_energy` == `.layers`) and `pretrained/*/model.pth` style checkpoints load.
+The COMPUTE is different: every forward goes through the HIP ops of `gemnet_pytorch_amd.ops`
+(f32-MFMA GEMMs, CSR-segmented gather/reduce kernels, closed-form basis kernels); nothing here
+builds the reference's zero-padded (E,Kmax,.) tensors or calls sympy/torch_scatter.
+
+Reference counterparts (file:line under /root/reference/gemnet/model/layers):
+  Dense/ScaledSiLU/ResidualLayer  base_layers.py:5-89
+  AtomEmbedding/EdgeEmbedding     embedding_block.py:7-75
+  AtomUpdateBlock/OutputBlock     atom_update_block.py:9-193
+  EfficientInteractionDownProjection/Bilinear  efficient.py:5-57,120-189
+  BesselBasisLayer/SphericalBasisLayer/TensorBasisLayer  basis_layers.py:9-295
+  TripletInteraction/QuadrupletInteraction/InteractionBlock(TripletsOnly)  interaction_block.py:11-696
+"""
+import math
+
+import numpy as np
+import torch
+from scipy import special as _sp
+from scipy.optimize import brentq as _brentq
+
+from .. import ops
+from .initializers import he_orthogonal_init
+from .scaling import ScalingFactor
+
+INV_SQRT_2 = 1 / (2.0 ** 0.5)
+INV_SQRT_3 = 1 / (3.0 ** 0.5)
+
+
+# ------------------------------------------------------------------------------ dense stack
+class Dense(torch.nn.Module):
+    """Bias-free linear layer + optional ScaledSiLU; y = ssilu(x W^T)."""
+
+    def __init__(self, in_features, out_features, bias=False, activation=None, name=None):
+        super().__init__()
+        self.linear = torch.nn.Linear(in_features, out_features, bias=bias)
+        he_orthogonal_init(self.linear.weight)
+        if self.linear.bias is not None:
+            self.linear.bias.data.fill_(0)
+        self.weight = self.linear.weight  # alias: both keys appear in state_dict like the reference
+        self.bias = self.linear.bias
+        if isinstance(activation, str):
+            activation = activation.lower()
+        if activation in ("swish", "silu"):
+            self.act = True
+        elif activation is None:
+            self.act = False
+        else:
+            raise NotImplementedError("Activation function not implemented for GemNet (yet).")
+
+    def forward(self, x):
+        y = ops.linear(x, self.weight)
+        if self.bias is not None:
+            y = y + self.bias
+        return ops.ssilu(y) if self.act else y
+
+
+class ResidualLayer(torch.nn.Module):
+    """(x + MLP(x)) / sqrt(2)."""
+
+    def __init__(self, units: int, nLayers: int = 2, activation=None, name=None):
+        super().__init__()
+        self.dense_mlp = torch.nn.Sequential(
+            *[Dense(units, units, activation=activation, bias=False) for _ in range(nLayers)])
+
+    def forward(self, inputs):
+        return (inputs + self.dense_mlp(inputs)) * INV_SQRT_2
+
+
+class AtomEmbedding(torch.nn.Module):
+    def __init__(self, emb_size, name=None):
+        super().__init__()
+        self.emb_size = emb_size
+        self.embeddings = torch.nn.Embedding(93, emb_size)
+        torch.nn.init.uniform_(self.embeddings.weight, a=-np.sqrt(3), b=np.sqrt(3))
+
+    def forward(self, z_rows):
+        """z_rows: RowIndex of Z-1 into the 93-row table."""
+        return ops.gather_rows(self.embeddings.weight, z_rows)
+
+
+class EdgeEmbedding(torch.nn.Module):
+    """Dense(cat[h[id_c], h[id_a], m]) evaluated WITHOUT materialising the concatenation:
+    (h @ W_c^T)[id_c] + (h @ W_a^T)[id_a] + m @ W_m^T — the two atom terms are GEMMs over nAtoms
+    rows instead of nEdges rows (embedding_block.py:60-75 does cat + one (E, 2A+F) GEMM)."""
+
+    def __init__(self, atom_features, edge_features, out_features, activation=None, name=None):
+        super().__init__()
+        self.atom_features = atom_features
+        self.dense = Dense(2 * atom_features + edge_features, out_features, activation=activation, bias=False)
+
+    def forward(self, h, m_rbf, id_c, id_a):
+        A = self.atom_features
+        W = self.dense.weight
+        z = (ops.gather_rows(ops.linear(h, W[:, :A]), id_c)
+             + ops.gather_rows(ops.linear(h, W[:, A:2 * A]), id_a)
+             + ops.linear(m_rbf, W[:, 2 * A:]))
+        return ops.ssilu(z) if self.dense.act else z
+
+
+class AtomUpdateBlock(torch.nn.Module):
+    def __init__(self, emb_size_atom, emb_size_edge, emb_size_rbf, nHidden, activation=None,
+                 scale_file=None, name="atom_update"):
+        super().__init__()
+        self.name = name
+        self.emb_size_edge = emb_size_edge
+        self.dense_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
+        self.scale_sum = ScalingFactor(scale_file=scale_file, name=name + "_sum")
+        self.layers = self.get_mlp(emb_size_atom, nHidden, activation)
+
+    def get_mlp(self, units, nHidden, activation):
+        dense1 = Dense(self.emb_size_edge, units, activation=activation, bias=False)
+        res = [ResidualLayer(units, nLayers=2, activation=activation) for _ in range(nHidden)]
+        return torch.nn.ModuleList([dense1] + res)
+
+    def forward(self, h, m, rbf, id_a):
+        x = m * self.dense_rbf(rbf)
+        x2 = ops.segsum_rows(x, id_a)
+        x = self.scale_sum(m, x2)
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class OutputBlock(AtomUpdateBlock):
+    def __init__(self, emb_size_atom, emb_size_edge, emb_size_rbf, nHidden, num_targets,
+                 activation=None, direct_forces=True, output_init="HeOrthogonal", scale_file=None,
+                 name="output", **kwargs):
+        super().__init__(name=name, emb_size_atom=emb_size_atom, emb_size_edge=emb_size_edge,
+                         emb_size_rbf=emb_size_rbf, nHidden=nHidden, activation=activation,
+                         scale_file=scale_file)
+        assert isinstance(output_init, str)
+        self.output_init = output_init
+        self.direct_forces = direct_forces
+        self.dense_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
+        self.seq_energy = self.layers  # alias (reference atom_update_block.py:130)
+        self.out_energy = Dense(emb_size_atom, num_targets, bias=False, activation=None)
+        if self.direct_forces:
+            self.scale_rbf = ScalingFactor(scale_file=scale_file, name=name + "_had")
+            self.seq_forces = self.get_mlp(emb_size_edge, nHidden, activation)
+            self.out_forces = Dense(emb_size_edge, num_targets, bias=False, activation=None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        mode = self.output_init.lower()
+        heads = [self.out_energy] + ([self.out_forces] if self.direct_forces else [])
+        if mode == "heorthogonal":
+            for d in heads:
+                he_orthogonal_init(d.weight)
+        elif mode == "zeros":
+            for d in heads:
+                torch.nn.init.zeros_(d.weight)
+        else:
+            raise UserWarning(f"Unknown output_init: {self.output_init}")
+
+    def forward(self, h, m, rbf, id_a):
+        x = m * self.dense_rbf(rbf)
+        x_E = self.scale_sum(m, ops.segsum_rows(x, id_a))
+        for layer in self.seq_energy:
+            x_E = layer(x_E)
+        x_E = self.out_energy(x_E)
+        if self.direct_forces:
+            x_F = self.scale_rbf(m, x)
+            for layer in self.seq_forces:
+                x_F = layer(x_F)
+            x_F = self.out_forces(x_F)
+        else:
+            x_F = 0
+        return x_E, x_F
+
+
+# ---------------------------------------------------------------------- efficient bilinear
+class EfficientInteractionDownProjection(torch.nn.Module):
+    """rbf_W1[e,s,i] = sum_r rad[e,l(s),r] W[s,r,i]  (efficient.py:41-57).
+
+    `rad` arrives as (E, L, R) with one row per degree l.  For the circular basis s == l; for the
+    tensor basis (num_spherical = L^2 slots) the reference first repeats row l (2l+1) times
+    (basis_layers.py:254-256) — here the repeat is folded into a block-structured weight so the
+    (E, L^2, R) tensor never exists.  Output layout is (E, S, I); the reference's (E, I, S) and its
+    transposed zero-padded harmonics are not needed."""
+
+    def __init__(self, num_spherical, num_radial, emb_size_interm, name="EfficientDownProj"):
+        super().__init__()
+        self.num_spherical = num_spherical
+        self.num_radial = num_radial
+        self.emb_size_interm = emb_size_interm
+        self.weight = torch.nn.Parameter(torch.empty((num_spherical, num_radial, emb_size_interm)))
+        he_orthogonal_init(self.weight)
+
+    def forward(self, rad):
+        S, R, I = self.weight.shape
+        L = rad.shape[1]
+        if L == S:
+            sizes = [1] * L
+        else:
+            assert L * L == S, "tensor basis expects num_spherical**2 weight slots"
+            sizes = [2 * l + 1 for l in range(L)]
+        blocks, start = [], 0
+        for n in sizes:  # rows (r) x cols (slot-in-l, i)
+            blocks.append(self.weight[start:start + n].permute(1, 0, 2).reshape(R, n * I))
+            start += n
+        Wbd = torch.block_diag(*blocks)                               # (L*R, S*I)
+        out = ops.mm(rad.reshape(-1, L * R), Wbd, False, True)        # (E, S*I)
+        return out.reshape(-1, S, I)
+
+
+class EfficientInteractionBilinear(torch.nn.Module):
+    """out[e,o] = sum_{t in seg(e)} sum_s sum_i sum_c sph[t,s] rbfW1[e,i,s] x[g(t),c] W[c,i,o]
+    (efficient.py:159-189) as K1 segmented reduce -> K2 per-edge (I,S)x(S,C) -> K3 GEMM."""
+
+    def __init__(self, emb_size, emb_size_interm, units_out, name="EfficientBilinear"):
+        super().__init__()
+        self.emb_size = emb_size
+        self.emb_size_interm = emb_size_interm
+        self.units_out = units_out
+        self.weight = torch.nn.Parameter(torch.empty((emb_size, emb_size_interm, units_out)))
+        he_orthogonal_init(self.weight)
+
+    def forward(self, rbf_W1, sph, x, seg_plan):
+        C, I, O = self.weight.shape
+        Sm = ops.bil_reduce(sph, x, seg_plan)                # (E,S,C)
+        P = ops.bmm(rbf_W1, Sm, True, False)                 # (E,S,I)^T @ (E,S,C) -> (E,I,C)
+        W2 = self.weight.permute(1, 0, 2).reshape(I * C, O)  # rows ordered (i,c) like P.reshape
+        return ops.mm(P.reshape(-1, I * C), W2, False, True)
+
+
+# ------------------------------------------------------------------------------ basis layers
+def _jn_zeros(n, k):
+    """float32 roots of j_l (l<n), found between the float32-rounded roots of j_{l-1}
+    (same bracketing scheme as the reference, basis_utils.py:14-29)."""
+    zerosj = np.zeros((n, k), dtype="float32")
+    zerosj[0] = np.arange(1, k + 1) * np.pi
+    points = np.arange(1, k + n) * np.pi
+    racines = np.zeros(k + n - 1, dtype="float32")
+    for i in range(1, n):
+        for j in range(k + n - 1 - i):
+            racines[j] = _brentq(lambda r: _sp.spherical_jn(i, r), points[j], points[j + 1])
+        points = racines
+        zerosj[i][:k] = racines[:k]
+    return zerosj
+
+
+def _sph_normalizer(z):
+    n, k = z.shape
+    return np.array([[1.0 / math.sqrt(0.5 * _sp.spherical_jn(l + 1, z[l, i]) ** 2) for i in range(k)]
+                     for l in range(n)], dtype=np.float64)
+
+
+class BesselBasisLayer(torch.nn.Module):
+    def __init__(self, num_radial, cutoff, envelope_exponent=5, name="bessel_basis"):
+        super().__init__()
+        self.num_radial = num_radial
+        self.cutoff = float(cutoff)
+        self.p = int(envelope_exponent)
+        self.frequencies = torch.nn.Parameter(
+            torch.tensor(np.pi * np.arange(1, num_radial + 1, dtype=np.float32)), requires_grad=True)
+
+    def forward(self, d):
+        return ops.bessel_rbf(d, self.frequencies, self.cutoff, self.p)
+
+
+class _RadialTables(torch.nn.Module):
+    def __init__(self, num_spherical, num_radial, cutoff, envelope_exponent):
+        super().__init__()
+        assert num_radial <= 64
+        self.num_radial = num_radial
+        self.num_spherical = num_spherical
+        self.cutoff = float(cutoff)
+        self.p = int(envelope_exponent)
+        z = _jn_zeros(num_spherical, num_radial)
+        self.register_buffer("z_ln", torch.tensor(z), persistent=False)
+        self.register_buffer("n_ln", torch.tensor(_sph_normalizer(z)), persistent=False)
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        # .double()/.float()/.half() must not touch the tables the kernels expect
+        self.z_ln = self.z_ln.to(torch.float32)
+        self.n_ln = self.n_ln.to(torch.float64)
+        return self
+
+    def radial(self, d):
+        return ops.sph_radial(d, self.z_ln, self.n_ln, self.cutoff, self.p)  # (E,S,R)
+
+
+class SphericalBasisLayer(_RadialTables):
+    """Radial (E,S,R) + Y_l0 (T,S).  efficient=True returns the pair for the bilinear layer;
+    efficient=False returns the (T, S*R) product (basis_layers.py:132-144)."""
+
+    def __init__(self, num_spherical, num_radial, cutoff, envelope_exponent=5, efficient=False,
+                 name="spherical_basis"):
+        super().__init__(num_spherical, num_radial, cutoff, envelope_exponent)
+        self.efficient = efficient
+
+    def forward(self, D, angle, reduce_rows=None):
+        rad = self.radial(D)
+        sph = ops.ylm0(angle, self.num_spherical)
+        if self.efficient:
+            return rad, sph
+        rad_t = ops.gather_rows(rad, reduce_rows)                      # (T,S,R)
+        return (rad_t * sph[:, :, None]).reshape(-1, self.num_spherical * self.num_radial)
+
+
+class TensorBasisLayer(_RadialTables):
+    """Radial repeated (2l+1)x -> (E,S^2,R) and real Y_lm (Q,S^2) (basis_layers.py:239-295)."""
+
+    def __init__(self, num_spherical, num_radial, cutoff, envelope_exponent=5, efficient=False,
+                 name="tensor_basis"):
+        super().__init__(num_spherical, num_radial, cutoff, envelope_exponent)
+        self.efficient = efficient
+
+    def forward(self, D, theta, phi):
+        # radial stays (E,S,R); the (2l+1)x repeat happens inside the down projection's weight
+        return self.radial(D), ops.ylm(theta, phi, self.num_spherical)
+
+
+# ------------------------------------------------------------------------ interaction blocks
+class TripletInteraction(torch.nn.Module):
+    def __init__(self, emb_size_edge, emb_size_trip, emb_size_bilinear, emb_size_rbf, emb_size_cbf,
+                 activation=None, scale_file=None, name="TripletInteraction", **kwargs):
+        super().__init__()
+        self.name = name
+        self.dense_ba = Dense(emb_size_edge, emb_size_edge, activation=activation, bias=False)
+        self.mlp_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
+        self.scale_rbf = ScalingFactor(scale_file=scale_file, name=name + "_had_rbf")
+        self.mlp_cbf = EfficientInteractionBilinear(emb_size_trip, emb_size_cbf, emb_size_bilinear)
+        self.scale_cbf_sum = ScalingFactor(scale_file=scale_file, name=name + "_sum_cbf")
+        self.down_projection = Dense(emb_size_edge, emb_size_trip, activation=activation, bias=False)
+        self.up_projection_ca = Dense(emb_size_bilinear, emb_size_edge, activation=activation, bias=False)
+        self.up_projection_ac = Dense(emb_size_bilinear, emb_size_edge, activation=activation, bias=False)
+
+    def forward(self, m, rbf3, cbf3, plan):
+        rbf_W1, sph = cbf3
+        x_ba = self.dense_ba(m)
+        x_ba = self.scale_rbf(x_ba, x_ba * self.mlp_rbf(rbf3))
+        x_ba = self.down_projection(x_ba)
+        # gather by id3_expand_ba is fused into the segmented reduce (no (T,C) tensor)
+        x = self.mlp_cbf(rbf_W1, sph, x_ba, plan.trip)
+        x = self.scale_cbf_sum(x_ba, x)
+        x_ca = self.up_projection_ca(x)
+        x_ac = ops.gather_rows(self.up_projection_ac(x), plan.id_swap)
+        return (x_ca + x_ac) * INV_SQRT_2
+
+
+class QuadrupletInteraction(torch.nn.Module):
+    def __init__(self, emb_size_edge, emb_size_quad, emb_size_bilinear, emb_size_rbf, emb_size_cbf,
+                 emb_size_sbf, activation=None, scale_file=None, name="QuadrupletInteraction", **kwargs):
+        super().__init__()
+        self.name = name
+        self.dense_db = Dense(emb_size_edge, emb_size_edge, activation=activation, bias=False)
+        self.mlp_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
+        self.scale_rbf = ScalingFactor(scale_file=scale_file, name=name + "_had_rbf")
+        self.mlp_cbf = Dense(emb_size_cbf, emb_size_quad, activation=None, bias=False)
+        self.scale_cbf = ScalingFactor(scale_file=scale_file, name=name + "_had_cbf")
+        self.mlp_sbf = EfficientInteractionBilinear(emb_size_quad, emb_size_sbf, emb_size_bilinear)
+        self.scale_sbf_sum = ScalingFactor(scale_file=scale_file, name=name + "_sum_sbf")
+        self.down_projection = Dense(emb_size_edge, emb_size_quad, activation=activation, bias=False)
+        self.up_projection_ca = Dense(emb_size_bilinear, emb_size_edge, activation=activation, bias=False)
+        self.up_projection_ac = Dense(emb_size_bilinear, emb_size_edge, activation=activation, bias=False)
+
+    def forward(self, m, rbf, cbf, sbf, plan):
+        rbf_W1, sph = sbf
+        x_db = self.dense_db(m)
+        x_db = self.scale_rbf(x_db, x_db * self.mlp_rbf(rbf))
+        x_db = self.down_projection(x_db)
+        x_db = ops.gather_rows(x_db, plan.intm_db)                 # (I, emb_quad)
+        x_db = self.scale_cbf(x_db, x_db * self.mlp_cbf(cbf))
+        x = self.mlp_sbf(rbf_W1, sph, x_db, plan.quad)             # gather by id4_expand_abd fused
+        x = self.scale_sbf_sum(x_db, x)
+        x_ca = self.up_projection_ca(x)
+        x_ac = ops.gather_rows(self.up_projection_ac(x), plan.id_swap)
+        return (x_ca + x_ac) * INV_SQRT_2
+
+
+class _InteractionBase(torch.nn.Module):
+    def _build_common(self, emb_size_atom, emb_size_edge, emb_size_rbf, num_before_skip, num_after_skip,
+                      num_concat, num_atom, activation, scale_file, block_nr):
+        self.layers_before_skip = torch.nn.ModuleList(
+            [ResidualLayer(emb_size_edge, activation=activation) for _ in range(num_before_skip)])
+        self.layers_after_skip = torch.nn.ModuleList(
+            [ResidualLayer(emb_size_edge, activation=activation) for _ in range(num_after_skip)])
+        self.atom_update = AtomUpdateBlock(emb_size_atom=emb_size_atom, emb_size_edge=emb_size_edge,
+                                           emb_size_rbf=emb_size_rbf, nHidden=num_atom, activation=activation,
+                                           scale_file=scale_file, name=f"AtomUpdate_{block_nr}")
+        self.concat_layer = EdgeEmbedding(emb_size_atom, emb_size_edge, emb_size_edge, activation=activation)
+        self.residual_m = torch.nn.ModuleList(
+            [ResidualLayer(emb_size_edge, activation=activation) for _ in range(num_concat)])
+
+    def _update(self, h, m, x, rbf_h, plan):
+        for layer in self.layers_before_skip:
+            x = layer(x)
+        m = (m + x) * INV_SQRT_2
+        for layer in self.layers_after_skip:
+            m = layer(m)
+        h2 = self.atom_update(h, m, rbf_h, plan.id_a)
+        h = (h + h2) * INV_SQRT_2
+        m2 = self.concat_layer(h, m, plan.id_c, plan.id_a)
+        for layer in self.residual_m:
+            m2 = layer(m2)
+        m = (m + m2) * INV_SQRT_2
+        return h, m
+
+
+class InteractionBlockTripletsOnly(_InteractionBase):
+    def __init__(self, emb_size_atom, emb_size_edge, emb_size_trip, emb_size_quad, emb_size_rbf,
+                 emb_size_cbf, emb_size_bil_trip, num_before_skip, num_after_skip, num_concat, num_atom,
+                 activation=None, scale_file=None, name="Interaction", **kwargs):
+        super().__init__()
+        self.name = name
+        block_nr = name.split("_")[-1]
+        self.dense_ca = Dense(emb_size_edge, emb_size_edge, activation=activation, bias=False)
+        self.trip_interaction = TripletInteraction(
+            emb_size_edge=emb_size_edge, emb_size_trip=emb_size_trip, emb_size_bilinear=emb_size_bil_trip,
+            emb_size_rbf=emb_size_rbf, emb_size_cbf=emb_size_cbf, activation=activation,
+            scale_file=scale_file, name=f"TripInteraction_{block_nr}")
+        self._build_common(emb_size_atom, emb_size_edge, emb_size_rbf, num_before_skip, num_after_skip,
+                           num_concat, num_atom, activation, scale_file, block_nr)
+
+    def forward(self, h, m, rbf3, cbf3, rbf_h, plan, **kwargs):
+        x = (self.dense_ca(m) + self.trip_interaction(m, rbf3, cbf3, plan)) * INV_SQRT_2
+        return self._update(h, m, x, rbf_h, plan)
+
+
+class InteractionBlock(_InteractionBase):
+    def __init__(self, emb_size_atom, emb_size_edge, emb_size_trip, emb_size_quad, emb_size_rbf,
+                 emb_size_cbf, emb_size_sbf, emb_size_bil_trip, emb_size_bil_quad, num_before_skip,
+                 num_after_skip, num_concat, num_atom, activation=None, scale_file=None, name="Interaction"):
+        super().__init__()
+        self.name = name
+        block_nr = name.split("_")[-1]
+        self.dense_ca = Dense(emb_size_edge, emb_size_edge, activation=activation, bias=False)
+        self.quad_interaction = QuadrupletInteraction(
+            emb_size_edge=emb_size_edge, emb_size_quad=emb_size_quad, emb_size_bilinear=emb_size_bil_quad,
+            emb_size_rbf=emb_size_rbf, emb_size_cbf=emb_size_cbf, emb_size_sbf=emb_size_sbf,
+            activation=activation, scale_file=scale_file, name=f"QuadInteraction_{block_nr}")
+        self.trip_interaction = TripletInteraction(
+            emb_size_edge=emb_size_edge, emb_size_trip=emb_size_trip, emb_size_bilinear=emb_size_bil_trip,
+            emb_size_rbf=emb_size_rbf, emb_size_cbf=emb_size_cbf, activation=activation,
+            scale_file=scale_file, name=f"TripInteraction_{block_nr}")
+        self._build_common(emb_size_atom, emb_size_edge, emb_size_rbf, num_before_skip, num_after_skip,
+                           num_concat, num_atom, activation, scale_file, block_nr)
+
+    def forward(self, h, m, rbf4, cbf4, sbf4, rbf3, cbf3, rbf_h, plan, **kwargs):
+        x4 = self.quad_interaction(m, rbf4, cbf4, sbf4, plan)
+        x3 = self.trip_interaction(m, rbf3, cbf3, plan)
+        x = (self.dense_ca(m) + x3 + x4) * INV_SQRT_3
+        return self._update(h, m, x, rbf_h, plan)

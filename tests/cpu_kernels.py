@@ -1,0 +1,166 @@
+"""TEST-ONLY CPU emulation of the launchers in gemnet_pytorch_amd/kernels.py.
+
+Lets the CPU test-suite exercise the host logic that sits ABOVE the C ABI — the autograd closure
+of gemnet_pytorch_amd/ops.py (first- and second-order), the index plans and the GemNet module
+wiring — on a machine without a GPU, by monkeypatching the launchers with restatements of the
+kernel semantics documented in include/gemnet_hip.h.  It is not importable from the product
+package and is never used when a GPU is present (the -m gpu tests call the real library).
+"""
+import contextlib
+
+import torch
+
+from oracle import basis_oracle as B
+
+import gemnet_pytorch_amd.kernels as K
+
+
+def _act(z, k):
+    s = torch.sigmoid(z)
+    if k == 0:
+        return z * s / 0.6
+    if k == 1:
+        return s * (1 + z * (1 - s)) / 0.6
+    if k == 2:
+        return s * (1 - s) * (2 + z * (1 - 2 * s)) / 0.6
+    return s * (1 - s) * (3 * (1 - 2 * s) + z * (1 - 6 * s + 6 * s * s)) / 0.6
+
+
+def gemm(A, B_, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_out=False, mul=None,
+         alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None):
+    a = A
+    if a_dact_pre is not None:
+        a = a * _act(a_dact_pre, 1)
+    a = a.t() if trans_a else a
+    b = B_ if trans_b else B_.t()
+    z = a @ b
+    if gadd1 is not None:
+        z = z + gadd1[gidx1.long()]
+    if gadd2 is not None:
+        z = z + gadd2[gidx2.long()]
+    y = _act(z, 0) if act else z
+    if mul is not None:
+        y = y * mul
+    y = y * alpha
+    if res is not None:
+        y = (y + res) * beta
+    return (y, z) if pre_out else y
+
+
+def gather(x, idx32):
+    return x[idx32.long()]
+
+
+def segsum(y, perm, seg_off, n_rows):
+    src = y if perm is None else y[perm.long()]
+    counts = (seg_off[1:] - seg_off[:-1]).long()
+    dest = torch.repeat_interleave(torch.arange(n_rows), counts)
+    out = torch.zeros((n_rows,) + tuple(y.shape[1:]), dtype=y.dtype)
+    return out.index_add(0, dest, src[: dest.shape[0]])
+
+
+def bmm(A, B_, ta, tb):
+    a = A.transpose(1, 2) if ta else A
+    b = B_.transpose(1, 2) if tb else B_
+    return torch.bmm(a, b)
+
+
+def ssilu(x, k):
+    return _act(x, k)
+
+
+def bil_reduce(Y, x, sp):
+    xt = x[sp.expand.idx32.long()]
+    out = torch.zeros((sp.n_reduce, Y.shape[1], x.shape[1]), dtype=x.dtype)
+    return out.index_add(0, sp.reduce.idx32.long(), Y[:, :, None] * xt[:, None, :])
+
+
+def bil_reduce_t(Y, D, sp):
+    contrib = torch.einsum("ts,tsc->tc", Y, D[sp.reduce.idx32.long()])
+    out = torch.zeros((sp.n_expand, D.shape[2]), dtype=D.dtype)
+    return out.index_add(0, sp.expand.idx32.long(), contrib)
+
+
+def bil_dot(D, x, sp):
+    return torch.einsum("tsc,tc->ts", D[sp.reduce.idx32.long()], x[sp.expand.idx32.long()])
+
+
+def _nth(fn, x, order):
+    """order-th derivative of every output column w.r.t. the 1-D x (autograd on the oracle formula)."""
+    if order == 0:
+        with torch.no_grad():
+            return fn(x.detach())
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_(True)
+        y = fn(xx)
+        flat = y.reshape(y.shape[0], -1)
+        cols = []
+        for j in range(flat.shape[1]):
+            g = flat[:, j]
+            for _ in range(order):
+                g = torch.autograd.grad(g.sum(), xx, create_graph=True, allow_unused=True)[0]
+                if g is None or not g.requires_grad:
+                    g = torch.zeros_like(xx) if g is None else g
+                    break
+            cols.append(g.detach())
+        return torch.stack(cols, 1).reshape(y.shape)
+
+
+def bessel_rbf(d, freq, cutoff, p, kd, kf):
+    """Elementwise mixed derivative on the (E, R) grid via autograd on the oracle formula."""
+    with torch.enable_grad():
+        D = d.detach()[:, None].expand(-1, freq.shape[0]).clone().requires_grad_(True)
+        F = freq.detach()[None, :].expand(d.shape[0], -1).clone().requires_grad_(True)
+        ds = D / cutoff
+        y = B.envelope(ds, p) * (2 / cutoff) ** 0.5 * torch.sin(F * ds) / D
+        for _ in range(kd):
+            y = torch.autograd.grad(y.sum(), D, create_graph=True)[0]
+        for _ in range(kf):
+            y = torch.autograd.grad(y.sum(), F, create_graph=True)[0]
+    return y.detach()
+
+
+def sph_radial(d, z, nrm, cutoff, p, kd):
+    S, R = z.shape
+    return _nth(lambda x: B.sph_bessel_radial(x, S, R, cutoff, p), d, kd)
+
+
+def ylm0(theta, S, k):
+    return _nth(lambda x: B.real_sph_harm_l0(S, x), theta, k)
+
+
+def ylm(theta, phi, S, kt, kp):
+    with torch.enable_grad():
+        tt = theta.detach().clone().requires_grad_(True)
+        pp = phi.detach().clone().requires_grad_(True)
+        y = B.real_sph_harm_full(S, tt, pp)
+        cols = []
+        for j in range(S * S):
+            g = y[:, j]
+            for var, n in ((tt, kt), (pp, kp)):
+                for _ in range(n):
+                    if not g.requires_grad:
+                        g = torch.zeros_like(tt)
+                        break
+                    g = torch.autograd.grad(g.sum(), var, create_graph=True, allow_unused=True)[0]
+                    if g is None:
+                        g = torch.zeros_like(tt)
+            cols.append(g.detach())
+    return torch.stack(cols, 1)
+
+
+_NAMES = ["gemm", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+          "bessel_rbf", "sph_radial", "ylm0", "ylm"]
+
+
+@contextlib.contextmanager
+def emulate():
+    """Swap the HIP launchers for the CPU restatements above (tests only)."""
+    saved = {n: getattr(K, n) for n in _NAMES}
+    try:
+        for n in _NAMES:
+            setattr(K, n, globals()[n])
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(K, n, f)

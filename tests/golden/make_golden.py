@@ -285,11 +285,26 @@ def golden_models():
     print("model.npz", len(out), "arrays")
 
 
+def golden_keys():
+    import json
+    out = {}
+    for name, cfg in (("T", cfg_small(True)), ("Q", cfg_small(False)),
+                      ("dT", dict(cfg_small(True), direct_forces=True))):
+        m = GemNet(**cfg, scale_file=SCALE_FILE)
+        out[name] = {"state_dict": {k: list(v.shape) for k, v in m.state_dict().items()},
+                     "named_parameters": [n for n, _ in m.named_parameters()]}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("state_dict_keys.json", {k: len(v["state_dict"]) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["basis", "indices", "models"]
+    which = sys.argv[1:] or ["basis", "indices", "models", "keys"]
     if "basis" in which:
         golden_basis()
     if "indices" in which:
         golden_indices()
     if "models" in which:
         golden_models()
+    if "keys" in which:
+        golden_keys()

@@ -1,0 +1,20 @@
+// TEST-ONLY host shim: exposes the GN_HD math of gemnet_pytorch_amd/csrc/basis_math.h and the
+// ScaledSiLU derivative formulas to ctypes so they can be checked against the reference goldens
+// on a machine without a GPU.  Compiled with g++ by tests/test_host_math.py; not product code.
+#include <math.h>
+#include <stdint.h>
+#include "../gemnet_pytorch_amd/csrc/basis_math.h"
+
+extern "C" {
+void shim_bessel_rbf(const double* d, const double* f, double* out, int n, int R, double cutoff, int p, int kd, int kf) {
+  for (int i = 0; i < n; ++i) for (int r = 0; r < R; ++r) out[i * R + r] = bessel_rbf_eval(d[i], f[r], cutoff, p, kd, kf);
+}
+void shim_sph_radial(const double* d, const float* z, const double* nrm, double* out, int n, int S, int R, double cutoff, int p, int kd) {
+  for (int i = 0; i < n; ++i) for (int lr = 0; lr < S * R; ++lr)
+    out[i * S * R + lr] = sph_radial_eval(d[i], (double)z[lr], nrm[lr], lr / R, cutoff, p, kd);
+}
+void shim_ylm0(const double* th, float* out, int n, int S, int k) { for (int i = 0; i < n; ++i) ylm0_row(th[i], S, k, out + i * S); }
+void shim_ylm(const double* th, const double* ph, float* out, int n, int S, int kt, int kp) {
+  for (int i = 0; i < n; ++i) ylm_row(th[i], ph[i], S, kt, kp, out + i * S * S);
+}
+}

@@ -1,0 +1,184 @@
+"""-m gpu: every C-ABI entry point against its CPU restatement (tests/cpu_kernels.py, float64) on the
+same seeded inputs — through the real libgemnet_hip.so on a MI355X.  Shapes include ragged /
+non-multiple-of-tile sizes, empty inputs and unaligned leading dimensions."""
+import numpy as np
+import pytest
+import torch
+
+import cpu_kernels as CK
+from gemnet_pytorch_amd import kernels as K
+from gemnet_pytorch_amd.graph import RowIndex, SegmentPlan
+from oracle import basis_oracle as B
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(gen, *shape):
+    return torch.randn(*shape, generator=gen, dtype=torch.float64)
+
+
+def close(out, ref, rtol=2e-5, atol=None):
+    ref = ref.to(torch.float64)
+    out = out.detach().cpu().to(torch.float64)
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    if atol is None:
+        atol = 2e-5 * max(1.0, float(ref.abs().max())) if ref.numel() else 0.0
+    err = (out - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), f"max err {float(err.max()):.3e} (atol {atol:.1e}) at {int(bad.sum())} of {ref.numel()}"
+
+
+def f32(t):
+    return t.to(torch.float32).to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 32), (300, 128, 128), (1000, 64, 128), (257, 32, 64),
+                                    (130, 16, 6), (77, 1, 128), (513, 128, 384), (95, 100, 42),
+                                    (2048, 64, 1024), (5, 7, 3)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_plain(M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = rnd(g, *((K, M) if ta else (M, K)))
+    Bm = rnd(g, *((K, N) if tb else (N, K)))
+    ref = CK.gemm(A, Bm, ta, tb)
+    out = K.gemm(f32(A), f32(Bm), ta, tb)
+    close(out, ref, rtol=1e-5, atol=1e-5 * np.sqrt(K) * 4)
+
+
+def test_gemm_is_transpose_detecting():
+    # asymmetric operands: A = identity-like, B = i*100 + j pattern
+    M = N = Kd = 64
+    A = torch.eye(M, dtype=torch.float64)
+    Bm = (torch.arange(N)[:, None] * 100 + torch.arange(Kd)[None, :]).to(torch.float64)
+    out = K.gemm(f32(A), f32(Bm), False, False)  # A @ B^T
+    close(out, Bm.t(), rtol=0, atol=1e-3)
+
+
+def test_gemm_fused_epilogue_and_prologue():
+    g = torch.Generator().manual_seed(5)
+    M, N, Kd, A_rows = 333, 128, 128, 50
+    A, W = rnd(g, M, Kd), rnd(g, N, Kd) / np.sqrt(Kd)
+    mul, res = rnd(g, M, N), rnd(g, M, N)
+    g1, g2 = rnd(g, A_rows, N), rnd(g, A_rows, N)
+    i1 = torch.randint(0, A_rows, (M,), generator=g, dtype=torch.int32)
+    i2 = torch.randint(0, A_rows, (M,), generator=g, dtype=torch.int32)
+    pre = rnd(g, M, Kd)
+    kw = dict(act=True, pre_out=True, alpha=0.7, beta=0.5)
+    ref_y, ref_z = CK.gemm(A, W, a_dact_pre=pre, mul=mul, res=res, gadd1=g1, gidx1=i1, gadd2=g2, gidx2=i2, **kw)
+    y, z = K.gemm(f32(A), f32(W), a_dact_pre=f32(pre), mul=f32(mul), res=f32(res), gadd1=f32(g1),
+                  gidx1=i1.to(DEV), gadd2=f32(g2), gidx2=i2.to(DEV), **kw)
+    close(z, ref_z, atol=5e-5)
+    close(y, ref_y, atol=5e-5)
+
+
+def test_gemm_strided_weight_slices():
+    g = torch.Generator().manual_seed(6)
+    W = rnd(g, 64, 2 * 32 + 6)  # like edge_emb: (out, 2*atom + rbf); row stride 70 -> scalar loads
+    x = rnd(g, 91, 6)
+    Wd = f32(W)
+    close(K.gemm(f32(x), Wd[:, 64:], False, False), x @ W[:, 64:].t())
+    h = rnd(g, 40, 32)
+    close(K.gemm(f32(h), Wd[:, 32:64], False, False), h @ W[:, 32:64].t())
+
+
+@pytest.mark.parametrize("b,m,n,k", [(100, 16, 64, 7), (33, 32, 32, 49), (7, 5, 3, 2)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_bmm(b, m, n, k, ta, tb):
+    g = torch.Generator().manual_seed(b + m)
+    A = rnd(g, *((b, k, m) if ta else (b, m, k)))
+    Bm = rnd(g, *((b, n, k) if tb else (b, k, n)))
+    close(K.bmm(f32(A), f32(Bm), ta, tb), CK.bmm(A, Bm, ta, tb))
+
+
+@pytest.mark.parametrize("C", [1, 3, 32, 128, 7 * 6])
+def test_gather_segsum(C):
+    g = torch.Generator().manual_seed(C)
+    N, T = 97, 1000
+    idx = torch.randint(0, N, (T,), generator=g)
+    x, y = rnd(g, N, C), rnd(g, T, C)
+    ri = RowIndex(idx.to(DEV), N)
+    close(K.gather(f32(x), ri.idx32), x[idx])
+    perm, seg = ri.csr
+    ref = torch.zeros(N, C, dtype=torch.float64).index_add(0, idx, y)
+    close(K.segsum(f32(y), perm, seg, N), ref)
+    sidx = torch.sort(idx).values
+    rs = RowIndex(sidx.to(DEV), N, is_sorted=True)
+    ref = torch.zeros(N, C, dtype=torch.float64).index_add(0, sidx, y)
+    close(K.segsum(f32(y), None, rs.csr[1], N), ref)
+
+
+def test_empty_inputs_are_noops():
+    e = torch.zeros(0, 8, device=DEV)
+    ri = RowIndex(torch.zeros(0, dtype=torch.long, device=DEV), 5)
+    assert K.gather(torch.zeros(5, 8, device=DEV), ri.idx32).shape == (0, 8)
+    out = K.segsum(e, *ri.csr, 5)
+    assert out.shape == (5, 8) and float(out.abs().sum()) == 0.0
+
+
+def _segplan(g, E, J, mean_k):
+    counts = torch.randint(0, 2 * mean_k, (E,), generator=g)
+    red = torch.repeat_interleave(torch.arange(E), counts)
+    exp = torch.randint(0, J, (red.shape[0],), generator=g)
+    cpu = SegmentPlan(red, exp, E, J)
+    dev = SegmentPlan(red.to(DEV), exp.to(DEV), E, J)
+    return cpu, dev
+
+
+@pytest.mark.parametrize("S,C,E,J,mk", [(7, 64, 500, 500, 18), (7, 32, 77, 77, 5), (49, 32, 60, 300, 80)])
+def test_bilinear_kernels(S, C, E, J, mk):
+    g = torch.Generator().manual_seed(S * C)
+    cpu, dev = _segplan(g, E, J, mk)
+    T = cpu.size
+    Y, x, D = rnd(g, T, S), rnd(g, J, C), rnd(g, E, S, C)
+    close(K.bil_reduce(f32(Y), f32(x), dev), CK.bil_reduce(Y, x, cpu), atol=1e-4)
+    close(K.bil_reduce_t(f32(Y), f32(D), dev), CK.bil_reduce_t(Y, D, cpu), atol=1e-4)
+    close(K.bil_dot(f32(D), f32(x), dev), CK.bil_dot(D, x, cpu), atol=1e-4)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_ssilu(k):
+    x = torch.linspace(-12, 12, 1001, dtype=torch.float64)
+    close(K.ssilu(f32(x), k), CK.ssilu(x, k), atol=2e-6)
+
+
+@pytest.mark.parametrize("kd,kf", [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1)])
+def test_bessel_rbf(kd, kf, golden_basis):
+    d = torch.tensor(golden_basis["d"])
+    f = torch.tensor(golden_basis["freq"])
+    close(K.bessel_rbf(f32(d), f32(f), 5.0, 5, kd, kf), CK.bessel_rbf(d, f, 5.0, 5, kd, kf), atol=3e-6 * (1 + 9 * kd))
+    if (kd, kf) == (0, 0):
+        close(K.bessel_rbf(f32(d), f32(f), 5.0, 5, 0, 0), torch.tensor(golden_basis["bessel_rbf"]), atol=3e-6)
+
+
+@pytest.mark.parametrize("cutoff,dkey,gkey", [(5.0, "d", "c5"), (10.0, "d10", "c10")])
+@pytest.mark.parametrize("kd", [0, 1, 2])
+def test_sph_radial(cutoff, dkey, gkey, kd, golden_basis):
+    d = torch.tensor(golden_basis[dkey])
+    z = torch.tensor(B.jn_zeros(7, 6))
+    nrm = torch.tensor(B.sph_bessel_normalizer(7, 6))
+    out = K.sph_radial(f32(d), z.to(DEV), nrm.to(DEV), cutoff, 5, kd)
+    # inputs are rounded to f32 before evaluation: compare against the restatement on the same f32 d
+    d32 = d.to(torch.float32).to(torch.float64)
+    close(out, CK.sph_radial(d32, z, nrm, cutoff, 5, kd), rtol=1e-5, atol=2e-6 * (1 + 20 * kd))
+    if kd == 0:
+        close(out, torch.tensor(golden_basis[f"radial_{gkey}"]), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_ylm0(k, golden_basis):
+    th = torch.tensor(golden_basis["theta"])
+    th32 = th.to(torch.float32).to(torch.float64)
+    close(K.ylm0(f32(th), 7, k), CK.ylm0(th32, 7, k), atol=1e-5)
+    if k == 0:
+        close(K.ylm0(f32(th), 7, 0), torch.tensor(golden_basis["y_l0"]), atol=1e-5)
+
+
+@pytest.mark.parametrize("kt,kp", [(0, 0), (1, 0), (0, 1), (2, 0), (1, 1), (0, 2)])
+def test_ylm(kt, kp, golden_basis):
+    th, ph = torch.tensor(golden_basis["theta"]), torch.tensor(golden_basis["phi"])
+    th32, ph32 = th.to(torch.float32).to(torch.float64), ph.to(torch.float32).to(torch.float64)
+    ref = CK.ylm(th32, ph32, 7, kt, kp)
+    close(K.ylm(f32(th), f32(ph), 7, kt, kp), ref, atol=2e-6 * max(1.0, float(ref.abs().max())))
+    if (kt, kp) == (0, 0):
+        close(K.ylm(f32(th), f32(ph), 7, 0, 0), torch.tensor(golden_basis["y_lm"]), atol=1e-5)

@@ -1,0 +1,88 @@
+"""GemNet module wiring (gemnet_pytorch_amd.model) checked on CPU in float64 with the HIP launchers
+emulated (tests/cpu_kernels.py): energies, forces and training gradients against the reference's
+goldens, state_dict key set against the reference's, and the no-CPU-fallback guarantee."""
+import ast
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, SCALE_FILE
+from oracle import gemnet_oracle as GO
+from gemnet_pytorch_amd.model.gemnet import GemNet
+import cpu_kernels
+from test_oracle_model import load_case
+
+
+def build(cfg, params, dtype=torch.float64):
+    model = GemNet(**cfg, scale_file=SCALE_FILE)
+    model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
+    model = model.to(dtype)
+    model._check_inputs = lambda R: None
+    return model
+
+
+@pytest.mark.parametrize("tag", ["t1", "q1", "t2"])
+def test_energy_force_and_training_grads(golden_model, tag):
+    g = golden_model
+    cfg, params, inputs = load_case(g, tag)
+    with cpu_kernels.emulate():
+        model = build(cfg, params)
+        model.train()
+        inputs["R"] = inputs["R"].double()
+        E, F = model(inputs)
+        Eref, Fref = g[f"{tag}.E"], g[f"{tag}.F"]
+        assert np.abs(E.detach().numpy() - Eref).max() <= 1e-9 * max(1.0, np.abs(Eref).max())
+        assert np.abs(F.detach().numpy() - Fref).mean() <= 1e-9 * max(1.0, float(np.abs(Fref).mean()))
+        loss = GO.training_loss(E, F, torch.tensor(g[f"{tag}.Et"]).double()[:, None],
+                                torch.tensor(g[f"{tag}.Ft"]).double())
+        np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=1e-9)
+        loss.backward()
+    named = dict(model.named_parameters())
+    names = [str(n) for n in g[f"{tag}.grad_names"]]
+    norms = np.array([0.0 if named[n].grad is None else float(named[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(norms, g[f"{tag}.grad_norms"], rtol=1e-7, atol=1e-12)
+    for n in names:
+        key = f"{tag}.grad.{n}"
+        if key in g:
+            np.testing.assert_allclose(named[n].grad.numpy(), g[key], rtol=1e-6, atol=1e-10)
+
+
+def test_eval_mode_first_order_only(golden_model):
+    g = golden_model
+    cfg, params, inputs = load_case(g, "t1")
+    with cpu_kernels.emulate():
+        model = build(cfg, params).eval()
+        inputs["R"] = inputs["R"].double()
+        E, F = model(inputs)
+    assert not F.requires_grad and inputs["R"].requires_grad is False
+    assert np.abs(F.numpy() - g["t1.F"]).mean() <= 1e-9 * max(1.0, float(np.abs(g["t1.F"]).mean()))
+
+
+@pytest.mark.parametrize("variant,extra", [("T", {}), ("Q", {}), ("dT", {"direct_forces": True})])
+def test_state_dict_keys_match_reference(variant, extra):
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        ref = json.load(f)[variant]
+    cfg = dict(num_spherical=7, num_radial=6, num_blocks=1, emb_size_atom=64, emb_size_edge=64,
+               emb_size_trip=32, emb_size_quad=32, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=32,
+               emb_size_bil_quad=32, emb_size_bil_trip=32, num_before_skip=1, num_after_skip=1,
+               num_concat=1, num_atom=2, triplets_only=variant != "Q", **extra)
+    model = GemNet(**cfg, scale_file=SCALE_FILE)
+    sd = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert sd == ref["state_dict"]
+    assert [n for n, _ in model.named_parameters()] == ref["named_parameters"]
+
+
+def test_no_cpu_fallback():
+    cfg = dict(num_spherical=7, num_radial=6, num_blocks=1, emb_size_atom=16, emb_size_edge=16,
+               emb_size_trip=16, emb_size_quad=16, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=16,
+               emb_size_bil_quad=16, emb_size_bil_trip=16, num_before_skip=1, num_after_skip=1,
+               num_concat=1, num_atom=1, triplets_only=True)
+    model = GemNet(**cfg, scale_file=SCALE_FILE)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        model({"R": torch.zeros(2, 3), "Z": torch.ones(2, dtype=torch.long)})
+    from gemnet_pytorch_amd import kernels
+    with pytest.raises(RuntimeError, match="no CPU fallback|CPU fallback"):
+        kernels.ssilu(torch.zeros(4), 0)

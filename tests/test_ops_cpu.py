@@ -1,0 +1,124 @@
+"""Host logic above the C ABI, exercised on CPU with the launchers emulated (tests/cpu_kernels.py):
+autograd closure of gemnet_pytorch_amd.ops (gradcheck + gradgradcheck in float64) and the index
+plans of gemnet_pytorch_amd.graph."""
+import numpy as np
+import pytest
+import torch
+from torch.autograd import gradcheck, gradgradcheck
+
+from gemnet_pytorch_amd import ops
+from gemnet_pytorch_amd.graph import RowIndex, SegmentPlan
+import cpu_kernels
+
+
+@pytest.fixture(autouse=True)
+def _emulated():
+    with cpu_kernels.emulate():
+        yield
+
+
+def rnd(*shape):
+    return torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+
+
+def test_rowindex_csr():
+    idx = torch.tensor([3, 1, 3, 0, 1, 3])
+    ri = RowIndex(idx, 5)
+    perm, seg = ri.csr
+    assert seg.tolist() == [0, 1, 3, 3, 6, 6]
+    assert idx[perm.long()].tolist() == [0, 1, 1, 3, 3, 3]
+    assert perm.tolist() == [3, 1, 4, 0, 2, 5]  # stable
+    rs = RowIndex(torch.tensor([0, 0, 2, 2, 2]), 4, is_sorted=True)
+    assert rs.csr[0] is None and rs.csr[1].tolist() == [0, 2, 2, 5, 5]
+
+
+def test_gather_segsum_adjoint():
+    idx = torch.tensor([3, 1, 3, 0, 1, 3])
+    ri = RowIndex(idx, 5)
+    x = rnd(5, 4)
+    assert gradcheck(lambda t: ops.gather_rows(t, ri), (x,))
+    assert gradgradcheck(lambda t: ops.gather_rows(t, ri), (x,))
+    y = rnd(6, 4)
+    out = ops.segsum_rows(y, ri)
+    ref = torch.zeros(5, 4, dtype=torch.float64).index_add(0, idx, y)
+    assert torch.allclose(out, ref)
+    assert gradcheck(lambda t: ops.segsum_rows(t, ri), (y,))
+
+
+def test_swap_involution():
+    swap = torch.tensor([2, 3, 0, 1])
+    ri = RowIndex(swap, 4)
+    ri.inverse = ri
+    x = rnd(4, 3)
+    assert gradcheck(lambda t: ops.gather_rows(t, ri), (x,))
+
+
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("tb", [False, True])
+def test_mm(ta, tb):
+    A = rnd(*((5, 7) if ta else (7, 5)))
+    Bm = rnd(*((5, 3) if tb else (3, 5)))
+    a = A.t() if ta else A
+    b = Bm if tb else Bm.t()
+    assert torch.allclose(ops.mm(A, Bm, ta, tb), a @ b)
+    assert gradcheck(lambda x, y: ops.mm(x, y, ta, tb), (A, Bm))
+    assert gradgradcheck(lambda x, y: ops.mm(x, y, ta, tb), (A, Bm))
+
+
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("tb", [False, True])
+def test_bmm(ta, tb):
+    A = rnd(*((4, 3, 2) if ta else (4, 2, 3)))
+    Bm = rnd(*((4, 5, 3) if tb else (4, 3, 5)))
+    assert gradcheck(lambda x, y: ops.bmm(x, y, ta, tb), (A, Bm))
+    assert gradgradcheck(lambda x, y: ops.bmm(x, y, ta, tb), (A, Bm))
+
+
+def test_param_grads_switch():
+    A, W = rnd(4, 3), rnd(2, 3)
+    with ops.param_grads(False):
+        gA, gW = torch.autograd.grad(ops.linear(A, W).sum(), (A, W), allow_unused=True)
+    assert gA is not None and gW is None
+
+
+def test_ssilu_chain():
+    x = rnd(6)
+    assert torch.allclose(ops.ssilu(x), torch.nn.functional.silu(x) / 0.6)
+    assert gradcheck(ops.ssilu, (x,))
+    assert gradgradcheck(ops.ssilu, (x,))
+
+
+def _segplan():
+    red = torch.tensor([0, 0, 0, 2, 2, 3])
+    exp = torch.tensor([1, 3, 2, 0, 1, 1])
+    return SegmentPlan(red, exp, 4, 4)
+
+
+def test_bilinear_closure():
+    sp = _segplan()
+    Y, x = rnd(6, 3), rnd(4, 5)
+    f = lambda a, b: ops.bil_reduce(a, b, sp)
+    ref = torch.zeros(4, 3, 5, dtype=torch.float64).index_add(
+        0, sp.reduce.idx64, Y[:, :, None] * x[sp.expand.idx64][:, None, :])
+    assert torch.allclose(f(Y, x), ref)
+    assert gradcheck(f, (Y, x))
+    assert gradgradcheck(f, (Y, x))
+
+
+def test_basis_ops_first_and_second_order():
+    d = (torch.rand(5, dtype=torch.float64) * 3.5 + 1.0).requires_grad_(True)
+    freq = (torch.arange(1, 4, dtype=torch.float64) * np.pi).requires_grad_(True)
+    f = lambda a, b: ops.bessel_rbf(a, b, 5.0, 5)
+    assert gradcheck(f, (d, freq))
+    assert gradgradcheck(lambda a: ops.bessel_rbf(a, freq.detach(), 5.0, 5), (d,))
+    th = (torch.rand(5, dtype=torch.float64) * 3.0 + 0.05).requires_grad_(True)
+    ph = (torch.rand(5, dtype=torch.float64) * 3.0 + 0.05).requires_grad_(True)
+    assert gradcheck(lambda t: ops.ylm0(t, 4), (th,))
+    assert gradgradcheck(lambda t: ops.ylm0(t, 4), (th,))
+    assert gradcheck(lambda t, p: ops.ylm(t, p, 3), (th, ph))
+    assert gradgradcheck(lambda t, p: ops.ylm(t, p, 3), (th, ph))
+    from oracle import basis_oracle as B
+    z = torch.tensor(B.jn_zeros(3, 2))
+    nrm = torch.tensor(B.sph_bessel_normalizer(3, 2))
+    assert gradcheck(lambda t: ops.sph_radial(t, z, nrm, 5.0, 5), (d,))
+    assert gradgradcheck(lambda t: ops.sph_radial(t, z, nrm, 5.0, 5), (d,))
