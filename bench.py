@@ -1,0 +1,315 @@
+#!/usr/bin/env python
+"""bench.py — molecules/s (forward + force) of GemNet-T on COLL-shaped batches, N x MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run)
+prints ONE JSON line on rank 0.  A "step" is one pass of the hot path over one batch:
+GemNet-T full (4 blocks, emb 128; pretrained/GemNet-T/model_kwargs.json of the reference) on a
+synthetic batch of 32 molecules x 32 atoms per GPU (BASELINE.json configs[1]), forward + force
+(F = -dE/dR), fp32, inputs resident in HBM.  Weak scaling: every rank owns its own batch of
+`--batch` molecules; no data-path collective is needed for forward+force (molecules are independent).
+
+  --mode train   times the full training step instead (fwd + force + loss.backward + RCCL gradient
+                 all-reduce + AdamW), reported under the same JSON keys with metric suffix.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel family of the step, measured live with HIP events around every launch
+                in one instrumented (eager) pass over the same batch
+  cpu_baseline  the oracle (plain-PyTorch CPU restatement, kind "port") timed on the host cores,
+                rank 0 / N=1 only, on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GEMNET_T = dict(num_spherical=7, num_radial=6, num_blocks=4, emb_size_atom=128, emb_size_edge=128,
+                emb_size_trip=64, emb_size_quad=32, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=32,
+                emb_size_bil_trip=64, emb_size_bil_quad=32, num_before_skip=1, num_after_skip=1,
+                num_concat=1, num_atom=2, triplets_only=True, num_targets=1, direct_forces=False,
+                cutoff=5.0, int_cutoff=10.0, envelope_exponent=5, extensive=True, forces_coupled=False,
+                output_init="HeOrthogonal", activation="swish")
+SCALE_FILE = os.path.join(ROOT, "gemnet_pytorch_amd", "scaling_factors.json")
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_batch(cfg, n_mol, n_atoms, first, device):
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    from gemnet_pytorch_amd.training.data_container import DataContainer
+    ds = make_dataset(n_mol, n_atoms, config=2, first=first)
+    dc = DataContainer.from_arrays(ds, cfg["cutoff"], cfg["int_cutoff"], triplets_only=cfg["triplets_only"])
+    batch = dc[list(range(n_mol))]
+    targets = {k: batch.pop(k).to(device) for k in ("E", "F")}
+    inputs = {k: v.to(device) for k, v in batch.items()}
+    return inputs, targets
+
+
+class LaunchTimer:
+    """Wraps every launcher of gemnet_pytorch_amd.kernels with a pair of HIP events (recorded on the
+    stream the kernels are launched on = torch's current stream) and the algorithmic flops/bytes of
+    the launch."""
+
+    def __init__(self):
+        from gemnet_pytorch_amd import kernels as K
+        self.K = K
+        self.records = []
+        self.saved = {}
+
+    @staticmethod
+    def cost(name, args, kwargs, out):
+        f32 = 4
+        if name == "gemm":
+            A, B = args[0], args[1]
+            ta = args[2] if len(args) > 2 else kwargs.get("trans_a", False)
+            o = out[0] if isinstance(out, tuple) else out
+            M, N = o.shape
+            Kd = A.shape[0] if ta else A.shape[1]
+            by = (M * Kd + N * Kd + M * N * (2 if isinstance(out, tuple) else 1)) * f32
+            for k in ("mul", "res", "a_dact_pre"):
+                if kwargs.get(k) is not None:
+                    by += kwargs[k].numel() * f32
+            return 2.0 * M * N * Kd, by
+        if name == "bmm":
+            o = out
+            b, m, n = o.shape
+            k = args[0].numel() // (b * m)
+            return 2.0 * b * m * n * k, (args[0].numel() + args[1].numel() + o.numel()) * f32
+        if name in ("bil_reduce", "bil_reduce_t", "bil_dot"):
+            sp = args[2]
+            S = args[0].shape[1]
+            C = args[1].shape[-1]
+            by = sp.size * (S * f32 + 8) + sp.n_expand * C * f32 + sp.n_reduce * S * C * f32
+            return 2.0 * sp.size * S * C, by
+        numel = sum(a.numel() for a in args if torch.is_tensor(a))
+        o = out[0] if isinstance(out, tuple) else out
+        return 0.0, (numel + o.numel()) * f32
+
+    def __enter__(self):
+        for name in ["gemm", "bmm", "gather", "segsum", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+                     "bessel_rbf", "sph_radial", "ylm0", "ylm"]:
+            fn = getattr(self.K, name)
+            self.saved[name] = fn
+
+            def wrapped(*args, _fn=fn, _name=name, **kwargs):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = _fn(*args, **kwargs)
+                e.record()
+                fl, by = self.cost(_name, args, kwargs, out)
+                self.records.append((_name, s, e, fl, by))
+                return out
+
+            setattr(self.K, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.K, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, s, e, fl, by in self.records:
+            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+            d["launches"] += 1
+        return fam
+
+
+def roofline_from(fam):
+    name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    sec = d["ms"] * 1e-3
+    if name in ("gemm", "bmm"):
+        ach = d["flops"] / sec / 1e12
+        return dict(kernel=name, bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2), launches=d["launches"],
+                    share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
+    ach = d["bytes"] / sec / 1e9
+    return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None,
+                avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2), launches=d["launches"],
+                share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
+
+
+def cpu_baseline(cfg, n_atoms, budget_s=20.0):
+    """Oracle (CPU restatement, fp32, all host cores) forward+force on a bounded sample."""
+    from oracle import gemnet_oracle as GO
+    n_mol = 8
+    inputs, _ = make_batch(cfg, n_mol, n_atoms, first=0, device="cpu")
+    params = GO.make_params(cfg, 0, GO.load_scale_factors(SCALE_FILE), dtype=torch.float32)
+    cores = torch.get_num_threads()
+    GO.forward(cfg, params, inputs)  # warm-up (page faults, thread pools)
+    t0 = time.time()
+    steps = 0
+    while True:
+        GO.forward(cfg, params, inputs)
+        steps += 1
+        if time.time() - t0 > budget_s or steps >= 20:
+            break
+    dt = time.time() - t0
+    return dict(value=round(n_mol * steps / dt, 3), unit="molecules/s", cores=cores, kind="port",
+                sample=f"{steps} steps of forward+force on {n_mol} molecules x {n_atoms} atoms "
+                       f"(same generator/config as the GPU workload), torch CPU fp32, {cores} threads",
+                ms_per_step=round(dt / steps * 1e3, 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="molecules per GPU")
+    ap.add_argument("--atoms", type=int, default=32)
+    ap.add_argument("--mode", choices=["force", "train"], default="force")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from gemnet_pytorch_amd.graph import GraphPlan
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+
+    cfg = dict(GEMNET_T)
+    torch.manual_seed(1234)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(device)
+    inputs, targets = make_batch(cfg, args.batch, args.atoms, first=rank * args.batch, device=device)
+    plan = GraphPlan.from_inputs(inputs, cfg["triplets_only"]).warm()
+    sizes = dict(atoms=plan.n_atoms, edges=plan.n_edges, triplets=plan.trip.size)
+    log(f"[bench] rank {rank}/{world}: {args.batch} molecules, {sizes}")
+
+    use_graph = not args.no_graph
+    if args.mode == "force":
+        model.eval()
+        model.requires_grad_(False)  # inference: only dE/dR is needed, no parameter-gradient graph
+
+        def step():
+            return model(inputs)
+    else:
+        from gemnet_pytorch_amd.training.ddp import TrainStep
+        ts = TrainStep(model, world_size=world)
+        use_graph = False
+
+        def step():
+            return ts(inputs, targets)
+
+    # eager warm-up (also validates the path before capture)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    graph = None
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_out = step()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            ref = step()
+            torch.cuda.synchronize()
+            if not (torch.allclose(g_out[0], ref[0]) and torch.allclose(g_out[1], ref[1])):
+                raise RuntimeError("hipGraph replay disagrees with eager")
+        except Exception as ex:  # noqa: BLE001
+            log(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches")
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        with LaunchTimer() as lt:
+            for _ in range(3):
+                step()
+        fam = lt.summary()
+        roof = roofline_from(fam)
+        tot = sum(v["ms"] for v in fam.values())
+        log("[bench] per-family kernel time of the instrumented pass (3 steps):")
+        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+            log(f"    {k:14s} {v['ms']:8.3f} ms  {100 * v['ms'] / tot:5.1f} %  {v['launches']:5d} launches"
+                f"  {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.2f} TFLOP/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "force":
+        cpu = cpu_baseline(cfg, args.atoms)
+
+    if rank == 0:
+        mol_per_s = world * args.batch * args.steps / elapsed
+        line = {
+            "metric": "molecules/sec (forward+force) GemNet-T on COLL-shaped batches"
+                      + ("" if args.mode == "force" else " [training step: fwd+force+backward+allreduce+AdamW]"),
+            "value": round(mol_per_s, 2), "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"GemNet-T full (4 blocks, emb 128), batch {args.batch} molecules x "
+                                   f"{args.atoms} atoms per GPU, forward+force, fp32 (BASELINE.json configs[1])",
+                       "mode": args.mode, "hipgraph": graph is not None, "per_gpu": sizes,
+                       "parallelism": f"dp{world} (independent molecule shards, no data-path collective)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

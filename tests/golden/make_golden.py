@@ -57,6 +57,8 @@ def install_shims():
 
 install_shims()
 from gemnet.model.gemnet import GemNet  # noqa: E402  (the reference)
+import inspect  # noqa: E402
+assert inspect.getsourcefile(GemNet).startswith(REF), "make_golden must import the REFERENCE GemNet"
 from gemnet.model.layers import basis_utils as ref_bu  # noqa: E402
 from gemnet.model.layers.basis_layers import (BesselBasisLayer, SphericalBasisLayer,  # noqa: E402
                                               TensorBasisLayer)

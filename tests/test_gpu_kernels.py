@@ -33,17 +33,17 @@ def f32(t):
     return t.to(torch.float32).to(DEV)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 128, 32), (300, 128, 128), (1000, 64, 128), (257, 32, 64),
+@pytest.mark.parametrize("M,N,Kd", [(64, 128, 32), (300, 128, 128), (1000, 64, 128), (257, 32, 64),
                                     (130, 16, 6), (77, 1, 128), (513, 128, 384), (95, 100, 42),
                                     (2048, 64, 1024), (5, 7, 3)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_plain(M, N, K, ta, tb):
-    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
-    A = rnd(g, *((K, M) if ta else (M, K)))
-    Bm = rnd(g, *((K, N) if tb else (N, K)))
+def test_gemm_plain(M, N, Kd, ta, tb):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + Kd)
+    A = rnd(g, *((Kd, M) if ta else (M, Kd)))
+    Bm = rnd(g, *((Kd, N) if tb else (N, Kd)))
     ref = CK.gemm(A, Bm, ta, tb)
     out = K.gemm(f32(A), f32(Bm), ta, tb)
-    close(out, ref, rtol=1e-5, atol=1e-5 * np.sqrt(K) * 4)
+    close(out, ref, rtol=1e-5, atol=1e-5 * np.sqrt(Kd) * 4)
 
 
 def test_gemm_is_transpose_detecting():

@@ -40,8 +40,8 @@ def test_energy_force_parity(golden_model, tag):
     Eref, Fref = g[f"{tag}.E"], g[f"{tag}.F"]
     fscale = max(1.0, float(np.abs(Fref).mean()))
     escale = max(1.0, float(np.abs(Eref).max()))
-    f_mae = float(np.abs(F.cpu().numpy() - Fref).mean())
-    e_err = float(np.abs(E.cpu().numpy() - Eref).max())
+    f_mae = float(np.abs(F.detach().cpu().numpy() - Fref).mean())
+    e_err = float(np.abs(E.detach().cpu().numpy() - Eref).max())
     print(f"{tag}: force MAE {f_mae:.3e} (scale {fscale:.2e}), energy err {e_err:.3e} (scale {escale:.2e})")
     assert f_mae <= FORCE_TOL * fscale
     assert e_err <= 2e-5 * escale
