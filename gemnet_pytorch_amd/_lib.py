@@ -32,12 +32,16 @@ class GemmArgs(ctypes.Structure):
         ("gadd1", _vp), ("gidx1", _vp),
         ("gadd2", _vp), ("gidx2", _vp),
         ("ldg", _i),
+        ("ridx", _vp),
+        ("res2", _vp), ("ldres2", _i),
+        ("beta2", _f),
     ]
 
 
 # name -> argtypes; every function returns int (0 = ok)
 SIGNATURES = {
     "gn_gemm_f32": [ctypes.POINTER(GemmArgs), _vp],
+    "gn_gemm_f32_cfg": [ctypes.POINTER(GemmArgs), _i, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
@@ -49,6 +53,7 @@ SIGNATURES = {
     "gn_ylm0_f32": [_vp, _vp, _i64, _i, _i, _vp],
     "gn_ylm_f32": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_ssilu_f32": [_vp, _vp, _i64, _i, _vp],
+    "gn_dact_mul_f32": [_vp, _vp, _i, _vp, _f, _vp, _vp, _i64, _vp],
 }
 
 _lib = None

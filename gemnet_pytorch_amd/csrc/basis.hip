@@ -60,6 +60,19 @@ __global__ void ssilu_kernel(const float* __restrict__ x, float* __restrict__ ou
   }
 }
 
+__global__ void dact_mul_kernel(const float* __restrict__ g, const float* __restrict__ z, int act,
+                                const float* __restrict__ mul, float c, float* __restrict__ dz,
+                                float* __restrict__ gmul, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gv = g[i] * c;
+    const float zv = z ? z[i] : 0.f;
+    const float a = act ? gn_dssilu(zv) : 1.0f;
+    dz[i] = gv * (mul ? mul[i] : 1.0f) * a;
+    if (gmul) gmul[i] = gv * (act ? gn_ssilu(zv) : zv);
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -115,5 +128,15 @@ extern "C" int gn_ssilu_f32(const float* x, float* out, int64_t n, int k, void* 
   return 0;
 }
 
-extern "C" int gn_abi_version(void) { return 1; }
+extern "C" int gn_dact_mul_f32(const float* g, const float* z, int act, const float* mul, float c,
+                               float* dz, float* gmul, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if ((act || gmul) && !z) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(dact_mul_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     g, z, act, mul, c, dz, gmul, n);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_abi_version(void) { return 2; }
 extern "C" const char* gn_error_string(int code) { return hipGetErrorString((hipError_t)code); }

@@ -1,37 +1,52 @@
 // Dense contractions on the f32 MFMA (v_mfma_f32_32x32x2_f32): exact-f32 numerics at the
 // f32 vector rate (157 TF peak on MI355X), fused prologue (activation derivative on the A
-// operand) and fused epilogue (gather-add, ScaledSiLU, Hadamard, scale, residual).
+// operand) and fused epilogue (gather-add, ScaledSiLU, Hadamard, scale, two residual adds).
 //
 // Replaces every `Dense` (nn.Linear + ScaledSiLU) of the reference
 // (gemnet/model/layers/base_layers.py:5-58), ResidualLayer (:61-89), the concat-Dense of
 // embedding_block.py:60-75 and the final (E, C*I) x (C*I, O) contraction of the bilinear
 // layer (efficient.py:185-188).
 //
-// Tiling: 256 threads = 4 waves (wave64).  Block tile BM x BN, K-step 32 staged through LDS
-// as As[BM][36] / Bs[BN][36] (k contiguous, +4 pad: rows 144 B apart -> ds_read_b128 of 16
-// consecutive rows hits 16 distinct 16-B slots).  Each lane fetches one float4 (4 consecutive
-// k) per 32-row fragment; lanes 0-31 take k = kb..kb+3, lanes 32-63 take k = kb+4..kb+7, and
-// MFMA step s consumes component s of both operands — the k permutation is the same for A and
-// B so the sum over k is unchanged.
+// Tiling: NW waves (wave64) per block, each wave owns TM x TN tiles of 32x32.  K-step 32 staged
+// through LDS as As[BM][36] / Bs[BN][36] (k contiguous, +4 pad: rows 144 B apart -> ds_read_b128
+// of 16 consecutive rows hits 16 distinct 16-B slots).  Each lane fetches one float4 (4
+// consecutive k) per 32-row fragment; lanes 0-31 take k = kb..kb+3, lanes 32-63 take
+// k = kb+4..kb+7, and MFMA step s consumes component s of both operands — the k permutation is
+// the same for A and B so the sum over k is unchanged.
+//
+// Two kernels:
+//   gemm_nt_pipe   "NT" operands (both k-contiguous, 16-B aligned rows): the next K-step's global
+//                  loads are issued into registers BEFORE the MFMA loop of the current step and
+//                  written to LDS after it, so HBM/L2 latency hides under the matrix pipe even at
+//                  one wave per SIMD (the E = 18 k-row GEMMs of a 32-molecule batch fill the chip
+//                  about once).  Small-M shapes (atom-side layers, M = 1024) get 32-row tiles so
+//                  the launch spreads over 4x more CUs and per-block latency drops 2x.
+//   gemm_generic   any transposition / alignment (weight-gradient GEMMs, K = 6 radial inputs,
+//                  unaligned weight slices): synchronous staging.
 #include "common.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = 32;          // K-step of the generic kernel
 constexpr int LDS_LD = BK + 4;
+
+__device__ __forceinline__ float4 dact4(float4 v, float4 z) {
+  v.x *= gn_dssilu(z.x); v.y *= gn_dssilu(z.y); v.z *= gn_dssilu(z.z); v.w *= gn_dssilu(z.w);
+  return v;
+}
 
 // Stage a ROWS x 32 tile T[r][k] = op(G)[row0 + r][k0 + k] into LDS (zero-filled out of range).
 //   trans == 0: op(G)[r][k] = G[r*ld + k]      trans == 1: op(G)[r][k] = G[k*ld + r]
 // If Z != nullptr the element is multiplied by dssilu(Z[same index]).
-template <int ROWS>
+template <int ROWS, int NT>
 __device__ __forceinline__ void stage_tile(float (*Ts)[LDS_LD], const float* __restrict__ G,
                                            const float* __restrict__ Z, int trans, int vec,
                                            int row0, int k0, int nrows, int K, int ld, int tid) {
   if (!trans) {
     if (vec) {
-      for (int f = tid; f < ROWS * (BK / 4); f += 256) {
+      for (int f = tid; f < ROWS * (BK / 4); f += NT) {
         const int r = f >> 3;
         const int kv = (f & 7) << 2;
         const int gr = row0 + r;
@@ -41,11 +56,7 @@ __device__ __forceinline__ void stage_tile(float (*Ts)[LDS_LD], const float* __r
           const size_t off = (size_t)gr * ld + gk;
           if (gk + 3 < K) {
             v = *reinterpret_cast<const float4*>(G + off);
-            if (Z) {
-              const float4 z = *reinterpret_cast<const float4*>(Z + off);
-              v.x *= gn_dssilu(z.x); v.y *= gn_dssilu(z.y);
-              v.z *= gn_dssilu(z.z); v.w *= gn_dssilu(z.w);
-            }
+            if (Z) v = dact4(v, *reinterpret_cast<const float4*>(Z + off));
           } else {
             float t[4] = {0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < 4; ++j)
@@ -56,7 +67,7 @@ __device__ __forceinline__ void stage_tile(float (*Ts)[LDS_LD], const float* __r
         *reinterpret_cast<float4*>(&Ts[r][kv]) = v;
       }
     } else {
-      for (int e = tid; e < ROWS * BK; e += 256) {
+      for (int e = tid; e < ROWS * BK; e += NT) {
         const int r = e >> 5;
         const int k = e & 31;
         const int gr = row0 + r;
@@ -73,7 +84,7 @@ __device__ __forceinline__ void stage_tile(float (*Ts)[LDS_LD], const float* __r
   } else {
     if (vec) {
       constexpr int RV = ROWS / 4;
-      for (int f = tid; f < BK * RV; f += 256) {
+      for (int f = tid; f < BK * RV; f += NT) {
         const int k = f / RV;
         const int rv = (f % RV) << 2;
         const int gk = k0 + k;
@@ -82,13 +93,9 @@ __device__ __forceinline__ void stage_tile(float (*Ts)[LDS_LD], const float* __r
         if (gk < K && gr < nrows) {
           const size_t off = (size_t)gk * ld + gr;
           if (gr + 3 < nrows) {
-            const float4 v = *reinterpret_cast<const float4*>(G + off);
+            float4 v = *reinterpret_cast<const float4*>(G + off);
+            if (Z) v = dact4(v, *reinterpret_cast<const float4*>(Z + off));
             t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-            if (Z) {
-              const float4 z = *reinterpret_cast<const float4*>(Z + off);
-              t[0] *= gn_dssilu(z.x); t[1] *= gn_dssilu(z.y);
-              t[2] *= gn_dssilu(z.z); t[3] *= gn_dssilu(z.w);
-            }
           } else {
             for (int j = 0; j < 4; ++j)
               if (gr + j < nrows) t[j] = G[off + j] * (Z ? gn_dssilu(Z[off + j]) : 1.0f);
@@ -98,7 +105,7 @@ __device__ __forceinline__ void stage_tile(float (*Ts)[LDS_LD], const float* __r
         for (int j = 0; j < 4; ++j) Ts[rv + j][k] = t[j];
       }
     } else {
-      for (int e = tid; e < ROWS * BK; e += 256) {
+      for (int e = tid; e < ROWS * BK; e += NT) {
         const int k = e / ROWS;
         const int r = e % ROWS;
         const int gk = k0 + k;
@@ -115,10 +122,64 @@ __device__ __forceinline__ void stage_tile(float (*Ts)[LDS_LD], const float* __r
   }
 }
 
+// 8 k-values of the staged tile: TM*TN*4 MFMAs
+template <int TM, int TN, int LD>
+__device__ __forceinline__ void mma_step(const float (*As)[LD], const float (*Bs)[LD],
+                                         int arow, int brow, int kcol, v16f (&acc)[TM][TN]) {
+  float4 a[TM], b[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&As[arow + i * 32][kcol]);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[brow + j * 32][kcol]);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+    }
+}
+
+// Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const gn_gemm_args& p, v16f (&acc)[TM][TN], int rbase,
+                                         int cbase, int lane) {
+  const int l31 = lane & 31;
+  const int rh = (lane >> 5) << 2;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = cbase + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + rh;
+        if (row < p.M && col < p.N) {
+          float z = acc[i][j][r];
+          if (p.gadd1) z += p.gadd1[(size_t)p.gidx1[row] * p.ldg + col];
+          if (p.gadd2) z += p.gadd2[(size_t)p.gidx2[row] * p.ldg + col];
+          const size_t co = (size_t)row * p.ldc + col;
+          if (p.pre_out) p.pre_out[co] = z;
+          float y = p.act ? gn_ssilu(z) : z;
+          if (p.mul) y *= p.mul[(size_t)row * p.ldmul + col];
+          y *= p.alpha;
+          if (p.res) {
+            const size_t rr = p.ridx ? (size_t)p.ridx[row] : (size_t)row;
+            y = (y + p.res[rr * p.ldres + col]) * p.beta;
+          }
+          if (p.res2) y = (y + p.res2[(size_t)row * p.ldres2 + col]) * p.beta2;
+          p.C[co] = y;
+        }
+      }
+    }
+}
+
 template <int BM, int BN, int WR, int WC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const gn_gemm_args p, const int vecA,
-                                                       const int vecB) {
-  static_assert(WR * WC == 4, "4 waves per block");
+__global__ __launch_bounds__(WR * WC * 64) void gemm_generic(const gn_gemm_args p, const int vecA,
+                                                             const int vecB) {
+  constexpr int NT = WR * WC * 64;
   constexpr int TM = BM / (WR * 32);
   constexpr int TN = BN / (WC * 32);
   static_assert(TM >= 1 && TN >= 1, "tile too small");
@@ -132,7 +193,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const gn_gemm_args p, con
   const int wc = wave % WC;
   const int row0 = blockIdx.x * BM;
   const int col0 = blockIdx.y * BN;
-  const int l31 = lane & 31;
+  const int arow = wr * TM * 32 + (lane & 31);
+  const int brow = wc * TN * 32 + (lane & 31);
   const int kh = (lane >> 5) << 2;  // 0 or 4
 
   v16f acc[TM][TN];
@@ -144,56 +206,99 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const gn_gemm_args p, con
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   for (int k0 = 0; k0 < p.K; k0 += BK) {
-    stage_tile<BM>(As, p.A, p.a_dact_pre, p.trans_a, vecA, row0, k0, p.M, p.K, p.lda, tid);
+    stage_tile<BM, NT>(As, p.A, p.a_dact_pre, p.trans_a, vecA, row0, k0, p.M, p.K, p.lda, tid);
     // Bs[n][k] = opB(B)[k][n]: trans_b == 0 means B is stored (N,K) = "row n, k contiguous"
-    stage_tile<BN>(Bs, p.B, nullptr, p.trans_b, vecB, col0, k0, p.N, p.K, p.ldb, tid);
+    stage_tile<BN, NT>(Bs, p.B, nullptr, p.trans_b, vecB, col0, k0, p.N, p.K, p.ldb, tid);
     __syncthreads();
 #pragma unroll
-    for (int kb = 0; kb < BK; kb += 8) {
-      float4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const float4*>(&As[(wr * TM + i) * 32 + l31][kb + kh]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const float4*>(&Bs[(wc * TN + j) * 32 + l31][kb + kh]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+    for (int kb = 0; kb < BK; kb += 8) mma_step<TM, TN, LDS_LD>(As, Bs, arow, brow, kb + kh, acc);
     __syncthreads();
   }
+  epilogue<TM, TN>(p, acc, row0 + wr * TM * 32, col0 + wc * TN * 32, lane);
+}
 
-  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int rh = (lane >> 5) << 2;
+// NT operands, rows 16-B aligned, K % 4 == 0.  Register-prefetch pipeline over K-steps of KS.
+template <int BM, int BN, int WR, int WC, int KS>
+__global__ __launch_bounds__(WR * WC * 64) void gemm_nt_pipe(const gn_gemm_args p) {
+  constexpr int NT = WR * WC * 64;
+  constexpr int TM = BM / (WR * 32);
+  constexpr int TN = BN / (WC * 32);
+  constexpr int LD = KS + 4;
+  constexpr int V = KS / 4;                    // float4 per tile row
+  constexpr int NA = (BM * V + NT - 1) / NT;   // float4 loads per thread per K-step
+  constexpr int NB = (BN * V + NT - 1) / NT;
+  static_assert(TM >= 1 && TN >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) float As[BM][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN][LD];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wr = wave / WC;
+  const int wc = wave % WC;
+  const int row0 = blockIdx.x * BM;
+  const int col0 = blockIdx.y * BN;
+  const int arow = wr * TM * 32 + (lane & 31);
+  const int brow = wc * TN * 32 + (lane & 31);
+  const int kh = (lane >> 5) << 2;
+  const bool dact = p.a_dact_pre != nullptr;
+
+  float4 ra[NA], rz[NA], rb[NB];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / V, kv = (f % V) << 2;
+      const int gr = row0 + r, gk = k0 + kv;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rz[i] = ra[i];
+      if (f < BM * V && gr < p.M && gk < p.K) {
+        const size_t off = (size_t)gr * p.lda + gk;
+        ra[i] = *reinterpret_cast<const float4*>(p.A + off);
+        if (dact) rz[i] = *reinterpret_cast<const float4*>(p.a_dact_pre + off);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / V, kv = (f % V) << 2;
+      const int gr = col0 + r, gk = k0 + kv;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < BN * V && gr < p.N && gk < p.K)
+        rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)gr * p.ldb + gk);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * NT;
+      if (f < BM * V) *reinterpret_cast<float4*>(&As[f / V][(f % V) << 2]) = dact ? dact4(ra[i], rz[i]) : ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * NT;
+      if (f < BN * V) *reinterpret_cast<float4*>(&Bs[f / V][(f % V) << 2]) = rb[i];
+    }
+  };
+
+  v16f acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = col0 + (wc * TN + j) * 32 + l31;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rh;
-        if (row < p.M && col < p.N) {
-          float z = acc[i][j][r];
-          if (p.gadd1) z += p.gadd1[(size_t)p.gidx1[row] * p.ldg + col];
-          if (p.gadd2) z += p.gadd2[(size_t)p.gidx2[row] * p.ldg + col];
-          const size_t co = (size_t)row * p.ldc + col;
-          if (p.pre_out) p.pre_out[co] = z;
-          float y = p.act ? gn_ssilu(z) : z;
-          if (p.mul) y *= p.mul[(size_t)row * p.ldmul + col];
-          y *= p.alpha;
-          if (p.res) y = (y + p.res[(size_t)row * p.ldres + col]) * p.beta;
-          p.C[co] = y;
-        }
-      }
-    }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load(0);
+  for (int k0 = 0; k0 < p.K; k0 += KS) {
+    store();
+    __syncthreads();
+    if (k0 + KS < p.K) load(k0 + KS);  // in flight while the matrix pipe works on this step
+#pragma unroll
+    for (int kb = 0; kb < KS; kb += 8) mma_step<TM, TN, LD>(As, Bs, arow, brow, kb + kh, acc);
+    __syncthreads();
+  }
+  epilogue<TM, TN>(p, acc, row0 + wr * TM * 32, col0 + wc * TN * 32, lane);
 }
 
 // C[b] = opA(A[b]) opB(B[b]) for tiny per-edge blocks (m*k, k*n <= 2048 floats).
@@ -231,27 +336,54 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+template <int BM, int BN, int WR, int WC, int KS>
+void launch(const gn_gemm_args& p, bool fast, int vecA, int vecB, hipStream_t st) {
+  dim3 grid(gn_cdiv(p.M, BM), gn_cdiv(p.N, BN)), block(WR * WC * 64);
+  if (fast) hipLaunchKernelGGL((gemm_nt_pipe<BM, BN, WR, WC, KS>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_generic<BM, BN, WR, WC>), grid, block, 0, st, p, vecA, vecB);
+}
+
 }  // namespace
 
-extern "C" int gn_gemm_f32(const gn_gemm_args* args, void* stream) {
+// cfg < 0: automatic tile selection; cfg >= 0: explicit variant (tuning / tests).
+extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) {
   const gn_gemm_args p = *args;
   if (p.M <= 0 || p.N <= 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int vecA = (p.lda % 4 == 0) && aligned16(p.A) && (!p.a_dact_pre || aligned16(p.a_dact_pre));
   const int vecB = (p.ldb % 4 == 0) && aligned16(p.B);
-  if (p.N > 64) {
-    dim3 grid(gn_cdiv(p.M, 64), gn_cdiv(p.N, 128));
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, p, vecA, vecB);
-  } else if (p.N > 32) {
-    dim3 grid(gn_cdiv(p.M, 64), 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p, vecA, vecB);
-  } else {
-    dim3 grid(gn_cdiv(p.M, 128), 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p, vecA, vecB);
+  const bool fast = !p.trans_a && !p.trans_b && vecA && vecB && (p.K % 4 == 0);
+  if (cfg < 0) {
+    // Measured on MI355X (tools/gemm_bench.py, profiles/r1_gemm_tiles.txt): up to ~40 k rows the
+    // launch is latency-bound, and 32-row tiles with one 32x32 tile per wave (2.2 waves/SIMD at
+    // E = 18 k) beat 64x128 (12.7 vs 17.1 us at N = K = 128); large M wants 128x128 tiles.
+    const bool huge = p.M > 40000;
+    if (p.N > 64) cfg = huge ? 13 : 1;
+    else if (p.N > 32) cfg = p.M > 4096 ? 11 : 3;
+    else cfg = p.M > 4096 ? 4 : 5;
+  }
+  switch (cfg) {
+    case 0: launch<64, 128, 2, 2, 32>(p, fast, vecA, vecB, st); break;
+    case 1: launch<32, 128, 1, 4, 32>(p, fast, vecA, vecB, st); break;
+    case 2: launch<64, 64, 2, 2, 32>(p, fast, vecA, vecB, st); break;
+    case 3: launch<32, 64, 1, 2, 32>(p, fast, vecA, vecB, st); break;
+    case 4: launch<128, 32, 4, 1, 32>(p, fast, vecA, vecB, st); break;
+    case 5: launch<32, 32, 1, 1, 32>(p, fast, vecA, vecB, st); break;
+    case 6: launch<64, 128, 2, 2, 64>(p, fast, vecA, vecB, st); break;
+    case 7: launch<32, 128, 1, 4, 64>(p, fast, vecA, vecB, st); break;
+    case 8: launch<64, 128, 2, 4, 32>(p, fast, vecA, vecB, st); break;
+    case 9: launch<64, 128, 2, 4, 64>(p, fast, vecA, vecB, st); break;
+    case 10: launch<32, 64, 1, 2, 64>(p, fast, vecA, vecB, st); break;
+    case 11: launch<64, 64, 2, 2, 64>(p, fast, vecA, vecB, st); break;
+    case 12: launch<128, 128, 4, 2, 32>(p, fast, vecA, vecB, st); break;
+    case 13: launch<128, 128, 4, 4, 32>(p, fast, vecA, vecB, st); break;
+    default: return (int)hipErrorInvalidValue;
   }
   GN_LAUNCH_CHECK();
   return 0;
 }
+
+extern "C" int gn_gemm_f32(const gn_gemm_args* args, void* stream) { return gn_gemm_f32_cfg(args, -1, stream); }
 
 extern "C" int gn_bmm_f32(const float* A, const float* B, float* C, int batch, int m, int n, int k,
                           int trans_a, int trans_b, void* stream) {

@@ -30,40 +30,46 @@ __global__ void gather_rows_s(const float* __restrict__ x, const int32_t* __rest
   }
 }
 
-__global__ void segsum_rows_v4(const float4* __restrict__ y, const int32_t* __restrict__ perm,
-                               const int32_t* __restrict__ seg_off, float4* __restrict__ x,
-                               int64_t N, int C4) {
-  const int64_t n = N * C4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / C4;
-    const int c = (int)(i - r * C4);
-    const int k0 = seg_off[r], k1 = seg_off[r + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = k0; k < k1; ++k) {
-      const int64_t src = perm ? perm[k] : k;
-      const float4 v = y[src * C4 + c];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    x[i] = acc;
-  }
-}
+// One wave per output row.  A row's CW lanes-per-entry (C/4 float4 lanes, or C scalar lanes) are
+// replicated EPL = 64/CW times so EPL segment entries are accumulated concurrently; the EPL partial
+// sums are combined through LDS in a fixed order (deterministic).  Long segments (the (T,3) -> (A,3)
+// position gradients: ~1000 entries per atom) no longer serialise on one lane.
+template <typename VT>
+__device__ __forceinline__ VT vzero();
+template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
+template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
+__device__ __forceinline__ void vadd(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-__global__ void segsum_rows_s(const float* __restrict__ y, const int32_t* __restrict__ perm,
-                              const int32_t* __restrict__ seg_off, float* __restrict__ x,
-                              int64_t N, int C) {
-  const int64_t n = N * C;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / C;
-    const int c = (int)(i - r * C);
-    const int k0 = seg_off[r], k1 = seg_off[r + 1];
-    float acc = 0.f;
-    for (int k = k0; k < k1; ++k) {
-      const int64_t src = perm ? perm[k] : k;
-      acc += y[src * C + c];
+template <typename VT>
+__global__ __launch_bounds__(256) void segsum_wave(const VT* __restrict__ y, const int32_t* __restrict__ perm,
+                                                   const int32_t* __restrict__ seg_off, VT* __restrict__ x,
+                                                   int64_t N, int CW) {
+  __shared__ VT part[4][64];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  const bool row_ok = r < N;
+  const int k0 = row_ok ? seg_off[r] : 0, k1 = row_ok ? seg_off[r + 1] : 0;
+  for (int cb = 0; cb < CW; cb += 64) {           // channel chunks (CW > 64 only for C > 256)
+    const int cw = min(64, CW - cb);
+    const int epl = 64 / cw;
+    const int slot = lane / cw;
+    const int c = cb + lane - slot * cw;
+    VT acc = vzero<VT>();
+    if (slot < epl)
+      for (int k = k0 + slot; k < k1; k += epl) {
+        const int64_t src = perm ? perm[k] : k;
+        vadd(acc, y[src * CW + c]);
+      }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (row_ok && lane < cw) {
+      VT t = part[wave][lane];
+      for (int s2 = 1; s2 < epl; ++s2) vadd(t, part[wave][s2 * cw + lane]);
+      x[r * CW + cb + lane] = t;
     }
-    x[i] = acc;
+    __syncthreads();
   }
 }
 
@@ -93,12 +99,12 @@ extern "C" int gn_segsum_rows_f32(const float* y, const int32_t* perm, const int
                                   float* x, int64_t N, int C, void* stream) {
   if (N <= 0 || C <= 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((N + 3) / 4)), block(256);
   if (C % 4 == 0 && aligned16(x) && aligned16(y)) {
-    hipLaunchKernelGGL(segsum_rows_v4, dim3(grid_for(N * (C / 4))), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(y), perm, seg_off,
-                       reinterpret_cast<float4*>(x), N, C / 4);
+    hipLaunchKernelGGL(segsum_wave<float4>, grid, block, 0, st, reinterpret_cast<const float4*>(y), perm,
+                       seg_off, reinterpret_cast<float4*>(x), N, C / 4);
   } else {
-    hipLaunchKernelGGL(segsum_rows_s, dim3(grid_for(N * C)), dim3(256), 0, st, y, perm, seg_off, x, N, C);
+    hipLaunchKernelGGL(segsum_wave<float>, grid, block, 0, st, y, perm, seg_off, x, N, C);
   }
   GN_LAUNCH_CHECK();
   return 0;

@@ -37,7 +37,8 @@ def _rowsize(t):
     return c
 
 def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_out=False,
-             mul=None, alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None):
+         mul=None, alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
+         ridx=None, res2=None, beta2=1.0, cfg=-1):
     """C = epilogue(opA(A) @ opB(B)); see gn_gemm_f32 in include/gemnet_hip.h.
     trans_b=False means B is a torch Linear weight (N, K).  Returns C or (C, pre)."""
     require_device(A, B)
@@ -68,9 +69,18 @@ def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_
     a.alpha = float(alpha)
     if res is not None:
         res = _f32c(res)
-        assert res.shape == C.shape
+        if ridx is None:
+            assert res.shape == C.shape
+        else:
+            assert res.shape[1] == N and ridx.dtype == torch.int32 and ridx.shape[0] == M
     a.res, a.ldres = ptr(res), N
     a.beta = float(beta)
+    a.ridx = ptr(ridx)
+    if res2 is not None:
+        res2 = _f32c(res2)
+        assert res2.shape == C.shape
+    a.res2, a.ldres2 = ptr(res2), N
+    a.beta2 = float(beta2)
     if gadd1 is not None:
         gadd1 = _f32c(gadd1)
         assert gadd1.shape[1] == N and gidx1.dtype == torch.int32 and gidx1.shape[0] == M
@@ -80,7 +90,7 @@ def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_
     a.gadd1, a.gidx1 = ptr(gadd1), ptr(gidx1)
     a.gadd2, a.gidx2 = ptr(gadd2), ptr(gidx2)
     a.ldg = N
-    check(_lib.load().gn_gemm_f32(ctypes.byref(a), stream()), "gn_gemm_f32")
+    check(_lib.load().gn_gemm_f32_cfg(ctypes.byref(a), int(cfg), stream()), "gn_gemm_f32")
     return (C, pre) if pre_out else C
 
 
@@ -121,6 +131,19 @@ def ssilu(x, k):
     out = torch.empty_like(x)
     check(_lib.load().gn_ssilu_f32(ptr(x), ptr(out), x.numel(), k, stream()), "gn_ssilu_f32")
     return out
+
+
+def dact_mul(g, z, act, mul, c, want_gmul=False):
+    """dz = g*c*(mul or 1)*(ssilu'(z) if act else 1); gmul = g*c*(ssilu(z) if act else z)."""
+    require_device(g)
+    g = _f32c(g)
+    z = None if z is None else _f32c(z)
+    mul = None if mul is None else _f32c(mul)
+    dz = torch.empty_like(g)
+    gmul = torch.empty_like(g) if want_gmul else None
+    check(_lib.load().gn_dact_mul_f32(ptr(g), ptr(z), int(bool(act)), ptr(mul), float(c), ptr(dz), ptr(gmul),
+                                      g.numel(), stream()), "gn_dact_mul_f32")
+    return dz, gmul
 
 
 def bil_reduce(Y, x, sp):

@@ -210,27 +210,32 @@ class GemNet(torch.nn.Module):
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
         if not self.direct_forces:
             inputs["R"].requires_grad = True
+        # second-order graph only when it can be used (see module docstring)
+        graph = self.force_graph
+        if graph is None:
+            graph = self.training and torch.is_grad_enabled() and not self.direct_forces
+        # fused single-launch layers whenever no double backward will run through them; the
+        # scale-factor fitting mode needs the unfused layer order to observe variances
+        fused = not graph and not AutomaticFit.fitting_mode
 
-        E_mol, F_ca, V_ca = self._energy(R, plan)
+        with ops.fused_first_order(fused):
+            E_mol, F_ca, V_ca = self._energy(R, plan)
 
-        if self.direct_forces:
-            if self.forces_coupled:  # enforce |F_ac| = |F_ca| (gemnet.py:588-592)
-                F_ca = ops.segsum_rows(F_ca, plan.id_undir) * 0.5
-                F_ca = ops.gather_rows(F_ca, plan.id_undir)
-            F_ji = F_ca[:, :, None] * V_ca[:, None, :]
-            F_j = ops.segsum_rows(F_ji, plan.id_a)                         # (nAtoms, num_targets, 3)
-        else:
-            graph = self.force_graph
-            if graph is None:
-                graph = self.training and torch.is_grad_enabled()
-            with ops.param_grads(False):  # only dE/dR is needed here
-                if self.num_targets > 1:
-                    F_j = torch.stack(
-                        [-torch.autograd.grad(E_mol[:, i].sum(), R, create_graph=graph, retain_graph=True)[0]
-                         for i in range(self.num_targets)], dim=1)
-                else:
-                    F_j = -torch.autograd.grad(E_mol.sum(), R, create_graph=graph)[0]
-            inputs["R"].requires_grad = False
+            if self.direct_forces:
+                if self.forces_coupled:  # enforce |F_ac| = |F_ca| (gemnet.py:588-592)
+                    F_ca = ops.segsum_rows(F_ca, plan.id_undir) * 0.5
+                    F_ca = ops.gather_rows(F_ca, plan.id_undir)
+                F_ji = F_ca[:, :, None] * V_ca[:, None, :]
+                F_j = ops.segsum_rows(F_ji, plan.id_a)                         # (nAtoms, num_targets, 3)
+            else:
+                with ops.param_grads(False):  # only dE/dR is needed here
+                    if self.num_targets > 1:
+                        F_j = torch.stack(
+                            [-torch.autograd.grad(E_mol[:, i].sum(), R, create_graph=graph, retain_graph=True)[0]
+                             for i in range(self.num_targets)], dim=1)
+                    else:
+                        F_j = -torch.autograd.grad(E_mol.sum(), R, create_graph=graph)[0]
+                inputs["R"].requires_grad = False
         return E_mol, F_j
 
     @staticmethod

@@ -51,11 +51,13 @@ class Dense(torch.nn.Module):
         else:
             raise NotImplementedError("Activation function not implemented for GemNet (yet).")
 
-    def forward(self, x):
-        y = ops.linear(x, self.weight)
+    def forward(self, x, **epilogue):
+        """`epilogue`: optional fused stages of ops.dense (mul/alpha/res/res_rows/beta/res2/beta2/g1..)."""
         if self.bias is not None:
-            y = y + self.bias
-        return ops.ssilu(y) if self.act else y
+            y = ops.linear(x, self.weight) + self.bias
+            assert not epilogue, "fused epilogues are not supported together with a bias"
+            return ops.ssilu(y) if self.act else y
+        return ops.dense(x, self.weight, self.act, **epilogue)
 
 
 class ResidualLayer(torch.nn.Module):
@@ -66,8 +68,17 @@ class ResidualLayer(torch.nn.Module):
         self.dense_mlp = torch.nn.Sequential(
             *[Dense(units, units, activation=activation, bias=False) for _ in range(nLayers)])
 
-    def forward(self, inputs):
-        return (inputs + self.dense_mlp(inputs)) * INV_SQRT_2
+    def forward(self, inputs, res2=None, beta2=1.0):
+        """(inputs + MLP(inputs))/sqrt(2), optionally followed by (. + res2)*beta2 — both residual adds
+        ride in the epilogue of the last GEMM."""
+        x = inputs
+        n = len(self.dense_mlp)
+        for i, layer in enumerate(self.dense_mlp):
+            if i + 1 < n:
+                x = layer(x)
+            else:
+                x = layer(x, res=inputs, beta=INV_SQRT_2, res2=res2, beta2=beta2)
+        return x
 
 
 class AtomEmbedding(torch.nn.Module):
@@ -95,10 +106,8 @@ class EdgeEmbedding(torch.nn.Module):
     def forward(self, h, m_rbf, id_c, id_a):
         A = self.atom_features
         W = self.dense.weight
-        z = (ops.gather_rows(ops.linear(h, W[:, :A]), id_c)
-             + ops.gather_rows(ops.linear(h, W[:, A:2 * A]), id_a)
-             + ops.linear(m_rbf, W[:, 2 * A:]))
-        return ops.ssilu(z) if self.dense.act else z
+        return ops.dense(m_rbf, W[:, 2 * A:], self.dense.act,
+                         g1=ops.dense(h, W[:, :A]), i1=id_c, g2=ops.dense(h, W[:, A:2 * A]), i2=id_a)
 
 
 class AtomUpdateBlock(torch.nn.Module):
@@ -116,12 +125,25 @@ class AtomUpdateBlock(torch.nn.Module):
         res = [ResidualLayer(units, nLayers=2, activation=activation) for _ in range(nHidden)]
         return torch.nn.ModuleList([dense1] + res)
 
-    def forward(self, h, m, rbf, id_a):
+    def _aggregate(self, m, rbf, id_a):
+        """scale * sum_{edges into atom} m * dense_rbf(rbf)   (atom_update_block.py:60-68)."""
+        if ops.is_fused():  # Hadamard and scale in the GEMM epilogue (linear: scale before the sum)
+            x = self.dense_rbf(rbf, mul=m, alpha=self.scale_sum.value())
+            return ops.segsum_rows(x, id_a), x
         x = m * self.dense_rbf(rbf)
-        x2 = ops.segsum_rows(x, id_a)
-        x = self.scale_sum(m, x2)
-        for layer in self.layers:
-            x = layer(x)
+        return self.scale_sum(m, ops.segsum_rows(x, id_a)), x
+
+    def forward(self, h, m, rbf, id_a, res2=None, beta2=1.0):
+        x, _ = self._aggregate(m, rbf, id_a)
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            if i + 1 == n and res2 is not None and isinstance(layer, ResidualLayer):
+                x = layer(x, res2=res2, beta2=beta2)
+                res2 = None
+            else:
+                x = layer(x)
+        if res2 is not None:
+            x = (x + res2) * beta2
         return x
 
 
@@ -157,13 +179,15 @@ class OutputBlock(AtomUpdateBlock):
             raise UserWarning(f"Unknown output_init: {self.output_init}")
 
     def forward(self, h, m, rbf, id_a):
-        x = m * self.dense_rbf(rbf)
-        x_E = self.scale_sum(m, ops.segsum_rows(x, id_a))
+        x_E, x = self._aggregate(m, rbf, id_a)
         for layer in self.seq_energy:
             x_E = layer(x_E)
         x_E = self.out_energy(x_E)
         if self.direct_forces:
-            x_F = self.scale_rbf(m, x)
+            if ops.is_fused():  # x already carries scale_sum: rescale to scale_rbf
+                x_F = x * (self.scale_rbf.value() / self.scale_sum.value())
+            else:
+                x_F = self.scale_rbf(m, x)
             for layer in self.seq_forces:
                 x_F = layer(x_F)
             x_F = self.out_forces(x_F)
@@ -219,12 +243,8 @@ class EfficientInteractionBilinear(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.empty((emb_size, emb_size_interm, units_out)))
         he_orthogonal_init(self.weight)
 
-    def forward(self, rbf_W1, sph, x, seg_plan):
-        C, I, O = self.weight.shape
-        Sm = ops.bil_reduce(sph, x, seg_plan)                # (E,S,C)
-        P = ops.bmm(rbf_W1, Sm, True, False)                 # (E,S,I)^T @ (E,S,C) -> (E,I,C)
-        W2 = self.weight.permute(1, 0, 2).reshape(I * C, O)  # rows ordered (i,c) like P.reshape
-        return ops.mm(P.reshape(-1, I * C), W2, False, True)
+    def forward(self, rbf_W1, sph, x, seg_plan, alpha=1.0):
+        return ops.bilinear(rbf_W1, sph, x, self.weight, seg_plan, alpha)
 
 
 # ------------------------------------------------------------------------------ basis layers
@@ -334,6 +354,12 @@ class TripletInteraction(torch.nn.Module):
     def forward(self, m, rbf3, cbf3, plan):
         rbf_W1, sph = cbf3
         x_ba = self.dense_ba(m)
+        if ops.is_fused():
+            x_ba = self.mlp_rbf(rbf3, mul=x_ba, alpha=self.scale_rbf.value())
+            x_ba = self.down_projection(x_ba)
+            x = self.mlp_cbf(rbf_W1, sph, x_ba, plan.trip, alpha=self.scale_cbf_sum.value())
+            # (up_ca(x) + up_ac(x)[id_swap]) / sqrt2: the swapped rows are gathered in the epilogue
+            return self.up_projection_ca(x, res=self.up_projection_ac(x), res_rows=plan.id_swap, beta=INV_SQRT_2)
         x_ba = self.scale_rbf(x_ba, x_ba * self.mlp_rbf(rbf3))
         x_ba = self.down_projection(x_ba)
         # gather by id3_expand_ba is fused into the segmented reduce (no (T,C) tensor)
@@ -363,6 +389,12 @@ class QuadrupletInteraction(torch.nn.Module):
     def forward(self, m, rbf, cbf, sbf, plan):
         rbf_W1, sph = sbf
         x_db = self.dense_db(m)
+        if ops.is_fused():
+            x_db = self.mlp_rbf(rbf, mul=x_db, alpha=self.scale_rbf.value())
+            x_db = ops.gather_rows(self.down_projection(x_db), plan.intm_db)
+            x_db = self.mlp_cbf(cbf, mul=x_db, alpha=self.scale_cbf.value())
+            x = self.mlp_sbf(rbf_W1, sph, x_db, plan.quad, alpha=self.scale_sbf_sum.value())
+            return self.up_projection_ca(x, res=self.up_projection_ac(x), res_rows=plan.id_swap, beta=INV_SQRT_2)
         x_db = self.scale_rbf(x_db, x_db * self.mlp_rbf(rbf))
         x_db = self.down_projection(x_db)
         x_db = ops.gather_rows(x_db, plan.intm_db)                 # (I, emb_quad)
@@ -388,18 +420,23 @@ class _InteractionBase(torch.nn.Module):
         self.residual_m = torch.nn.ModuleList(
             [ResidualLayer(emb_size_edge, activation=activation) for _ in range(num_concat)])
 
+    @staticmethod
+    def _chain_then_skip(layers, x, skip):
+        """(skip + layers(x)) / sqrt2 with the skip add folded into the last residual layer's epilogue."""
+        n = len(layers)
+        if n == 0:
+            return (skip + x) * INV_SQRT_2
+        for i, layer in enumerate(layers):
+            x = layer(x, res2=skip, beta2=INV_SQRT_2) if i + 1 == n else layer(x)
+        return x
+
     def _update(self, h, m, x, rbf_h, plan):
-        for layer in self.layers_before_skip:
-            x = layer(x)
-        m = (m + x) * INV_SQRT_2
+        m = self._chain_then_skip(self.layers_before_skip, x, m)
         for layer in self.layers_after_skip:
             m = layer(m)
-        h2 = self.atom_update(h, m, rbf_h, plan.id_a)
-        h = (h + h2) * INV_SQRT_2
+        h = self.atom_update(h, m, rbf_h, plan.id_a, res2=h, beta2=INV_SQRT_2)
         m2 = self.concat_layer(h, m, plan.id_c, plan.id_a)
-        for layer in self.residual_m:
-            m2 = layer(m2)
-        m = (m + m2) * INV_SQRT_2
+        m = self._chain_then_skip(self.residual_m, m2, m)
         return h, m
 
 
@@ -419,7 +456,7 @@ class InteractionBlockTripletsOnly(_InteractionBase):
                            num_concat, num_atom, activation, scale_file, block_nr)
 
     def forward(self, h, m, rbf3, cbf3, rbf_h, plan, **kwargs):
-        x = (self.dense_ca(m) + self.trip_interaction(m, rbf3, cbf3, plan)) * INV_SQRT_2
+        x = self.dense_ca(m, res=self.trip_interaction(m, rbf3, cbf3, plan), beta=INV_SQRT_2)
         return self._update(h, m, x, rbf_h, plan)
 
 
@@ -445,5 +482,5 @@ class InteractionBlock(_InteractionBase):
     def forward(self, h, m, rbf4, cbf4, sbf4, rbf3, cbf3, rbf_h, plan, **kwargs):
         x4 = self.quad_interaction(m, rbf4, cbf4, sbf4, plan)
         x3 = self.trip_interaction(m, rbf3, cbf3, plan)
-        x = (self.dense_ca(m) + x3 + x4) * INV_SQRT_3
+        x = self.dense_ca(m, res=x3, beta=1.0, res2=x4, beta2=INV_SQRT_3)
         return self._update(h, m, x, rbf_h, plan)

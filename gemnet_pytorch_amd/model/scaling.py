@@ -106,7 +106,18 @@ class ScalingFactor(torch.nn.Module):
         self.scale_factor = torch.nn.Parameter(torch.tensor(1.0, device=device), requires_grad=False)
         self.autofit = AutoScaleFit(self.scale_factor, scale_file, name)
 
+        self._cached = None  # (tensor version, python float)
+
     def forward(self, x_ref, y):
         y = y * self.scale_factor
         self.autofit.observe(x_ref, y)
         return y
+
+    def value(self) -> float:
+        """The factor as a host scalar (folded into GEMM epilogues by the fused path).  Read back from
+        the device once per change of the parameter (tensor version counter), never per forward."""
+        sf = self.scale_factor
+        c = self._cached
+        if c is None or c[0] != sf._version or c[2] != sf.data_ptr():
+            self._cached = c = (sf._version, float(sf.detach().cpu()), sf.data_ptr())
+        return c[1]

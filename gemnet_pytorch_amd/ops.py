@@ -309,3 +309,199 @@ class _Ylm(torch.autograd.Function):
 def ylm(theta, phi, S):
     """(Q,),(Q,) -> (Q, S^2) real Y_lm in the reference order   (TensorBasisLayer, basis_layers.py:269)."""
     return _Ylm.apply(theta, phi, int(S), 0, 0)
+
+
+# =========================================================================================
+# Fused first-order path
+# =========================================================================================
+# When no second-order graph is needed (inference forces, direct-force training) every Dense is ONE
+# GEMM launch forward (gather-add / ScaledSiLU / Hadamard / scale / residual(s) in the epilogue) and
+# ONE backward (the activation derivative applied to the A operand while it is staged into LDS),
+# instead of the ~6 launches of the composite closure above.  `fused_first_order(False)` — set by
+# GemNet.forward when it builds the force with create_graph=True — routes the same calls through
+# the differentiable composite ops instead.
+_FUSED = True
+
+
+@contextlib.contextmanager
+def fused_first_order(enabled: bool):
+    global _FUSED
+    old = _FUSED
+    _FUSED = enabled
+    try:
+        yield
+    finally:
+        _FUSED = old
+
+
+def is_fused():
+    return _FUSED
+
+
+_WT_CACHE = {}
+
+
+def transposed(W):
+    """W^T contiguous, so backward GEMMs also run the k-contiguous ("NT") pipelined kernel.  Cached
+    for frozen weights (inference); recomputed per call for trainable ones."""
+    if W.requires_grad:
+        return W.detach().t().contiguous()
+    key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()))
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0] == W._version:
+        return hit[1]
+    Wt = W.detach().t().contiguous()
+    if len(_WT_CACHE) > 4096:
+        _WT_CACHE.clear()
+    _WT_CACHE[key] = (W._version, Wt)
+    return Wt
+
+
+class _FusedDense(torch.autograd.Function):
+    """y = epilogue(x @ W^T); see gn_gemm_f32.  First-order backward only."""
+
+    @staticmethod
+    def forward(ctx, x, W, mul, res, res2, g1, g2, cfg):
+        act, alpha, beta, beta2, res_rows, i1, i2 = cfg
+        need_z = act or mul is not None
+        out = K.gemm(x, W, act=act, pre_out=need_z, mul=mul, alpha=alpha,
+                     res=res, ridx=None if res_rows is None else res_rows.idx32, beta=beta,
+                     res2=res2, beta2=beta2,
+                     gadd1=g1, gidx1=None if i1 is None else i1.idx32,
+                     gadd2=g2, gidx2=None if i2 is None else i2.idx32)
+        y, z = out if need_z else (out, None)
+        ctx.cfg = cfg
+        ctx.has = (mul is not None, res is not None, res2 is not None, g1 is not None, g2 is not None)
+        keep_x = W.requires_grad and _PARAM_GRADS
+        ctx.save_for_backward(x if keep_x else None, W, z, mul)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, W, z, mul = ctx.saved_tensors
+        act, alpha, beta, beta2, res_rows, i1, i2 = ctx.cfg
+        has_mul, has_res, has_res2, has_g1, has_g2 = ctx.has
+        need = ctx.needs_input_grad
+        g = g.contiguous()
+        gx = gW = gmul = gres = gres2 = gg1 = gg2 = None
+        c = 1.0
+        if has_res2:
+            if need[4]:
+                gres2 = g * beta2
+            c *= beta2
+        if has_res:
+            c *= beta
+            if need[3]:
+                t = g * c
+                if res_rows is None:
+                    gres = t
+                elif res_rows.inverse is not None:
+                    gres = K.gather(t, res_rows.inverse.idx32)
+                else:
+                    gres = K.segsum(t, *res_rows.csr, res_rows.n_rows)
+        c *= alpha
+        want_w = need[1] and _PARAM_GRADS and x is not None
+        want_gmul = has_mul and need[2]
+        explicit = has_mul or want_w or (has_g1 and need[5]) or (has_g2 and need[6])
+        if explicit:
+            dz, gmul = K.dact_mul(g, z, act, mul, c, want_gmul=want_gmul)
+            if need[0]:
+                gx = K.gemm(dz, transposed(W))
+            if has_g1 and need[5]:
+                gg1 = K.segsum(dz, *i1.csr, i1.n_rows)
+            if has_g2 and need[6]:
+                gg2 = K.segsum(dz, *i2.csr, i2.n_rows)
+            if want_w:
+                gW = K.gemm(dz, x, True, True)          # dz^T @ x  (N, K)
+        elif need[0]:
+            gx = K.gemm(g, transposed(W), a_dact_pre=z if act else None, alpha=c)
+        return gx, gW, gmul, gres, gres2, gg1, gg2, None
+
+
+def dense(x, W, act=False, *, mul=None, alpha=1.0, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0,
+          g1=None, i1=None, g2=None, i2=None):
+    """y0 = act(x W^T + g1[i1] + g2[i2]) (* mul) * alpha;  y1 = (y0 + res[res_rows]) * beta;
+    y = (y1 + res2) * beta2   — every optional stage skipped when its tensor is None."""
+    if _FUSED:
+        return _FusedDense.apply(x, W, mul, res, res2, g1, g2, (bool(act), float(alpha), float(beta), float(beta2),
+                                                                res_rows, i1, i2))
+    z = linear(x, W)
+    if g1 is not None:
+        z = z + gather_rows(g1, i1)
+    if g2 is not None:
+        z = z + gather_rows(g2, i2)
+    y = ssilu(z) if act else z
+    if mul is not None:
+        y = y * mul
+    if alpha != 1.0:
+        y = y * alpha
+    if res is not None:
+        y = (y + (res if res_rows is None else gather_rows(res, res_rows))) * beta
+    if res2 is not None:
+        y = (y + res2) * beta2
+    return y
+
+
+class _FusedBilinear(torch.autograd.Function):
+    """out = alpha * K3(K2(rbf_W1, K1(sph, x)))  (SURVEY.md Appendix D), first-order backward."""
+
+    @staticmethod
+    def forward(ctx, rbf_W1, sph, x, W, sp, alpha):
+        C, I, O = W.shape
+        Sm = K.bil_reduce(sph, x, sp)                       # (E,S,C)
+        P = K.bmm(rbf_W1, Sm, True, False)                  # (E,I,C)
+        W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)  # rows (i,c)
+        out = K.gemm(P.reshape(-1, I * C), transposed_2d(W2, W), alpha=alpha)
+        keep_p = W.requires_grad and _PARAM_GRADS
+        ctx.save_for_backward(rbf_W1, sph, x, W, Sm, P if keep_p else None)
+        ctx.sp, ctx.alpha = sp, alpha
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        rbf_W1, sph, x, W, Sm, P = ctx.saved_tensors
+        C, I, O = W.shape
+        sp, alpha = ctx.sp, ctx.alpha
+        need = ctx.needs_input_grad
+        g = g.contiguous()
+        W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)
+        dP = K.gemm(g, W2, alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is already (N=I*C, K=O)
+        gB = K.bmm(Sm, dP, False, True) if need[0] else None          # (E,S,C)@(E,I,C)^T -> (E,S,I)
+        gsph = gx = gW = None
+        if need[1] or need[2]:
+            dSm = K.bmm(rbf_W1, dP, False, False)                      # (E,S,I)@(E,I,C) -> (E,S,C)
+            if need[1]:
+                gsph = K.bil_dot(dSm, x, sp)
+            if need[2]:
+                gx = K.bil_reduce_t(sph, dSm, sp)
+        if need[3] and _PARAM_GRADS and P is not None:
+            gW2 = K.gemm(P.reshape(-1, I * C), g, True, True, alpha=alpha)   # P^T @ g  (I*C, O)
+            gW = gW2.reshape(I, C, O).permute(1, 0, 2)
+        return gB, gsph, gx, gW, None, None
+
+
+def transposed_2d(W2, owner):
+    """W2^T contiguous, cached on the owning (frozen) parameter's version."""
+    if owner.requires_grad:
+        return W2.t().contiguous()
+    key = ("bil", owner.data_ptr(), tuple(owner.shape))
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0] == owner._version:
+        return hit[1]
+    Wt = W2.t().contiguous()
+    _WT_CACHE[key] = (owner._version, Wt)
+    return Wt
+
+
+def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
+    """efficient.py:159-189: out[e,o] = alpha * sum_{t in seg(e)} sum_{s,i,c} sph[t,s] rbf_W1[e,s,i] x[g(t),c] W[c,i,o]."""
+    if _FUSED:
+        return _FusedBilinear.apply(rbf_W1, sph, x, W, sp, float(alpha))
+    C, I, O = W.shape
+    Sm = bil_reduce(sph, x, sp)
+    P = bmm(rbf_W1, Sm, True, False)
+    W2 = W.permute(1, 0, 2).reshape(I * C, O)
+    out = mm(P.reshape(-1, I * C), W2, False, True)
+    return out * alpha if alpha != 1.0 else out

@@ -39,7 +39,8 @@ const char* gn_error_string(int code);
  *   y = act ? ssilu(z) : z ;  ssilu(z) = z*sigmoid(z)/0.6   (base_layers.py:51-58)
  *   if mul: y *= mul[m*ldmul+n]
  *   y *= alpha
- *   if res: y = (y + res[m*ldres+n]) * beta
+ *   if res: y = (y + res[(ridx ? ridx[m] : m)*ldres+n]) * beta
+ *   if res2: y = (y + res2[m*ldres2+n]) * beta2
  *   C[m*ldc+n] = y
  */
 typedef struct {
@@ -57,8 +58,13 @@ typedef struct {
   const float* gadd1; const int32_t* gidx1;
   const float* gadd2; const int32_t* gidx2;
   int ldg;
+  const int32_t* ridx;
+  const float* res2; int ldres2;
+  float beta2;
 } gn_gemm_args;
 int gn_gemm_f32(const gn_gemm_args* args, void* stream);
+/* Same contraction with an explicit tile variant (cfg >= 0; tuning and tests).  cfg < 0 = automatic. */
+int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream);
 
 /* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
  * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */
@@ -107,6 +113,10 @@ int gn_ylm_f32(const float* theta, const float* phi, float* out, int64_t Q, int 
 /* ---- pointwise -------------------------------------------------------------------------
  * out[i] = d^k/dx^k ssilu(x[i]), k in {0,1,2,3}   (base_layers.py:51-58) */
 int gn_ssilu_f32(const float* x, float* out, int64_t n, int k, void* stream);
+/* backward glue of a fused Dense: with a = act ? ssilu'(z) : 1 and y0 = act ? ssilu(z) : z,
+ *   dz[i] = g[i] * c * (mul ? mul[i] : 1) * a      gmul[i] = g[i] * c * y0   (if gmul != NULL) */
+int gn_dact_mul_f32(const float* g, const float* z, int act, const float* mul, float c, float* dz,
+                    float* gmul, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ def _act(z, k):
 
 
 def gemm(A, B_, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_out=False, mul=None,
-         alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None):
+         alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
+         ridx=None, res2=None, beta2=1.0, cfg=-1):
     a = A
     if a_dact_pre is not None:
         a = a * _act(a_dact_pre, 1)
@@ -43,8 +44,17 @@ def gemm(A, B_, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre
         y = y * mul
     y = y * alpha
     if res is not None:
-        y = (y + res) * beta
+        y = (y + (res if ridx is None else res[ridx.long()])) * beta
+    if res2 is not None:
+        y = (y + res2) * beta2
     return (y, z) if pre_out else y
+
+
+def dact_mul(g, z, act, mul, c, want_gmul=False):
+    a = _act(z, 1) if act else 1.0
+    dz = g * c * (mul if mul is not None else 1.0) * a
+    gmul = g * c * (_act(z, 0) if act else z) if want_gmul else None
+    return dz, gmul
 
 
 def gather(x, idx32):
@@ -149,7 +159,7 @@ def ylm(theta, phi, S, kt, kp):
     return torch.stack(cols, 1)
 
 
-_NAMES = ["gemm", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -182,3 +182,34 @@ def test_ylm(kt, kp, golden_basis):
     close(K.ylm(f32(th), f32(ph), 7, kt, kp), ref, atol=2e-6 * max(1.0, float(ref.abs().max())))
     if (kt, kp) == (0, 0):
         close(K.ylm(f32(th), f32(ph), 7, 0, 0), torch.tensor(golden_basis["y_lm"]), atol=1e-5)
+
+
+def test_gemm_row_gathered_and_second_residual():
+    g = torch.Generator().manual_seed(9)
+    M, N, Kd = 515, 128, 64
+    A, W = rnd(g, M, Kd), rnd(g, N, Kd) / np.sqrt(Kd)
+    res, res2 = rnd(g, M, N), rnd(g, M, N)
+    ridx = torch.randperm(M, generator=g).to(torch.int32)
+    kw = dict(act=True, alpha=1.3, beta=0.7, beta2=0.6)
+    ref = CK.gemm(A, W, res=res, ridx=ridx, res2=res2, **kw)
+    out = K.gemm(f32(A), f32(W), res=f32(res), ridx=ridx.to(DEV), res2=f32(res2), **kw)
+    close(out, ref, atol=5e-5)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(1024, 128, 128), (1000, 64, 128), (300, 32, 64), (18000, 128, 128),
+                                    (18001, 64, 1024), (5000, 32, 128)])
+def test_gemm_pipelined_nt_all_tile_configs(M, N, Kd):
+    g = torch.Generator().manual_seed(M + N)
+    A, W, pre = rnd(g, M, Kd), rnd(g, N, Kd) / np.sqrt(Kd), rnd(g, M, Kd)
+    close(K.gemm(f32(A), f32(W)), CK.gemm(A, W), atol=1e-4)
+    close(K.gemm(f32(A), f32(W), a_dact_pre=f32(pre), alpha=0.5), CK.gemm(A, W, a_dact_pre=pre, alpha=0.5), atol=1e-4)
+
+
+@pytest.mark.parametrize("act,has_mul", [(True, True), (True, False), (False, True)])
+def test_dact_mul(act, has_mul):
+    g = torch.Generator().manual_seed(3)
+    gr, z, mul = rnd(g, 777, 64), rnd(g, 777, 64), rnd(g, 777, 64)
+    ref_dz, ref_gm = CK.dact_mul(gr, z, act, mul if has_mul else None, 0.37, want_gmul=True)
+    dz, gm = K.dact_mul(f32(gr), f32(z), act, f32(mul) if has_mul else None, 0.37, want_gmul=True)
+    close(dz, ref_dz, atol=1e-5)
+    close(gm, ref_gm, atol=1e-5)

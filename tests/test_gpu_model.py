@@ -83,6 +83,51 @@ def test_repeatable_bitwise(golden_model):
 def test_native_library_loaded():
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
-    assert lib.gn_abi_version() == 1
+    assert lib.gn_abi_version() == 2
     with open("/proc/self/maps") as f:
         assert "libgemnet_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("triplets_only", [True, False])
+def test_direct_forces_fused_equals_composite(golden_model, triplets_only):
+    """GemNet-dT/dQ on the GPU: fused single-launch layers vs the composite op closure."""
+    tag = "t1" if triplets_only else "q1"
+    cfg, _, inputs = load_case(golden_model, tag)
+    cfg = dict(cfg, direct_forces=True, forces_coupled=True)
+    params = GO.make_params(cfg, 11, GO.load_scale_factors(SCALE_FILE))
+    res = {}
+    for mode in ("fused", "composite"):
+        model = build(cfg, params).train()
+        model.force_graph = (mode == "composite")
+        E, F = model(to_dev(inputs))
+        (E.sum() + (F ** 2).sum()).backward()
+        res[mode] = (E.detach(), F.detach(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                              if p.grad is not None})
+    fs = max(1.0, float(res["composite"][1].abs().mean()))
+    assert float((res["fused"][1] - res["composite"][1]).abs().mean()) <= 1e-5 * fs
+    for n, gr in res["composite"][2].items():
+        ref = float(gr.norm())
+        assert abs(float(res["fused"][2][n].norm()) - ref) <= 2e-3 * ref + 1e-6, n
+
+
+def test_eval_forward_force_in_hipgraph(golden_model):
+    """The whole forward+force step replays from one hipGraph and matches the eager result."""
+    cfg, params, inputs = load_case(golden_model, "t2")
+    model = build(cfg, params).eval()
+    model.requires_grad_(False)
+    dev = to_dev(inputs)
+    for _ in range(2):
+        model(dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model(dev)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        Eg, Fg = model(dev)
+    graph.replay()
+    torch.cuda.synchronize()
+    E, F = model(dev)
+    assert torch.equal(E, Eg) and torch.equal(F, Fg)

@@ -50,15 +50,47 @@ def test_energy_force_and_training_grads(golden_model, tag):
             np.testing.assert_allclose(named[n].grad.numpy(), g[key], rtol=1e-6, atol=1e-10)
 
 
-def test_eval_mode_first_order_only(golden_model):
+@pytest.mark.parametrize("tag", ["t1", "q1", "t2"])
+def test_eval_mode_fused_first_order_path(golden_model, tag):
+    """eval(): single-launch fused layers + first-order backward; same E/F as the reference."""
     g = golden_model
-    cfg, params, inputs = load_case(g, "t1")
+    cfg, params, inputs = load_case(g, tag)
     with cpu_kernels.emulate():
         model = build(cfg, params).eval()
         inputs["R"] = inputs["R"].double()
         E, F = model(inputs)
     assert not F.requires_grad and inputs["R"].requires_grad is False
-    assert np.abs(F.numpy() - g["t1.F"]).mean() <= 1e-9 * max(1.0, float(np.abs(g["t1.F"]).mean()))
+    Fref, Eref = g[f"{tag}.F"], g[f"{tag}.E"]
+    assert np.abs(F.numpy() - Fref).mean() <= 1e-9 * max(1.0, float(np.abs(Fref).mean()))
+    assert np.abs(E.detach().numpy() - Eref).max() <= 1e-9 * max(1.0, np.abs(Eref).max())
+
+
+@pytest.mark.parametrize("triplets_only", [True, False])
+def test_direct_forces_fused_equals_composite(golden_model, triplets_only):
+    """GemNet-dT/dQ (first-order training): fused layers give the same outputs and parameter
+    gradients as the composite op closure."""
+    from gemnet_pytorch_amd import ops
+    tag = "t1" if triplets_only else "q1"
+    cfg, _, inputs = load_case(golden_model, tag)
+    cfg = dict(cfg, direct_forces=True, forces_coupled=True)
+    sf = GO.load_scale_factors(SCALE_FILE)
+    params = GO.make_params(cfg, 11, sf)
+    inputs["R"] = inputs["R"].double()
+    res = {}
+    with cpu_kernels.emulate():
+        for mode in ("fused", "composite"):
+            model = build(cfg, params).train()
+            model.force_graph = (mode == "composite")  # graph=True routes through the composite ops
+            E, F = model(inputs)
+            assert F.shape == (inputs["R"].shape[0], 1, 3)
+            (E.sum() + (F ** 2).sum()).backward()
+            res[mode] = (E.detach(), F.detach(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                                  if p.grad is not None})
+    assert torch.allclose(res["fused"][0], res["composite"][0], rtol=1e-10, atol=1e-12)
+    assert torch.allclose(res["fused"][1], res["composite"][1], rtol=1e-10, atol=1e-12)
+    assert res["fused"][2].keys() == res["composite"][2].keys() and len(res["fused"][2]) > 20
+    for n, gr in res["fused"][2].items():
+        assert torch.allclose(gr, res["composite"][2][n], rtol=1e-8, atol=1e-11), n
 
 
 @pytest.mark.parametrize("variant,extra", [("T", {}), ("Q", {}), ("dT", {"direct_forces": True})])
