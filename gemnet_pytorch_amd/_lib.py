@@ -52,6 +52,10 @@ SIGNATURES = {
     "gn_sph_radial_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _i, _vp],
     "gn_ylm0_f32": [_vp, _vp, _i64, _i, _i, _vp],
     "gn_ylm_f32": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "gn_edge_basis_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
+    "gn_edge_basis_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
+    "gn_trip_basis_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "gn_trip_basis_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_ssilu_f32": [_vp, _vp, _i64, _i, _vp],
     "gn_dact_mul_f32": [_vp, _vp, _i, _vp, _f, _vp, _vp, _i64, _vp],
 }

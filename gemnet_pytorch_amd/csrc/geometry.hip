@@ -1,0 +1,179 @@
+// Geometry fused with the basis evaluation (first-order path).
+//
+// Reference: calculate_interatomic_vectors gemnet/model/gemnet.py:261-286, calculate_neighbor_angles
+// :288-311, calculate_angles3 :420-451 feeding BesselBasisLayer / SphericalBasisLayer
+// (layers/basis_layers.py:45-49,119-131) — ~60 pointwise ATen launches over (E,3)/(T,3) temporaries
+// in the reference.  Here: one kernel per edge (distance -> Bessel rbf + spherical-Bessel radial
+// basis), one per triplet (angle -> Y_l0), and their adjoints, which recompute the geometry from R
+// instead of reading saved temporaries and emit per-edge / per-triplet position gradients that the
+// deterministic CSR segmented sum (rows.hip) reduces onto atoms.
+#include "common.h"
+#include "basis_math.h"
+
+namespace {
+
+// D[e] = |R[a]-R[c]|; rbf[e,n]; rad[e,l,n]
+__global__ void edge_basis_fwd_kernel(const float* __restrict__ R, const int32_t* __restrict__ id_c,
+                                      const int32_t* __restrict__ id_a, const float* __restrict__ freq,
+                                      const float* __restrict__ z, const double* __restrict__ nrm,
+                                      float* __restrict__ D, float* __restrict__ V, float* __restrict__ rbf,
+                                      float* __restrict__ rad, int64_t E, int NR, int S, double cutoff, int p) {
+  const int per = 1 + NR + S * NR;  // work items per edge: distance, rbf, radial
+  const int64_t n = E * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / per;
+    const int j = (int)(i - e * per);
+    const float* Ra = R + 3 * (int64_t)id_a[e];
+    const float* Rc = R + 3 * (int64_t)id_c[e];
+    // same f32 arithmetic as the reference: V = Rt - Rs; D = sqrt(sum(V^2))
+    const float vx = Ra[0] - Rc[0], vy = Ra[1] - Rc[1], vz = Ra[2] - Rc[2];
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    if (j == 0) {
+      D[e] = d;
+      if (V) { V[3 * e] = vx / d; V[3 * e + 1] = vy / d; V[3 * e + 2] = vz / d; }
+    } else if (j <= NR) {
+      rbf[e * NR + (j - 1)] = (float)bessel_rbf_eval((double)d, (double)freq[j - 1], cutoff, p, 0, 0);
+    } else {
+      const int lr = j - 1 - NR;
+      rad[e * S * NR + lr] = (float)sph_radial_eval((double)d, (double)z[lr], nrm[lr], lr / NR, cutoff, p, 0);
+    }
+  }
+}
+
+// W[e,:] = gD[e] * V[e,:] with gD = g_D + sum_n g_rbf f'_n(d) + sum_{l,n} g_rad R'_ln(d)
+__global__ void edge_basis_bwd_kernel(const float* __restrict__ g_D, const float* __restrict__ g_rbf,
+                                      const float* __restrict__ g_rad, const float* __restrict__ R,
+                                      const int32_t* __restrict__ id_c, const int32_t* __restrict__ id_a,
+                                      const float* __restrict__ freq, const float* __restrict__ z,
+                                      const double* __restrict__ nrm, float* __restrict__ Wout, int64_t E,
+                                      int NR, int S, double cutoff, int p) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const float* Ra = R + 3 * (int64_t)id_a[e];
+    const float* Rc = R + 3 * (int64_t)id_c[e];
+    const float vx = Ra[0] - Rc[0], vy = Ra[1] - Rc[1], vz = Ra[2] - Rc[2];
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    double g = g_D ? (double)g_D[e] : 0.0;
+    if (g_rbf)
+      for (int n = 0; n < NR; ++n)
+        g += (double)g_rbf[e * NR + n] * bessel_rbf_eval((double)d, (double)freq[n], cutoff, p, 1, 0);
+    if (g_rad)
+      for (int lr = 0; lr < S * NR; ++lr)
+        g += (double)g_rad[e * S * NR + lr] * sph_radial_eval((double)d, (double)z[lr], nrm[lr], lr / NR, cutoff, p, 1);
+    const float s = (float)(g / (double)d);
+    Wout[3 * e] = s * vx; Wout[3 * e + 1] = s * vy; Wout[3 * e + 2] = s * vz;
+  }
+}
+
+struct Ang { float ux, uy, uz, vx, vy, vz, wx, wy, wz, x, y; bool clamped; };
+
+__device__ __forceinline__ Ang angle_of(const float* __restrict__ R, int c, int a, int b) {
+  Ang g;
+  const float* Ra = R + 3 * (int64_t)a;
+  const float* Rc = R + 3 * (int64_t)c;
+  const float* Rb = R + 3 * (int64_t)b;
+  g.ux = Rc[0] - Ra[0]; g.uy = Rc[1] - Ra[1]; g.uz = Rc[2] - Ra[2];
+  g.vx = Rb[0] - Ra[0]; g.vy = Rb[1] - Ra[1]; g.vz = Rb[2] - Ra[2];
+  g.x = g.ux * g.vx + g.uy * g.vy + g.uz * g.vz;
+  g.wx = g.uy * g.vz - g.uz * g.vy;
+  g.wy = g.uz * g.vx - g.ux * g.vz;
+  g.wz = g.ux * g.vy - g.uy * g.vx;
+  const float yn = sqrtf(g.wx * g.wx + g.wy * g.wy + g.wz * g.wz);
+  g.clamped = yn < 1e-9f;          // torch.max(y, 1e-9): gradient through y vanishes (gemnet.py:309)
+  g.y = g.clamped ? 1e-9f : yn;
+  return g;
+}
+
+// Y[t,l] = Y_l0(angle(c<-a->b)); optionally theta[t]
+__global__ void trip_basis_fwd_kernel(const float* __restrict__ R, const int32_t* __restrict__ tc,
+                                      const int32_t* __restrict__ ta, const int32_t* __restrict__ tb,
+                                      float* __restrict__ Y, float* __restrict__ theta, int64_t T, int S) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < T;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const Ang g = angle_of(R, tc[t], ta[t], tb[t]);
+    const float th = atan2f(g.y, g.x);
+    if (theta) theta[t] = th;
+    ylm0_row((double)th, S, 0, Y + t * S);
+  }
+}
+
+// Gc[t,:] = dE/dR_c, Gb[t,:] = dE/dR_b of triplet t given gY[t,:]  (dE/dR_a = -(Gc+Gb))
+__global__ void trip_basis_bwd_kernel(const float* __restrict__ gY, const float* __restrict__ R,
+                                      const int32_t* __restrict__ tc, const int32_t* __restrict__ ta,
+                                      const int32_t* __restrict__ tb, float* __restrict__ Gc,
+                                      float* __restrict__ Gb, int64_t T, int S) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < T;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const Ang g = angle_of(R, tc[t], ta[t], tb[t]);
+    const float th = atan2f(g.y, g.x);
+    float dY[8];
+    ylm0_row((double)th, S, 1, dY);
+    float gth = 0.f;
+    for (int l = 0; l < S; ++l) gth += gY[t * S + l] * dY[l];
+    const float r2 = g.x * g.x + g.y * g.y;
+    const float dx = -g.y / r2 * gth;                    // dtheta/dx * g
+    const float dy = g.clamped ? 0.f : g.x / r2 * gth;   // dtheta/dy * g
+    // y = |w|, w = u x v, n = w/|w|: dy/du = v x n, dy/dv = n x u
+    const float iy = g.clamped ? 0.f : 1.0f / g.y;
+    const float nx = g.wx * iy, ny = g.wy * iy, nz = g.wz * iy;
+    Gc[3 * t] = dx * g.vx + dy * (g.vy * nz - g.vz * ny);
+    Gc[3 * t + 1] = dx * g.vy + dy * (g.vz * nx - g.vx * nz);
+    Gc[3 * t + 2] = dx * g.vz + dy * (g.vx * ny - g.vy * nx);
+    Gb[3 * t] = dx * g.ux + dy * (ny * g.uz - nz * g.uy);
+    Gb[3 * t + 1] = dx * g.uy + dy * (nz * g.ux - nx * g.uz);
+    Gb[3 * t + 2] = dx * g.uz + dy * (nx * g.uy - ny * g.ux);
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int gn_edge_basis_fwd_f32(const float* R, const int32_t* id_c, const int32_t* id_a,
+                                     const float* freq, const float* z, const double* nrm, float* D, float* V,
+                                     float* rbf, float* rad, int64_t E, int NR, int S, float cutoff, int p,
+                                     void* stream) {
+  if (E <= 0) return 0;
+  if (p < 2 || S > 8) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(edge_basis_fwd_kernel, dim3(grid_for(E * (1 + NR + S * NR))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), R, id_c, id_a, freq, z, nrm, D, V, rbf, rad, E, NR, S,
+                     (double)cutoff, p);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_edge_basis_bwd_f32(const float* g_D, const float* g_rbf, const float* g_rad, const float* R,
+                                     const int32_t* id_c, const int32_t* id_a, const float* freq,
+                                     const float* z, const double* nrm, float* W, int64_t E, int NR, int S,
+                                     float cutoff, int p, void* stream) {
+  if (E <= 0) return 0;
+  if (p < 2 || S > 8) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(edge_basis_bwd_kernel, dim3(grid_for(E)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     g_D, g_rbf, g_rad, R, id_c, id_a, freq, z, nrm, W, E, NR, S, (double)cutoff, p);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_trip_basis_fwd_f32(const float* R, const int32_t* tc, const int32_t* ta, const int32_t* tb,
+                                     float* Y, float* theta, int64_t T, int S, void* stream) {
+  if (T <= 0) return 0;
+  if (S > 8) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(trip_basis_fwd_kernel, dim3(grid_for(T)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     R, tc, ta, tb, Y, theta, T, S);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_trip_basis_bwd_f32(const float* gY, const float* R, const int32_t* tc, const int32_t* ta,
+                                     const int32_t* tb, float* Gc, float* Gb, int64_t T, int S, void* stream) {
+  if (T <= 0) return 0;
+  if (S > 8) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(trip_basis_bwd_kernel, dim3(grid_for(T)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     gY, R, tc, ta, tb, Gc, Gb, T, S);
+  GN_LAUNCH_CHECK();
+  return 0;
+}

@@ -216,3 +216,65 @@ def ylm(theta, phi, S, kt, kp):
     check(_lib.load().gn_ylm_f32(ptr(theta), ptr(phi), ptr(out), theta.shape[0], S, kt, kp, stream()),
           "gn_ylm_f32")
     return out
+
+
+def edge_basis_fwd(R, idx_c, idx_a, freq, z, nrm, cutoff, p, want_V=False, want_rbf=True):
+    """-> D (E,), V (E,3)|None, rbf (E,NR)|None, rad (E,S,NR)   (gemnet.py:261-286 + basis_layers.py:45-49,121-128)."""
+    require_device(R, idx_c, idx_a, z, nrm)
+    R = _f32c(R)
+    E = idx_c.shape[0]
+    S, NR = z.shape
+    D = torch.empty(E, device=R.device, dtype=torch.float32)
+    V = torch.empty((E, 3), device=R.device, dtype=torch.float32) if want_V else None
+    rbf = torch.empty((E, NR), device=R.device, dtype=torch.float32) if want_rbf else None
+    rad = torch.empty((E, S, NR), device=R.device, dtype=torch.float32)
+    if want_rbf:
+        freq = _f32c(freq)
+    # without rbf the kernel still walks NR "rbf" work items per edge; give it a scratch target
+    rbf_t = rbf if want_rbf else torch.empty((E, NR), device=R.device, dtype=torch.float32)
+    fr = freq if want_rbf else torch.zeros(NR, device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_edge_basis_fwd_f32(ptr(R), ptr(idx_c), ptr(idx_a), ptr(fr), ptr(z), ptr(nrm), ptr(D),
+                                            ptr(V), ptr(rbf_t), ptr(rad), E, NR, S, cutoff, p, stream()),
+          "gn_edge_basis_fwd_f32")
+    return D, V, rbf, rad
+
+
+def edge_basis_bwd(gD, g_rbf, g_rad, R, idx_c, idx_a, freq, z, nrm, cutoff, p):
+    """-> W (E,3) per-edge position gradient: dE/dR = segsum(W, id_a) - segsum(W, id_c)."""
+    require_device(R, idx_c, idx_a)
+    R = _f32c(R)
+    E = idx_c.shape[0]
+    S, NR = z.shape
+    gD = None if gD is None else _f32c(gD)
+    g_rbf = None if g_rbf is None else _f32c(g_rbf)
+    g_rad = None if g_rad is None else _f32c(g_rad)
+    fr = _f32c(freq) if freq is not None else torch.zeros(NR, device=R.device, dtype=torch.float32)
+    W = torch.empty((E, 3), device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_edge_basis_bwd_f32(ptr(gD), ptr(g_rbf), ptr(g_rad), ptr(R), ptr(idx_c), ptr(idx_a),
+                                            ptr(fr), ptr(z), ptr(nrm), ptr(W), E, NR, S, cutoff, p, stream()),
+          "gn_edge_basis_bwd_f32")
+    return W
+
+
+def trip_basis_fwd(R, tc, ta, tb, S, want_theta=False):
+    """-> Y (T,S) = Y_l0(angle c<-a->b), theta (T,)|None   (gemnet.py:288-311,420-451 + basis_layers.py:130-131)."""
+    require_device(R, tc, ta, tb)
+    R = _f32c(R)
+    T = tc.shape[0]
+    Y = torch.empty((T, S), device=R.device, dtype=torch.float32)
+    theta = torch.empty(T, device=R.device, dtype=torch.float32) if want_theta else None
+    check(_lib.load().gn_trip_basis_fwd_f32(ptr(R), ptr(tc), ptr(ta), ptr(tb), ptr(Y), ptr(theta), T, S, stream()),
+          "gn_trip_basis_fwd_f32")
+    return Y, theta
+
+
+def trip_basis_bwd(gY, R, tc, ta, tb):
+    """-> Gc, Gb (T,3): dE/dR_c, dE/dR_b per triplet (dE/dR_a = -(Gc+Gb))."""
+    require_device(gY, R)
+    gY, R = _f32c(gY), _f32c(R)
+    T, S = gY.shape
+    Gc = torch.empty((T, 3), device=R.device, dtype=torch.float32)
+    Gb = torch.empty((T, 3), device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_trip_basis_bwd_f32(ptr(gY), ptr(R), ptr(tc), ptr(ta), ptr(tb), ptr(Gc), ptr(Gb), T, S,
+                                            stream()), "gn_trip_basis_bwd_f32")
+    return Gc, Gb

@@ -68,6 +68,8 @@ class GemNet(torch.nn.Module):
         self.triplets_only = triplets_only
         self.num_spherical = num_spherical
         self.force_graph = None  # None: auto (training & grad enabled); True/False: forced
+        self.overlap_output_blocks = True
+        self._side = None
 
         AutomaticFit.reset()
 
@@ -167,15 +169,23 @@ class GemNet(torch.nn.Module):
     # ---------------------------------------------------------------------------------- forward
     def _energy(self, R, plan):
         T = self.triplets_only
-        D_ca, V_ca = self.calculate_interatomic_vectors(R, plan.id_c, plan.id_a)
+        b3 = self.cbf_basis3
+        if ops.is_fused():
+            # one launch: distances + Bessel rbf + spherical-Bessel radial basis; one launch: angles + Y_l0
+            D_ca, V_ca, rbf, rad3 = ops.edge_basis(R, self.rbf_basis.frequencies, plan.id_c, plan.id_a,
+                                                   b3.z_ln, b3.n_ln, b3.cutoff, b3.p,
+                                                   want_V=self.direct_forces)
+            sph3 = ops.trip_basis(R, plan.t_c, plan.t_a, plan.t_b, self.num_spherical)
+        else:
+            D_ca, V_ca = self.calculate_interatomic_vectors(R, plan.id_c, plan.id_a)
+            rbf = self.rbf_basis(D_ca)
+            rad3, sph3 = b3(D_ca, self.calculate_angles3(R, plan))
         if not T:
             D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
             Phi_cab, Phi_abd, Theta_cabd = self.calculate_angles(R, plan)
             cbf4 = self.cbf_basis(D_ab, Phi_abd, plan.intm_ab)           # (I, S*R)
-            sbf4 = self.sbf_basis(D_ca, Phi_cab, Theta_cabd)              # ((E,S,R), (Q,S^2))
-        rbf = self.rbf_basis(D_ca)
-        Angles3 = self.calculate_angles3(R, plan)
-        rad3, sph3 = self.cbf_basis3(D_ca, Angles3)
+            # the tensor basis shares cutoff and radial tables with cbf_basis3: reuse rad3
+            sbf4 = (rad3, ops.ylm(Phi_cab, Theta_cabd, self.num_spherical))  # ((E,S,R), (Q,S^2))
 
         h = self.atom_emb(plan.z_rows)
         m = self.edge_emb(h, rbf, plan.id_c, plan.id_a)
@@ -191,11 +201,33 @@ class GemNet(torch.nn.Module):
         rbf_h = self.mlp_rbf_h(rbf)
         rbf_out = self.mlp_rbf_out(rbf)
 
-        E_a, F_ca = self.out_blocks[0](h, m, rbf_out, plan.id_a)
+        # OutputBlock i only feeds the final energy sum: it runs on a side stream, concurrently with
+        # InteractionBlock i+1 (and, since autograd replays a node on its forward stream, so does its
+        # backward).  Its kernels are atom-side (A = 1024 rows: 32 workgroups) and latency-bound, so
+        # overlapping them is free.  Captured hipGraphs keep the fork/join as graph edges.
+        side = self._side_stream(R.device) if self.overlap_output_blocks and R.is_cuda else None
+        outs = []
+
+        def out_block(i, h, m):
+            if side is None:
+                outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a))
+                return
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for t in (h, m, rbf_out):
+                    t.record_stream(side)
+                outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a))
+
+        out_block(0, h, m)
         for i in range(self.num_blocks):
             h, m = self.int_blocks[i](h=h, m=m, rbf4=rbf4, cbf4=cbf4, sbf4=sbf4, rbf3=rbf3, cbf3=cbf3,
                                       rbf_h=rbf_h, plan=plan)
-            E, F = self.out_blocks[i + 1](h, m, rbf_out, plan.id_a)
+            out_block(i + 1, h, m)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        E_a, F_ca = outs[0]
+        for E, F in outs[1:]:
             F_ca = F_ca + F
             E_a = E_a + E
 
@@ -237,6 +269,11 @@ class GemNet(torch.nn.Module):
                         F_j = -torch.autograd.grad(E_mol.sum(), R, create_graph=graph)[0]
                 inputs["R"].requires_grad = False
         return E_mol, F_j
+
+    def _side_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     @staticmethod
     def _check_inputs(R):

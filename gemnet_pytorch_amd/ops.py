@@ -505,3 +505,65 @@ def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
     W2 = W.permute(1, 0, 2).reshape(I * C, O)
     out = mm(P.reshape(-1, I * C), W2, False, True)
     return out * alpha if alpha != 1.0 else out
+
+
+# ---------------------------------------------------------------- fused geometry + basis
+class _EdgeBasis(torch.autograd.Function):
+    """(R) -> D, V, rbf, rad in one launch; adjoint recomputes the geometry (first-order only)."""
+
+    @staticmethod
+    def forward(ctx, R, freq, ri_c, ri_a, z, nrm, cutoff, p, want_V, want_rbf):
+        D, V, rbf, rad = K.edge_basis_fwd(R, ri_c.idx32, ri_a.idx32, freq, z, nrm, cutoff, p, want_V, want_rbf)
+        ctx.save_for_backward(R, freq, z, nrm, D)
+        ctx.cfg = (ri_c, ri_a, cutoff, p, want_V, want_rbf)
+        ctx.mark_non_differentiable(*[t for t in (V,) if t is not None])
+        outs = (D, V if want_V else R.new_zeros(0), rbf if want_rbf else R.new_zeros(0), rad)
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gD, gV, g_rbf, g_rad):
+        R, freq, z, nrm, D = ctx.saved_tensors
+        ri_c, ri_a, cutoff, p, want_V, want_rbf = ctx.cfg
+        gR = gf = None
+        if not want_rbf:
+            g_rbf = None
+        if ctx.needs_input_grad[0]:
+            W = K.edge_basis_bwd(gD, g_rbf, g_rad, R, ri_c.idx32, ri_a.idx32, freq if want_rbf else None,
+                                 z, nrm, cutoff, p)
+            gR = K.segsum(W, *ri_a.csr, ri_a.n_rows) - K.segsum(W, *ri_c.csr, ri_c.n_rows)
+        if want_rbf and ctx.needs_input_grad[1] and _PARAM_GRADS and g_rbf is not None:
+            gf = (g_rbf * K.bessel_rbf(D, freq, cutoff, p, 0, 1)).sum(dim=0)
+        return gR, gf, None, None, None, None, None, None, None, None
+
+
+def edge_basis(R, freq, ri_c, ri_a, z, nrm, cutoff, p, want_V=False, want_rbf=True):
+    D, V, rbf, rad = _EdgeBasis.apply(R, freq, ri_c, ri_a, z, nrm, float(cutoff), int(p), want_V, want_rbf)
+    return D, (V if want_V else None), (rbf if want_rbf else None), rad
+
+
+class _TripBasis(torch.autograd.Function):
+    """(R) -> Y_l0 of every triplet angle in one launch (first-order adjoint)."""
+
+    @staticmethod
+    def forward(ctx, R, ri_c, ri_a, ri_b, S):
+        Y, _ = K.trip_basis_fwd(R, ri_c.idx32, ri_a.idx32, ri_b.idx32, S)
+        ctx.save_for_backward(R)
+        ctx.cfg = (ri_c, ri_a, ri_b)
+        return Y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gY):
+        (R,) = ctx.saved_tensors
+        ri_c, ri_a, ri_b = ctx.cfg
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        Gc, Gb = K.trip_basis_bwd(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32)
+        gR = (K.segsum(Gc, *ri_c.csr, ri_c.n_rows) + K.segsum(Gb, *ri_b.csr, ri_b.n_rows)
+              - K.segsum(Gc + Gb, *ri_a.csr, ri_a.n_rows))
+        return gR, None, None, None, None
+
+
+def trip_basis(R, ri_c, ri_a, ri_b, S):
+    return _TripBasis.apply(R, ri_c, ri_a, ri_b, int(S))

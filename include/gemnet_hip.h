@@ -110,6 +110,26 @@ int gn_ylm0_f32(const float* theta, float* out, int64_t T, int S, int k, void* s
 int gn_ylm_f32(const float* theta, const float* phi, float* out, int64_t Q, int S, int kt, int kp,
                void* stream);
 
+/* ---- geometry fused with the basis evaluation (P9 + P6/P7, first-order path) ---------------
+ * gemnet.py:261-286 (interatomic vectors) -> basis_layers.py:45-49,121-128:
+ *   D[e] = |R[id_a[e]] - R[id_c[e]]|, V[e,:] unit vector (V may be NULL), rbf (E,NR), rad (E,S,NR). */
+int gn_edge_basis_fwd_f32(const float* R, const int32_t* id_c, const int32_t* id_a, const float* freq,
+                          const float* z, const double* nrm, float* D, float* V, float* rbf, float* rad,
+                          int64_t E, int NR, int S, float cutoff, int p, void* stream);
+/* adjoint: W[e,:] = (g_D[e] + sum g_rbf * d rbf/dd + sum g_rad * d rad/dd) * V[e,:]  (any g_* may be NULL);
+ * dE/dR = segsum(W, id_a) - segsum(W, id_c) */
+int gn_edge_basis_bwd_f32(const float* g_D, const float* g_rbf, const float* g_rad, const float* R,
+                          const int32_t* id_c, const int32_t* id_a, const float* freq, const float* z,
+                          const double* nrm, float* W, int64_t E, int NR, int S, float cutoff, int p,
+                          void* stream);
+/* gemnet.py:288-311,420-451 -> basis_layers.py:130-131: Y[t,l] = Y_l0(atan2(max(|u x v|,1e-9), u.v)),
+ * u = R[tc]-R[ta], v = R[tb]-R[ta]; theta (T,) optional output */
+int gn_trip_basis_fwd_f32(const float* R, const int32_t* tc, const int32_t* ta, const int32_t* tb, float* Y,
+                          float* theta, int64_t T, int S, void* stream);
+/* adjoint: Gc[t,:] = dE/dR_c, Gb[t,:] = dE/dR_b per triplet (dE/dR_a = -(Gc+Gb)) given gY (T,S) */
+int gn_trip_basis_bwd_f32(const float* gY, const float* R, const int32_t* tc, const int32_t* ta,
+                          const int32_t* tb, float* Gc, float* Gb, int64_t T, int S, void* stream);
+
 /* ---- pointwise -------------------------------------------------------------------------
  * out[i] = d^k/dx^k ssilu(x[i]), k in {0,1,2,3}   (base_layers.py:51-58) */
 int gn_ssilu_f32(const float* x, float* out, int64_t n, int k, void* stream);

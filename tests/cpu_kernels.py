@@ -159,7 +159,64 @@ def ylm(theta, phi, S, kt, kp):
     return torch.stack(cols, 1)
 
 
-_NAMES = ["gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+def _edge_geom(R, idx_c, idx_a):
+    Vv = R[idx_a.long()] - R[idx_c.long()]
+    D = torch.sqrt((Vv ** 2).sum(1))
+    return D, Vv / D[:, None]
+
+
+def edge_basis_fwd(R, idx_c, idx_a, freq, z, nrm, cutoff, p, want_V=False, want_rbf=True):
+    D, V = _edge_geom(R, idx_c, idx_a)
+    S, NR = z.shape
+    rbf = B.bessel_rbf(D, freq, cutoff, p) if want_rbf else None
+    rad = B.sph_bessel_radial(D, S, NR, cutoff, p)
+    return D, (V if want_V else None), rbf, rad
+
+
+def edge_basis_bwd(gD, g_rbf, g_rad, R, idx_c, idx_a, freq, z, nrm, cutoff, p):
+    with torch.enable_grad():
+        S, NR = z.shape
+        Rr = R.detach().clone().requires_grad_(True)
+        Vv = Rr[idx_a.long()] - Rr[idx_c.long()]
+        D = torch.sqrt((Vv ** 2).sum(1))
+        tot = 0.0
+        if gD is not None:
+            tot = tot + (gD * D).sum()
+        if g_rbf is not None:
+            tot = tot + (g_rbf * B.bessel_rbf(D, freq.detach(), cutoff, p)).sum()
+        if g_rad is not None:
+            tot = tot + (g_rad * B.sph_bessel_radial(D, S, NR, cutoff, p)).sum()
+        (gDtot,) = torch.autograd.grad(tot, D)
+    return (gDtot[:, None] * (Vv / D[:, None])).detach()
+
+
+def _angle(R, tc, ta, tb):
+    u = R[tc.long()] - R[ta.long()]
+    v = R[tb.long()] - R[ta.long()]
+    x = (u * v).sum(1)
+    y = torch.linalg.cross(u, v, dim=-1).norm(dim=-1).clamp(min=1e-9)
+    return torch.atan2(y, x)
+
+
+def trip_basis_fwd(R, tc, ta, tb, S, want_theta=False):
+    th = _angle(R, tc, ta, tb)
+    return B.real_sph_harm_l0(S, th), (th if want_theta else None)
+
+
+def trip_basis_bwd(gY, R, tc, ta, tb):
+    with torch.enable_grad():
+        Rc = R[tc.long()].detach().clone().requires_grad_(True)
+        Ra = R[ta.long()].detach()
+        Rb = R[tb.long()].detach().clone().requires_grad_(True)
+        u, v = Rc - Ra, Rb - Ra
+        x = (u * v).sum(1)
+        y = torch.linalg.cross(u, v, dim=-1).norm(dim=-1).clamp(min=1e-9)
+        Y = B.real_sph_harm_l0(gY.shape[1], torch.atan2(y, x))
+        Gc, Gb = torch.autograd.grad((gY * Y).sum(), (Rc, Rb))
+    return Gc, Gb
+
+
+_NAMES = ["edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -213,3 +213,49 @@ def test_dact_mul(act, has_mul):
     dz, gm = K.dact_mul(f32(gr), f32(z), act, f32(mul) if has_mul else None, 0.37, want_gmul=True)
     close(dz, ref_dz, atol=1e-5)
     close(gm, ref_gm, atol=1e-5)
+
+
+def _rand_geometry(g, n_atoms=40, n_edges=300, n_trip=900):
+    R = (torch.rand(n_atoms, 3, generator=g, dtype=torch.float64) * 6.0)
+    ic = torch.randint(0, n_atoms, (n_edges,), generator=g)
+    ia = (ic + 1 + torch.randint(0, n_atoms - 1, (n_edges,), generator=g)) % n_atoms  # != ic
+    tc = torch.randint(0, n_atoms, (n_trip,), generator=g)
+    ta = (tc + 1 + torch.randint(0, n_atoms - 1, (n_trip,), generator=g)) % n_atoms
+    tb = torch.randint(0, n_atoms, (n_trip,), generator=g)
+    ok = (tb != ta) & (tb != tc)
+    return R, ic.int(), ia.int(), tc[ok].int(), ta[ok].int(), tb[ok].int()
+
+
+def test_edge_basis_fused_fwd_bwd():
+    g = torch.Generator().manual_seed(21)
+    R, ic, ia, *_ = _rand_geometry(g)
+    R32 = R.float().double()  # the kernel sees f32 positions
+    z, nrm = torch.tensor(B.jn_zeros(7, 6)), torch.tensor(B.sph_bessel_normalizer(7, 6))
+    freq = torch.arange(1, 7, dtype=torch.float64) * np.pi
+    D, V, rbf, rad = K.edge_basis_fwd(f32(R), ic.to(DEV), ia.to(DEV), f32(freq), z.to(DEV), nrm.to(DEV), 8.0, 5, True, True)
+    rD, rV, rrbf, rrad = CK.edge_basis_fwd(R32, ic, ia, freq, z, nrm, 8.0, 5, True, True)
+    close(D, rD, atol=2e-6); close(V, rV, atol=2e-6); close(rbf, rrbf, atol=1e-5); close(rad, rrad, rtol=1e-4, atol=2e-5)
+    gD, grbf, grad = rnd(g, ic.shape[0]), rnd(g, ic.shape[0], 6), rnd(g, ic.shape[0], 7, 6)
+    W = K.edge_basis_bwd(f32(gD), f32(grbf), f32(grad), f32(R), ic.to(DEV), ia.to(DEV), f32(freq), z.to(DEV), nrm.to(DEV), 8.0, 5)
+    rW = CK.edge_basis_bwd(gD, grbf, grad, R32, ic, ia, freq, z, nrm, 8.0, 5)
+    close(W, rW, rtol=2e-4, atol=2e-4 * float(rW.abs().max()))
+
+
+def test_trip_basis_fused_fwd_bwd_including_collinear():
+    g = torch.Generator().manual_seed(22)
+    R, _, _, tc, ta, tb = _rand_geometry(g)
+    # make atoms 0,1,2 exactly collinear and add that triplet: exercises the 1e-9 clamp
+    R[0] = torch.tensor([0.0, 0.0, 0.0]); R[1] = torch.tensor([1.0, 0.0, 0.0]); R[2] = torch.tensor([2.5, 0.0, 0.0])
+    tc = torch.cat([tc, torch.tensor([1], dtype=torch.int32)]); ta = torch.cat([ta, torch.tensor([0], dtype=torch.int32)])
+    tb = torch.cat([tb, torch.tensor([2], dtype=torch.int32)])
+    R32 = R.float().double()
+    Y, th = K.trip_basis_fwd(f32(R), tc.to(DEV), ta.to(DEV), tb.to(DEV), 7, want_theta=True)
+    rY, rth = CK.trip_basis_fwd(R32, tc, ta, tb, 7, want_theta=True)
+    close(th, rth, atol=5e-6); close(Y, rY, atol=2e-5)
+    gY = rnd(g, tc.shape[0], 7)
+    Gc, Gb = K.trip_basis_bwd(f32(gY), f32(R), tc.to(DEV), ta.to(DEV), tb.to(DEV))
+    rGc, rGb = CK.trip_basis_bwd(gY, R32, tc, ta, tb)
+    # near-collinear triplets amplify f32 rounding of the angle: compare with a scale-aware tolerance
+    close(Gc[:-1], rGc[:-1], rtol=2e-3, atol=2e-3 * float(rGc.abs().median()))
+    close(Gb[:-1], rGb[:-1], rtol=2e-3, atol=2e-3 * float(rGb.abs().median()))
+    assert torch.isfinite(Gc).all() and torch.isfinite(Gb).all()
