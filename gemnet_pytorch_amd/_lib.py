@@ -35,13 +35,40 @@ class GemmArgs(ctypes.Structure):
         ("ridx", _vp),
         ("res2", _vp), ("ldres2", _i),
         ("beta2", _f),
+        ("splitk_ws", _vp), ("splitk", _i),
     ]
+
+
+GN_OP_LOAD, GN_OP_SCALE, GN_OP_GEMM, GN_OP_STORE = 0, 1, 2, 3
+GN_CHAIN_MAX_OPS = 20
+
+
+class ChainOp(ctypes.Structure):
+    """Mirror of `gn_chain_op` (include/gemnet_hip.h)."""
+    _fields_ = [
+        ("kind", _i), ("slot", _i), ("a_slot", _i), ("width", _i), ("ld", _i),
+        ("src", _vp), ("rows", _vp),
+        ("W", _vp), ("N", _i), ("K", _i),
+        ("act", _i), ("alpha", _f),
+        ("gadd1", _vp), ("gidx1", _vp), ("gadd2", _vp), ("gidx2", _vp),
+        ("pre_out", _vp),
+        ("mul_slot", _i), ("mul_g", _vp),
+        ("res_slot", _i), ("res_g", _vp), ("res_rows", _vp), ("beta", _f),
+        ("res2_slot", _i), ("res2_g", _vp), ("beta2", _f),
+        ("out", _vp),
+    ]
+
+
+class ChainArgs(ctypes.Structure):
+    """Mirror of `gn_chain_args`."""
+    _fields_ = [("M", _i), ("n_ops", _i), ("ops", ChainOp * GN_CHAIN_MAX_OPS)]
 
 
 # name -> argtypes; every function returns int (0 = ok)
 SIGNATURES = {
     "gn_gemm_f32": [ctypes.POINTER(GemmArgs), _vp],
     "gn_gemm_f32_cfg": [ctypes.POINTER(GemmArgs), _i, _vp],
+    "gn_chain_f32": [ctypes.POINTER(ChainArgs), _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],

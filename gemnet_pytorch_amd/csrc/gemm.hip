@@ -205,7 +205,15 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_generic(const gn_gemm_args 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int k0 = 0; k0 < p.K; k0 += BK) {
+  // split-K: blockIdx.z owns the K-range [kbeg, kend) (multiples of BK)
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    const int steps = (p.K + BK - 1) / BK;
+    const int per = (steps + p.splitk - 1) / p.splitk;
+    kbeg = blockIdx.z * per * BK;
+    kend = min(p.K, kbeg + per * BK);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     stage_tile<BM, NT>(As, p.A, p.a_dact_pre, p.trans_a, vecA, row0, k0, p.M, p.K, p.lda, tid);
     // Bs[n][k] = opB(B)[k][n]: trans_b == 0 means B is stored (N,K) = "row n, k contiguous"
     stage_tile<BN, NT>(Bs, p.B, nullptr, p.trans_b, vecB, col0, k0, p.N, p.K, p.ldb, tid);
@@ -214,7 +222,34 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_generic(const gn_gemm_args 
     for (int kb = 0; kb < BK; kb += 8) mma_step<TM, TN, LDS_LD>(As, Bs, arow, brow, kb + kh, acc);
     __syncthreads();
   }
+  if (p.splitk > 1) {
+    // raw partial sums -> workspace slice z (epilogue applied by splitk_reduce)
+    float* __restrict__ ws = p.splitk_ws + (size_t)blockIdx.z * p.M * p.N;
+    const int l31 = lane & 31, rh = (lane >> 5) << 2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = col0 + (wc * TN + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rh;
+          if (row < p.M && col < p.N) ws[(size_t)row * p.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   epilogue<TM, TN>(p, acc, row0 + wr * TM * 32, col0 + wc * TN * 32, lane);
+}
+
+__global__ void splitk_reduce(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
+                              int splitk, float alpha) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int z = 0; z < splitk; ++z) acc += ws[(size_t)z * n + i];
+    C[(i / N) * ldc + (i % N)] = acc * alpha;
+  }
 }
 
 // NT operands, rows 16-B aligned, K % 4 == 0.  Register-prefetch pipeline over K-steps of KS.
@@ -301,6 +336,125 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt_pipe(const gn_gemm_args 
   epilogue<TM, TN>(p, acc, row0 + wr * TM * 32, col0 + wc * TN * 32, lane);
 }
 
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Variant on v_mfma_f32_16x16x4_f32 with 8 waves per 32x128 block tile: wave (rg, cg) owns rows
+// 16*rg..+16 and columns 32*cg..+32 (two 16x16 tiles, two independent accumulators for the 40-cycle
+// dependent latency).  Same LDS image and register-prefetch pipeline as gemm_nt_pipe, but twice the
+// waves per SIMD (4.4 instead of 2.2 at E = 18 k rows) so more of the load/barrier latency of one
+// wave hides under the matrix work of another.  Epilogue shared through epilogue_elem().
+__device__ __forceinline__ void epilogue_elem(const gn_gemm_args& p, float z, int row, int col) {
+  if (p.gadd1) z += p.gadd1[(size_t)p.gidx1[row] * p.ldg + col];
+  if (p.gadd2) z += p.gadd2[(size_t)p.gidx2[row] * p.ldg + col];
+  const size_t co = (size_t)row * p.ldc + col;
+  if (p.pre_out) p.pre_out[co] = z;
+  float y = p.act ? gn_ssilu(z) : z;
+  if (p.mul) y *= p.mul[(size_t)row * p.ldmul + col];
+  y *= p.alpha;
+  if (p.res) {
+    const size_t rr = p.ridx ? (size_t)p.ridx[row] : (size_t)row;
+    y = (y + p.res[rr * p.ldres + col]) * p.beta;
+  }
+  if (p.res2) y = (y + p.res2[(size_t)row * p.ldres2 + col]) * p.beta2;
+  p.C[co] = y;
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void gemm_nt_pipe16(const gn_gemm_args p) {
+  constexpr int BM = 32, BN = 128, NT = 512;
+  constexpr int LD = KS + 4;
+  constexpr int V = KS / 4;
+  constexpr int NA = (BM * V + NT - 1) / NT;
+  constexpr int NB = (BN * V + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float As[BM][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN][LD];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int rg = wave >> 2;   // 0..1
+  const int cg = wave & 3;    // 0..3
+  const int row0 = blockIdx.x * BM;
+  const int col0 = blockIdx.y * BN;
+  const int l15 = lane & 15;
+  const int kq = (lane >> 4) << 2;   // 0,4,8,12: this lane group's 4 consecutive k of a 16-k chunk
+  const bool dact = p.a_dact_pre != nullptr;
+
+  float4 ra[NA], rz[NA], rb[NB];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / V, kv = (f % V) << 2;
+      const int gr = row0 + r, gk = k0 + kv;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rz[i] = ra[i];
+      if (f < BM * V && gr < p.M && gk < p.K) {
+        const size_t off = (size_t)gr * p.lda + gk;
+        ra[i] = *reinterpret_cast<const float4*>(p.A + off);
+        if (dact) rz[i] = *reinterpret_cast<const float4*>(p.a_dact_pre + off);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / V, kv = (f % V) << 2;
+      const int gr = col0 + r, gk = k0 + kv;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < BN * V && gr < p.N && gk < p.K)
+        rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)gr * p.ldb + gk);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * NT;
+      if (f < BM * V) *reinterpret_cast<float4*>(&As[f / V][(f % V) << 2]) = dact ? dact4(ra[i], rz[i]) : ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * NT;
+      if (f < BN * V) *reinterpret_cast<float4*>(&Bs[f / V][(f % V) << 2]) = rb[i];
+    }
+  };
+
+  v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int arow = rg * 16 + l15;
+  const int brow = cg * 32 + l15;
+  load(0);
+  for (int k0 = 0; k0 < p.K; k0 += KS) {
+    store();
+    __syncthreads();
+    if (k0 + KS < p.K) load(k0 + KS);
+#pragma unroll
+    for (int kb = 0; kb < KS; kb += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[arow][kb + kq]);
+      const float4 b0 = *reinterpret_cast<const float4*>(&Bs[brow][kb + kq]);
+      const float4 b1 = *reinterpret_cast<const float4*>(&Bs[brow + 16][kb + kq]);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  const int rbase = row0 + rg * 16 + ((lane >> 4) << 2);
+  const int cbase = col0 + cg * 32 + l15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rbase + r;
+    if (row < p.M) {
+      if (cbase < p.N) epilogue_elem(p, acc0[r], row, cbase);
+      if (cbase + 16 < p.N) epilogue_elem(p, acc1[r], row, cbase + 16);
+    }
+  }
+}
+
 // C[b] = opA(A[b]) opB(B[b]) for tiny per-edge blocks (m*k, k*n <= 2048 floats).
 __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ A,
                                                       const float* __restrict__ B,
@@ -338,7 +492,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <int BM, int BN, int WR, int WC, int KS>
 void launch(const gn_gemm_args& p, bool fast, int vecA, int vecB, hipStream_t st) {
-  dim3 grid(gn_cdiv(p.M, BM), gn_cdiv(p.N, BN)), block(WR * WC * 64);
+  dim3 grid(gn_cdiv(p.M, BM), gn_cdiv(p.N, BN), p.splitk > 1 ? p.splitk : 1), block(WR * WC * 64);
   if (fast) hipLaunchKernelGGL((gemm_nt_pipe<BM, BN, WR, WC, KS>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((gemm_generic<BM, BN, WR, WC>), grid, block, 0, st, p, vecA, vecB);
 }
@@ -352,13 +506,27 @@ extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int vecA = (p.lda % 4 == 0) && aligned16(p.A) && (!p.a_dact_pre || aligned16(p.a_dact_pre));
   const int vecB = (p.ldb % 4 == 0) && aligned16(p.B);
-  const bool fast = !p.trans_a && !p.trans_b && vecA && vecB && (p.K % 4 == 0);
+  const bool fast = !p.trans_a && !p.trans_b && vecA && vecB && (p.K % 4 == 0) && p.splitk <= 1;
+  if (p.splitk > 1) {
+    if (!p.splitk_ws) return (int)hipErrorInvalidValue;
+    if (p.N > 64) launch<32, 128, 1, 4, 32>(p, false, vecA, vecB, st);
+    else if (p.N > 32) launch<32, 64, 1, 2, 32>(p, false, vecA, vecB, st);
+    else launch<32, 32, 1, 1, 32>(p, false, vecA, vecB, st);
+    GN_LAUNCH_CHECK();
+    const int64_t n = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.splitk_ws, p.C, p.M,
+                       p.N, p.ldc, p.splitk, p.alpha);
+    GN_LAUNCH_CHECK();
+    return 0;
+  }
   if (cfg < 0) {
     // Measured on MI355X (tools/gemm_bench.py, profiles/r1_gemm_tiles.txt): up to ~40 k rows the
     // launch is latency-bound, and 32-row tiles with one 32x32 tile per wave (2.2 waves/SIMD at
     // E = 18 k) beat 64x128 (12.7 vs 17.1 us at N = K = 128); large M wants 128x128 tiles.
+    // The 8-wave 16x16x4 variant (cfg 14/15) doubles the waves per SIMD: 12.5 vs 12.8 us at E = 18 k,
+    // 5.9 vs 7.3 us at M = 1024.
     const bool huge = p.M > 40000;
-    if (p.N > 64) cfg = huge ? 13 : 1;
+    if (p.N > 64) cfg = huge ? 13 : (p.M > 4096 ? 14 : 15);
     else if (p.N > 32) cfg = p.M > 4096 ? 11 : 3;
     else cfg = p.M > 4096 ? 4 : 5;
   }
@@ -377,6 +545,12 @@ extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) 
     case 11: launch<64, 64, 2, 2, 64>(p, fast, vecA, vecB, st); break;
     case 12: launch<128, 128, 4, 2, 32>(p, fast, vecA, vecB, st); break;
     case 13: launch<128, 128, 4, 4, 32>(p, fast, vecA, vecB, st); break;
+    case 14:
+    case 15:
+      if (!fast) { launch<32, 128, 1, 4, 32>(p, fast, vecA, vecB, st); break; }
+      if (cfg == 14) hipLaunchKernelGGL((gemm_nt_pipe16<32>), dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((gemm_nt_pipe16<64>), dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(512), 0, st, p);
+      break;
     default: return (int)hipErrorInvalidValue;
   }
   GN_LAUNCH_CHECK();

@@ -90,6 +90,15 @@ def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_
     a.gadd1, a.gidx1 = ptr(gadd1), ptr(gidx1)
     a.gadd2, a.gidx2 = ptr(gadd2), ptr(gidx2)
     a.ldg = N
+    # split-K for "weight-gradient shaped" products: few output tiles, very long contraction
+    a.splitk, a.splitk_ws = 0, None
+    plain = (a_dact_pre is None and not act and not pre_out and mul is None and res is None and res2 is None
+             and gadd1 is None and gadd2 is None)
+    tiles = ((M + 31) // 32) * ((N + 127) // 128)
+    if plain and K >= 2048 and tiles <= 64:
+        splitk = max(2, min(256, K // 512, 512 // tiles))
+        ws = torch.empty((splitk, M, N), device=A.device, dtype=torch.float32)
+        a.splitk, a.splitk_ws = splitk, ptr(ws)
     check(_lib.load().gn_gemm_f32_cfg(ctypes.byref(a), int(cfg), stream()), "gn_gemm_f32")
     return (C, pre) if pre_out else C
 
@@ -278,3 +287,88 @@ def trip_basis_bwd(gY, R, tc, ta, tb):
     check(_lib.load().gn_trip_basis_bwd_f32(ptr(gY), ptr(R), ptr(tc), ptr(ta), ptr(tb), ptr(Gc), ptr(Gb), T, S,
                                             stream()), "gn_trip_basis_bwd_f32")
     return Gc, Gb
+
+
+class ChainProgram:
+    """A program for gn_chain_f32: ops over LDS slots of a 32-row tile (see include/gemnet_hip.h).
+    Operands named `mul/res/res2` are either an int (LDS slot) or a tensor (global (M,N))."""
+    NSLOT = 2
+
+    def __init__(self, M):
+        self.M = int(M)
+        self.ops = []
+
+    def load(self, slot, src, rows=None):
+        self.ops.append(dict(kind="load", slot=slot, src=src, rows=rows))
+
+    def scale(self, dst, a, alpha=1.0, Z=None, out=None, width=None):
+        self.ops.append(dict(kind="scale", slot=dst, a_slot=a, alpha=float(alpha), Z=Z, out=out, width=width))
+
+    def gemm(self, W, a_slot, y_slot=-1, act=False, alpha=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
+             pre_out=None, mul=None, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0, out=None):
+        self.ops.append(dict(kind="gemm", W=W, a_slot=a_slot, slot=y_slot, act=bool(act), alpha=float(alpha),
+                             gadd1=gadd1, gidx1=gidx1, gadd2=gadd2, gidx2=gidx2, pre_out=pre_out, mul=mul,
+                             res=res, res_rows=res_rows, beta=float(beta), res2=res2, beta2=float(beta2), out=out))
+
+    def store(self, slot, out):
+        self.ops.append(dict(kind="store", slot=slot, out=out))
+
+
+def _sel(x):
+    """(slot, tensor) of a slot-or-global operand."""
+    if x is None:
+        return -1, None
+    if isinstance(x, int):
+        return x, None
+    return -1, x
+
+
+def chain(prog):
+    """Run a ChainProgram (one launch)."""
+    from ._lib import ChainArgs, GN_CHAIN_MAX_OPS, GN_OP_GEMM, GN_OP_LOAD, GN_OP_SCALE, GN_OP_STORE
+    if len(prog.ops) > GN_CHAIN_MAX_OPS:
+        raise ValueError("chain program too long")
+    a = ChainArgs()
+    a.M, a.n_ops = prog.M, len(prog.ops)
+    M = prog.M
+
+    def mat(t, cols=None):
+        require_device(t)
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2, "chain operands: contiguous fp32 2-D"
+        if cols is not None:
+            assert t.shape[1] == cols, (t.shape, cols)
+        return t
+
+    for i, o in enumerate(prog.ops):
+        c = a.ops[i]
+        c.slot, c.a_slot, c.mul_slot, c.res_slot, c.res2_slot = -1, -1, -1, -1, -1
+        if o["kind"] == "load":
+            src = mat(o["src"])
+            assert o["rows"] is not None or src.shape[0] == M
+            c.kind, c.slot, c.width, c.ld = GN_OP_LOAD, o["slot"], src.shape[1], src.stride(0)
+            c.src, c.rows = ptr(src), ptr(o["rows"])
+        elif o["kind"] == "scale":
+            Z, out = o["Z"], o["out"]
+            w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
+            c.kind, c.slot, c.a_slot, c.width, c.ld, c.alpha = GN_OP_SCALE, o["slot"], o["a_slot"], w, w, o["alpha"]
+            c.src = ptr(mat(Z, w)) if Z is not None else None
+            c.out = ptr(mat(out, w)) if out is not None else None
+        elif o["kind"] == "store":
+            out = mat(o["out"])
+            c.kind, c.slot, c.width, c.ld, c.out = GN_OP_STORE, o["slot"], out.shape[1], out.stride(0), ptr(out)
+        else:
+            W = mat(o["W"])
+            N, Kd = W.shape
+            c.kind, c.W, c.N, c.K, c.a_slot, c.slot = GN_OP_GEMM, ptr(W), N, Kd, o["a_slot"], o["slot"]
+            c.act, c.alpha, c.beta, c.beta2 = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
+            for name in ("gadd1", "gadd2"):
+                if o[name] is not None:
+                    mat(o[name], N)
+            c.gadd1, c.gidx1, c.gadd2, c.gidx2 = ptr(o["gadd1"]), ptr(o["gidx1"]), ptr(o["gadd2"]), ptr(o["gidx2"])
+            c.pre_out = ptr(mat(o["pre_out"], N)) if o["pre_out"] is not None else None
+            c.out = ptr(mat(o["out"], N)) if o["out"] is not None else None
+            c.mul_slot, t = _sel(o["mul"]); c.mul_g = ptr(mat(t, N)) if t is not None else None
+            c.res_slot, t = _sel(o["res"]); c.res_g = ptr(mat(t, N)) if t is not None else None
+            c.res_rows = ptr(o["res_rows"])
+            c.res2_slot, t = _sel(o["res2"]); c.res2_g = ptr(mat(t, N)) if t is not None else None
+    check(_lib.load().gn_chain_f32(ctypes.byref(a), stream()), "gn_chain_f32")

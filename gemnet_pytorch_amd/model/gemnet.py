@@ -250,7 +250,10 @@ class GemNet(torch.nn.Module):
         # scale-factor fitting mode needs the unfused layer order to observe variances
         fused = not graph and not AutomaticFit.fitting_mode
 
-        with ops.fused_first_order(fused):
+        # force-by-autograd without a second-order graph: the graph of E is consumed right here, so
+        # parameter gradients can never be requested -> weights are constants (enables ops.stack)
+        const_w = fused and not self.direct_forces
+        with ops.fused_first_order(fused), ops.param_grads(not const_w):
             E_mol, F_ca, V_ca = self._energy(R, plan)
 
             if self.direct_forces:
@@ -271,9 +274,27 @@ class GemNet(torch.nn.Module):
         return E_mol, F_j
 
     def _side_stream(self, device):
-        if self._side is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+        """One side stream per calling stream (several molecule shards may run this module concurrently)."""
+        if self._side is None:
+            self._side = {}
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        st = self._side.get(key)
+        if st is None:
+            st = self._side[key] = torch.cuda.Stream(device=device)
+        return st
+
+    def __deepcopy__(self, memo):
+        side, self._side = self._side, None  # HIP stream handles are not copyable
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            import copy
+            for k, v in self.__dict__.items():
+                setattr(new, k, copy.deepcopy(v, memo))
+            return new
+        finally:
+            self._side = side
 
     @staticmethod
     def _check_inputs(R):

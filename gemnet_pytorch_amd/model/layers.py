@@ -68,6 +68,12 @@ class ResidualLayer(torch.nn.Module):
         self.dense_mlp = torch.nn.Sequential(
             *[Dense(units, units, activation=activation, bias=False) for _ in range(nLayers)])
 
+    def stackable(self):
+        return len(self.dense_mlp) == 2 and all(d.act and d.bias is None for d in self.dense_mlp)
+
+    def as_stack_layer(self, skip=None, skip_beta=1.0):
+        return dict(W1=self.dense_mlp[0].weight, W2=self.dense_mlp[1].weight, skip=skip, skip_beta=skip_beta)
+
     def forward(self, inputs, res2=None, beta2=1.0):
         """(inputs + MLP(inputs))/sqrt(2), optionally followed by (. + res2)*beta2 — both residual adds
         ride in the epilogue of the last GEMM."""
@@ -133,8 +139,26 @@ class AtomUpdateBlock(torch.nn.Module):
         x = m * self.dense_rbf(rbf)
         return self.scale_sum(m, ops.segsum_rows(x, id_a)), x
 
+    def _mlp_stack(self, x, layers, res2=None, beta2=1.0):
+        """Dense + ResidualLayers of the atom MLP as one LDS-resident launch (ops.stack)."""
+        first = dict(W=layers[0].weight, act=layers[0].act)
+        res_layers = [l.as_stack_layer() for l in layers[1:]]
+        if res2 is not None:
+            if res_layers:
+                res_layers[-1].update(skip=res2, skip_beta=beta2)
+            else:
+                first.update(res=res2, beta=beta2)
+        return ops.stack(x, first=first, layers=res_layers, s=INV_SQRT_2)
+
+    @staticmethod
+    def _stackable(layers):
+        return (ops.constant_weights() and isinstance(layers[0], Dense) and layers[0].bias is None
+                and all(isinstance(l, ResidualLayer) and l.stackable() for l in layers[1:]))
+
     def forward(self, h, m, rbf, id_a, res2=None, beta2=1.0):
         x, _ = self._aggregate(m, rbf, id_a)
+        if self._stackable(self.layers):
+            return self._mlp_stack(x, self.layers, res2, beta2)
         n = len(self.layers)
         for i, layer in enumerate(self.layers):
             if i + 1 == n and res2 is not None and isinstance(layer, ResidualLayer):
@@ -180,8 +204,11 @@ class OutputBlock(AtomUpdateBlock):
 
     def forward(self, h, m, rbf, id_a):
         x_E, x = self._aggregate(m, rbf, id_a)
-        for layer in self.seq_energy:
-            x_E = layer(x_E)
+        if self._stackable(self.seq_energy):
+            x_E = self._mlp_stack(x_E, self.seq_energy)
+        else:
+            for layer in self.seq_energy:
+                x_E = layer(x_E)
         x_E = self.out_energy(x_E)
         if self.direct_forces:
             if ops.is_fused():  # x already carries scale_sum: rescale to scale_rbf
@@ -430,6 +457,35 @@ class _InteractionBase(torch.nn.Module):
             x = layer(x, res2=skip, beta2=INV_SQRT_2) if i + 1 == n else layer(x)
         return x
 
+    def _stack_ok(self):
+        res = list(self.layers_before_skip) + list(self.layers_after_skip) + list(self.residual_m)
+        return (ops.constant_weights() and self.dense_ca.bias is None and self.concat_layer.dense.bias is None
+                and all(l.stackable() for l in res) and len(self.layers_before_skip) > 0
+                and len(self.residual_m) > 0)
+
+    def _update_stacked(self, h, m, x3, x4, rbf_h, plan):
+        """Edge update as two LDS-resident stacks (+ the atom stack in between):
+        {dense_ca(+x3[,x4]) -> residuals before skip (+m) -> residuals after skip} and
+        {concat-Dense (atom terms gathered in its epilogue) -> residual_m (+m)}."""
+        first = dict(W=self.dense_ca.weight, act=self.dense_ca.act)
+        if x4 is None:
+            first.update(res=x3, beta=INV_SQRT_2)
+        else:
+            first.update(res=x3, beta=1.0, res2=x4, beta2=INV_SQRT_3)
+        layers = [l.as_stack_layer() for l in self.layers_before_skip]
+        layers[-1].update(skip=m, skip_beta=INV_SQRT_2)
+        layers += [l.as_stack_layer() for l in self.layers_after_skip]
+        m = ops.stack(m, first=first, layers=layers, s=INV_SQRT_2)
+        h = self.atom_update(h, m, rbf_h, plan.id_a, res2=h, beta2=INV_SQRT_2)
+        A = self.concat_layer.atom_features
+        W = self.concat_layer.dense.weight
+        first = dict(W=W[:, 2 * A:], act=self.concat_layer.dense.act,
+                     g1=ops.dense(h, W[:, :A]), i1=plan.id_c, g2=ops.dense(h, W[:, A:2 * A]), i2=plan.id_a)
+        layers = [l.as_stack_layer() for l in self.residual_m]
+        layers[-1].update(skip=m, skip_beta=INV_SQRT_2)
+        m = ops.stack(m, first=first, layers=layers, s=INV_SQRT_2)
+        return h, m
+
     def _update(self, h, m, x, rbf_h, plan):
         m = self._chain_then_skip(self.layers_before_skip, x, m)
         for layer in self.layers_after_skip:
@@ -456,7 +512,10 @@ class InteractionBlockTripletsOnly(_InteractionBase):
                            num_concat, num_atom, activation, scale_file, block_nr)
 
     def forward(self, h, m, rbf3, cbf3, rbf_h, plan, **kwargs):
-        x = self.dense_ca(m, res=self.trip_interaction(m, rbf3, cbf3, plan), beta=INV_SQRT_2)
+        x3 = self.trip_interaction(m, rbf3, cbf3, plan)
+        if self._stack_ok():
+            return self._update_stacked(h, m, x3, None, rbf_h, plan)
+        x = self.dense_ca(m, res=x3, beta=INV_SQRT_2)
         return self._update(h, m, x, rbf_h, plan)
 
 
@@ -482,5 +541,7 @@ class InteractionBlock(_InteractionBase):
     def forward(self, h, m, rbf4, cbf4, sbf4, rbf3, cbf3, rbf_h, plan, **kwargs):
         x4 = self.quad_interaction(m, rbf4, cbf4, sbf4, plan)
         x3 = self.trip_interaction(m, rbf3, cbf3, plan)
+        if self._stack_ok():
+            return self._update_stacked(h, m, x3, x4, rbf_h, plan)
         x = self.dense_ca(m, res=x3, beta=1.0, res2=x4, beta2=INV_SQRT_3)
         return self._update(h, m, x, rbf_h, plan)

@@ -567,3 +567,155 @@ class _TripBasis(torch.autograd.Function):
 
 def trip_basis(R, ri_c, ri_a, ri_b, S):
     return _TripBasis.apply(R, ri_c, ri_a, ri_b, int(S))
+
+
+# ------------------------------------------------------------------ LDS-resident layer stacks
+def constant_weights():
+    """True while weights are treated as constants (force-by-autograd inference: the graph of E is
+    consumed inside GemNet.forward, so parameter gradients can never be requested)."""
+    return _FUSED and not _PARAM_GRADS
+
+
+def contiguous_weight(W):
+    """Row-contiguous copy of a (possibly sliced) frozen weight, cached on its version."""
+    if W.is_contiguous():
+        return W.detach()
+    key = ("c", W.data_ptr(), tuple(W.shape), tuple(W.stride()))
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0] == W._version:
+        return hit[1]
+    Wc = W.detach().contiguous()
+    _WT_CACHE[key] = (W._version, Wc)
+    return Wc
+
+
+class _Stack(torch.autograd.Function):
+    """[Dense] + ResidualLayer* as ONE launch (gn_chain_f32), activations resident in LDS.
+
+    y0 = ((act(x W0^T + g1[i1] + g2[i2]) + res) * beta + res2) * beta2            (optional leading Dense)
+    y_k = ((y_{k-1} + act(act(y_{k-1} W1^T) W2^T)) * s + skip_k) * skip_beta_k     (ResidualLayers)
+    Weights are constants here (see constant_weights()); the adjoint is another chain program."""
+
+    @staticmethod
+    def forward(ctx, spec, x, res, res2, g1, g2, *skips):
+        first, layers, s = spec["first"], spec["layers"], spec["s"]
+        M = x.shape[0]
+        dev, dt = x.device, x.dtype
+        prog = K.ChainProgram(M)
+        x = x.contiguous()
+        prog.load(0, x)
+        cur, oth = 0, 1
+        zs = []
+        width = x.shape[1]
+        n_out = (layers[-1]["W2"].shape[0] if layers else first["W"].shape[0])
+        y = torch.empty((M, n_out), device=dev, dtype=dt)
+        if first is not None:
+            W0 = contiguous_weight(first["W"])
+            z0 = torch.empty((M, W0.shape[0]), device=dev, dtype=dt) if first["act"] else None
+            prog.gemm(W0, a_slot=0, y_slot=1, act=first["act"],
+                      gadd1=g1, gidx1=None if g1 is None else first["i1"].idx32,
+                      gadd2=g2, gidx2=None if g2 is None else first["i2"].idx32,
+                      pre_out=z0, res=res, beta=first["beta"], res2=res2, beta2=first["beta2"],
+                      out=None if layers else y)
+            zs.append(z0)
+            cur, oth = 1, 0
+            width = W0.shape[0]
+        for k, L in enumerate(layers):
+            W1, W2 = contiguous_weight(L["W1"]), contiguous_weight(L["W2"])
+            z1 = torch.empty((M, width), device=dev, dtype=dt)
+            z2 = torch.empty((M, width), device=dev, dtype=dt)
+            last = k + 1 == len(layers)
+            prog.gemm(W1, a_slot=cur, y_slot=oth, act=True, pre_out=z1)
+            prog.gemm(W2, a_slot=oth, y_slot=cur, act=True, pre_out=z2, res=cur, beta=s,
+                      res2=skips[k], beta2=L["skip_beta"], out=y if last else None)
+            zs += [z1, z2]
+        K.chain(prog)
+        ctx.spec = spec
+        ctx.has = (res is not None, res2 is not None, g1 is not None, g2 is not None,
+                   tuple(sk is not None for sk in skips))
+        ctx.save_for_backward(*[z for z in zs if z is not None])
+        ctx.z_mask = [z is not None for z in zs]
+        ctx.in_width = x.shape[1]
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        spec = ctx.spec
+        first, layers, s = spec["first"], spec["layers"], spec["s"]
+        has_res, has_res2, has_g1, has_g2, has_skips = ctx.has
+        need = ctx.needs_input_grad  # (spec, x, res, res2, g1, g2, *skips)
+        saved = list(ctx.saved_tensors)
+        zs = [saved.pop(0) if m else None for m in ctx.z_mask]
+        g = g.contiguous()
+        M, dev, dt = g.shape[0], g.device, g.dtype
+        prog = K.ChainProgram(M)
+        prog.load(0, g)
+        cur, oth = 0, 1
+        width = g.shape[1]
+        g_skips = [None] * len(layers)
+        zi = len(zs)
+        for k in range(len(layers) - 1, -1, -1):
+            L = layers[k]
+            z2, z1 = zs[zi - 1], zs[zi - 2]
+            zi -= 2
+            c = s
+            if has_skips[k]:
+                if need[6 + k]:
+                    g_skips[k] = torch.empty((M, width), device=dev, dtype=dt)
+                    prog.scale(cur, cur, L["skip_beta"], out=g_skips[k], width=width)
+                else:
+                    c = s * L["skip_beta"]
+            prog.scale(cur, cur, c, width=width)                  # G = dL/d(x + f(x))
+            prog.scale(oth, cur, 1.0, Z=z2)                        # dz2
+            prog.gemm(transposed(L["W2"]), a_slot=oth, y_slot=oth)   # dh1 = dz2 @ W2
+            prog.scale(oth, oth, 1.0, Z=z1)                        # dz1
+            prog.gemm(transposed(L["W1"]), a_slot=oth, y_slot=cur, res=cur, beta=1.0)  # dx = dz1 @ W1 + G
+        gx = g_res = g_res2 = gg1 = gg2 = None
+        if first is not None:
+            z0 = zs[0]
+            c = 1.0
+            if has_res2:
+                if need[3]:
+                    g_res2 = torch.empty((M, width), device=dev, dtype=dt)
+                    prog.scale(cur, cur, first["beta2"], out=g_res2, width=width)
+                else:
+                    c *= first["beta2"]
+            if has_res:
+                c *= first["beta"]
+                if need[2]:
+                    g_res = torch.empty((M, width), device=dev, dtype=dt)
+                    prog.scale(cur, cur, c, out=g_res, width=width)
+                    c = 1.0
+            want_dz = (has_g1 and need[4]) or (has_g2 and need[5])
+            dz0 = torch.empty((M, width), device=dev, dtype=dt) if want_dz else None
+            if z0 is not None or c != 1.0 or want_dz:
+                prog.scale(cur, cur, c, Z=z0, out=dz0, width=width)
+            if need[1]:
+                gx = torch.empty((M, ctx.in_width), device=dev, dtype=dt)
+                prog.gemm(transposed(first["W"]), a_slot=cur, y_slot=-1, out=gx)
+            K.chain(prog)
+            if has_g1 and need[4]:
+                gg1 = K.segsum(dz0, *first["i1"].csr, first["i1"].n_rows)
+            if has_g2 and need[5]:
+                gg2 = K.segsum(dz0, *first["i2"].csr, first["i2"].n_rows)
+        else:
+            gx = torch.empty((M, width), device=dev, dtype=dt)
+            prog.store(cur, gx)
+            K.chain(prog)
+        return (None, gx, g_res, g_res2, gg1, gg2) + tuple(g_skips)
+
+
+def stack(x, first=None, layers=(), s=0.7071067811865475):
+    """first: dict(W, act, res=None, beta=1, res2=None, beta2=1, g1=None, i1=None, g2=None, i2=None) or None;
+    layers: sequence of dict(W1, W2, skip=None, skip_beta=1).  Requires constant_weights()."""
+    assert constant_weights(), "ops.stack is the constant-weight inference path"
+    spec = dict(first=None, layers=[dict(W1=L["W1"], W2=L["W2"], skip_beta=float(L.get("skip_beta", 1.0)))
+                                    for L in layers], s=float(s))
+    res = res2 = g1 = g2 = None
+    if first is not None:
+        spec["first"] = dict(W=first["W"], act=bool(first.get("act", False)), beta=float(first.get("beta", 1.0)),
+                             beta2=float(first.get("beta2", 1.0)), i1=first.get("i1"), i2=first.get("i2"))
+        res, res2, g1, g2 = first.get("res"), first.get("res2"), first.get("g1"), first.get("g2")
+    skips = [L.get("skip") for L in layers]
+    return _Stack.apply(spec, x, res, res2, g1, g2, *skips)

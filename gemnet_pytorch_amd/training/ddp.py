@@ -110,8 +110,7 @@ class TrainStep:
         f_term = torch.norm(F - targets["F"], p=2, dim=1).sum() / A
         return (1 - self.rho) * e_term + self.rho * f_term
 
-    def __call__(self, inputs, targets, step_optimizer=True):
-        self.model.train()
+    def _forward_backward(self, inputs, targets):
         E, F = self.model(inputs)
         if F.dim() == 3:
             F = F[:, 0]
@@ -119,10 +118,38 @@ class TrainStep:
         self.buf.zero()
         # restrict the double backward to the parameters: no gradient w.r.t. the positions
         torch.autograd.backward(loss, inputs=self.buf.params)
+        return loss.detach()
+
+    def capture(self, inputs, targets):
+        """Capture forward + force + loss + double backward (thousands of small launches) into one
+        hipGraph for this (static-shape) batch; the collective, clipping and optimizer stay eager.
+        The graph reads the parameters in place, so optimizer updates are seen by every replay."""
+        self.model.train()
+        self._counts(int(inputs["N"].shape[0]), int(inputs["Z"].shape[0]), inputs["Z"].device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._forward_backward(inputs, targets)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_loss = self._forward_backward(inputs, targets)
+        self._graph_key = id(inputs)
+        return self
+
+    def __call__(self, inputs, targets, step_optimizer=True):
+        self.model.train()
+        if getattr(self, "_graph", None) is not None and self._graph_key == id(inputs):
+            self._graph.replay()
+            loss = self._graph_loss
+        else:
+            loss = self._forward_backward(inputs, targets)
         self.buf.all_reduce()
         scale_shared_grads(self.model)
         torch.nn.utils.clip_grad_norm_(self.buf.params, max_norm=self.clip)
         if step_optimizer:
             self.opt.step()
-        self.last_loss = loss.detach()
+        self.last_loss = loss
         return self.last_loss

@@ -61,10 +61,56 @@ typedef struct {
   const int32_t* ridx;
   const float* res2; int ldres2;
   float beta2;
+  /* split-K (weight-gradient GEMMs: tiny M x N, K = number of edges): `splitk` > 1 slices of K are
+   * accumulated by separate workgroups into splitk_ws (splitk * M * N floats, caller-owned) and summed
+   * in a fixed order by a second kernel; only `alpha` of the epilogue is applied. */
+  float* splitk_ws; int splitk;
 } gn_gemm_args;
 int gn_gemm_f32(const gn_gemm_args* args, void* stream);
 /* Same contraction with an explicit tile variant (cfg >= 0; tuning and tests).  cfg < 0 = automatic. */
 int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream);
+
+/* ---- LDS-resident layer chains ----------------------------------------------------------------
+ * One launch runs a whole stack of Dense / ResidualLayer (base_layers.py:44-89) — or its adjoint —
+ * for a 32-row tile whose activations stay in LDS between layers; only the weights stream (from L2)
+ * and only pre-activations / the final result go back to memory.  A chain is a short program of ops
+ * over LDS "slots" (32 rows x up to 128 columns each):
+ *   GN_OP_LOAD   slot <- src[(rows ? rows[m] : m), 0:width]                       (global -> LDS)
+ *   GN_OP_SCALE  dst_slot <- a_slot * alpha * (src ? ssilu'(src[m, :]) : 1); optional copy to `out`
+ *   GN_OP_GEMM   z = slot[a_slot] (32 x K) @ W^T (W is (N,K), k-contiguous) + gadd1[gidx1[m]] + gadd2[gidx2[m]]
+ *                pre_out <- z;  y = act ? ssilu(z) : z;  y *= mul;  y *= alpha;
+ *                y = (y + res) * beta;  y = (y + res2) * beta2      (mul/res/res2: an LDS slot or a global (M,N))
+ *                slot[y_slot] <- y (may alias a_slot / res slots);  out <- y
+ *   GN_OP_STORE  out[m, 0:width] <- slot                                           (LDS -> global)
+ * Constraints: N, K <= 128, K % 8 == 0, every global matrix row-major with row length N (resp. `ld` for
+ * LOAD/SCALE/STORE), W rows 16-byte aligned. */
+enum { GN_OP_LOAD = 0, GN_OP_SCALE = 1, GN_OP_GEMM = 2, GN_OP_STORE = 3 };
+#define GN_CHAIN_MAX_OPS 20
+typedef struct {
+  int kind;
+  int slot;                 /* LOAD/STORE: slot; SCALE: dst slot; GEMM: y_slot (-1 none) */
+  int a_slot;               /* SCALE: source slot; GEMM: A operand slot */
+  int width;                /* LOAD/SCALE/STORE: columns */
+  int ld;                   /* LOAD/SCALE/STORE: leading dimension of src/out */
+  const float* src;         /* LOAD: source; SCALE: Z for ssilu'(Z) (NULL: plain scale) */
+  const int32_t* rows;      /* LOAD: optional row gather */
+  const float* W; int N; int K;
+  int act;
+  float alpha;
+  const float* gadd1; const int32_t* gidx1;
+  const float* gadd2; const int32_t* gidx2;
+  float* pre_out;
+  int mul_slot; const float* mul_g;
+  int res_slot; const float* res_g; const int32_t* res_rows; float beta;
+  int res2_slot; const float* res2_g; float beta2;
+  float* out;
+} gn_chain_op;
+typedef struct {
+  int M;
+  int n_ops;
+  gn_chain_op ops[GN_CHAIN_MAX_OPS];
+} gn_chain_args;
+int gn_chain_f32(const gn_chain_args* args, void* stream);
 
 /* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
  * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */

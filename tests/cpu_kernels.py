@@ -216,7 +216,71 @@ def trip_basis_bwd(gY, R, tc, ta, tb):
     return Gc, Gb
 
 
-_NAMES = ["edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+def chain(prog):
+    """Interpret a ChainProgram on whole matrices (slots = (M, 128) tensors)."""
+    M = prog.M
+    dt = None
+    for o in prog.ops:
+        for k in ("src", "W"):
+            if o.get(k) is not None:
+                dt = o[k].dtype
+    slots = [torch.zeros(M, 128, dtype=dt) for _ in range(2)]
+
+    def sel(x, N):
+        if x is None:
+            return None
+        return slots[x][:, :N] if isinstance(x, int) else x
+
+    for o in prog.ops:
+        if o["kind"] == "load":
+            src = o["src"] if o["rows"] is None else o["src"][o["rows"].long()]
+            slots[o["slot"]] = torch.zeros(M, 128, dtype=dt)
+            slots[o["slot"]][:, :src.shape[1]] = src
+        elif o["kind"] == "scale":
+            Z, out = o["Z"], o["out"]
+            w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
+            v = slots[o["a_slot"]][:, :w] * o["alpha"]
+            if Z is not None:
+                v = v * _act(Z, 1)
+            new = slots[o["slot"]].clone()
+            new[:, :w] = v
+            slots[o["slot"]] = new
+            if out is not None:
+                out.copy_(v)
+        elif o["kind"] == "store":
+            o["out"].copy_(slots[o["slot"]][:, :o["out"].shape[1]])
+        else:
+            W = o["W"]
+            N, Kd = W.shape
+            z = slots[o["a_slot"]][:, :Kd] @ W.t()
+            if o["gadd1"] is not None:
+                z = z + o["gadd1"][o["gidx1"].long()]
+            if o["gadd2"] is not None:
+                z = z + o["gadd2"][o["gidx2"].long()]
+            if o["pre_out"] is not None:
+                o["pre_out"].copy_(z)
+            y = _act(z, 0) if o["act"] else z
+            mul = sel(o["mul"], N)
+            if mul is not None:
+                y = y * mul
+            y = y * o["alpha"]
+            res = sel(o["res"], N)
+            if res is not None:
+                if o["res_rows"] is not None:
+                    res = res[o["res_rows"].long()]
+                y = (y + res) * o["beta"]
+            res2 = sel(o["res2"], N)
+            if res2 is not None:
+                y = (y + res2) * o["beta2"]
+            if o["out"] is not None:
+                o["out"].copy_(y)
+            if o["slot"] >= 0:
+                new = slots[o["slot"]].clone()
+                new[:, :N] = y
+                slots[o["slot"]] = new
+
+
+_NAMES = ["chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -259,3 +259,54 @@ def test_trip_basis_fused_fwd_bwd_including_collinear():
     close(Gc[:-1], rGc[:-1], rtol=2e-3, atol=2e-3 * float(rGc.abs().median()))
     close(Gb[:-1], rGb[:-1], rtol=2e-3, atol=2e-3 * float(rGb.abs().median()))
     assert torch.isfinite(Gc).all() and torch.isfinite(Gb).all()
+
+
+def _stack_programs(M, width, g, dev):
+    """A residual-stack-like program with every op kind, slots aliasing and slot/global operands."""
+    def mk(*shape):
+        return rnd(g, *shape)
+    x, W0, W1, W2 = mk(M, 64), mk(width, 64) / 8, mk(width, width) / 11, mk(width, width) / 11
+    res, skip, ga = mk(M, width), mk(M, width), mk(50, width)
+    gi = torch.randint(0, 50, (M,), generator=g, dtype=torch.int32)
+    rows = torch.randperm(M, generator=g).to(torch.int32)
+    Z = mk(M, width)
+
+    def build(conv, idx):
+        t = {k: conv(v) for k, v in dict(x=x, W0=W0, W1=W1, W2=W2, res=res, skip=skip, ga=ga, Z=Z).items()}
+        outs = {k: conv(torch.zeros(M, width, dtype=torch.float64)) for k in ("z0", "z1", "z2", "y", "sc", "st")}
+        p = K.ChainProgram(M)
+        p.load(0, t["x"], rows=idx(rows))
+        p.gemm(t["W0"], a_slot=0, y_slot=1, act=True, gadd1=t["ga"], gidx1=idx(gi), pre_out=outs["z0"],
+               res=t["res"], beta=0.7)
+        p.gemm(t["W1"], a_slot=1, y_slot=0, act=True, pre_out=outs["z1"])
+        p.gemm(t["W2"], a_slot=0, y_slot=1, act=True, pre_out=outs["z2"], res=1, beta=0.7, res2=t["skip"], beta2=0.6,
+               out=outs["y"], mul=None)
+        p.scale(0, 1, 0.3, Z=t["Z"], out=outs["sc"])
+        p.gemm(t["W1"], a_slot=0, y_slot=0, act=False, mul=1, alpha=1.5)
+        p.store(0, outs["st"])
+        return p, outs
+    return build
+
+
+@pytest.mark.parametrize("M,width", [(1000, 128), (33, 64), (18122, 128)])
+def test_chain_kernel_vs_interpreter(M, width):
+    g = torch.Generator().manual_seed(M)
+    build = _stack_programs(M, width, g, DEV)
+    p_ref, o_ref = build(lambda t: t.clone(), lambda i: i)
+    CK.chain(p_ref)
+    p_dev, o_dev = build(lambda t: f32(t), lambda i: i.to(DEV))
+    K.chain(p_dev)
+    for k in o_ref:
+        close(o_dev[k], o_ref[k], rtol=1e-4, atol=2e-4 * max(1.0, float(o_ref[k].abs().max())))
+
+
+@pytest.mark.parametrize("M,N,Kd,ta,tb", [(128, 128, 18122, True, True), (64, 128, 5000, True, True),
+                                          (16, 6, 20000, True, True), (128, 1024, 18122, True, True)])
+def test_gemm_splitk_weight_gradient_shapes(M, N, Kd, ta, tb):
+    g = torch.Generator().manual_seed(M + N)
+    A = rnd(g, *((Kd, M) if ta else (M, Kd))) / 10
+    Bm = rnd(g, *((Kd, N) if tb else (N, Kd))) / 10
+    ref = CK.gemm(A, Bm, ta, tb, alpha=0.5)
+    out = K.gemm(f32(A), f32(Bm), ta, tb, alpha=0.5)
+    close(out, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    assert torch.equal(out, K.gemm(f32(A), f32(Bm), ta, tb, alpha=0.5))  # deterministic reduction order

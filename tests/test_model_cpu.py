@@ -55,10 +55,21 @@ def test_eval_mode_fused_first_order_path(golden_model, tag):
     """eval(): single-launch fused layers + first-order backward; same E/F as the reference."""
     g = golden_model
     cfg, params, inputs = load_case(g, tag)
+    import gemnet_pytorch_amd.kernels as K
+    calls = {"chain": 0}
     with cpu_kernels.emulate():
+        emu_chain = K.chain
+
+        def counting_chain(prog):
+            calls["chain"] += 1
+            return emu_chain(prog)
+
+        K.chain = counting_chain
         model = build(cfg, params).eval()
         inputs["R"] = inputs["R"].double()
         E, F = model(inputs)
+    # every block: 2 edge stacks + atom stack, every output block: 1 stack; each once forward, once backward
+    assert calls["chain"] == 2 * (3 * cfg["num_blocks"] + cfg["num_blocks"] + 1), calls
     assert not F.requires_grad and inputs["R"].requires_grad is False
     Fref, Eref = g[f"{tag}.F"], g[f"{tag}.E"]
     assert np.abs(F.numpy() - Fref).mean() <= 1e-9 * max(1.0, float(np.abs(Fref).mean()))

@@ -25,16 +25,15 @@ def timeit(fn, iters=200):
 
 
 CFGS = {0: "64x128 2x2 k32", 1: "32x128 1x4 k32", 6: "64x128 2x2 k64", 7: "32x128 1x4 k64", 8: "64x128 2x4 k32",
-        9: "64x128 2x4 k64", 12: "128x128 4x2 k32", 13: "128x128 4x4 k32",
+        9: "64x128 2x4 k64", 12: "128x128 4x2 k32", 13: "128x128 4x4 k32", 14: "32x128 8w 16x16 k32", 15: "32x128 8w 16x16 k64",
         2: "64x64 2x2 k32", 3: "32x64 1x2 k32", 10: "32x64 1x2 k64", 11: "64x64 2x2 k64", 4: "128x32 4x1", 5: "32x32 1x1"}
-for M, N, Kd in [(18122, 128, 128), (1024, 128, 128), (18122, 64, 128), (18122, 128, 64), (18122, 64, 1024),
-                 (18122, 32, 128), (65536, 128, 128)]:
+for M, N, Kd in [(18122, 128, 128), (1024, 128, 128), (18122, 128, 64), (9061, 128, 128), (65536, 128, 128)]:
     A = torch.randn(M, Kd, device=dev); W = torch.randn(N, Kd, device=dev); Z = torch.randn(M, Kd, device=dev)
     Wt = W.t().contiguous()
     tt = timeit(lambda: torch.mm(A, Wt))
     ref = A @ Wt
     print(f"shape {(M, N, Kd)}: torch.mm {tt:.2f} us")
-    cands = [c for c in CFGS if (N > 64 and c in (0, 1, 6, 7, 8, 9, 12, 13)) or (32 < N <= 64 and c in (2, 3, 10, 11))
+    cands = [c for c in CFGS if (N > 64 and c in (0, 1, 7, 13, 14, 15)) or (32 < N <= 64 and c in (2, 3, 10, 11))
              or (N <= 32 and c in (4, 5))]
     for c in cands:
         out = K.gemm(A, W, cfg=c)
