@@ -102,6 +102,113 @@ __global__ __launch_bounds__(256) void bil_dot_kernel(const float* __restrict__ 
   }
 }
 
+// Fused K1 + K2: the S partial sums of an edge stay in registers and are
+// immediately projected with the edge's rbf_W1 block:
+//   Sm[e,s,c] = sum_{t in seg(e)} Y[t,s] x[g(t),c]        (also written: the adjoint needs it)
+//   P[e,i,c]  = sum_s B[e,s,i] Sm[e,s,c]
+// replacing the separate per-edge bmm launch (torch.matmul(rbf_W1, sum_k), efficient.py:180).
+// B[e] (S x I) is staged in LDS once per edge group; lanes of one edge read it as broadcasts.
+template <int S>
+__global__ __launch_bounds__(256) void bil_reduce_project_kernel(
+    const float* __restrict__ Y, const float* __restrict__ x, const int32_t* __restrict__ expand_idx,
+    const int32_t* __restrict__ seg_off, const float* __restrict__ B, float* __restrict__ Sm,
+    float* __restrict__ P, int64_t E, int C, int I) {
+  extern __shared__ __attribute__((aligned(16))) float Bl[];   // [epb][S*I]
+  const int epb = blockDim.x / C;
+  const int el = threadIdx.x / C;
+  const int c = threadIdx.x - el * C;
+  const int64_t e0 = (int64_t)blockIdx.x * epb;
+  const int SI = S * I;
+  for (int i = threadIdx.x; i < epb * SI; i += blockDim.x) {
+    const int64_t ee = e0 + i / SI;
+    Bl[i] = ee < E ? B[ee * SI + (i % SI)] : 0.f;
+  }
+  __syncthreads();
+  const int64_t e = e0 + el;
+  if (e >= E) return;
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  float acc[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) acc[s] = 0.f;
+  for (int t = t0; t < t1; ++t) {
+    const float xv = x[(int64_t)expand_idx[t] * C + c];
+    const float* __restrict__ y = Y + (int64_t)t * S;
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = fmaf(y[s], xv, acc[s]);
+  }
+  float* __restrict__ so = Sm + e * S * C + c;
+#pragma unroll
+  for (int s = 0; s < S; ++s) so[(int64_t)s * C] = acc[s];
+  const float* bl = Bl + el * SI;
+  float* __restrict__ po = P + e * (int64_t)I * C + c;
+  for (int i = 0; i < I; ++i) {
+    float p = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) p = fmaf(bl[s * I + i], acc[s], p);
+    po[(int64_t)i * C] = p;
+  }
+}
+
+// Adjoint of K2 fused with the K1 adjoint w.r.t. Y, one workgroup per reduce edge:
+//   gB[e,s,i]  = sum_c Sm[e,s,c] dP[e,i,c]
+//   dSm[e,s,c] = sum_i B[e,s,i] dP[e,i,c]                  (written: bil_reduce_t consumes it)
+//   dY[t,s]    = sum_c dSm[e,s,c] x[g(t),c]   for t in seg(e)
+// replacing two bmm launches and bil_dot.  LDS: dP[e] (I x (C+4)), Sm[e]/dSm[e] (S x (C+4)), B[e].
+__global__ __launch_bounds__(256) void bil_project_bwd_kernel(
+    const float* __restrict__ dP, const float* __restrict__ Sm, const float* __restrict__ B,
+    const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
+    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int S, int C, int I) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = C + 4;
+  float* dPl = sm;                 // [I][ld]
+  float* Sl = dPl + I * ld;        // [S][ld]  Sm, later dSm
+  float* Dl = Sl + S * ld;         // [S][ld]  dSm
+  float* Bl = Dl + S * ld;         // [S*I]
+  const int64_t e = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < I * C; i += nt) dPl[(i / C) * ld + (i % C)] = dP[e * (int64_t)I * C + i];
+  for (int i = tid; i < S * C; i += nt) Sl[(i / C) * ld + (i % C)] = Sm[e * (int64_t)S * C + i];
+  for (int i = tid; i < S * I; i += nt) Bl[i] = B[e * (int64_t)S * I + i];
+  __syncthreads();
+  // gB[s,i] = <Sm[s,:], dP[i,:]>
+  for (int o = tid; o < S * I; o += nt) {
+    const int s = o / I, i = o - s * I;
+    const float* a = Sl + s * ld;
+    const float* b = dPl + i * ld;
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 4) {
+      const float4 u = *reinterpret_cast<const float4*>(a + c);
+      const float4 v = *reinterpret_cast<const float4*>(b + c);
+      acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+    }
+    gB[e * (int64_t)S * I + o] = acc;
+  }
+  // dSm[s,c] = sum_i B[s,i] dP[i,c]
+  for (int o = tid; o < S * C; o += nt) {
+    const int s = o / C, c = o - s * C;
+    float acc = 0.f;
+    for (int i = 0; i < I; ++i) acc = fmaf(Bl[s * I + i], dPl[i * ld + c], acc);
+    Dl[s * ld + c] = acc;
+    dSm[e * (int64_t)S * C + o] = acc;
+  }
+  __syncthreads();
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  const int n = (t1 - t0) * S;
+  for (int p = tid; p < n; p += nt) {
+    const int tt = p / S, s = p - tt * S;
+    const int t = t0 + tt;
+    const float* __restrict__ xr = x + (int64_t)expand_idx[t] * C;
+    const float* dr = Dl + s * ld;
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(dr + c);
+      const float4 b = *reinterpret_cast<const float4*>(xr + c);
+      acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+    }
+    dY[(int64_t)t * S + s] = acc;
+  }
+}
+
 inline bool ok_channels(int C) { return C > 0 && C <= 256 && (256 % C) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -155,6 +262,40 @@ extern "C" int gn_bil_dot_f32(const float* dSm, const float* x, const int32_t* e
   const int vec = (C % 4 == 0) && aligned16(x);
   hipLaunchKernelGGL(bil_dot_kernel, dim3((unsigned)E), dim3(S <= 7 ? 128 : 256), smem,
                      static_cast<hipStream_t>(stream), dSm, x, expand_idx, seg_off, dY, S, C, vec);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_reduce_project_f32(const float* Y, const float* x, const int32_t* expand_idx,
+                                         const int32_t* seg_off, const float* B, float* Sm, float* P,
+                                         int64_t E, int S, int C, int I, void* stream) {
+  if (E <= 0) return 0;
+  if (!ok_channels(C) || I <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int epb = 256 / C;
+  const size_t smem = (size_t)epb * S * I * sizeof(float);
+  if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
+  dim3 grid(gn_cdiv(E, epb)), block(256);
+  if (S == 7) {
+    hipLaunchKernelGGL(bil_reduce_project_kernel<7>, grid, block, smem, st, Y, x, expand_idx, seg_off, B, Sm, P, E, C, I);
+  } else if (S == 49) {
+    hipLaunchKernelGGL(bil_reduce_project_kernel<49>, grid, block, smem, st, Y, x, expand_idx, seg_off, B, Sm, P, E, C, I);
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,
+                                      const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm,
+                                      float* dY, int64_t E, int S, int C, int I, void* stream) {
+  if (E <= 0) return 0;
+  if (S <= 0 || C <= 0 || (C % 4) != 0 || I <= 0) return (int)hipErrorInvalidValue;
+  const size_t smem = ((size_t)(I + 2 * S) * (C + 4) + (size_t)S * I) * sizeof(float);
+  if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bil_project_bwd_kernel, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream),
+                     dP, Sm, B, x, expand_idx, seg_off, gB, dSm, dY, S, C, I);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -376,3 +376,31 @@ def chain(prog):
             c.res_rows = ptr(o["res_rows"])
             c.res2_slot, t = _sel(o["res2"]); c.res2_g = ptr(mat(t, N)) if t is not None else None
     check(_lib.load().gn_chain_f32(ctypes.byref(a), stream()), "gn_chain_f32")
+
+
+def bil_reduce_project(Y, x, B, sp):
+    """Fused K1+K2 -> (Sm (E,S,C), P (E,I,C)); B = rbf_W1 (E,S,I)."""
+    require_device(Y, x, B)
+    Y, x, B = _f32c(Y), _f32c(x), _f32c(B)
+    S, C, I = Y.shape[1], x.shape[1], B.shape[2]
+    Sm = torch.empty((sp.n_reduce, S, C), device=x.device, dtype=torch.float32)
+    P = torch.empty((sp.n_reduce, I, C), device=x.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_reduce_project_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
+                                                ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
+          "gn_bil_reduce_project_f32")
+    return Sm, P
+
+
+def bil_project_bwd(dP, Sm, B, x, sp):
+    """Fused adjoint of K2 and of K1 w.r.t. Y -> (gB (E,S,I), dSm (E,S,C), dY (T,S))."""
+    require_device(dP, Sm, B, x)
+    dP, Sm, B, x = _f32c(dP), _f32c(Sm), _f32c(B), _f32c(x)
+    E, S, C = Sm.shape
+    I = B.shape[2]
+    gB = torch.empty((E, S, I), device=x.device, dtype=torch.float32)
+    dSm = torch.empty((E, S, C), device=x.device, dtype=torch.float32)
+    dY = torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_project_bwd_f32(ptr(dP), ptr(Sm), ptr(B), ptr(x), ptr(sp.expand.idx32),
+                                             ptr(sp.seg_off), ptr(gB), ptr(dSm), ptr(dY), E, S, C, I, stream()),
+          "gn_bil_project_bwd_f32")
+    return gB, dSm, dY

@@ -152,7 +152,7 @@ class AtomUpdateBlock(torch.nn.Module):
 
     @staticmethod
     def _stackable(layers):
-        return (ops.constant_weights() and isinstance(layers[0], Dense) and layers[0].bias is None
+        return (ops.stacks_enabled() and isinstance(layers[0], Dense) and layers[0].bias is None
                 and all(isinstance(l, ResidualLayer) and l.stackable() for l in layers[1:]))
 
     def forward(self, h, m, rbf, id_a, res2=None, beta2=1.0):
@@ -459,7 +459,7 @@ class _InteractionBase(torch.nn.Module):
 
     def _stack_ok(self):
         res = list(self.layers_before_skip) + list(self.layers_after_skip) + list(self.residual_m)
-        return (ops.constant_weights() and self.dense_ca.bias is None and self.concat_layer.dense.bias is None
+        return (ops.stacks_enabled() and self.dense_ca.bias is None and self.concat_layer.dense.bias is None
                 and all(l.stackable() for l in res) and len(self.layers_before_skip) > 0
                 and len(self.residual_m) > 0)
 

@@ -449,8 +449,7 @@ class _FusedBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rbf_W1, sph, x, W, sp, alpha):
         C, I, O = W.shape
-        Sm = K.bil_reduce(sph, x, sp)                       # (E,S,C)
-        P = K.bmm(rbf_W1, Sm, True, False)                  # (E,I,C)
+        Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)
         W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)  # rows (i,c)
         out = K.gemm(P.reshape(-1, I * C), transposed_2d(W2, W), alpha=alpha)
         keep_p = W.requires_grad and _PARAM_GRADS
@@ -468,14 +467,14 @@ class _FusedBilinear(torch.autograd.Function):
         g = g.contiguous()
         W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)
         dP = K.gemm(g, W2, alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is already (N=I*C, K=O)
-        gB = K.bmm(Sm, dP, False, True) if need[0] else None          # (E,S,C)@(E,I,C)^T -> (E,S,I)
-        gsph = gx = gW = None
-        if need[1] or need[2]:
-            dSm = K.bmm(rbf_W1, dP, False, False)                      # (E,S,I)@(E,I,C) -> (E,S,C)
-            if need[1]:
-                gsph = K.bil_dot(dSm, x, sp)
-            if need[2]:
-                gx = K.bil_reduce_t(sph, dSm, sp)
+        gB, dSm, gsph = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp)      # 2 bmm + bil_dot in one launch
+        gx = gW = None
+        if not need[0]:
+            gB = None
+        if not need[1]:
+            gsph = None
+        if need[2]:
+            gx = K.bil_reduce_t(sph, dSm, sp)
         if need[3] and _PARAM_GRADS and P is not None:
             gW2 = K.gemm(P.reshape(-1, I * C), g, True, True, alpha=alpha)   # P^T @ g  (I*C, O)
             gW = gW2.reshape(I, C, O).permute(1, 0, 2)
@@ -574,6 +573,18 @@ def constant_weights():
     """True while weights are treated as constants (force-by-autograd inference: the graph of E is
     consumed inside GemNet.forward, so parameter gradients can never be requested)."""
     return _FUSED and not _PARAM_GRADS
+
+
+# LDS-resident layer stacks (gn_chain_f32) are correct and tested but, measured on MI355X at the
+# 32-molecule batch (profiles/r1_chain_bench.txt), one chain op costs 8 us (M = 1024) / 15-17 us
+# (E = 18 k) against 5.9 / 12.5 us for the stand-alone 8-wave GEMM: per-op latency inside the chain
+# (4 barrier-separated K-steps on one accumulator per wave, 153 VGPRs -> 2 waves/SIMD) is not yet
+# lower than a launch.  Off by default until the persistent weight-stationary variant lands.
+USE_STACKS = False
+
+
+def stacks_enabled():
+    return USE_STACKS and constant_weights()
 
 
 def contiguous_weight(W):

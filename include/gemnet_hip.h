@@ -140,6 +140,17 @@ int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32_t* reduce_
 int gn_bil_dot_f32(const float* dSm, const float* x, const int32_t* expand_idx,
                    const int32_t* seg_off, float* dY, int64_t E, int S, int C, void* stream);
 
+/* Fused K1 + K2: Sm as above and P[e,i,c] = sum_s B[e,s,i] Sm[e,s,c]  (B = rbf_W1 (E,S,I); replaces the
+ * per-edge bmm of efficient.py:180).  Both Sm (E,S,C) and P (E,I,C) are written. */
+int gn_bil_reduce_project_f32(const float* Y, const float* x, const int32_t* expand_idx,
+                              const int32_t* seg_off, const float* B, float* Sm, float* P, int64_t E, int S,
+                              int C, int I, void* stream);
+/* Fused adjoint: gB[e,s,i] = sum_c Sm[e,s,c] dP[e,i,c]; dSm[e,s,c] = sum_i B[e,s,i] dP[e,i,c];
+ * dY[t,s] = sum_c dSm[r(t),s,c] x[g(t),c].  x rows 16-byte aligned, C % 4 == 0. */
+int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,
+                           const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
+                           int64_t E, int S, int C, int I, void* stream);
+
 /* ---- basis functions (P6-P8; closed forms of SURVEY.md Appendix A, evaluated in f64 in-kernel) */
 /* out[e,n] = d^kd/dd^kd d^kf/df_n^kf [ u(d/c) sqrt(2/c) sin(f_n d/c)/d ]   (basis_layers.py:45-49);
  * (kd,kf) in {(0,0),(1,0),(2,0),(0,1),(1,1)} */

@@ -280,7 +280,18 @@ def chain(prog):
                 slots[o["slot"]] = new
 
 
-_NAMES = ["chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+def bil_reduce_project(Y, x, Bm, sp):
+    Sm = bil_reduce(Y, x, sp)
+    return Sm, torch.bmm(Bm.transpose(1, 2), Sm)
+
+
+def bil_project_bwd(dP, Sm, Bm, x, sp):
+    gB = torch.bmm(Sm, dP.transpose(1, 2))
+    dSm = torch.bmm(Bm, dP)
+    return gB, dSm, bil_dot(dSm, x, sp)
+
+
+_NAMES = ["bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -310,3 +310,18 @@ def test_gemm_splitk_weight_gradient_shapes(M, N, Kd, ta, tb):
     out = K.gemm(f32(A), f32(Bm), ta, tb, alpha=0.5)
     close(out, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
     assert torch.equal(out, K.gemm(f32(A), f32(Bm), ta, tb, alpha=0.5))  # deterministic reduction order
+
+
+@pytest.mark.parametrize("S,C,I,E,J,mk", [(7, 64, 16, 500, 500, 18), (7, 32, 16, 77, 77, 5), (49, 32, 32, 60, 300, 80)])
+def test_bilinear_fused_project_kernels(S, C, I, E, J, mk):
+    g = torch.Generator().manual_seed(S * C + 1)
+    cpu, dev = _segplan(g, E, J, mk)
+    T = cpu.size
+    Y, x, Bm, dP = rnd(g, T, S), rnd(g, J, C), rnd(g, E, S, I), rnd(g, E, I, C)
+    Sm, P = K.bil_reduce_project(f32(Y), f32(x), f32(Bm), dev)
+    rSm, rP = CK.bil_reduce_project(Y, x, Bm, cpu)
+    close(Sm, rSm, atol=1e-4); close(P, rP, atol=2e-4 * float(rP.abs().max()))
+    gB, dSm, dY = K.bil_project_bwd(f32(dP), f32(rSm), f32(Bm), f32(x), dev)
+    rgB, rdSm, rdY = CK.bil_project_bwd(dP, rSm, Bm, x, cpu)
+    close(gB, rgB, atol=2e-4 * float(rgB.abs().max())); close(dSm, rdSm, atol=1e-4)
+    close(dY, rdY, atol=2e-4 * float(rdY.abs().max()))

@@ -131,3 +131,17 @@ def test_eval_forward_force_in_hipgraph(golden_model):
     torch.cuda.synchronize()
     E, F = model(dev)
     assert torch.equal(E, Eg) and torch.equal(F, Fg)
+
+
+def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch):
+    """The LDS-resident stack path (gn_chain_f32, off by default) gives the same E/F as per-layer GEMMs."""
+    from gemnet_pytorch_amd import ops
+    cfg, params, inputs = load_case(golden_model, "t2")
+    model = build(cfg, params).eval()
+    dev = to_dev(inputs)
+    E0, F0 = model(dev)
+    monkeypatch.setattr(ops, "USE_STACKS", True)
+    E1, F1 = model(dev)
+    fs = max(1.0, float(F0.abs().mean()))
+    assert float((F1 - F0).abs().mean()) <= 1e-5 * fs
+    assert float((E1 - E0).abs().max()) <= 2e-5 * max(1.0, float(E0.abs().max()))

@@ -50,12 +50,16 @@ def test_energy_force_and_training_grads(golden_model, tag):
             np.testing.assert_allclose(named[n].grad.numpy(), g[key], rtol=1e-6, atol=1e-10)
 
 
+@pytest.mark.parametrize("stacks", [False, True])
 @pytest.mark.parametrize("tag", ["t1", "q1", "t2"])
-def test_eval_mode_fused_first_order_path(golden_model, tag):
-    """eval(): single-launch fused layers + first-order backward; same E/F as the reference."""
+def test_eval_mode_fused_first_order_path(golden_model, tag, stacks, monkeypatch):
+    """eval(): single-launch fused layers (optionally LDS-resident layer stacks) + first-order
+    backward; same E/F as the reference."""
     g = golden_model
     cfg, params, inputs = load_case(g, tag)
     import gemnet_pytorch_amd.kernels as K
+    from gemnet_pytorch_amd import ops
+    monkeypatch.setattr(ops, "USE_STACKS", stacks)
     calls = {"chain": 0}
     with cpu_kernels.emulate():
         emu_chain = K.chain
@@ -69,7 +73,7 @@ def test_eval_mode_fused_first_order_path(golden_model, tag):
         inputs["R"] = inputs["R"].double()
         E, F = model(inputs)
     # every block: 2 edge stacks + atom stack, every output block: 1 stack; each once forward, once backward
-    assert calls["chain"] == 2 * (3 * cfg["num_blocks"] + cfg["num_blocks"] + 1), calls
+    assert calls["chain"] == (2 * (3 * cfg["num_blocks"] + cfg["num_blocks"] + 1) if stacks else 0), calls
     assert not F.requires_grad and inputs["R"].requires_grad is False
     Fref, Eref = g[f"{tag}.F"], g[f"{tag}.E"]
     assert np.abs(F.numpy() - Fref).mean() <= 1e-9 * max(1.0, float(np.abs(Fref).mean()))
