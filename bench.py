@@ -86,19 +86,24 @@ class LaunchTimer:
             b, m, n = o.shape
             k = args[0].numel() // (b * m)
             return 2.0 * b * m * n * k, (args[0].numel() + args[1].numel() + o.numel()) * f32
-        if name in ("bil_reduce", "bil_reduce_t", "bil_dot"):
-            sp = args[2]
-            S = args[0].shape[1]
-            C = args[1].shape[-1]
+        if name in ("bil_reduce", "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd"):
+            sp = args[-1]
+            if name == "bil_project_bwd":
+                S, C = args[1].shape[1], args[1].shape[2]
+            else:
+                S = args[0].shape[1]
+                C = args[1].shape[-1]
             by = sp.size * (S * f32 + 8) + sp.n_expand * C * f32 + sp.n_reduce * S * C * f32
             return 2.0 * sp.size * S * C, by
         numel = sum(a.numel() for a in args if torch.is_tensor(a))
-        o = out[0] if isinstance(out, tuple) else out
-        return 0.0, (numel + o.numel()) * f32
+        outs = out if isinstance(out, tuple) else (out,)
+        return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
     def __enter__(self):
-        for name in ["gemm", "bmm", "gather", "segsum", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
-                     "bessel_rbf", "sph_radial", "ylm0", "ylm"]:
+        for name in ["gemm", "bmm", "gather", "segsum", "ssilu", "dact_mul", "chain", "bil_reduce", "bil_reduce_t",
+                     "bil_dot", "bil_reduce_project", "bil_project_bwd", "bessel_rbf", "sph_radial", "ylm0", "ylm",
+                     "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
+                     "quad_basis_bwd"]:
             fn = getattr(self.K, name)
             self.saved[name] = fn
 

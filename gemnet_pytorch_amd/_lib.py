@@ -85,6 +85,8 @@ SIGNATURES = {
     "gn_edge_basis_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "gn_trip_basis_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_trip_basis_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "gn_quad_basis_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "gn_quad_basis_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_ssilu_f32": [_vp, _vp, _i64, _i, _vp],
     "gn_dact_mul_f32": [_vp, _vp, _i, _vp, _f, _vp, _vp, _i64, _vp],
 }

@@ -147,11 +147,12 @@ GN_HD void ylm0_row(double theta, int S, int k, float* out) {
   }
 }
 
-// out[j] = d^kt/dtheta^kt d^kp/dphi^kp Y_j(theta, phi), j < S*S; per degree l the slots hold
-// m = 0, +1..+l, -l..-1 (negative list indices at basis_utils.py:237).
-// Y_l,+m = sqrt2 N_lm Q_l^m cos(m phi), Y_l,-m = sqrt2 N_lm Q_l^m sin(m phi), Q_l^m = phase-free
-// associated Legendre in (cos theta, sin theta)  (basis_utils.py:137-159,226-243).
-GN_HD void ylm_row(double theta, double ph, int S, int kt, int kp, float* o) {
+// Visit every real Y_j(theta, phi), j < S*S, with its kt-th theta / kp-th phi derivative:
+// emit(slot, value).  Per degree l the slots hold m = 0, +1..+l, -l..-1 (negative list indices at
+// basis_utils.py:237).  Y_l,+m = sqrt2 N_lm Q_l^m cos(m phi), Y_l,-m = sqrt2 N_lm Q_l^m sin(m phi),
+// Q_l^m = phase-free associated Legendre in (cos theta, sin theta)  (basis_utils.py:137-159,226-243).
+template <typename F>
+GN_HD void ylm_visit(double theta, double ph, int S, int kt, int kp, F emit) {
   double sn, cs;
   sincos(theta, &sn, &cs);
   const Jet js = {sn, cs, -sn};
@@ -179,12 +180,24 @@ GN_HD void ylm_row(double theta, double ph, int S, int kt, int kp, float* o) {
       const double tv = (kt == 0) ? ql.v : (kt == 1 ? ql.d1 : ql.d2);
       const int base = l * l;  // first slot of degree l
       if (m == 0) {
-        o[base] = (float)(kp == 0 ? ylm_prefactor(l, 0) * tv : 0.0);
+        emit(base, kp == 0 ? ylm_prefactor(l, 0) * tv : 0.0);
       } else {
         const double pf = 1.4142135623730951 * ylm_prefactor(l, m) * tv;
-        o[base + m] = (float)(pf * fc);              // +m
-        o[base + 2 * l + 1 - m] = (float)(pf * fs);  // -m
+        emit(base + m, pf * fc);              // +m
+        emit(base + 2 * l + 1 - m, pf * fs);  // -m
       }
     }
   }
+}
+
+// out[j] = d^kt/dtheta^kt d^kp/dphi^kp Y_j(theta, phi), j < S*S
+GN_HD void ylm_row(double theta, double ph, int S, int kt, int kp, float* o) {
+  ylm_visit(theta, ph, S, kt, kp, [o](int slot, double v) { o[slot] = (float)v; });
+}
+
+// sum_j g[j] * d^kt/dtheta^kt d^kp/dphi^kp Y_j(theta, phi)
+GN_HD double ylm_dot(double theta, double ph, int S, int kt, int kp, const float* g) {
+  double acc = 0.0;
+  ylm_visit(theta, ph, S, kt, kp, [&acc, g](int slot, double v) { acc += (double)g[slot] * v; });
+  return acc;
 }

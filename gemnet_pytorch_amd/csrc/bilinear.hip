@@ -26,7 +26,19 @@ __global__ __launch_bounds__(256) void bil_reduce_kernel(const float* __restrict
   float acc[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) acc[s] = 0.f;
-  for (int t = t0; t < t1; ++t) {
+  // 4 triplets per trip: the 4 index loads, then the 4 gathered x rows, are independent and in
+  // flight together (the serial idx -> x dependency otherwise exposes one L2 latency per triplet)
+  int t = t0;
+  for (; S <= 8 && t + 4 <= t1; t += 4) {   // (S = 49: the 4x register footprint costs more than it buys)
+    const int g0 = expand_idx[t], g1 = expand_idx[t + 1], g2 = expand_idx[t + 2], g3 = expand_idx[t + 3];
+    const float x0 = x[(int64_t)g0 * C + c], x1 = x[(int64_t)g1 * C + c];
+    const float x2 = x[(int64_t)g2 * C + c], x3 = x[(int64_t)g3 * C + c];
+    const float* __restrict__ y = Y + (int64_t)t * S;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      acc[s] = fmaf(y[3 * S + s], x3, fmaf(y[2 * S + s], x2, fmaf(y[S + s], x1, fmaf(y[s], x0, acc[s]))));
+  }
+  for (; t < t1; ++t) {
     const float xv = x[(int64_t)expand_idx[t] * C + c];
     const float* __restrict__ y = Y + (int64_t)t * S;
 #pragma unroll
@@ -51,15 +63,31 @@ __global__ __launch_bounds__(256) void bil_reduce_t_kernel(const float* __restri
   const int64_t j = (int64_t)blockIdx.x * rpb + rl;
   if (rl >= rpb || j >= J) return;
   const int k0 = segT_off[j], k1 = segT_off[j + 1];
-  float acc = 0.f;
-  for (int k = k0; k < k1; ++k) {
+  float acc = 0.f, acc2 = 0.f;
+  int k = k0;
+  // two entries in flight (permT -> reduce_idx -> dSm row is a 3-deep dependent chain); for the
+  // tensor basis (S = 49) the doubled register footprint costs more than the overlap buys
+  for (; S <= 8 && k + 2 <= k1; k += 2) {
+    const int ta = permT[k], tb = permT[k + 1];
+    const int ra = reduce_idx[ta], rb = reduce_idx[tb];
+    const float* __restrict__ ya = Y + (int64_t)ta * S;
+    const float* __restrict__ yb = Y + (int64_t)tb * S;
+    const float* __restrict__ da = dSm + (int64_t)ra * S * C + c;
+    const float* __restrict__ db = dSm + (int64_t)rb * S * C + c;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      acc = fmaf(ya[s], da[(int64_t)s * C], acc);
+      acc2 = fmaf(yb[s], db[(int64_t)s * C], acc2);
+    }
+  }
+  for (; k < k1; ++k) {
     const int t = permT[k];
     const float* __restrict__ y = Y + (int64_t)t * S;
     const float* __restrict__ d = dSm + (int64_t)reduce_idx[t] * S * C + c;
 #pragma unroll
     for (int s = 0; s < S; ++s) acc = fmaf(y[s], d[(int64_t)s * C], acc);
   }
-  dx[j * C + c] = acc;
+  dx[j * C + c] = acc + acc2;
 }
 
 // dY[t,s] = sum_c dSm[r(t),s,c] * x[g(t),c]; one block per reduce edge, dSm[e] staged in LDS
@@ -130,7 +158,19 @@ __global__ __launch_bounds__(256) void bil_reduce_project_kernel(
   float acc[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) acc[s] = 0.f;
-  for (int t = t0; t < t1; ++t) {
+  // 4 triplets per trip: the 4 index loads, then the 4 gathered x rows, are independent and in
+  // flight together (the serial idx -> x dependency otherwise exposes one L2 latency per triplet)
+  int t = t0;
+  for (; S <= 8 && t + 4 <= t1; t += 4) {   // (S = 49: the 4x register footprint costs more than it buys)
+    const int g0 = expand_idx[t], g1 = expand_idx[t + 1], g2 = expand_idx[t + 2], g3 = expand_idx[t + 3];
+    const float x0 = x[(int64_t)g0 * C + c], x1 = x[(int64_t)g1 * C + c];
+    const float x2 = x[(int64_t)g2 * C + c], x3 = x[(int64_t)g3 * C + c];
+    const float* __restrict__ y = Y + (int64_t)t * S;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      acc[s] = fmaf(y[3 * S + s], x3, fmaf(y[2 * S + s], x2, fmaf(y[S + s], x1, fmaf(y[s], x0, acc[s]))));
+  }
+  for (; t < t1; ++t) {
     const float xv = x[(int64_t)expand_idx[t] * C + c];
     const float* __restrict__ y = Y + (int64_t)t * S;
 #pragma unroll

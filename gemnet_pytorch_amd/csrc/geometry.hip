@@ -41,28 +41,41 @@ __global__ void edge_basis_fwd_kernel(const float* __restrict__ R, const int32_t
   }
 }
 
-// W[e,:] = gD[e] * V[e,:] with gD = g_D + sum_n g_rbf f'_n(d) + sum_{l,n} g_rad R'_ln(d)
+// W[e,:] = gD[e] * V[e,:] with gD = g_D + sum_n g_rbf f'_n(d) + sum_{l,n} g_rad R'_ln(d).
+// 16 lanes per edge share the NR + S*NR (= 48) f64 derivative evaluations and combine them with
+// xor-shuffles inside their 16-lane group (fixed order: deterministic).
 __global__ void edge_basis_bwd_kernel(const float* __restrict__ g_D, const float* __restrict__ g_rbf,
                                       const float* __restrict__ g_rad, const float* __restrict__ R,
                                       const int32_t* __restrict__ id_c, const int32_t* __restrict__ id_a,
                                       const float* __restrict__ freq, const float* __restrict__ z,
                                       const double* __restrict__ nrm, float* __restrict__ Wout, int64_t E,
                                       int NR, int S, double cutoff, int p) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
-       e += (int64_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & 15;
+  const int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const bool ok = e < E;
+  float vx = 0.f, vy = 0.f, vz = 0.f, d = 1.f;
+  double g = 0.0;
+  if (ok) {
     const float* Ra = R + 3 * (int64_t)id_a[e];
     const float* Rc = R + 3 * (int64_t)id_c[e];
-    const float vx = Ra[0] - Rc[0], vy = Ra[1] - Rc[1], vz = Ra[2] - Rc[2];
-    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
-    double g = g_D ? (double)g_D[e] : 0.0;
-    if (g_rbf)
-      for (int n = 0; n < NR; ++n)
-        g += (double)g_rbf[e * NR + n] * bessel_rbf_eval((double)d, (double)freq[n], cutoff, p, 1, 0);
-    if (g_rad)
-      for (int lr = 0; lr < S * NR; ++lr)
+    vx = Ra[0] - Rc[0]; vy = Ra[1] - Rc[1]; vz = Ra[2] - Rc[2];
+    d = sqrtf(vx * vx + vy * vy + vz * vz);
+    const int nfun = NR + S * NR;
+    for (int j = sub; j < nfun; j += 16) {
+      if (j < NR) {
+        if (g_rbf) g += (double)g_rbf[e * NR + j] * bessel_rbf_eval((double)d, (double)freq[j], cutoff, p, 1, 0);
+      } else if (g_rad) {
+        const int lr = j - NR;
         g += (double)g_rad[e * S * NR + lr] * sph_radial_eval((double)d, (double)z[lr], nrm[lr], lr / NR, cutoff, p, 1);
-    const float s = (float)(g / (double)d);
-    Wout[3 * e] = s * vx; Wout[3 * e + 1] = s * vy; Wout[3 * e + 2] = s * vz;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) g += __shfl_xor(g, m, 16);
+  if (ok && sub == 0) {
+    if (g_D) g += (double)g_D[e];
+    const float sc = (float)(g / (double)d);
+    Wout[3 * e] = sc * vx; Wout[3 * e + 1] = sc * vy; Wout[3 * e + 2] = sc * vz;
   }
 }
 
@@ -126,6 +139,87 @@ __global__ void trip_basis_bwd_kernel(const float* __restrict__ gY, const float*
   }
 }
 
+// ---- quadruplets c -> a - b <- d (gemnet.py:334-418) fused with the real Y_lm (basis_layers.py:269) --
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// theta = atan2(max(|u x v|, 1e-9), u.v) and, for a given dL/dtheta, dL/du and dL/dv
+__device__ __forceinline__ float angle_uv(V3 u, V3 v) {
+  const V3 w = cross(u, v);
+  const float yn = sqrtf(dot(w, w));
+  return atan2f(yn < 1e-9f ? 1e-9f : yn, dot(u, v));
+}
+__device__ __forceinline__ void angle_uv_bwd(V3 u, V3 v, float gth, V3& gu, V3& gv) {
+  const V3 w = cross(u, v);
+  const float x = dot(u, v);
+  const float yn = sqrtf(dot(w, w));
+  const bool clamped = yn < 1e-9f;
+  const float y = clamped ? 1e-9f : yn;
+  const float r2 = x * x + y * y;
+  const float dx = -y / r2 * gth;
+  const float dy = clamped ? 0.f : x / r2 * gth;
+  const V3 n = (clamped ? 0.f : 1.0f / y) * w;
+  gu = dx * v + dy * cross(v, n);
+  gv = dx * u + dy * cross(n, u);
+}
+// r = x - (x.n / n.n) n  (vector_rejection, gemnet.py:313-332) and its adjoint
+__device__ __forceinline__ V3 reject(V3 x, V3 n) { return x - (dot(x, n) / dot(n, n)) * n; }
+__device__ __forceinline__ void reject_bwd(V3 x, V3 n, V3 gr, V3& gx, V3& gn) {
+  const float s = dot(x, n), q = dot(n, n), a = s / q, gn_dot = dot(gr, n);
+  gx = gr - (gn_dot / q) * n;
+  gn = (-a) * gr - gn_dot * ((1.0f / q) * x - (2.0f * s / (q * q)) * n);
+}
+
+// Y[q, :] = Y_lm(Phi_cab, Theta_cabd)
+__global__ void quad_basis_fwd_kernel(const float* __restrict__ R, const int32_t* __restrict__ qc,
+                                      const int32_t* __restrict__ qa, const int32_t* __restrict__ qb,
+                                      const int32_t* __restrict__ qd, float* __restrict__ Y, int64_t Q, int S) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {
+    const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
+    const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
+    const V3 uba = (-1.0f) * uab;
+    const float phi_cab = angle_uv(uab, uac);
+    const float theta = angle_uv(reject(uac, uab), reject(ubd, uba));
+    ylm_row((double)phi_cab, (double)theta, S, 0, 0, Y + q * (int64_t)S * S);
+  }
+}
+
+// Gc, Gb, Gd (Q,3): dE/dR of atoms c, b, d per quadruplet (dE/dR_a = -(Gc+Gb+Gd)) given gY (Q,S^2)
+__global__ void quad_basis_bwd_kernel(const float* __restrict__ gY, const float* __restrict__ R,
+                                      const int32_t* __restrict__ qc, const int32_t* __restrict__ qa,
+                                      const int32_t* __restrict__ qb, const int32_t* __restrict__ qd,
+                                      float* __restrict__ Gc, float* __restrict__ Gb, float* __restrict__ Gd,
+                                      int64_t Q, int S) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {
+    const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
+    const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
+    const V3 uba = (-1.0f) * uab;
+    const V3 p1 = reject(uac, uab), p2 = reject(ubd, uba);
+    const float phi_cab = angle_uv(uab, uac);
+    const float theta = angle_uv(p1, p2);
+    const float* g = gY + q * (int64_t)S * S;
+    const float g_phi = (float)ylm_dot((double)phi_cab, (double)theta, S, 1, 0, g);   // d/d(first angle)
+    const float g_th = (float)ylm_dot((double)phi_cab, (double)theta, S, 0, 1, g);    // d/d(second angle)
+    V3 g_ab, g_ac, gp1, gp2, t1, t2, g_bd, g_ba;
+    angle_uv_bwd(uab, uac, g_phi, g_ab, g_ac);
+    angle_uv_bwd(p1, p2, g_th, gp1, gp2);
+    reject_bwd(uac, uab, gp1, t1, t2);   // d p1 / d(uac, uab)
+    g_ac = g_ac + t1; g_ab = g_ab + t2;
+    reject_bwd(ubd, uba, gp2, g_bd, g_ba);
+    g_ab = g_ab - g_ba;                   // uba = -uab
+    // uac = Rc - Ra, uab = Rb - Ra, ubd = Rd - Rb
+    const V3 gc = g_ac, gd = g_bd, gb = g_ab - g_bd;
+    Gc[3 * q] = gc.x; Gc[3 * q + 1] = gc.y; Gc[3 * q + 2] = gc.z;
+    Gb[3 * q] = gb.x; Gb[3 * q + 1] = gb.y; Gb[3 * q + 2] = gb.z;
+    Gd[3 * q] = gd.x; Gd[3 * q + 1] = gd.y; Gd[3 * q + 2] = gd.z;
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -152,7 +246,7 @@ extern "C" int gn_edge_basis_bwd_f32(const float* g_D, const float* g_rbf, const
                                      float cutoff, int p, void* stream) {
   if (E <= 0) return 0;
   if (p < 2 || S > 8) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(edge_basis_bwd_kernel, dim3(grid_for(E)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(edge_basis_bwd_kernel, dim3((unsigned)((E * 16 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      g_D, g_rbf, g_rad, R, id_c, id_a, freq, z, nrm, W, E, NR, S, (double)cutoff, p);
   GN_LAUNCH_CHECK();
   return 0;
@@ -174,6 +268,27 @@ extern "C" int gn_trip_basis_bwd_f32(const float* gY, const float* R, const int3
   if (S > 8) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(trip_basis_bwd_kernel, dim3(grid_for(T)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      gY, R, tc, ta, tb, Gc, Gb, T, S);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_quad_basis_fwd_f32(const float* R, const int32_t* qc, const int32_t* qa, const int32_t* qb,
+                                     const int32_t* qd, float* Y, int64_t Q, int S, void* stream) {
+  if (Q <= 0) return 0;
+  if (S > 7) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(quad_basis_fwd_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     R, qc, qa, qb, qd, Y, Q, S);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_quad_basis_bwd_f32(const float* gY, const float* R, const int32_t* qc, const int32_t* qa,
+                                     const int32_t* qb, const int32_t* qd, float* Gc, float* Gb, float* Gd,
+                                     int64_t Q, int S, void* stream) {
+  if (Q <= 0) return 0;
+  if (S > 7) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(quad_basis_bwd_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     gY, R, qc, qa, qb, qd, Gc, Gb, Gd, Q, S);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -111,6 +111,10 @@ class GraphPlan:
                 "b_of_red": RowIndex(i_b[red_ab], A),
                 "reduce_cab": RowIndex(inputs["id4_reduce_cab"], self.n_intm),
             }
+            # the four atoms of every quadruplet c -> a - b <- d (data_container.py:393-397)
+            q_ca, q_db = inputs["id4_reduce_ca"], inputs["id4_expand_db"]
+            self.q_c, self.q_a = RowIndex(id_c[q_ca], A), RowIndex(id_a[q_ca], A)
+            self.q_d, self.q_b = RowIndex(id_c[q_db], A), RowIndex(id_a[q_db], A)
         self.device = dev
 
     @staticmethod
@@ -126,7 +130,7 @@ class GraphPlan:
                self.t_c, self.t_a, self.t_b, self.z_rows, self.id_undir]
         if not self.triplets_only:
             out += [self.int_a, self.int_b, self.intm_db, self.intm_ab, self.quad.reduce, self.quad.expand]
-            out += list(self.quad_geom.values())
+            out += list(self.quad_geom.values()) + [self.q_c, self.q_a, self.q_b, self.q_d]
         return out
 
     def warm(self):

@@ -404,3 +404,25 @@ def bil_project_bwd(dP, Sm, B, x, sp):
                                              ptr(sp.seg_off), ptr(gB), ptr(dSm), ptr(dY), E, S, C, I, stream()),
           "gn_bil_project_bwd_f32")
     return gB, dSm, dY
+
+
+def quad_basis_fwd(R, qc, qa, qb, qd, S):
+    """-> Y (Q, S^2) = Y_lm(Phi_cab, Theta_cabd) from the 4 atoms of every quadruplet (gemnet.py:334-418)."""
+    require_device(R, qc, qa, qb, qd)
+    R = _f32c(R)
+    Q = qc.shape[0]
+    Y = torch.empty((Q, S * S), device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_quad_basis_fwd_f32(ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Y), Q, S, stream()),
+          "gn_quad_basis_fwd_f32")
+    return Y
+
+
+def quad_basis_bwd(gY, R, qc, qa, qb, qd, S):
+    """-> Gc, Gb, Gd (Q,3); dE/dR_a = -(Gc+Gb+Gd)."""
+    require_device(gY, R)
+    gY, R = _f32c(gY), _f32c(R)
+    Q = qc.shape[0]
+    Gc, Gb, Gd = (torch.empty((Q, 3), device=R.device, dtype=torch.float32) for _ in range(3))
+    check(_lib.load().gn_quad_basis_bwd_f32(ptr(gY), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), ptr(Gb),
+                                            ptr(Gd), Q, S, stream()), "gn_quad_basis_bwd_f32")
+    return Gc, Gb, Gd

@@ -180,7 +180,17 @@ class GemNet(torch.nn.Module):
             D_ca, V_ca = self.calculate_interatomic_vectors(R, plan.id_c, plan.id_a)
             rbf = self.rbf_basis(D_ca)
             rad3, sph3 = b3(D_ca, self.calculate_angles3(R, plan))
-        if not T:
+        if not T and ops.is_fused():
+            b4, qg = self.cbf_basis, plan.quad_geom
+            # interaction-edge radial basis (cutoff = int_cutoff), a-b<-d angles and the quadruplet
+            # harmonics, each one launch, straight from the positions
+            _, _, _, rad4 = ops.edge_basis(R, None, plan.int_b, plan.int_a, b4.z_ln, b4.n_ln, b4.cutoff, b4.p,
+                                           want_rbf=False)
+            y_abd = ops.trip_basis(R, qg["a_of_exp"], qg["b_of_exp"], qg["d_of_exp"], self.num_spherical)
+            S, NR = self.num_spherical, b4.num_radial
+            cbf4 = (ops.gather_rows(rad4, plan.intm_ab) * y_abd[:, :, None]).reshape(-1, S * NR)
+            sbf4 = (rad3, ops.quad_basis(R, plan.q_c, plan.q_a, plan.q_b, plan.q_d, S))
+        elif not T:
             D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
             Phi_cab, Phi_abd, Theta_cabd = self.calculate_angles(R, plan)
             cbf4 = self.cbf_basis(D_ab, Phi_abd, plan.intm_ab)           # (I, S*R)

@@ -513,6 +513,8 @@ class _EdgeBasis(torch.autograd.Function):
     @staticmethod
     def forward(ctx, R, freq, ri_c, ri_a, z, nrm, cutoff, p, want_V, want_rbf):
         D, V, rbf, rad = K.edge_basis_fwd(R, ri_c.idx32, ri_a.idx32, freq, z, nrm, cutoff, p, want_V, want_rbf)
+        if freq is None:
+            freq = R.new_zeros(0)
         ctx.save_for_backward(R, freq, z, nrm, D)
         ctx.cfg = (ri_c, ri_a, cutoff, p, want_V, want_rbf)
         ctx.mark_non_differentiable(*[t for t in (V,) if t is not None])
@@ -730,3 +732,30 @@ def stack(x, first=None, layers=(), s=0.7071067811865475):
         res, res2, g1, g2 = first.get("res"), first.get("res2"), first.get("g1"), first.get("g2")
     skips = [L.get("skip") for L in layers]
     return _Stack.apply(spec, x, res, res2, g1, g2, *skips)
+
+
+class _QuadBasis(torch.autograd.Function):
+    """(R) -> real Y_lm(Phi_cab, Theta_cabd) of every quadruplet in one launch (first-order adjoint)."""
+
+    @staticmethod
+    def forward(ctx, R, ri_c, ri_a, ri_b, ri_d, S):
+        Y = K.quad_basis_fwd(R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
+        ctx.save_for_backward(R)
+        ctx.cfg = (ri_c, ri_a, ri_b, ri_d, S)
+        return Y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gY):
+        (R,) = ctx.saved_tensors
+        ri_c, ri_a, ri_b, ri_d, S = ctx.cfg
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 6
+        Gc, Gb, Gd = K.quad_basis_bwd(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
+        gR = (K.segsum(Gc, *ri_c.csr, ri_c.n_rows) + K.segsum(Gb, *ri_b.csr, ri_b.n_rows)
+              + K.segsum(Gd, *ri_d.csr, ri_d.n_rows) - K.segsum(Gc + Gb + Gd, *ri_a.csr, ri_a.n_rows))
+        return (gR,) + (None,) * 5
+
+
+def quad_basis(R, ri_c, ri_a, ri_b, ri_d, S):
+    return _QuadBasis.apply(R, ri_c, ri_a, ri_b, ri_d, int(S))

@@ -187,6 +187,16 @@ int gn_trip_basis_fwd_f32(const float* R, const int32_t* tc, const int32_t* ta, 
 int gn_trip_basis_bwd_f32(const float* gY, const float* R, const int32_t* tc, const int32_t* ta,
                           const int32_t* tb, float* Gc, float* Gb, int64_t T, int S, void* stream);
 
+/* Quadruplets c -> a - b <- d (gemnet.py:334-418: two neighbour angles, two vector rejections, the
+ * dihedral) fused with the real Y_lm (basis_layers.py:269): Y[q,:] = Y_lm(Phi_cab, Theta_cabd) from
+ * the four atom indices of each quadruplet. */
+int gn_quad_basis_fwd_f32(const float* R, const int32_t* qc, const int32_t* qa, const int32_t* qb,
+                          const int32_t* qd, float* Y, int64_t Q, int S, void* stream);
+/* adjoint: Gc, Gb, Gd (Q,3) = dE/dR of atoms c, b, d per quadruplet; dE/dR_a = -(Gc+Gb+Gd) */
+int gn_quad_basis_bwd_f32(const float* gY, const float* R, const int32_t* qc, const int32_t* qa,
+                          const int32_t* qb, const int32_t* qd, float* Gc, float* Gb, float* Gd, int64_t Q,
+                          int S, void* stream);
+
 /* ---- pointwise -------------------------------------------------------------------------
  * out[i] = d^k/dx^k ssilu(x[i]), k in {0,1,2,3}   (base_layers.py:51-58) */
 int gn_ssilu_f32(const float* x, float* out, int64_t n, int k, void* stream);

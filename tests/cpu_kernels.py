@@ -291,7 +291,35 @@ def bil_project_bwd(dP, Sm, Bm, x, sp):
     return gB, dSm, bil_dot(dSm, x, sp)
 
 
-_NAMES = ["bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+def _quad_angles(Rc, Ra, Rb, Rd):
+    def ang(u, v):
+        x = (u * v).sum(1)
+        y = torch.linalg.cross(u, v, dim=-1).norm(dim=-1).clamp(min=1e-9)
+        return torch.atan2(y, x)
+
+    def rej(x, n):
+        return x - ((x * n).sum(1) / (n * n).sum(1))[:, None] * n
+    uac, uab, ubd = Rc - Ra, Rb - Ra, Rd - Rb
+    return ang(uab, uac), ang(rej(uac, uab), rej(ubd, -uab))
+
+
+def quad_basis_fwd(R, qc, qa, qb, qd, S):
+    phi, th = _quad_angles(R[qc.long()], R[qa.long()], R[qb.long()], R[qd.long()])
+    return B.real_sph_harm_full(S, phi, th)
+
+
+def quad_basis_bwd(gY, R, qc, qa, qb, qd, S):
+    with torch.enable_grad():
+        Rc = R[qc.long()].detach().clone().requires_grad_(True)
+        Rb = R[qb.long()].detach().clone().requires_grad_(True)
+        Rd = R[qd.long()].detach().clone().requires_grad_(True)
+        Ra = R[qa.long()].detach()
+        phi, th = _quad_angles(Rc, Ra, Rb, Rd)
+        Gc, Gb, Gd = torch.autograd.grad((gY * B.real_sph_harm_full(S, phi, th)).sum(), (Rc, Rb, Rd))
+    return Gc, Gb, Gd
+
+
+_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 
