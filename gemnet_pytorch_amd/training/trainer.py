@@ -1,0 +1,270 @@
+"""`Trainer` — counterpart of the reference's gemnet/training/trainer.py:9-520 with the call surface used by
+train.ipynb / train_seml.py / fit_scaling.py (H2 of SURVEY.md §8):
+
+    train_on_batch / test_on_batch / eval_on_batch / predict_on_batch / predict / dict2device,
+    save_variable_backups / load_averaged_variables / restore_variable_backups / decay_maybe,
+    schedulers[i].get_last_lr(), optimizers, tracked_metrics, state_dict / load_state_dict.
+
+Same numerics as the reference: loss = (1-rho) * MAE(E) + rho * {MAE | mean L2}(F) (trainer.py:280-343) or
+the Gaussian NLL pair for mean-variance estimation; AdamW (weights) + Adam (atom_emb / frequencies / bias),
+amsgrad, eps 1e-7 (:115-160); shared-gradient rescale (:250-278); global-norm or adaptive gradient clipping
+(:218-248,349-356); linear-warmup exponential decay + reduce-on-plateau; EMA of the parameters.
+
+Native differences: all gradients live in ONE flat buffer (`FlatGradBuffer`), so in a multi-process run
+(one process per GPU, `torch.distributed` initialised) the step issues exactly one RCCL all-reduce, with the
+loss terms normalised by the GLOBAL molecule / atom counts (see training/ddp.py); `loss.backward()` is
+restricted to the parameters (no gradient w.r.t. positions); `load_state_dict` works (upstream's iterates a
+bound method, trainer.py:508).
+"""
+import torch
+import torch.distributed as dist
+
+from .ddp import FlatGradBuffer, scale_shared_grads
+from .ema_decay import ExponentialMovingAverage
+from .schedules import LinearWarmupExponentialDecay, ReduceLROnPlateau
+
+
+class MultiWrapper:
+    """Treat several optimizers / schedules as one (zero_grad, step, state_dict, indexing)."""
+
+    def __init__(self, *ops):
+        self.wrapped = ops
+
+    def __getitem__(self, idx):
+        return self.wrapped[idx]
+
+    def zero_grad(self):
+        for op in self.wrapped:
+            op.zero_grad()
+
+    def step(self):
+        for op in self.wrapped:
+            op.step()
+
+    def state_dict(self):
+        return {i: op.state_dict() for i, op in enumerate(self.wrapped)}
+
+    def load_state_dict(self, state_dict):
+        for i, op in enumerate(self.wrapped):
+            op.load_state_dict(state_dict[i])
+
+
+class Trainer:
+    _SUBSTATE = ("schedulers", "optimizers", "plateau_callback", "exp_decay")
+
+    def __init__(self, model, learning_rate: float = 1e-3, decay_steps: int = 100000, decay_rate: float = 0.96,
+                 warmup_steps: int = 0, weight_decay: float = 0.001, staircase: bool = False,
+                 grad_clip_max: float = 1000, decay_patience: int = 10, decay_factor: float = 0.5,
+                 decay_cooldown: int = 10, ema_decay: float = 0.999, rho_force: float = 0.99, loss: str = "mae",
+                 mve: bool = False, agc=False):
+        assert 0 <= rho_force <= 1
+        self.model = model
+        self.ema_decay = ema_decay
+        self.grad_clip_max = grad_clip_max
+        self.rho_force = float(rho_force)
+        self.mve = mve
+        self.loss = loss
+        self.agc = agc
+        self.tracked_metrics = (["loss", "energy_mae", "energy_nll", "energy_var", "force_mae", "force_rmse",
+                                 "force_nll", "force_var"] if mve
+                                else ["loss", "energy_mae", "force_mae", "force_rmse"])
+        self._grads = None
+        self.reset_optimizer(learning_rate, weight_decay, warmup_steps, decay_steps, decay_rate, staircase,
+                             decay_patience, decay_factor, decay_cooldown)
+
+    # ------------------------------------------------------------------------------------ optimiser
+    def reset_optimizer(self, learning_rate, weight_decay, warmup_steps, decay_steps, decay_rate, staircase,
+                        decay_patience, decay_factor, decay_cooldown):
+        adam_kw = dict(lr=learning_rate, betas=(0.9, 0.999), eps=1e-07, amsgrad=True)
+        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+        if weight_decay > 0:
+            plain = lambda n: any(s in n for s in ("atom_emb", "frequencies", "bias"))
+            opts = [torch.optim.AdamW([p for n, p in named if not plain(n)], weight_decay=weight_decay, **adam_kw),
+                    torch.optim.Adam([p for n, p in named if plain(n)], **adam_kw)]
+        else:
+            opts = [torch.optim.Adam(self.model.parameters(), **adam_kw)]
+        self.optimizers = MultiWrapper(*opts)
+        self.schedulers = MultiWrapper(*[LinearWarmupExponentialDecay(o, warmup_steps, decay_steps, decay_rate,
+                                                                      staircase) for o in opts])
+        self.plateau_callback = ReduceLROnPlateau(optimizer=self.optimizers, scheduler=self.schedulers,
+                                                  factor=decay_factor, patience=decay_patience,
+                                                  cooldown=decay_cooldown, verbose=True)
+        if self.agc:  # (the reference's selection, trainer.py:193-198: the output heads)
+            self.params_except_last = [p for n, p in named if "out_energy" in n or "out_forces" in n]
+        self.exp_decay = ExponentialMovingAverage([p for _, p in named], self.ema_decay)
+
+    def save_variable_backups(self):
+        self.exp_decay.store()
+
+    def load_averaged_variables(self):
+        self.exp_decay.copy_to()
+
+    def restore_variable_backups(self):
+        self.exp_decay.restore()
+
+    def decay_maybe(self, val_loss):
+        self.plateau_callback.step(val_loss)
+
+    # -------------------------------------------------------------------------------------- gradients
+    @staticmethod
+    def _unitwise_norm(x, norm_type=2.0):
+        if x.ndim <= 1:
+            return x.norm(norm_type)
+        return x.norm(norm_type, dim=tuple(range(1, x.ndim)), keepdim=True)
+
+    @staticmethod
+    def _adaptive_gradient_clipping(parameters, clip_factor=0.05, eps=1e-3, norm_type=2.0):
+        """Unit-wise adaptive gradient clipping (Brock et al., 2021): |g_unit| <= clip_factor * max(|w_unit|, eps)."""
+        with torch.no_grad():
+            for p in ([parameters] if isinstance(parameters, torch.Tensor) else parameters):
+                if p.grad is None:
+                    continue
+                max_norm = Trainer._unitwise_norm(p, norm_type).clamp_(min=eps).mul_(clip_factor)
+                grad_norm = Trainer._unitwise_norm(p.grad, norm_type)
+                clipped = p.grad * (max_norm / grad_norm.clamp(min=1e-6))
+                p.grad.copy_(torch.where(grad_norm < max_norm, p.grad, clipped))
+
+    def scale_shared_grads(self):
+        scale_shared_grads(self.model)
+
+    # ----------------------------------------------------------------------------------------- losses
+    @staticmethod
+    def get_mae(targets, pred):
+        return torch.nn.functional.l1_loss(pred, targets, reduction="mean")
+
+    @staticmethod
+    def get_rmse(targets, pred):
+        return torch.mean(torch.norm(pred - targets, p=2, dim=1))
+
+    @staticmethod
+    def get_nll(targets, mean_pred, var_pred):
+        return torch.nn.functional.gaussian_nll_loss(mean_pred, targets, var_pred, reduction="mean")
+
+    def predict(self, inputs):
+        energy, forces = self.model(inputs)
+        if self.mve:
+            return (energy[:, :1], torch.nn.functional.softplus(energy[:, 1:]),
+                    forces[:, 0, :], torch.nn.functional.softplus(forces[:, 1, :]))
+        if forces.dim() == 3:
+            forces = forces[:, 0]
+        return energy, None, forces, None
+
+    @staticmethod
+    def dict2device(data, device=None):
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        for key in data:
+            data[key] = data[key].to(device)
+        return data
+
+    def predict_on_batch(self, dataset_iter):
+        inputs, _ = next(dataset_iter)
+        return self.predict(self.dict2device(inputs))
+
+    def _world(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _objective(self, targets, mean_energy, var_energy, mean_forces, var_forces):
+        """-> (loss for this rank, dict of metric tensors).  In a multi-process run the energy/force means are
+        taken over the GLOBAL batch: local sums divided by all-reduced counts, so summed gradients are exact."""
+        out = {}
+        if self.mve:
+            out["energy_nll"] = self.get_nll(targets["E"], mean_energy, var_energy)
+            out["force_nll"] = self.get_nll(targets["F"], mean_forces, var_forces)
+            loss = out["energy_nll"] * (1 - self.rho_force) + self.rho_force * out["force_nll"]
+            return loss, out
+        out["energy_mae"] = self.get_mae(targets["E"], mean_energy)
+        force_metric = self.get_mae(targets["F"], mean_forces) if self.loss == "mae" \
+            else self.get_rmse(targets["F"], mean_forces)
+        out["force_mae" if self.loss == "mae" else "force_rmse"] = force_metric
+        loss = out["energy_mae"] * (1 - self.rho_force) + self.rho_force * force_metric
+        if self._world() > 1:
+            counts = torch.tensor([mean_energy.shape[0], mean_forces.shape[0]], dtype=torch.float64,
+                                  device=mean_energy.device)
+            local = counts.clone()
+            dist.all_reduce(counts)
+            w = (local / counts).to(loss.dtype)  # B_r / B, A_r / A
+            loss = out["energy_mae"] * w[0] * (1 - self.rho_force) + self.rho_force * force_metric * w[1]
+        return loss, out
+
+    # ------------------------------------------------------------------------------------------ steps
+    def train_on_batch(self, dataset_iter, metrics):
+        self.model.train()
+        inputs, targets = next(dataset_iter)
+        inputs, targets = self.dict2device(inputs), self.dict2device(targets)
+        mean_energy, var_energy, mean_forces, var_forces = self.predict(inputs)
+        loss, parts = self._objective(targets, mean_energy, var_energy, mean_forces, var_forces)
+
+        if self._grads is None:
+            self._grads = FlatGradBuffer(self.model.parameters())
+        self._grads.zero()
+        torch.autograd.backward(loss, inputs=self._grads.params)
+        self._grads.all_reduce()  # ONE collective (no-op in a single process)
+        self.scale_shared_grads()
+        if self.agc:
+            self._adaptive_gradient_clipping(self.params_except_last, clip_factor=self.grad_clip_max)
+        else:
+            torch.nn.utils.clip_grad_norm_(self._grads.params, max_norm=self.grad_clip_max)
+        self.optimizers.step()
+        self.schedulers.step()
+        self.exp_decay.update()
+
+        loss = loss.detach()
+        with torch.no_grad():
+            self._update_metrics(metrics, loss, targets, mean_energy, var_energy, mean_forces, var_forces, parts)
+        return loss
+
+    def _update_metrics(self, metrics, loss, targets, mean_energy, var_energy, mean_forces, var_forces, parts):
+        energy_mae = parts.get("energy_mae")
+        if energy_mae is None:
+            energy_mae = self.get_mae(targets["E"], mean_energy)
+        force_mae = parts.get("force_mae")
+        if force_mae is None:
+            force_mae = self.get_mae(targets["F"], mean_forces)
+        force_rmse = parts.get("force_rmse")
+        if force_rmse is None:
+            force_rmse = self.get_rmse(targets["F"], mean_forces)
+        if self.mve:
+            metrics.update_state(nsamples=mean_energy.shape[0], loss=loss, energy_mae=energy_mae,
+                                 energy_nll=parts["energy_nll"], energy_var=var_energy)
+            metrics.update_state(nsamples=mean_forces.shape[0], force_mae=force_mae, force_rmse=force_rmse,
+                                 force_nll=parts["force_nll"], force_var=var_forces)
+        else:
+            metrics.update_state(nsamples=mean_energy.shape[0], loss=loss, energy_mae=energy_mae)
+            metrics.update_state(nsamples=mean_forces.shape[0], force_mae=force_mae, force_rmse=force_rmse)
+
+    def test_on_batch(self, dataset_iter, metrics):
+        self.model.eval()
+        inputs, targets = next(dataset_iter)
+        inputs, targets = self.dict2device(inputs), self.dict2device(targets)
+        if self.model.direct_forces:
+            with torch.no_grad():
+                outs = self.predict(inputs)
+        else:
+            outs = self.predict(inputs)  # forces need dE/dR (first-order, fused path in eval mode)
+        mean_energy, var_energy, mean_forces, var_forces = (None if o is None else o.detach() for o in outs)
+        with torch.no_grad():
+            loss, parts = self._objective(targets, mean_energy, var_energy, mean_forces, var_forces)
+            self._update_metrics(metrics, loss, targets, mean_energy, var_energy, mean_forces, var_forces, parts)
+        return loss
+
+    def eval_on_batch(self, dataset_iter):
+        self.model.eval()
+        inputs, targets = next(dataset_iter)
+        inputs, targets = self.dict2device(inputs), self.dict2device(targets)
+        energy, _, forces, _ = self.predict(inputs)
+        return (energy.detach(), forces.detach()), targets
+
+    # ------------------------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        skip = ("model", "_grads") + self._SUBSTATE
+        state = {k: v for k, v in self.__dict__.items() if k not in skip and k != "params_except_last"}
+        state.update({attr: getattr(self, attr).state_dict() for attr in self._SUBSTATE})
+        return state
+
+    def load_state_dict(self, state_dict):
+        for k, v in state_dict.items():
+            if k in self._SUBSTATE:
+                getattr(self, k).load_state_dict(v)
+            else:
+                setattr(self, k, v)

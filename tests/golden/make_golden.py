@@ -9,7 +9,8 @@ with load_state_dict.
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
 Oracle-side shims (never shipped as product):
-  torch_scatter.scatter -> index_add based;  numba.njit -> identity;  np.math -> math.
+  torch_scatter.scatter -> index_add based;  numba.njit -> identity;  np.math -> math;
+  LambdaLR accepting (and dropping) the `verbose=` keyword torch >= 2.7 removed.
 """
 import math
 import os
@@ -52,6 +53,13 @@ def install_shims():
     nb.njit = njit
     sys.modules["numba"] = nb
     np.math = math
+    import torch.optim.lr_scheduler as lrs
+
+    class LambdaLR(lrs.LambdaLR):
+        def __init__(self, optimizer, lr_lambda, last_epoch=-1, verbose=False):
+            super().__init__(optimizer, lr_lambda, last_epoch=last_epoch)
+
+    lrs.LambdaLR = LambdaLR
     sys.path.insert(0, REF)
 
 
@@ -300,8 +308,92 @@ def golden_keys():
     print("state_dict_keys.json", {k: len(v["state_dict"]) for k, v in out.items()})
 
 
+# ----------------------------------------------------------------------------- G5 trainer
+TRAINER_CASES = {
+    # tag: (model cfg, model seed, Trainer keywords)
+    "rmse": (cfg_small(True), 21, dict(learning_rate=2e-3, decay_steps=3, decay_rate=0.5, warmup_steps=2,
+                                       weight_decay=0.01, staircase=False, grad_clip_max=0.5, ema_decay=0.9,
+                                       rho_force=0.99, loss="rmse")),
+    "mae_agc": (cfg_small(True), 22, dict(learning_rate=1e-3, decay_steps=2, decay_rate=0.9, warmup_steps=0,
+                                          weight_decay=0.0, staircase=True, grad_clip_max=0.05, ema_decay=0.99,
+                                          rho_force=0.9, loss="mae", agc=True)),
+    "quad": (cfg_small(False), 23, dict(learning_rate=1e-3, decay_steps=10, decay_rate=0.9, warmup_steps=3,
+                                        weight_decay=0.001, grad_clip_max=10.0, ema_decay=0.999,
+                                        rho_force=0.999, loss="rmse")),
+}
+TRAINER_STEPS = 4
+
+
+def golden_trainer():
+    """Four `Trainer.train_on_batch` steps + one `test_on_batch` with the EMA weights, run by the REFERENCE
+    Trainer / Metrics (gemnet/training/trainer.py:325-420) in float64 on two fixed batches."""
+    from gemnet.training.trainer import Trainer
+    from gemnet.training.metrics import Metrics
+    out = {}
+    mols = [make_molecule(10, 500, box=4.2), make_molecule(7, 501, box=3.6), make_molecule(9, 502, box=4.0)]
+    sf = GO.load_scale_factors(SCALE_FILE)
+    for tag, (cfg, seed, kw) in TRAINER_CASES.items():
+        to = cfg["triplets_only"]
+        N = np.array([len(m["R"]) for m in mols], dtype=np.int32)
+        R = np.concatenate([m["R"] for m in mols]).astype(np.float32)
+        Z = np.concatenate([m["Z"] for m in mols]).astype(np.int32)
+        rs = np.random.RandomState(seed)
+        Et = rs.standard_normal(len(N)).astype(np.float32)
+        Ft = (0.3 * rs.standard_normal(R.shape)).astype(np.float32)
+        dc = _MemContainer(dict(N=N, Z=Z, R=R, E=Et, F=Ft), 5.0, 10.0, to)
+        batches = [[0, 1], [2, 1], [0, 2], [1]]
+
+        def stream():
+            i = 0
+            while True:
+                b = dc[batches[i % len(batches)]]
+                inputs = {k: v for k, v in b.items() if k not in ("E", "F")}
+                inputs["R"] = inputs["R"].double()
+                yield inputs, {"E": b["E"].double(), "F": b["F"].double()}
+                i += 1
+
+        model = GemNet(**cfg, scale_file=SCALE_FILE).double()
+        model.load_state_dict(GO.expand_to_reference_state_dict(GO.make_params(cfg, seed, sf, dtype=torch.float64)),
+                              strict=True)
+        trainer = Trainer(model, **kw)
+        metrics = Metrics("train", trainer.tracked_metrics)
+        it = stream()
+        losses, lrs_ = [], []
+        for _ in range(TRAINER_STEPS):
+            losses.append(float(trainer.train_on_batch(it, metrics)))
+            lrs_.append([s.get_last_lr()[0] for s in trainer.schedulers.wrapped])
+        unused = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+        assert not unused, unused
+        res = metrics.result(append_tag=False)
+        out[f"{tag}.N"], out[f"{tag}.Z"], out[f"{tag}.R"], out[f"{tag}.Et"], out[f"{tag}.Ft"] = N, Z, R, Et, Ft
+        out[f"{tag}.cfg"], out[f"{tag}.kw"], out[f"{tag}.seed"] = np.array(repr(cfg)), np.array(repr(kw)), np.array(seed)
+        out[f"{tag}.batches"] = np.array([",".join(map(str, b)) for b in batches])
+        out[f"{tag}.losses"] = np.array(losses)
+        out[f"{tag}.lrs"] = np.array(lrs_)
+        out[f"{tag}.metric_names"] = np.array(sorted(res))
+        out[f"{tag}.metric_values"] = np.array([float(res[k]) for k in sorted(res)])
+        names = [n for n, _ in model.named_parameters()]
+        out[f"{tag}.param_names"] = np.array(names)
+        out[f"{tag}.param_norms"] = np.array([float(p.detach().norm()) for _, p in model.named_parameters()])
+        out[f"{tag}.ema_norms"] = np.array([float(s.norm()) for s in trainer.exp_decay.shadow_params])
+        # plateau decay + evaluation with the averaged weights (train.ipynb's validation block)
+        for v in (1.0, 1.0, 1.0):
+            trainer.decay_maybe(v)
+        trainer.save_variable_backups()
+        trainer.load_averaged_variables()
+        val = Metrics("val", trainer.tracked_metrics)
+        out[f"{tag}.val_loss"] = np.array(float(trainer.test_on_batch(it, val)))
+        trainer.restore_variable_backups()
+        out[f"{tag}.restored_norms"] = np.array([float(p.detach().norm()) for _, p in model.named_parameters()])
+        print(tag, "losses", losses, "lr", lrs_[-1], "val", float(out[f"{tag}.val_loss"]))
+    np.savez_compressed(os.path.join(HERE, "trainer.npz"), **out)
+    print("trainer.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["basis", "indices", "models", "keys"]
+    which = sys.argv[1:] or ["basis", "indices", "models", "keys", "trainer"]
+    if "trainer" in which:
+        golden_trainer()
     if "basis" in which:
         golden_basis()
     if "indices" in which:
