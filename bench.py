@@ -57,9 +57,9 @@ def make_batch(cfg, n_mol, n_atoms, first, device):
 
 
 class LaunchTimer:
-    """Wraps every launcher of gemnet_pytorch_amd.kernels with a pair of HIP events (recorded on the
-    stream the kernels are launched on = torch's current stream) and the algorithmic flops/bytes of
-    the launch."""
+    """Records every launch of one step (launcher, arguments, algorithmic flops/bytes: DESIGN.md §kernels);
+    `summary()` then times each launcher family by replaying exactly those launches back-to-back between two
+    HIP events on the stream the kernels are launched on (= torch's current stream)."""
 
     def __init__(self):
         from gemnet_pytorch_amd import kernels as K
@@ -70,6 +70,10 @@ class LaunchTimer:
     @staticmethod
     def cost(name, args, kwargs, out):
         f32 = 4
+        if name == "gemm_tn":
+            A, B = args[0], args[1]
+            Kd, M, N = A.shape[0], A.shape[1], B.shape[1]
+            return 2.0 * M * N * Kd, (M * Kd + N * Kd + M * N) * f32
         if name == "gemm":
             A, B = args[0], args[1]
             ta = args[2] if len(args) > 2 else kwargs.get("trans_a", False)
@@ -99,21 +103,27 @@ class LaunchTimer:
         outs = out if isinstance(out, tuple) else (out,)
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
+    FAMILIES = ["gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "dact_mul", "chain", "bil_reduce",
+                "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd", "bessel_rbf", "sph_radial", "ylm0",
+                "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
+                "quad_basis_bwd"]
+
     def __enter__(self):
-        for name in ["gemm", "bmm", "gather", "segsum", "ssilu", "dact_mul", "chain", "bil_reduce", "bil_reduce_t",
-                     "bil_dot", "bil_reduce_project", "bil_project_bwd", "bessel_rbf", "sph_radial", "ylm0", "ylm",
-                     "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
-                     "quad_basis_bwd"]:
+        self.depth = 0
+        for name in self.FAMILIES:
             fn = getattr(self.K, name)
             self.saved[name] = fn
 
             def wrapped(*args, _fn=fn, _name=name, **kwargs):
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                out = _fn(*args, **kwargs)
-                e.record()
+                if self.depth:  # a launcher calling another launcher (gemm -> gemm_tn): count once
+                    return _fn(*args, **kwargs)
+                self.depth += 1
+                try:
+                    out = _fn(*args, **kwargs)
+                finally:
+                    self.depth -= 1
                 fl, by = self.cost(_name, args, kwargs, out)
-                self.records.append((_name, s, e, fl, by))
+                self.records.append((_name, _fn, args, kwargs, fl, by))
                 return out
 
             setattr(self.K, name, wrapped)
@@ -123,22 +133,50 @@ class LaunchTimer:
         for name, fn in self.saved.items():
             setattr(self.K, name, fn)
 
-    def summary(self):
+    def summary(self, reps=5):
+        """Per launcher family: the recorded launches of ONE step (same arguments, same order) are captured
+        into a hipGraph and replayed back-to-back `reps` times between two HIP events on the launch stream,
+        so the figure is kernel time without host dispatch gaps (what rocprofv3's average duration shows)."""
         torch.cuda.synchronize()
         fam = {}
-        for name, s, e, fl, by in self.records:
-            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-            d["ms"] += s.elapsed_time(e)
+        for name, fn, args, kwargs, fl, by in self.records:
+            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, calls=[]))
             d["flops"] += fl
             d["bytes"] += by
             d["launches"] += 1
+            d["calls"].append((fn, args, kwargs))
+        with torch.no_grad():
+            for name, d in fam.items():
+                calls = d.pop("calls")
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for fn, args, kwargs in calls:
+                        fn(*args, **kwargs)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for fn, args, kwargs in calls:
+                        fn(*args, **kwargs)
+                g.replay()
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(reps):
+                    g.replay()
+                e.record()
+                torch.cuda.synchronize()
+                d["ms"] = s.elapsed_time(e) / reps
+                del g
+        self.records = []
         return fam
 
 
 def roofline_from(fam):
     name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     sec = d["ms"] * 1e-3
-    if name in ("gemm", "bmm"):
+    if name in ("gemm", "gemm_tn", "bmm"):
         ach = d["flops"] / sec / 1e12
         return dict(kernel=name, bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
@@ -309,13 +347,17 @@ def main():
 
     roof = None
     if not args.no_roofline and rank == 0:
+        held = None
+        if args.mode == "train":  # the captured training step bypasses the launchers: instrument it eagerly
+            held, ts._graph = getattr(ts, "_graph", None), None
         with LaunchTimer() as lt:
-            for _ in range(3):
-                step()
+            step()
+        if held is not None:
+            ts._graph = held
         fam = lt.summary()
         roof = roofline_from(fam)
         tot = sum(v["ms"] for v in fam.values())
-        log("[bench] per-family kernel time of the instrumented pass (3 steps):")
+        log("[bench] per-family kernel time of one step's launches, replayed back-to-back:")
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"    {k:14s} {v['ms']:8.3f} ms  {100 * v['ms'] / tot:5.1f} %  {v['launches']:5d} launches"
                 f"  {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.2f} TFLOP/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s")

@@ -69,6 +69,8 @@ SIGNATURES = {
     "gn_gemm_f32": [ctypes.POINTER(GemmArgs), _vp],
     "gn_gemm_f32_cfg": [ctypes.POINTER(GemmArgs), _i, _vp],
     "gn_chain_f32": [ctypes.POINTER(ChainArgs), _vp],
+    "gn_gemm_tn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
+    "gn_gemm_tn_splitk": [_i, _i, _i],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],

@@ -138,5 +138,5 @@ extern "C" int gn_dact_mul_f32(const float* g, const float* z, int act, const fl
   return 0;
 }
 
-extern "C" int gn_abi_version(void) { return 3; }
+extern "C" int gn_abi_version(void) { return 4; }
 extern "C" const char* gn_error_string(int code) { return hipGetErrorString((hipError_t)code); }

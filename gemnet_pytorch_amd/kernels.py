@@ -42,6 +42,9 @@ def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_
     """C = epilogue(opA(A) @ opB(B)); see gn_gemm_f32 in include/gemnet_hip.h.
     trans_b=False means B is a torch Linear weight (N, K).  Returns C or (C, pre)."""
     require_device(A, B)
+    if (trans_a and trans_b and cfg < 0 and a_dact_pre is None and not act and not pre_out and mul is None
+            and res is None and res2 is None and gadd1 is None and gadd2 is None):
+        return gemm_tn(A, B, alpha)
     if trans_b and not trans_a and B.numel() <= (1 << 20) and A.shape[0] >= 512:
         # x @ B with a weight-sized (K,N) operand: a 64-256 KB transpose buys the k-contiguous pipelined
         # kernel (14 us) instead of the transposed-staging generic one (46 us at E = 18 k rows)
@@ -106,6 +109,24 @@ def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_
     check(_lib.load().gn_gemm_f32_cfg(ctypes.byref(a), int(cfg), stream()), "gn_gemm_f32")
     return (C, pre) if pre_out else C
 
+
+
+def gemm_tn(A, B, alpha=1.0, splitk=-1):
+    """alpha * A^T @ B for A (K,M), B (K,N): weight-gradient shaped products (split-K, deterministic)."""
+    require_device(A, B)
+    A, B = _rowmajor(A), _rowmajor(B)
+    K, M = A.shape
+    N = B.shape[1]
+    if B.shape[0] != K:
+        raise ValueError(f"gemm_tn shape mismatch: {tuple(A.shape)} x {tuple(B.shape)}")
+    lib = _lib.load()
+    C = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    if splitk < 0:
+        splitk = lib.gn_gemm_tn_splitk(M, N, K)
+    ws = torch.empty((splitk, M, N), device=A.device, dtype=torch.float32) if splitk > 1 else None
+    check(lib.gn_gemm_tn_f32(ptr(A), ptr(B), ptr(C), M, N, K, A.stride(0), B.stride(0), N, float(alpha), ptr(ws),
+                             int(splitk), stream()), "gn_gemm_tn_f32")
+    return C
 
 
 def gather(x, idx32):

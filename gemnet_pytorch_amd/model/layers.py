@@ -24,7 +24,7 @@ from scipy.optimize import brentq as _brentq
 
 from .. import ops
 from .initializers import he_orthogonal_init
-from .scaling import ScalingFactor
+from .scaling import AutomaticFit, ScalingFactor
 
 INV_SQRT_2 = 1 / (2.0 ** 0.5)
 INV_SQRT_3 = 1 / (3.0 ** 0.5)
@@ -391,7 +391,8 @@ class TripletInteraction(torch.nn.Module):
         x_ba = self.down_projection(x_ba)
         # gather by id3_expand_ba is fused into the segmented reduce (no (T,C) tensor)
         x = self.mlp_cbf(rbf_W1, sph, x_ba, plan.trip)
-        x = self.scale_cbf_sum(x_ba, x)
+        # the reference observes the variance of the GATHERED rows (interaction_block.py:678-682)
+        x = self.scale_cbf_sum(ops.gather_rows(x_ba, plan.trip.expand) if AutomaticFit.fitting_mode else x_ba, x)
         x_ca = self.up_projection_ca(x)
         x_ac = ops.gather_rows(self.up_projection_ac(x), plan.id_swap)
         return (x_ca + x_ac) * INV_SQRT_2
@@ -427,7 +428,7 @@ class QuadrupletInteraction(torch.nn.Module):
         x_db = ops.gather_rows(x_db, plan.intm_db)                 # (I, emb_quad)
         x_db = self.scale_cbf(x_db, x_db * self.mlp_cbf(cbf))
         x = self.mlp_sbf(rbf_W1, sph, x_db, plan.quad)             # gather by id4_expand_abd fused
-        x = self.scale_sbf_sum(x_db, x)
+        x = self.scale_sbf_sum(ops.gather_rows(x_db, plan.quad.expand) if AutomaticFit.fitting_mode else x_db, x)
         x_ca = self.up_projection_ca(x)
         x_ac = ops.gather_rows(self.up_projection_ac(x), plan.id_swap)
         return (x_ca + x_ac) * INV_SQRT_2

@@ -112,6 +112,14 @@ typedef struct {
 } gn_chain_args;
 int gn_chain_f32(const gn_chain_args* args, void* stream);
 
+/* C (M,N) = alpha * A^T B with A (K,M), B (K,N) row-major: the weight-gradient product dW = dY^T X of every
+ * Dense (base_layers.py:5-48; autograd of torch.nn.Linear in the reference) and the weight adjoints of the double
+ * backward.  Split-K over `splitk` slices (gn_gemm_tn_splitk(M,N,K) gives the recommended count); `ws` is a
+ * caller-owned workspace of splitk*M*N floats (may be NULL when splitk <= 1).  Deterministic (no atomics). */
+int gn_gemm_tn_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                   float alpha, float* ws, int splitk, void* stream);
+int gn_gemm_tn_splitk(int M, int N, int K);
+
 /* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
  * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */
 int gn_bmm_f32(const float* A, const float* B, float* C, int batch, int m, int n, int k,

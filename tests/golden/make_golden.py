@@ -390,8 +390,66 @@ def golden_trainer():
     print("trainer.npz", len(out), "arrays")
 
 
+# ------------------------------------------------------------------------ G6 scale-factor fit
+def golden_scaling():
+    """fit_scaling.py:94-159 run with the REFERENCE GemNet / Trainer / AutomaticFit: every scale factor of a
+    direct-force model fitted in creation order from two fixed batches (float64).  -> scaling_fit.json"""
+    import json
+    import tempfile
+    from gemnet.model.layers.scaling import AutomaticFit
+    from gemnet.model.utils import write_json
+    from gemnet.training.trainer import Trainer
+    from gemnet.training.metrics import Metrics
+    result = {}
+    mols = [make_molecule(10, 500, box=4.2), make_molecule(7, 501, box=3.6), make_molecule(9, 502, box=4.0)]
+    for tag, to, seed in (("T", True, 31), ("Q", False, 32)):
+        cfg = dict(cfg_small(to), direct_forces=True)
+        N = np.array([len(m["R"]) for m in mols], dtype=np.int32)
+        R = np.concatenate([m["R"] for m in mols]).astype(np.float32)
+        Z = np.concatenate([m["Z"] for m in mols]).astype(np.int32)
+        dc = _MemContainer(dict(N=N, Z=Z, R=R, E=np.zeros(len(N), np.float32), F=np.zeros_like(R)), 5.0, 10.0, to)
+        batches = [[0, 1], [2]]
+
+        def stream():
+            i = 0
+            while True:
+                b = dc[batches[i % len(batches)]]
+                inputs = {k: v for k, v in b.items() if k not in ("E", "F")}
+                inputs["R"] = inputs["R"].double()
+                yield inputs, {"E": b["E"].double(), "F": b["F"].double()}
+                i += 1
+
+        with tempfile.TemporaryDirectory() as tmp:
+            scale_file = os.path.join(tmp, "scaling.json")
+            write_json(scale_file, {"comment": "golden"})
+            AutomaticFit.set2fitmode()
+            model = GemNet(**cfg, scale_file=scale_file).double()
+            model.load_state_dict(GO.expand_to_reference_state_dict(GO.make_params(cfg, seed, None, torch.float64)),
+                                  strict=True)
+            trainer = Trainer(model)
+            metrics = Metrics("train", trainer.tracked_metrics, None)
+            it = stream()
+            order = []
+            while not AutomaticFit.fitting_completed():
+                for _ in range(len(batches)):
+                    trainer.test_on_batch(it, metrics)
+                order.append(AutomaticFit.activeVar._name)
+                AutomaticFit.activeVar.fit()
+            AutomaticFit.fitting_mode = False
+            with open(scale_file) as f:
+                fitted = json.load(f)
+        fitted.pop("comment")
+        result[tag] = dict(cfg=cfg, seed=seed, batches=batches, order=order, fitted=fitted,
+                           N=N.tolist(), Z=Z.tolist(), R=[[float(x) for x in r] for r in R])
+        print(tag, fitted)
+    with open(os.path.join(HERE, "scaling_fit.json"), "w") as f:
+        json.dump(result, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["basis", "indices", "models", "keys", "trainer"]
+    which = sys.argv[1:] or ["basis", "indices", "models", "keys", "trainer", "scaling"]
+    if "scaling" in which:
+        golden_scaling()
     if "trainer" in which:
         golden_trainer()
     if "basis" in which:

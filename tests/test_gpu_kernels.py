@@ -347,3 +347,29 @@ def test_quad_basis_fused_fwd_bwd():
         assert torch.isfinite(out).all()
         assert float(err.median()) <= 1e-4 * float(scale)
         assert float(torch.quantile(err, 0.99)) <= 3e-2 * float(scale)
+
+
+@pytest.mark.parametrize("Kd,M,N", [(1024, 128, 128), (17800, 128, 128), (17801, 128, 16), (5003, 64, 128),
+                                    (18000, 1024, 64), (1024, 1, 128), (3000, 16, 6), (2500, 42, 112),
+                                    (33, 128, 128), (1, 5, 3), (100000, 128, 128)])
+def test_gemm_tn_weight_gradient_shapes(Kd, M, N):
+    """gn_gemm_tn_f32: A^T B over the edge/atom dimension for every (M, N) the model's weight gradients have."""
+    g = torch.Generator().manual_seed(Kd + M)
+    A, Bm = rnd(g, Kd, M), rnd(g, Kd, N)
+    ref = 0.5 * (A.t() @ Bm)
+    tol = dict(rtol=1e-5, atol=2e-5 * np.sqrt(Kd))
+    close(K.gemm(f32(A), f32(Bm), True, True, alpha=0.5), ref, **tol)  # routed to the split-K kernel
+    for splitk in (1, 2, 7, 64):
+        close(K.gemm_tn(f32(A), f32(Bm), alpha=0.5, splitk=splitk), ref, **tol)
+    again = K.gemm_tn(f32(A), f32(Bm), alpha=0.5)
+    assert torch.equal(again, K.gemm_tn(f32(A), f32(Bm), alpha=0.5))  # deterministic (no atomics)
+
+
+def test_gemm_tn_strided_operands_and_empty_contraction():
+    g = torch.Generator().manual_seed(77)
+    X = rnd(g, 4000, 384)  # column slices of a concatenated activation: row stride 384
+    Xd = f32(X)
+    close(K.gemm_tn(Xd[:, 128:256], Xd[:, 256:320]), X[:, 128:256].t() @ X[:, 256:320], rtol=1e-5, atol=2e-3)
+    close(K.gemm_tn(Xd[:, 1:43], Xd[:, 130:258]), X[:, 1:43].t() @ X[:, 130:258], rtol=1e-5, atol=2e-3)
+    out = K.gemm_tn(f32(torch.zeros(0, 128)), f32(torch.zeros(0, 16)))
+    assert out.shape == (128, 16) and float(out.abs().max()) == 0.0

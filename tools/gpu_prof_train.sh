@@ -7,8 +7,8 @@ import pandas as pd, glob
 f = glob.glob('$OUT/prof/*kernel_stats.csv')[0]
 df = pd.read_csv(f)
 n = 7 + 2  # steps incl. warmup + eager warmups
-df['ms_per_step'] = df['TotalDurationNs'] / 9 / 1e6
-df['calls_per_step'] = df['Calls'] / 9
+df['ms_per_step'] = df['TotalDurationNs'] / 7 / 1e6
+df['calls_per_step'] = df["Calls"] / 7
 df['name'] = df['Name'].str.replace(r'\(anonymous namespace\)::','',regex=True).str.replace('void ','').str.replace('at::native::','').str.slice(0,80)
 print(df[['name','calls_per_step','ms_per_step','AverageNs']].head(28).round(2).to_string())
 print('total', df['ms_per_step'].sum(), df['calls_per_step'].sum())
