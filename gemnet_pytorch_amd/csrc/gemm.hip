@@ -360,15 +360,20 @@ __device__ __forceinline__ void epilogue_elem(const gn_gemm_args& p, float z, in
   p.C[co] = y;
 }
 
-template <int KS>
+// BKM = false: B is (N,K) (a Linear weight, k contiguous).  BKM = true: B is (K,N) (n contiguous; the
+// input-gradient product dX = dY W of every Dense): the tile is staged k-major, Bs[k][n], so the global
+// load and the LDS store stay float4 along n and a fragment is four conflict-free ds_read_b32
+// (row stride 132 words: the four 16-lane groups, 4 rows apart, land 16 banks apart).
+template <int KS, bool BKM>
 __global__ __launch_bounds__(512) void gemm_nt_pipe16(const gn_gemm_args p) {
   constexpr int BM = 32, BN = 128, NT = 512;
   constexpr int LD = KS + 4;
+  constexpr int LDB = BKM ? BN + 4 : KS + 4;
   constexpr int V = KS / 4;
   constexpr int NA = (BM * V + NT - 1) / NT;
   constexpr int NB = (BN * V + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float As[BM][LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BN][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BKM ? KS : BN][LDB];
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
@@ -398,11 +403,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe16(const gn_gemm_args p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int f = tid + i * NT;
-      const int r = f / V, kv = (f % V) << 2;
-      const int gr = col0 + r, gk = k0 + kv;
       rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < BN * V && gr < p.N && gk < p.K)
-        rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)gr * p.ldb + gk);
+      if (BKM) {
+        const int k = f / (BN / 4), nv = (f % (BN / 4)) << 2;
+        const int gk = k0 + k, gn = col0 + nv;
+        if (f < BN * V && gk < p.K && gn < p.N)
+          rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)gk * p.ldb + gn);
+      } else {
+        const int r = f / V, kv = (f % V) << 2;
+        const int gr = col0 + r, gk = k0 + kv;
+        if (f < BN * V && gr < p.N && gk < p.K)
+          rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)gr * p.ldb + gk);
+      }
     }
   };
   auto store = [&]() {
@@ -414,7 +426,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe16(const gn_gemm_args p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int f = tid + i * NT;
-      if (f < BN * V) *reinterpret_cast<float4*>(&Bs[f / V][(f % V) << 2]) = rb[i];
+      if (f < BN * V) {
+        if (BKM) *reinterpret_cast<float4*>(&Bs[f / (BN / 4)][(f % (BN / 4)) << 2]) = rb[i];
+        else *reinterpret_cast<float4*>(&Bs[f / V][(f % V) << 2]) = rb[i];
+      }
     }
   };
 
@@ -429,8 +444,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe16(const gn_gemm_args p) {
 #pragma unroll
     for (int kb = 0; kb < KS; kb += 16) {
       const float4 a = *reinterpret_cast<const float4*>(&As[arow][kb + kq]);
-      const float4 b0 = *reinterpret_cast<const float4*>(&Bs[brow][kb + kq]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&Bs[brow + 16][kb + kq]);
+      float4 b0, b1;
+      if (BKM) {
+        b0 = make_float4(Bs[kb + kq][brow], Bs[kb + kq + 1][brow], Bs[kb + kq + 2][brow], Bs[kb + kq + 3][brow]);
+        b1 = make_float4(Bs[kb + kq][brow + 16], Bs[kb + kq + 1][brow + 16], Bs[kb + kq + 2][brow + 16],
+                         Bs[kb + kq + 3][brow + 16]);
+      } else {
+        b0 = *reinterpret_cast<const float4*>(&Bs[brow][kb + kq]);
+        b1 = *reinterpret_cast<const float4*>(&Bs[brow + 16][kb + kq]);
+      }
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
@@ -507,6 +529,15 @@ extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) 
   const int vecA = (p.lda % 4 == 0) && aligned16(p.A) && (!p.a_dact_pre || aligned16(p.a_dact_pre));
   const int vecB = (p.ldb % 4 == 0) && aligned16(p.B);
   const bool fast = !p.trans_a && !p.trans_b && vecA && vecB && (p.K % 4 == 0) && p.splitk <= 1;
+  // x @ B with B (K,N): k-major staging in the 8-wave kernel (any N; rows of B 16-byte aligned)
+  if (cfg < 0 && !p.trans_a && p.trans_b && vecA && vecB && (p.K % 4 == 0) && (p.N % 4 == 0) && p.splitk <= 1 &&
+      p.M >= 512) {
+    dim3 grid(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128));
+    if (p.M > 4096) hipLaunchKernelGGL((gemm_nt_pipe16<32, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_nt_pipe16<64, true>), grid, dim3(512), 0, st, p);
+    GN_LAUNCH_CHECK();
+    return 0;
+  }
   if (p.splitk > 1) {
     if (!p.splitk_ws) return (int)hipErrorInvalidValue;
     if (p.N > 64) launch<32, 128, 1, 4, 32>(p, false, vecA, vecB, st);
@@ -548,8 +579,8 @@ extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) 
     case 14:
     case 15:
       if (!fast) { launch<32, 128, 1, 4, 32>(p, fast, vecA, vecB, st); break; }
-      if (cfg == 14) hipLaunchKernelGGL((gemm_nt_pipe16<32>), dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((gemm_nt_pipe16<64>), dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(512), 0, st, p);
+      if (cfg == 14) hipLaunchKernelGGL((gemm_nt_pipe16<32, false>), dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((gemm_nt_pipe16<64, false>), dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(512), 0, st, p);
       break;
     default: return (int)hipErrorInvalidValue;
   }

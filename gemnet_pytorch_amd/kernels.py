@@ -45,10 +45,6 @@ def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_
     if (trans_a and trans_b and cfg < 0 and a_dact_pre is None and not act and not pre_out and mul is None
             and res is None and res2 is None and gadd1 is None and gadd2 is None):
         return gemm_tn(A, B, alpha)
-    if trans_b and not trans_a and B.numel() <= (1 << 20) and A.shape[0] >= 512:
-        # x @ B with a weight-sized (K,N) operand: a 64-256 KB transpose buys the k-contiguous pipelined
-        # kernel (14 us) instead of the transposed-staging generic one (46 us at E = 18 k rows)
-        B, trans_b = B.t().contiguous(), False
     A, B = _rowmajor(A), _rowmajor(B)
     M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
     N, Kb = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])

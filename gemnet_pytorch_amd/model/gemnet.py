@@ -70,6 +70,7 @@ class GemNet(torch.nn.Module):
         self.force_graph = None  # None: auto (training & grad enabled); True/False: forced
         self.overlap_output_blocks = True
         self._side = None
+        self._wcache = {}  # derived (transposed / contiguous) copies of frozen weights, see ops.weight_cache
 
         AutomaticFit.reset()
 
@@ -263,7 +264,7 @@ class GemNet(torch.nn.Module):
         # force-by-autograd without a second-order graph: the graph of E is consumed right here, so
         # parameter gradients can never be requested -> weights are constants (enables ops.stack)
         const_w = fused and not self.direct_forces
-        with ops.fused_first_order(fused), ops.param_grads(not const_w):
+        with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w):
             E_mol, F_ca, V_ca = self._energy(R, plan)
 
             if self.direct_forces:
@@ -293,8 +294,17 @@ class GemNet(torch.nn.Module):
             st = self._side[key] = torch.cuda.Stream(device=device)
         return st
 
+    def _apply(self, fn, *args, **kwargs):
+        self._wcache = {}  # .to()/.float()/.cuda() replace the parameters' storage
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._wcache = {}
+        return super().load_state_dict(*args, **kwargs)
+
     def __deepcopy__(self, memo):
         side, self._side = self._side, None  # HIP stream handles are not copyable
+        cache, self._wcache = self._wcache, {}  # keyed by this instance's weight addresses
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -305,6 +315,7 @@ class GemNet(torch.nn.Module):
             return new
         finally:
             self._side = side
+            self._wcache = cache
 
     @staticmethod
     def _check_inputs(R):

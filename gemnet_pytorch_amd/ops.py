@@ -18,6 +18,8 @@ computes forces, so no weight-gradient GEMMs are launched for them.
 """
 import contextlib
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -338,7 +340,35 @@ def is_fused():
     return _FUSED
 
 
-_WT_CACHE = {}
+# Derived-weight cache (transposes / contiguous copies of FROZEN weights).  Entries are keyed by the address
+# of the source, so the dict must not outlive the tensors it was filled from: it is owned by a model
+# (GemNet._wcache, dropped on _apply / load_state_dict / deepcopy) and only active inside
+# `weight_cache(...)`; outside of one nothing is cached (a process-global dict returned another model's
+# transposes once the allocator reused a freed weight's address).
+_WT_CACHE = None
+
+
+@contextlib.contextmanager
+def weight_cache(cache):
+    global _WT_CACHE
+    prev, _WT_CACHE = _WT_CACHE, cache
+    try:
+        yield
+    finally:
+        _WT_CACHE = prev
+
+
+def _cached(key, version, make):
+    if _WT_CACHE is None:
+        return make()
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0] == version:
+        return hit[1]
+    if len(_WT_CACHE) > 4096:
+        _WT_CACHE.clear()
+    val = make()
+    _WT_CACHE[key] = (version, val)
+    return val
 
 
 def transposed(W):
@@ -346,15 +376,8 @@ def transposed(W):
     for frozen weights (inference); recomputed per call for trainable ones."""
     if W.requires_grad:
         return W.detach().t().contiguous()
-    key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()))
-    hit = _WT_CACHE.get(key)
-    if hit is not None and hit[0] == W._version:
-        return hit[1]
-    Wt = W.detach().t().contiguous()
-    if len(_WT_CACHE) > 4096:
-        _WT_CACHE.clear()
-    _WT_CACHE[key] = (W._version, Wt)
-    return Wt
+    return _cached(("t", W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version,
+                   lambda: W.detach().t().contiguous())
 
 
 class _FusedDense(torch.autograd.Function):
@@ -485,13 +508,7 @@ def transposed_2d(W2, owner):
     """W2^T contiguous, cached on the owning (frozen) parameter's version."""
     if owner.requires_grad:
         return W2.t().contiguous()
-    key = ("bil", owner.data_ptr(), tuple(owner.shape))
-    hit = _WT_CACHE.get(key)
-    if hit is not None and hit[0] == owner._version:
-        return hit[1]
-    Wt = W2.t().contiguous()
-    _WT_CACHE[key] = (owner._version, Wt)
-    return Wt
+    return _cached(("bil", owner.data_ptr(), tuple(owner.shape)), owner._version, lambda: W2.t().contiguous())
 
 
 def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
@@ -582,7 +599,7 @@ def constant_weights():
 # (E = 18 k) against 5.9 / 12.5 us for the stand-alone 8-wave GEMM: per-op latency inside the chain
 # (4 barrier-separated K-steps on one accumulator per wave, 153 VGPRs -> 2 waves/SIMD) is not yet
 # lower than a launch.  Off by default until the persistent weight-stationary variant lands.
-USE_STACKS = False
+USE_STACKS = os.environ.get("GEMNET_STACKS", "0") == "1"
 
 
 def stacks_enabled():
@@ -593,13 +610,8 @@ def contiguous_weight(W):
     """Row-contiguous copy of a (possibly sliced) frozen weight, cached on its version."""
     if W.is_contiguous():
         return W.detach()
-    key = ("c", W.data_ptr(), tuple(W.shape), tuple(W.stride()))
-    hit = _WT_CACHE.get(key)
-    if hit is not None and hit[0] == W._version:
-        return hit[1]
-    Wc = W.detach().contiguous()
-    _WT_CACHE[key] = (W._version, Wc)
-    return Wc
+    return _cached(("c", W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version,
+                   lambda: W.detach().contiguous())
 
 
 class _Stack(torch.autograd.Function):

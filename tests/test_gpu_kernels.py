@@ -373,3 +373,19 @@ def test_gemm_tn_strided_operands_and_empty_contraction():
     close(K.gemm_tn(Xd[:, 1:43], Xd[:, 130:258]), X[:, 1:43].t() @ X[:, 130:258], rtol=1e-5, atol=2e-3)
     out = K.gemm_tn(f32(torch.zeros(0, 128)), f32(torch.zeros(0, 16)))
     assert out.shape == (128, 16) and float(out.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,Kd", [(18000, 128, 128), (18001, 64, 1024), (5000, 32, 128), (18122, 16, 128),
+                                    (1024, 128, 64), (700, 384, 128), (4097, 128, 20)])
+def test_gemm_k_major_weight_operand(M, N, Kd):
+    """x @ B with B (K,N) — the input-gradient product of every Dense — on the k-major-staged 8-wave kernel,
+    plain and with the fused prologue/epilogue."""
+    g = torch.Generator().manual_seed(M + N + Kd)
+    A, Bm = rnd(g, M, Kd), rnd(g, Kd, N) / np.sqrt(Kd)
+    close(K.gemm(f32(A), f32(Bm), False, True), A @ Bm, rtol=1e-5, atol=2e-5 * np.sqrt(Kd))
+    pre, mul, res = rnd(g, M, Kd), rnd(g, M, N), rnd(g, M, N)
+    kw = dict(act=True, pre_out=True, alpha=0.7, beta=0.5)
+    ref_y, ref_z = CK.gemm(A, Bm, False, True, a_dact_pre=pre, mul=mul, res=res, **kw)
+    y, z = K.gemm(f32(A), f32(Bm), False, True, a_dact_pre=f32(pre), mul=f32(mul), res=f32(res), **kw)
+    close(z, ref_z, atol=1e-4)
+    close(y, ref_y, atol=1e-4)

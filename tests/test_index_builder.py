@@ -4,6 +4,7 @@ import ctypes
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import index_oracle as IO
 from gemnet_pytorch_amd.training import data_container as DC
@@ -80,3 +81,39 @@ def test_datacontainer_dict_contract():
     assert batch["batch_seg"].tolist() == [0] * 12 + [1] * 12
     one = dc[1]
     assert one["N"].tolist() == [12]
+
+
+def test_single_molecule_subclass_contract_of_ase_calculator():
+    """ase_calculator.py:23-99 subclasses DataContainer WITHOUT calling its __init__: it sets index_keys,
+    cutoffs, keys, R (float64 ASE positions), Z, N, E, F, N_cumsum, addID, merges get_dtypes() and then
+    uses __getitem__(0).  The same pattern must work on the native container."""
+    from gemnet_pytorch_amd.training.data_container import DataContainer, INDEX_KEYS_Q, INDEX_KEYS_T
+
+    class OneMolecule(DataContainer):
+        def __init__(self, R, Z, cutoff, int_cutoff, triplets_only=False):
+            self.index_keys = list(INDEX_KEYS_T) + ([] if triplets_only else list(INDEX_KEYS_Q))
+            self.triplets_only, self.cutoff, self.int_cutoff = triplets_only, cutoff, int_cutoff
+            self.keys = ["N", "Z", "R", "F", "E"]
+            self.R, self.Z = R, Z
+            self.N = np.array([len(Z)], dtype=np.int32)
+            self.E = np.zeros((1, 1), dtype=np.float32)
+            self.F = np.zeros((len(Z), 3), dtype=np.float32)
+            self.N_cumsum = np.concatenate([[0], np.cumsum(self.N)])
+            self.addID = False
+            self.dtypes, more = self.get_dtypes()
+            self.dtypes.update(more)
+
+    from gemnet_pytorch_amd.synthetic import make_molecule
+    mol = make_molecule(9, 77, box=4.5)
+    for triplets_only in (True, False):
+        one = OneMolecule(mol["R"].astype(np.float64), mol["Z"], 5.0, 10.0, triplets_only)
+        first = one[0]
+        assert first["R"].dtype == torch.float32 and first["id_a"].dtype == torch.int64
+        assert set(one.index_keys) <= set(first)
+        moved = mol["R"].astype(np.float64) + 0.05 * np.random.RandomState(0).standard_normal((9, 3))
+        one.R = moved  # Molecule.update
+        second = one[0]
+        ref = IO.build_indices(moved, np.array([9]), 5.0, 10.0, triplets_only)  # float64 distances
+        assert second["id3_reduce_ca"].shape[0] > 0
+        for k in one.index_keys:
+            np.testing.assert_array_equal(second[k].numpy(), ref[k])

@@ -133,3 +133,27 @@ def test_no_cpu_fallback():
     from gemnet_pytorch_amd import kernels
     with pytest.raises(RuntimeError, match="no CPU fallback|CPU fallback"):
         kernels.ssilu(torch.zeros(4), 0)
+
+
+def test_derived_weight_cache_is_owned_by_the_model(golden_model):
+    """Transposed / contiguous weight copies are cached per model instance and only while that model's forward
+    runs: a process-global, address-keyed cache handed one model's transposes to the next model allocated at
+    the same addresses (seen on the GPU as a force error of 0.46 in a multi-model test session)."""
+    from gemnet_pytorch_amd import ops
+    g = golden_model
+    cfg, params, inputs = load_case(g, "t1")
+    assert ops._WT_CACHE is None
+    W = torch.randn(8, 4, dtype=torch.float64)
+    assert ops.transposed(W) is not ops.transposed(W)          # nothing cached outside a model forward
+    with cpu_kernels.emulate():
+        a = build(cfg, params).eval().requires_grad_(False)   # frozen weights: derived copies are cached
+        inputs["R"] = inputs["R"].double()
+        a(inputs)
+        assert len(a._wcache) > 0 and ops._WT_CACHE is None
+        b = build(cfg, {k: v * 1.5 for k, v in params.items()}).eval()
+        assert b._wcache == {} and b._wcache is not a._wcache
+        import copy
+        c = copy.deepcopy(a)
+        assert c._wcache == {} and len(a._wcache) > 0
+        a.double()
+        assert a._wcache == {}
