@@ -70,6 +70,29 @@ class LaunchTimer:
     @staticmethod
     def cost(name, args, kwargs, out):
         f32 = 4
+        if name == "chain":
+            prog = args[0]
+            fl = by = 0.0
+            for o in prog.ops:
+                if o["kind"] == "gemm":
+                    N, Kd = o["W"].shape
+                    fl += 2.0 * prog.M * N * Kd
+                    by += N * Kd * f32
+                    for k in ("pre_out", "out", "gadd1", "gadd2"):
+                        if torch.is_tensor(o.get(k)):
+                            by += prog.M * N * f32
+                    for k in ("mul", "res", "res2"):
+                        if torch.is_tensor(o.get(k)):
+                            by += prog.M * N * f32
+                elif o["kind"] == "load":
+                    by += prog.M * o["src"].shape[1] * f32
+                elif o["kind"] == "store":
+                    by += prog.M * o["out"].shape[1] * f32
+                else:
+                    for k in ("Z", "out"):
+                        if torch.is_tensor(o.get(k)):
+                            by += o[k].numel() * f32
+            return fl, by
         if name == "gemm_tn":
             A, B = args[0], args[1]
             Kd, M, N = A.shape[0], A.shape[1], B.shape[1]
@@ -176,7 +199,7 @@ class LaunchTimer:
 def roofline_from(fam):
     name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     sec = d["ms"] * 1e-3
-    if name in ("gemm", "gemm_tn", "bmm"):
+    if name in ("gemm", "gemm_tn", "bmm", "chain"):
         ach = d["flops"] / sec / 1e12
         return dict(kernel=name, bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,

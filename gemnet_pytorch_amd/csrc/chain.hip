@@ -24,6 +24,15 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifdef GN_CHAIN_TRACE
+// diagnosis build only (tools/chain_trace.py): shader-clock stamps of wave 0 of two workgroups
+__device__ unsigned long long gn_chain_trace_buf[2][GN_CHAIN_MAX_OPS][8];
+#define GN_STAMP(i) do { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) \
+    gn_chain_trace_buf[blockIdx.x == 100][oi][i] = clock64(); } while (0)
+#else
+#define GN_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int SW = 128;           // max slot width / max N, K of a GEMM op
@@ -43,17 +52,21 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
   const int lg = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int M = P.M;
-
-  auto sel = [&](int slot, const float* g, const int32_t* rows, int row, int64_t grow, int col, int N) -> float {
-    if (slot >= 0) return S[slot][row][col];
-    const int64_t r = rows ? (int64_t)rows[grow] : grow;
-    return g[r * N + col];
-  };
+  // index of the next GEMM op after each op (whose weights get prefetched), resolved once
+  __shared__ int next_gemm[GN_CHAIN_MAX_OPS];
+  if (tid < P.n_ops) {
+    int j = tid + 1;
+    while (j < P.n_ops && P.ops[j].kind != GN_OP_GEMM) ++j;
+    next_gemm[tid] = j < P.n_ops ? j : -1;
+  }
+  __syncthreads();
 
   // this wave's B fragments of one GEMM op: W rows 16 wave .. +15, lane (l15, lg) holds
   // W[16 wave + l15][kc + 4 lg .. +3] for the 16-k chunks kc = 0, 16, .. (K <= 128 -> 8 float4)
   float4 bcur[8], bnext[8];
-  bool prefetched = false;
+  // Weight distribution is the slow resource of this kernel: every CU pulls the same 64 KB per op and the
+  // L2 -> CU path delivers it in ~8-14 k cycles when all CUs ask at once (traced with -DGN_CHAIN_TRACE), longer
+  // than one op's MFMA phase.  Fragments are therefore prefetched TWO GEMM ops ahead (bn1, bn2).
   auto wload = [&](float4 (&dst)[8], const float* __restrict__ W, int N, int K) {
     const int n = wave * 16 + l15;
     const float* __restrict__ row = W + (size_t)n * K + (lg << 2);
@@ -63,6 +76,8 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
       if (n < N && c * 16 < K) dst[c] = *reinterpret_cast<const float4*>(row + c * 16);
     }
   };
+  float4 bn2[8];
+  int pf = 0;   // how many of (bnext, bn2) hold the fragments of the upcoming GEMM ops
 
   for (int oi = 0; oi < P.n_ops; ++oi) {
     const gn_chain_op& op = P.ops[oi];
@@ -126,23 +141,26 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
       const float* __restrict__ const res_g = op.res_g;
       const float* __restrict__ const res2_g = op.res2_g;
       const int32_t* __restrict__ const res_rows = op.res_rows;
-      const bool has_mul = mul_slot >= 0 || mul_g, has_res = res_slot >= 0 || res_g, has_res2 = res2_slot >= 0 || res2_g;
-      const float* nW = nullptr;
-      int nN = 0, nK = 0;
-      for (int oj = oi + 1; oj < P.n_ops; ++oj)
-        if (P.ops[oj].kind == GN_OP_GEMM) { nW = P.ops[oj].W; nN = P.ops[oj].N; nK = P.ops[oj].K; break; }
-
-      if (prefetched) {
+      const int nj = __builtin_amdgcn_readfirstlane(next_gemm[oi]);
+      const int nj2 = nj >= 0 ? __builtin_amdgcn_readfirstlane(next_gemm[nj]) : -1;
+      GN_STAMP(0);
+      if (pf >= 1) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) bcur[c] = bnext[c];
+        if (pf == 2) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) bnext[c] = bn2[c];
+        }
+        --pf;
       } else {
         wload(bcur, W, N, K);
       }
-      prefetched = false;
-      if (nW) {        // the next GEMM's fragments fly in under this op's MFMAs and epilogue
-        wload(bnext, nW, nN, nK);
-        prefetched = true;
-      }
+      if (pf == 0 && nj >= 0) { wload(bnext, P.ops[nj].W, P.ops[nj].N, P.ops[nj].K); pf = 1; }
+      if (pf == 1 && nj2 >= 0) { wload(bn2, P.ops[nj2].W, P.ops[nj2].N, P.ops[nj2].K); pf = 2; }
+#ifdef GN_CHAIN_TRACE
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // bcur landed (up to 16 newer loads: bnext, bn2)
+#endif
+      GN_STAMP(1);
       const bool active = wave * 16 < N;   // this wave's 16 output columns exist
       v4f acc[RT];
 #pragma unroll
@@ -150,51 +168,96 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
       if (active) {
         const int kq = lg << 2;
         // lanes of group lg supply k = kc + 4 lg + j to MFMA j (same permutation for A and B)
+        auto chunk = [&](int c, const float4 (&a)[RT]) {
+          const float4 b = bcur[c];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (c * 16 < K) {
-            const float4 b = bcur[c];
-            float4 a[RT];
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4*>(&S[a_slot][16 * t + l15][c * 16 + kq]);
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b.y, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, acc[t], 0, 0, 0);
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b.z, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b.y, acc[t], 0, 0, 0);
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b.w, acc[t], 0, 0, 0);
+        };
+        auto afrag = [&](int c, float4 (&a)[RT]) {
 #pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b.z, acc[t], 0, 0, 0);
+          for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4*>(&S[a_slot][16 * t + l15][c * 16 + kq]);
+        };
+        if (K == SW) {
+          // straight-line, double-buffered fragments: chunk c+1's ds_reads are issued before chunk c's MFMAs
+          float4 a0[RT], a1[RT];
+          afrag(0, a0);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b.w, acc[t], 0, 0, 0);
+          for (int c = 0; c < 8; c += 2) {
+            afrag(c + 1, a1);
+            chunk(c, a0);
+            if (c + 2 < 8) afrag(c + 2, a0);
+            chunk(c + 1, a1);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (c * 16 < K) {
+              float4 a[RT];
+              afrag(c, a);
+              chunk(c, a);
+            }
           }
         }
       }
+#ifdef GN_CHAIN_TRACE
+      if (active) { float sink = 0.f; for (int t = 0; t < RT; ++t) sink += acc[t][0]; if (sink == 1.2345e30f) S[0][0][0] = sink; }
+#endif
+      GN_STAMP(2);
       if (y_slot == a_slot) __syncthreads();   // all reads of a_slot must finish before it is overwritten
       if (active) {
-        const int col = wave * 16 + l15;   // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+        // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg.  The epilogue is written
+        // stage-major (one uniform branch per stage, the RT*4 values of a stage unrolled and independent) — the
+        // value-major form serialised ~8 branches and up to 3 flat loads per value (10 k cycles per op at RT = 5).
+        const int col = wave * 16 + l15;
+        const int rbase = lg << 2;
+        const int64_t growb = row0 + rbase;                    // global row of (t = 0, r = 0)
+        const uint32_t off0 = (uint32_t)growb * (uint32_t)N + (uint32_t)col;
+        GN_STAMP(6);
+        float v[RT][4];
+        bool ok[RT][4];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * t + (lg << 2) + r;
-            const int64_t gr = row0 + row;
-            float y = 0.f;
-            if (gr < M) {
-              float z = acc[t][r];
-              if (gadd1) z += gadd1[(size_t)gidx1[gr] * N + col];
-              if (gadd2) z += gadd2[(size_t)gidx2[gr] * N + col];
-              if (pre_out) pre_out[gr * N + col] = z;
-              y = act ? gn_ssilu(z) : z;
-              if (has_mul) y *= sel(mul_slot, mul_g, nullptr, row, gr, col, N);
-              y *= alpha;
-              if (has_res) y = (y + sel(res_slot, res_g, res_rows, row, gr, col, N)) * beta;
-              if (has_res2) y = (y + sel(res2_slot, res2_g, nullptr, row, gr, col, N)) * beta2;
-              if (out) out[gr * N + col] = y;
-            }
-            if (y_slot >= 0) S[y_slot][row][col] = y;
+            v[t][r] = acc[t][r];
+            ok[t][r] = growb + 16 * t + r < M;
           }
+#define GN_EACH(body)                                                     \
+  _Pragma("unroll") for (int t = 0; t < RT; ++t)                          \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                         \
+    const int row = 16 * t + rbase + r;                                   \
+    const uint32_t off = off0 + (uint32_t)(16 * t + r) * (uint32_t)N;     \
+    (void)row; (void)off;                                                 \
+    body                                                                  \
+  }
+        if (gadd1) GN_EACH(if (ok[t][r]) v[t][r] += gadd1[(size_t)gidx1[row0 + row] * N + col];)
+        if (gadd2) GN_EACH(if (ok[t][r]) v[t][r] += gadd2[(size_t)gidx2[row0 + row] * N + col];)
+        if (pre_out) GN_EACH(if (ok[t][r]) pre_out[off] = v[t][r];)
+        if (act) GN_EACH(v[t][r] = gn_ssilu(v[t][r]);)
+        if (mul_slot >= 0) GN_EACH(v[t][r] *= S[mul_slot][row][col];)
+        else if (mul_g) GN_EACH(if (ok[t][r]) v[t][r] *= mul_g[off];)
+        if (alpha != 1.0f) GN_EACH(v[t][r] *= alpha;)
+        if (res_slot >= 0) GN_EACH(v[t][r] = (v[t][r] + S[res_slot][row][col]) * beta;)
+        else if (res_g) {
+          if (res_rows) GN_EACH(if (ok[t][r]) v[t][r] = (v[t][r] + res_g[(size_t)res_rows[row0 + row] * N + col]) * beta;)
+          else GN_EACH(if (ok[t][r]) v[t][r] = (v[t][r] + res_g[off]) * beta;)
         }
+        if (res2_slot >= 0) GN_EACH(v[t][r] = (v[t][r] + S[res2_slot][row][col]) * beta2;)
+        else if (res2_g) GN_EACH(if (ok[t][r]) v[t][r] = (v[t][r] + res2_g[off]) * beta2;)
+        GN_STAMP(5);
+        if (out) GN_EACH(if (ok[t][r]) out[off] = v[t][r];)
+        if (y_slot >= 0) GN_EACH(S[y_slot][row][col] = ok[t][r] ? v[t][r] : 0.f;)
+#undef GN_EACH
       }
+      GN_STAMP(3);
       __syncthreads();
+      GN_STAMP(4);
     }
   }
 }
@@ -219,9 +282,16 @@ int launch_chain(const gn_chain_args* args, hipStream_t st) {
 
 }  // namespace
 
+#ifdef GN_CHAIN_TRACE
+extern "C" int gn_chain_trace_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gn_chain_trace_buf), sizeof(gn_chain_trace_buf));
+}
+#endif
+
 extern "C" int gn_chain_f32(const gn_chain_args* args, void* stream) {
   if (args->M <= 0 || args->n_ops <= 0) return 0;
   if (args->n_ops > GN_CHAIN_MAX_OPS) return (int)hipErrorInvalidValue;
+  if (args->M > (1 << 24)) return (int)hipErrorInvalidValue;   // 32-bit element offsets (M * 128 < 2^32)
   for (int i = 0; i < args->n_ops; ++i) {
     const gn_chain_op& o = args->ops[i];
     if (o.kind == GN_OP_GEMM) {

@@ -599,7 +599,7 @@ def constant_weights():
 # (E = 18 k) against 5.9 / 12.5 us for the stand-alone 8-wave GEMM: per-op latency inside the chain
 # (4 barrier-separated K-steps on one accumulator per wave, 153 VGPRs -> 2 waves/SIMD) is not yet
 # lower than a launch.  Off by default until the persistent weight-stationary variant lands.
-USE_STACKS = os.environ.get("GEMNET_STACKS", "0") == "1"
+USE_STACKS = os.environ.get("GEMNET_STACKS", "1") == "1"
 
 
 def stacks_enabled():

@@ -134,11 +134,12 @@ def test_eval_forward_force_in_hipgraph(golden_model):
 
 
 def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch):
-    """The LDS-resident stack path (gn_chain_f32, off by default) gives the same E/F as per-layer GEMMs."""
+    """The LDS-resident stack path (gn_chain_f32, the default) gives the same E/F as per-layer GEMMs."""
     from gemnet_pytorch_amd import ops
     cfg, params, inputs = load_case(golden_model, "t2")
     model = build(cfg, params).eval()
     dev = to_dev(inputs)
+    monkeypatch.setattr(ops, "USE_STACKS", False)
     E0, F0 = model(dev)
     monkeypatch.setattr(ops, "USE_STACKS", True)
     E1, F1 = model(dev)
