@@ -143,36 +143,71 @@ __device__ __forceinline__ void mma_step(const float (*As)[LD], const float (*Bs
 }
 
 // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// Fused epilogue over the NV accumulator values a lane owns.  Stage-major: one uniform branch per stage and
+// the NV values of a stage unrolled and independent, so their loads are all in flight together (the value-major
+// form serialised ~8 branches and up to 5 dependent global loads per value).  FULL = tile entirely inside C.
+template <int NV, bool FULL>
+__device__ __forceinline__ void epilogue_vals(const gn_gemm_args& p, float (&v)[NV], const int (&row)[NV],
+                                              const int (&col)[NV]) {
+  const int M = p.M, N = p.N, ldc = p.ldc;
+  const float* __restrict__ const gadd1 = p.gadd1;
+  const float* __restrict__ const gadd2 = p.gadd2;
+  float* __restrict__ const pre_out = p.pre_out;
+  const float* __restrict__ const mul = p.mul;
+  const float* __restrict__ const res = p.res;
+  const float* __restrict__ const res2 = p.res2;
+  float* __restrict__ const C = p.C;
+  bool ok[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) ok[n] = FULL || (row[n] < M && col[n] < N);
+#define GN_EV(body) _Pragma("unroll") for (int n = 0; n < NV; ++n) { if (FULL || ok[n]) { body } }
+  if (gadd1) { const int32_t* __restrict__ const gi = p.gidx1; const int ldg = p.ldg;
+               GN_EV(v[n] += gadd1[(size_t)gi[row[n]] * ldg + col[n]];) }
+  if (gadd2) { const int32_t* __restrict__ const gi = p.gidx2; const int ldg = p.ldg;
+               GN_EV(v[n] += gadd2[(size_t)gi[row[n]] * ldg + col[n]];) }
+  if (pre_out) GN_EV(pre_out[(size_t)row[n] * ldc + col[n]] = v[n];)
+  if (p.act) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) v[n] = gn_ssilu(v[n]);
+  }
+  if (mul) { const int ld = p.ldmul; GN_EV(v[n] *= mul[(size_t)row[n] * ld + col[n]];) }
+  const float alpha = p.alpha;
+  if (alpha != 1.0f) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) v[n] *= alpha;
+  }
+  if (res) {
+    const int ld = p.ldres; const float beta = p.beta;
+    const int32_t* __restrict__ const ridx = p.ridx;
+    if (ridx) GN_EV(v[n] = (v[n] + res[(size_t)ridx[row[n]] * ld + col[n]]) * beta;)
+    else GN_EV(v[n] = (v[n] + res[(size_t)row[n] * ld + col[n]]) * beta;)
+  }
+  if (res2) { const int ld = p.ldres2; const float beta2 = p.beta2;
+              GN_EV(v[n] = (v[n] + res2[(size_t)row[n] * ld + col[n]]) * beta2;) }
+  GN_EV(C[(size_t)row[n] * ldc + col[n]] = v[n];)
+#undef GN_EV
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue(const gn_gemm_args& p, v16f (&acc)[TM][TN], int rbase,
                                          int cbase, int lane) {
   const int l31 = lane & 31;
   const int rh = (lane >> 5) << 2;
+  const bool full = rbase + TM * 32 <= p.M && cbase + TN * 32 <= p.N;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = cbase + j * 32 + l31;
+      float v[16];
+      int row[16], col[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + rh;
-        if (row < p.M && col < p.N) {
-          float z = acc[i][j][r];
-          if (p.gadd1) z += p.gadd1[(size_t)p.gidx1[row] * p.ldg + col];
-          if (p.gadd2) z += p.gadd2[(size_t)p.gidx2[row] * p.ldg + col];
-          const size_t co = (size_t)row * p.ldc + col;
-          if (p.pre_out) p.pre_out[co] = z;
-          float y = p.act ? gn_ssilu(z) : z;
-          if (p.mul) y *= p.mul[(size_t)row * p.ldmul + col];
-          y *= p.alpha;
-          if (p.res) {
-            const size_t rr = p.ridx ? (size_t)p.ridx[row] : (size_t)row;
-            y = (y + p.res[rr * p.ldres + col]) * p.beta;
-          }
-          if (p.res2) y = (y + p.res2[(size_t)row * p.ldres2 + col]) * p.beta2;
-          p.C[co] = y;
-        }
+        v[r] = acc[i][j][r];
+        row[r] = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + rh;
+        col[r] = cbase + j * 32 + l31;
       }
+      if (full) epilogue_vals<16, true>(p, v, row, col);
+      else epilogue_vals<16, false>(p, v, row, col);
     }
 }
 
@@ -343,23 +378,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // 16*rg..+16 and columns 32*cg..+32 (two 16x16 tiles, two independent accumulators for the 40-cycle
 // dependent latency).  Same LDS image and register-prefetch pipeline as gemm_nt_pipe, but twice the
 // waves per SIMD (4.4 instead of 2.2 at E = 18 k rows) so more of the load/barrier latency of one
-// wave hides under the matrix work of another.  Epilogue shared through epilogue_elem().
-__device__ __forceinline__ void epilogue_elem(const gn_gemm_args& p, float z, int row, int col) {
-  if (p.gadd1) z += p.gadd1[(size_t)p.gidx1[row] * p.ldg + col];
-  if (p.gadd2) z += p.gadd2[(size_t)p.gidx2[row] * p.ldg + col];
-  const size_t co = (size_t)row * p.ldc + col;
-  if (p.pre_out) p.pre_out[co] = z;
-  float y = p.act ? gn_ssilu(z) : z;
-  if (p.mul) y *= p.mul[(size_t)row * p.ldmul + col];
-  y *= p.alpha;
-  if (p.res) {
-    const size_t rr = p.ridx ? (size_t)p.ridx[row] : (size_t)row;
-    y = (y + p.res[rr * p.ldres + col]) * p.beta;
-  }
-  if (p.res2) y = (y + p.res2[(size_t)row * p.ldres2 + col]) * p.beta2;
-  p.C[co] = y;
-}
-
+// wave hides under the matrix work of another.  Epilogue: epilogue_vals().
 // BKM = false: B is (N,K) (a Linear weight, k contiguous).  BKM = true: B is (K,N) (n contiguous; the
 // input-gradient product dX = dY W of every Dense): the tile is staged k-major, Bs[k][n], so the global
 // load and the LDS store stay float4 along n and a fragment is four conflict-free ds_read_b32
@@ -467,14 +486,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe16(const gn_gemm_args p) {
   // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
   const int rbase = row0 + rg * 16 + ((lane >> 4) << 2);
   const int cbase = col0 + cg * 32 + l15;
+  float v[8];
+  int row[8], col[8];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = rbase + r;
-    if (row < p.M) {
-      if (cbase < p.N) epilogue_elem(p, acc0[r], row, cbase);
-      if (cbase + 16 < p.N) epilogue_elem(p, acc1[r], row, cbase + 16);
-    }
+    v[r] = acc0[r]; row[r] = rbase + r; col[r] = cbase;
+    v[4 + r] = acc1[r]; row[4 + r] = rbase + r; col[4 + r] = cbase + 16;
   }
+  if (row0 + BM <= p.M && col0 + BN <= p.N) epilogue_vals<8, true>(p, v, row, col);
+  else epilogue_vals<8, false>(p, v, row, col);
 }
 
 // C[b] = opA(A[b]) opB(B[b]) for tiny per-edge blocks (m*k, k*n <= 2048 floats).
