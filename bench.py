@@ -196,18 +196,30 @@ class LaunchTimer:
         return fam
 
 
+def pmc_traffic(name):
+    """HBM-side bytes per launch of a launcher family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes (profiles/r1_traffic.json, produced by tools/gpu_artifacts.sh; gfx950 FETCH_SIZE correction applied)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            return int(json.load(f)[name]["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline_from(fam):
     name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     sec = d["ms"] * 1e-3
     if name in ("gemm", "gemm_tn", "bmm", "chain"):
         ach = d["flops"] / sec / 1e12
         return dict(kernel=name, bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(name),
+                    algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
                     avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2), launches=d["launches"],
                     share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
     ach = d["bytes"] / sec / 1e9
     return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None,
+                frac=round(ach / PEAK_HBM_GBS, 4), traffic=pmc_traffic(name),
+                algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
                 avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2), launches=d["launches"],
                 share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
 
