@@ -71,6 +71,10 @@ SIGNATURES = {
     "gn_chain_f32": [ctypes.POINTER(ChainArgs), _vp],
     "gn_gemm_tn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "gn_gemm_tn_splitk": [_i, _i, _i],
+    "gn_index_gpu_stage1": [_vp, _i, _vp, _vp, _i, _i, _i, _i64, ctypes.c_double, ctypes.c_double, _i, _vp,
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gn_index_gpu_stage2": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
@@ -107,6 +111,8 @@ def load():
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     lib.gn_abi_version.restype = _i
+    lib.gn_index_gpu_ws_bytes.restype = _i64
+    lib.gn_index_gpu_ws_bytes.argtypes = [_i, _i64, _i]
     lib.gn_error_string.restype = ctypes.c_char_p
     lib.gn_error_string.argtypes = [_i]
     for name, argtypes in SIGNATURES.items():

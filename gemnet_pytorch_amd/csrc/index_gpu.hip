@@ -1,0 +1,485 @@
+// Device-resident index construction: what DataContainer.__getitem__ does on the host with
+// numpy + scipy.sparse + numba per batch (gemnet/training/data_container.py:244-408 edges / id_swap / id_undir,
+// :410-425 triplets, :427-489 quadruplets, :520-565 repeat_blocks / ragged_range), rebuilt every MD step in
+// ase_calculator.py:155-158.  Same output as the host builder csrc/index_build.cpp (canonical order: triplets
+// and quadruplets sorted by (reduce edge, expand edge); the reference's own order inside a reduce segment
+// depends on numpy's unstable argsort), bit-exact integers.
+//
+// Integer / byte work, bound by HBM writes of the quadruplet arrays (5 x int32 x Q).  Molecules are dense
+// (the reference builds the full n x n distance matrix per molecule, :255-258), so adjacency lives in per-
+// molecule n x n byte / int32 matrices; all ragged outputs are sized by a count pass + exclusive scan and
+// written by ballot-compaction (one wave per reduce edge walks its candidates in canonical order), so the
+// order is deterministic and no atomics are used.
+//
+// Distances are evaluated exactly like np.linalg.norm(R[:,None]-R[None,:], axis=-1) <= cutoff in R's dtype:
+// d = R_i - R_j, s = (d0*d0 + d1*d1) + d2*d2 with every operation rounded (no FMA contraction), correctly
+// rounded sqrt, comparison against the cutoff cast to that dtype.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct RN;
+template <> struct RN<float> {
+  static __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+  static __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+  static __device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
+  static __device__ __forceinline__ float sqrt(float a) { return __fsqrt_rn(a); }
+};
+template <> struct RN<double> {
+  static __device__ __forceinline__ double mul(double a, double b) { return __dmul_rn(a, b); }
+  static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
+  static __device__ __forceinline__ double sub(double a, double b) { return __dsub_rn(a, b); }
+  static __device__ __forceinline__ double sqrt(double a) { return __dsqrt_rn(a); }
+};
+
+template <typename T>
+__device__ __forceinline__ T dist(const T* __restrict__ R, int i, int j) {
+  const T d0 = RN<T>::sub(R[3 * i], R[3 * j]);
+  const T d1 = RN<T>::sub(R[3 * i + 1], R[3 * j + 1]);
+  const T d2 = RN<T>::sub(R[3 * i + 2], R[3 * j + 2]);
+  const T s = RN<T>::add(RN<T>::add(RN<T>::mul(d0, d0), RN<T>::mul(d1, d1)), RN<T>::mul(d2, d2));
+  return RN<T>::sqrt(s);
+}
+
+// adj / iadj: per molecule m an n x n byte matrix at sq_off[m]; grid (ceil(nmax^2 / 256), B)
+template <typename T>
+__global__ void idx_adj_kernel(const T* __restrict__ R, const int32_t* __restrict__ mol_off,
+                               const int32_t* __restrict__ sq_off, T cutoff, T int_cutoff, int quad,
+                               uint8_t* __restrict__ adj, uint8_t* __restrict__ iadj) {
+  const int m = blockIdx.y;
+  const int a0 = mol_off[m], n = mol_off[m + 1] - a0;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n * n) return;
+  const int x = p / n, y = p - x * n;
+  uint8_t w = 0, wi = 0;
+  if (x != y) {
+    const T d = dist<T>(R, a0 + x, a0 + y);
+    w = d <= cutoff;
+    wi = d <= int_cutoff;
+  }
+  adj[sq_off[m] + p] = w;
+  if (quad) iadj[sq_off[m] + p] = wi;
+}
+
+// per atom: degree, number of upper neighbours, interaction degree, molecule id
+__global__ void idx_deg_kernel(const int32_t* __restrict__ mol_off, const int32_t* __restrict__ sq_off,
+                               const int32_t* __restrict__ atom_mol, int A, int quad,
+                               const uint8_t* __restrict__ adj, const uint8_t* __restrict__ iadj,
+                               int32_t* __restrict__ deg, int32_t* __restrict__ up, int32_t* __restrict__ ideg) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A) return;
+  const int m = atom_mol[g];
+  const int a0 = mol_off[m], n = mol_off[m + 1] - a0, x = g - a0;
+  const uint8_t* __restrict__ row = adj + sq_off[m] + (size_t)x * n;
+  int d = 0, u = 0, di = 0;
+  for (int y = 0; y < n; ++y) {
+    d += row[y];
+    u += (y > x) & row[y];
+  }
+  if (quad) {
+    const uint8_t* __restrict__ irow = iadj + sq_off[m] + (size_t)x * n;
+    for (int y = 0; y < n; ++y) di += irow[y];
+  }
+  deg[g] = d;
+  up[g] = u;
+  if (quad) ideg[g] = di;
+}
+
+// single-block exclusive scan of n int32 (n up to a few million: n/1024 sequential chunks); out[n] = total
+__global__ __launch_bounds__(1024) void idx_scan_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                        int64_t n, int* __restrict__ overflow) {
+  __shared__ int64_t wsum[16];
+  __shared__ int64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + tid;
+    const int64_t v = i < n ? (int64_t)in[i] : 0;
+    int64_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t t = __shfl_up(s, o, 64);
+      if (lane >= o) s += t;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int64_t carry = carry_s;
+    const int64_t excl = carry + woff + s - v;
+    if (i < n) {
+      if (excl > 0x7fffffffLL) *overflow = 1;
+      out[i] = (int32_t)excl;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + s;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (carry_s > 0x7fffffffLL) *overflow = 1;
+    out[n] = (int32_t)carry_s;
+  }
+}
+
+// edges: pair (t < s) -> e = off_half[t] + k and e + H; M[x][y] = id of the edge with target x, source y
+__global__ void idx_edges_kernel(const int32_t* __restrict__ mol_off, const int32_t* __restrict__ sq_off,
+                                 const int32_t* __restrict__ atom_mol, int A, int quad,
+                                 const uint8_t* __restrict__ adj, const uint8_t* __restrict__ iadj,
+                                 const int32_t* __restrict__ off_half, const int32_t* __restrict__ off_int,
+                                 int32_t* __restrict__ id_a, int32_t* __restrict__ id_c,
+                                 int32_t* __restrict__ id_undir, int32_t* __restrict__ id_swap,
+                                 int32_t* __restrict__ int_a, int32_t* __restrict__ int_b,
+                                 int32_t* __restrict__ Mx, int32_t* __restrict__ MI) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A) return;
+  const int m = atom_mol[g];
+  const int a0 = mol_off[m], n = mol_off[m + 1] - a0, x = g - a0;
+  const int H = off_half[A];
+  const size_t base = (size_t)sq_off[m];
+  const uint8_t* __restrict__ row = adj + base + (size_t)x * n;
+  int e = off_half[g];
+  for (int y = x + 1; y < n; ++y) {
+    if (row[y]) {
+      id_a[e] = g; id_c[e] = a0 + y;
+      id_a[e + H] = a0 + y; id_c[e + H] = g;
+      id_undir[e] = e; id_undir[e + H] = e;
+      id_swap[e] = e + H; id_swap[e + H] = e;
+      Mx[base + (size_t)x * n + y] = e;
+      Mx[base + (size_t)y * n + x] = e + H;
+      ++e;
+    }
+  }
+  if (quad) {
+    const uint8_t* __restrict__ irow = iadj + base + (size_t)x * n;
+    int i = off_int[g];
+    for (int y = 0; y < n; ++y) {
+      if (irow[y]) {
+        int_a[i] = g; int_b[i] = a0 + y;
+        MI[base + (size_t)x * n + y] = i;
+        ++i;
+      }
+    }
+  }
+}
+
+// incoming edges of every atom ordered by source atom (scipy canonical CSR column order) + position of each edge
+__global__ void idx_in_kernel(const int32_t* __restrict__ mol_off, const int32_t* __restrict__ sq_off,
+                              const int32_t* __restrict__ atom_mol, int A, const uint8_t* __restrict__ adj,
+                              const int32_t* __restrict__ Mx, const int32_t* __restrict__ in_ptr,
+                              int32_t* __restrict__ in_edge, int32_t* __restrict__ pos_in) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A) return;
+  const int m = atom_mol[g];
+  const int a0 = mol_off[m], n = mol_off[m + 1] - a0, x = g - a0;
+  const size_t base = (size_t)sq_off[m] + (size_t)x * n;
+  int k = 0;
+  const int p0 = in_ptr[g];
+  for (int y = 0; y < n; ++y) {
+    if (adj[base + y]) {
+      const int e = Mx[base + y];
+      in_edge[p0 + k] = e;
+      pos_in[e] = k;
+      ++k;
+    }
+  }
+}
+
+__global__ void idx_cnt3_kernel(const int32_t* __restrict__ id_a, const int32_t* __restrict__ deg, int E,
+                                int32_t* __restrict__ cnt3) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < E) cnt3[r] = deg[id_a[r]] - 1;
+}
+
+// one wave per reduce edge r = (c -> a): expand edges x = (b -> a), b != c, ascending edge id
+// = sources b > a ascending (first-half ids), then sources b < a ascending (second-half ids)
+__global__ __launch_bounds__(256) void idx_trip_kernel(const int32_t* __restrict__ mol_off,
+                                                       const int32_t* __restrict__ sq_off,
+                                                       const int32_t* __restrict__ atom_mol,
+                                                       const int32_t* __restrict__ id_a, const int32_t* __restrict__ id_c,
+                                                       int E, const uint8_t* __restrict__ adj,
+                                                       const int32_t* __restrict__ Mx, const int32_t* __restrict__ off3,
+                                                       int32_t* __restrict__ red, int32_t* __restrict__ exp,
+                                                       int32_t* __restrict__ kidx) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= E) return;
+  const int ga = id_a[r], gc = id_c[r];
+  const int m = atom_mol[ga];
+  const int a0 = mol_off[m], n = mol_off[m + 1] - a0, a = ga - a0, c = gc - a0;
+  const size_t base = (size_t)sq_off[m] + (size_t)a * n;
+  int o = off3[r];
+  const int o0 = o;
+  // candidate index j in [0, n-1): b = a+1+j for j < n-1-a, else b = j - (n-1-a)
+  const int nup = n - 1 - a;
+  for (int j0 = 0; j0 < n - 1; j0 += 64) {
+    const int j = j0 + lane;
+    bool ok = false;
+    int b = 0;
+    if (j < n - 1) {
+      b = j < nup ? a + 1 + j : j - nup;
+      ok = adj[base + b] && b != c;
+    }
+    const uint64_t mask = __ballot(ok);
+    if (ok) {
+      const int w = o + __popcll(mask & ((1ull << lane) - 1ull));
+      red[w] = r;
+      exp[w] = Mx[base + b];
+      kidx[w] = w - o0;
+    }
+    o += __popcll(mask);
+  }
+}
+
+__global__ void idx_cnt_intm_kernel(const int32_t* __restrict__ int_a, const int32_t* __restrict__ int_b,
+                                    const int32_t* __restrict__ deg, int Eint, int32_t* __restrict__ cnt_ca,
+                                    int32_t* __restrict__ cnt_db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Eint) {
+    cnt_ca[i] = deg[int_a[i]];
+    cnt_db[i] = deg[int_b[i]];
+  }
+}
+
+__global__ void idx_intm_kernel(const int32_t* __restrict__ int_a, const int32_t* __restrict__ int_b, int Eint,
+                                const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
+                                const int32_t* __restrict__ off_ca, const int32_t* __restrict__ off_db,
+                                int32_t* __restrict__ red_intm_ca, int32_t* __restrict__ red_intm_ab,
+                                int32_t* __restrict__ exp_intm_db, int32_t* __restrict__ exp_intm_ab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Eint) return;
+  const int a = int_a[i], b = int_b[i];
+  int p = in_ptr[a], q = off_ca[i];
+  for (int k = in_ptr[a + 1] - p; k > 0; --k, ++p, ++q) { red_intm_ca[q] = in_edge[p]; red_intm_ab[q] = i; }
+  p = in_ptr[b]; q = off_db[i];
+  for (int k = in_ptr[b + 1] - p; k > 0; --k, ++p, ++q) { exp_intm_db[q] = in_edge[p]; exp_intm_ab[q] = i; }
+}
+
+// quadruplets of reduce edge r = (c -> a): all (b, d) with b in intN(a), d in N(b), c != b, a != d, c != d
+__global__ void idx_cnt4_kernel(const int32_t* __restrict__ mol_off, const int32_t* __restrict__ sq_off,
+                                const int32_t* __restrict__ atom_mol, const int32_t* __restrict__ id_a,
+                                const int32_t* __restrict__ id_c, int E, const uint8_t* __restrict__ adj,
+                                const uint8_t* __restrict__ iadj, const int32_t* __restrict__ deg,
+                                int32_t* __restrict__ cnt4) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= E) return;
+  const int ga = id_a[r], gc = id_c[r];
+  const int m = atom_mol[ga];
+  const int a0 = mol_off[m], n = mol_off[m + 1] - a0, a = ga - a0, c = gc - a0;
+  const size_t base = (size_t)sq_off[m];
+  int cnt = 0;
+  for (int b = 0; b < n; ++b)
+    if (iadj[base + (size_t)a * n + b] && b != c)
+      cnt += deg[a0 + b] - adj[base + (size_t)b * n + a] - adj[base + (size_t)b * n + c];
+  cnt4[r] = cnt;
+}
+
+// one wave per reduce edge; expand edges (d -> b) in ascending edge id: first-half ids (b < d) are ordered by
+// (b, d), second-half ids (b > d) by (d, b)
+__global__ __launch_bounds__(256) void idx_quad_kernel(
+    const int32_t* __restrict__ mol_off, const int32_t* __restrict__ sq_off, const int32_t* __restrict__ atom_mol,
+    const int32_t* __restrict__ id_a, const int32_t* __restrict__ id_c, int E, const uint8_t* __restrict__ adj,
+    const uint8_t* __restrict__ iadj, const int32_t* __restrict__ Mx, const int32_t* __restrict__ MI,
+    const int32_t* __restrict__ pos_in, const int32_t* __restrict__ off_ca, const int32_t* __restrict__ off_db,
+    const int32_t* __restrict__ off4, int32_t* __restrict__ red_ca, int32_t* __restrict__ exp_db,
+    int32_t* __restrict__ red_cab, int32_t* __restrict__ exp_abd, int32_t* __restrict__ kidx) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= E) return;
+  const int ga = id_a[r], gc = id_c[r];
+  const int m = atom_mol[ga];
+  const int a0 = mol_off[m], n = mol_off[m + 1] - a0, a = ga - a0, c = gc - a0;
+  const size_t base = (size_t)sq_off[m];
+  const uint8_t* __restrict__ irow = iadj + base + (size_t)a * n;
+  const int32_t* __restrict__ mirow = MI + base + (size_t)a * n;
+  const int pr = pos_in[r];
+  int o = off4[r];
+  const int o0 = o;
+  const int nn = n * n;
+  for (int phase = 0; phase < 2; ++phase) {
+    for (int j0 = 0; j0 < nn; j0 += 64) {
+      const int j = j0 + lane;
+      bool ok = false;
+      int b = 0, d = 0;
+      if (j < nn) {
+        const int hi = j / n, lo = j - hi * n;      // phase 0: (b, d) = (hi, lo), b < d; phase 1: (d, b) = (hi, lo), b > d
+        b = phase ? lo : hi;
+        d = phase ? hi : lo;
+        ok = hi < lo && irow[b] && b != c && d != a && d != c && adj[base + (size_t)b * n + d];
+      }
+      const uint64_t mask = __ballot(ok);
+      if (ok) {
+        const int w = o + __popcll(mask & ((1ull << lane) - 1ull));
+        const int x = Mx[base + (size_t)b * n + d];   // edge with target b, source d
+        const int i = mirow[b];                        // interaction edge (a, b)
+        red_ca[w] = r;
+        exp_db[w] = x;
+        red_cab[w] = off_ca[i] + pr;
+        exp_abd[w] = off_db[i] + pos_in[x];
+        kidx[w] = w - o0;
+      }
+      o += __popcll(mask);
+    }
+  }
+}
+
+__global__ void idx_atom_mol_kernel(const int32_t* __restrict__ mol_off, int B, int32_t* __restrict__ atom_mol,
+                                    int32_t* __restrict__ batch_seg) {
+  const int m = blockIdx.x;
+  for (int g = mol_off[m] + threadIdx.x; g < mol_off[m + 1]; g += blockDim.x) {
+    atom_mol[g] = m;
+    if (batch_seg) batch_seg[g] = m;
+  }
+}
+
+inline size_t al(size_t x) { return (x + 63) & ~(size_t)63; }
+
+}  // namespace
+
+// workspace layout (bytes, 64-B aligned sections); see gn_index_gpu_ws_bytes
+struct idx_ws {
+  uint8_t *adj, *iadj;
+  int32_t *Mx, *MI, *atom_mol, *deg, *up, *ideg, *off_half, *in_ptr, *off_int, *in_edge, *pos_in, *cnt, *off3, *off4,
+      *cnt2, *off_ca, *off_db;
+  int* overflow;
+};
+
+static size_t idx_layout(char* base, int A, int64_t sq, int64_t Emax, int64_t Eintmax, int quad, idx_ws* w) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
+  w->adj = (uint8_t*)take(sq);
+  w->iadj = (uint8_t*)take(quad ? sq : 0);
+  w->Mx = (int32_t*)take(4 * sq);
+  w->MI = (int32_t*)take(quad ? 4 * sq : 0);
+  w->atom_mol = (int32_t*)take(4 * (size_t)A);
+  w->deg = (int32_t*)take(4 * (size_t)A);
+  w->up = (int32_t*)take(4 * (size_t)A);
+  w->ideg = (int32_t*)take(4 * (size_t)A);
+  w->off_half = (int32_t*)take(4 * ((size_t)A + 1));
+  w->in_ptr = (int32_t*)take(4 * ((size_t)A + 1));
+  w->off_int = (int32_t*)take(4 * ((size_t)A + 1));
+  w->in_edge = (int32_t*)take(4 * (size_t)Emax);
+  w->pos_in = (int32_t*)take(4 * (size_t)Emax);
+  w->cnt = (int32_t*)take(4 * (size_t)(Emax > Eintmax ? Emax : Eintmax));
+  w->off3 = (int32_t*)take(4 * ((size_t)Emax + 1));
+  w->off4 = (int32_t*)take(4 * ((size_t)Emax + 1));
+  w->cnt2 = (int32_t*)take(4 * (size_t)Eintmax);
+  w->off_ca = (int32_t*)take(4 * ((size_t)Eintmax + 1));
+  w->off_db = (int32_t*)take(4 * ((size_t)Eintmax + 1));
+  w->overflow = (int*)take(64);
+  return o;
+}
+
+// Upper bounds used for the workspace: E <= sum n(n-1) = sq - A, Eint likewise.
+extern "C" int64_t gn_index_gpu_ws_bytes(int A, int64_t sum_n2, int triplets_only) {
+  idx_ws w;
+  const int64_t emax = sum_n2 - A > 0 ? sum_n2 - A : 0;
+  return (int64_t)idx_layout(nullptr, A, sum_n2, emax, triplets_only ? 0 : emax, !triplets_only, &w);
+}
+
+// Stage 1: adjacency, edges, incoming lists, counts.  sizes (host, 6 x int64) <- E, T, Eint, Ica, Idb, Q
+// (synchronises the stream once to read them back).  Edge-level outputs are written here (caller sizes them with
+// the upper bound E <= sum_n2 - A, or calls with NULL outputs first and again with buffers: idempotent).
+extern "C" int gn_index_gpu_stage1(const void* R, int r_is_f64, const int32_t* mol_off, const int32_t* sq_off, int B,
+                                   int A, int nmax, int64_t sum_n2, double cutoff, double int_cutoff, int triplets_only,
+                                   void* ws, int32_t* batch_seg, int32_t* id_a, int32_t* id_c, int32_t* id_undir,
+                                   int32_t* id_swap, int32_t* int_a, int32_t* int_b, int64_t* sizes, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int quad = !triplets_only;
+  for (int i = 0; i < 6; ++i) sizes[i] = 0;
+  if (A <= 0 || B <= 0) return 0;
+  if (sum_n2 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  idx_ws w;
+  const int64_t emax = sum_n2 - A;
+  idx_layout((char*)ws, A, sum_n2, emax, quad ? emax : 0, quad, &w);
+  hipError_t e = hipMemsetAsync(w.overflow, 0, sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(idx_atom_mol_kernel, dim3(B), dim3(64), 0, st, mol_off, B, w.atom_mol, batch_seg);
+  dim3 gadj(gn_cdiv((int64_t)nmax * nmax, 256), B);
+  if (r_is_f64)
+    hipLaunchKernelGGL((idx_adj_kernel<double>), gadj, dim3(256), 0, st, (const double*)R, mol_off, sq_off, cutoff,
+                       int_cutoff, quad, w.adj, w.iadj);
+  else
+    hipLaunchKernelGGL((idx_adj_kernel<float>), gadj, dim3(256), 0, st, (const float*)R, mol_off, sq_off,
+                       (float)cutoff, (float)int_cutoff, quad, w.adj, w.iadj);
+  GN_LAUNCH_CHECK();
+  const dim3 ga(gn_cdiv(A, 256));
+  hipLaunchKernelGGL(idx_deg_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, quad, w.adj, w.iadj, w.deg,
+                     w.up, w.ideg);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.up, w.off_half, (int64_t)A, w.overflow);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.deg, w.in_ptr, (int64_t)A, w.overflow);
+  if (quad) hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.ideg, w.off_int, (int64_t)A, w.overflow);
+  GN_LAUNCH_CHECK();
+  int32_t tot[3] = {0, 0, 0};
+  e = hipMemcpyAsync(&tot[0], w.off_half + A, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && quad) e = hipMemcpyAsync(&tot[1], w.off_int + A, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return (int)e;
+  const int64_t H = tot[0], E = 2 * H, Eint = tot[1];
+  sizes[0] = E;
+  sizes[2] = E == 0 ? 0 : Eint;   // no-edge early return (data_container.py:282-285): every index array is empty
+  if (E == 0) return 0;
+  if (!id_a) return 0;    // size query only
+  hipLaunchKernelGGL(idx_edges_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, quad, w.adj, w.iadj,
+                     w.off_half, w.off_int, id_a, id_c, id_undir, id_swap, int_a, int_b, w.Mx, w.MI);
+  hipLaunchKernelGGL(idx_in_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, w.adj, w.Mx, w.in_ptr,
+                     w.in_edge, w.pos_in);
+  hipLaunchKernelGGL(idx_cnt3_kernel, dim3(gn_cdiv(E, 256)), dim3(256), 0, st, id_a, w.deg, (int)E, w.cnt);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off3, E, w.overflow);
+  GN_LAUNCH_CHECK();
+  int32_t t3 = 0, t4 = 0, tca = 0, tdb = 0;
+  int ovf = 0;
+  e = hipMemcpyAsync(&t3, w.off3 + E, 4, hipMemcpyDeviceToHost, st);
+  if (quad && Eint > 0) {
+    hipLaunchKernelGGL(idx_cnt_intm_kernel, dim3(gn_cdiv(Eint, 256)), dim3(256), 0, st, int_a, int_b, w.deg, (int)Eint,
+                       w.cnt, w.cnt2);
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off_ca, Eint, w.overflow);
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt2, w.off_db, Eint, w.overflow);
+    hipLaunchKernelGGL(idx_cnt4_kernel, dim3(gn_cdiv(E, 256)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, id_a,
+                       id_c, (int)E, w.adj, w.iadj, w.deg, w.cnt);
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off4, E, w.overflow);
+    GN_LAUNCH_CHECK();
+    if (e == hipSuccess) e = hipMemcpyAsync(&tca, w.off_ca + Eint, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&tdb, w.off_db + Eint, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&t4, w.off4 + E, 4, hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&ovf, w.overflow, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return (int)e;
+  if (ovf) return (int)hipErrorInvalidValue;   // more than 2^31 - 1 entries in one array
+  sizes[1] = t3;
+  sizes[3] = tca;
+  sizes[4] = tdb;
+  sizes[5] = t4;
+  return 0;
+}
+
+// Stage 2: fill the triplet / quadruplet arrays (sizes from stage 1; same `ws`, untouched in between).
+extern "C" int gn_index_gpu_stage2(const int32_t* mol_off, const int32_t* sq_off, int B, int A, int64_t sum_n2,
+                                   int triplets_only, void* ws, const int32_t* id_a, const int32_t* id_c,
+                                   const int32_t* int_a, const int32_t* int_b, int64_t E, int64_t Eint,
+                                   int32_t* id3_reduce_ca, int32_t* id3_expand_ba, int32_t* Kidx3,
+                                   int32_t* id4_reduce_ca, int32_t* id4_expand_db, int32_t* id4_reduce_cab,
+                                   int32_t* id4_expand_abd, int32_t* Kidx4, int32_t* id4_reduce_intm_ca,
+                                   int32_t* id4_expand_intm_db, int32_t* id4_reduce_intm_ab,
+                                   int32_t* id4_expand_intm_ab, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (E <= 0) return 0;
+  const int quad = !triplets_only;
+  idx_ws w;
+  const int64_t emax = sum_n2 - A;
+  idx_layout((char*)ws, A, sum_n2, emax, quad ? emax : 0, quad, &w);
+  hipLaunchKernelGGL(idx_trip_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, id_a, id_c,
+                     (int)E, w.adj, w.Mx, w.off3, id3_reduce_ca, id3_expand_ba, Kidx3);
+  GN_LAUNCH_CHECK();
+  if (quad && Eint > 0) {
+    hipLaunchKernelGGL(idx_intm_kernel, dim3(gn_cdiv(Eint, 256)), dim3(256), 0, st, int_a, int_b, (int)Eint, w.in_ptr,
+                       w.in_edge, w.off_ca, w.off_db, id4_reduce_intm_ca, id4_reduce_intm_ab, id4_expand_intm_db,
+                       id4_expand_intm_ab);
+    hipLaunchKernelGGL(idx_quad_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, id_a, id_c,
+                       (int)E, w.adj, w.iadj, w.Mx, w.MI, w.pos_in, w.off_ca, w.off_db, w.off4, id4_reduce_ca,
+                       id4_expand_db, id4_reduce_cab, id4_expand_abd, Kidx4);
+    GN_LAUNCH_CHECK();
+  }
+  return 0;
+}

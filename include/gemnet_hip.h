@@ -125,6 +125,32 @@ int gn_gemm_tn_splitk(int M, int N, int K);
 int gn_bmm_f32(const float* A, const float* B, float* C, int batch, int m, int n, int k,
                int trans_a, int trans_b, void* stream);
 
+/* ---- index construction on the device (P12 of SURVEY.md §8 resident on the GPU, row N1) ---------------------------
+ * What DataContainer.__getitem__ builds on the host per batch (data_container.py:244-408 edges / id_swap /
+ * id_undir / batch_seg, :410-425 triplets, :427-489 quadruplets, :520-565 repeat_blocks / ragged_range) and
+ * ase_calculator.py:155-158 rebuilds every MD step.  Same arrays, same canonical order and the same distance
+ * rounding as the host builder (include/gemnet_index.h), as int32 device arrays.
+ *   R         (A,3) float32 or float64 (r_is_f64) device positions
+ *   mol_off   (B+1) int32 device: first atom of each molecule;  sq_off (B+1) int32 device: prefix sums of n_m^2
+ *   nmax      largest molecule;  sum_n2 = sq_off[B]  (both known on the host from N)
+ *   ws        caller-owned device workspace of gn_index_gpu_ws_bytes() bytes, shared by both stages
+ * stage1 writes batch_seg (A), the edge arrays (capacity sum_n2 - A each: upper bound of E resp. Eint) and
+ * sizes[6] = {E, T, Eint, Ica, Idb, Q} (host; one stream synchronisation).  With id_a == NULL only sizes[0] and
+ * sizes[2] are produced.  stage2 fills the triplet / quadruplet arrays (caller allocates them from `sizes`).
+ * Arrays with more than 2^31 - 1 entries are rejected. */
+int64_t gn_index_gpu_ws_bytes(int A, int64_t sum_n2, int triplets_only);
+int gn_index_gpu_stage1(const void* R, int r_is_f64, const int32_t* mol_off, const int32_t* sq_off, int B, int A,
+                        int nmax, int64_t sum_n2, double cutoff, double int_cutoff, int triplets_only, void* ws,
+                        int32_t* batch_seg, int32_t* id_a, int32_t* id_c, int32_t* id_undir, int32_t* id_swap,
+                        int32_t* id4_int_a, int32_t* id4_int_b, int64_t* sizes, void* stream);
+int gn_index_gpu_stage2(const int32_t* mol_off, const int32_t* sq_off, int B, int A, int64_t sum_n2,
+                        int triplets_only, void* ws, const int32_t* id_a, const int32_t* id_c,
+                        const int32_t* id4_int_a, const int32_t* id4_int_b, int64_t E, int64_t Eint,
+                        int32_t* id3_reduce_ca, int32_t* id3_expand_ba, int32_t* Kidx3, int32_t* id4_reduce_ca,
+                        int32_t* id4_expand_db, int32_t* id4_reduce_cab, int32_t* id4_expand_abd, int32_t* Kidx4,
+                        int32_t* id4_reduce_intm_ca, int32_t* id4_expand_intm_db, int32_t* id4_reduce_intm_ab,
+                        int32_t* id4_expand_intm_ab, void* stream);
+
 /* ---- row gather / segmented sum (P2/P3/P10: `x[id3_expand_ba]` interaction_block.py:678,
  *      `x[id4_expand_*]` :543,:548, `x_ac[id_swap]` :693, h[id] embedding_block.py:70-71 and
  *      torch_scatter.scatter(..., reduce="add") atom_update_block.py:67,172, gemnet.py:580) -- */
