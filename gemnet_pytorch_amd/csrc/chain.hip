@@ -52,12 +52,13 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
   const int lg = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int M = P.M;
-  // index of the next GEMM op after each op (whose weights get prefetched), resolved once
-  __shared__ int next_gemm[GN_CHAIN_MAX_OPS];
-  if (tid < P.n_ops) {
-    int j = tid + 1;
-    while (j < P.n_ops && P.ops[j].kind != GN_OP_GEMM) ++j;
-    next_gemm[tid] = j < P.n_ops ? j : -1;
+  // op indices of the GEMM ops in program order (their weights are prefetched two GEMMs ahead), resolved once
+  __shared__ int gemm_list[GN_CHAIN_MAX_OPS + 2];
+  if (tid == 0) {
+    int g = 0;
+    for (int j = 0; j < P.n_ops; ++j)
+      if (P.ops[j].kind == GN_OP_GEMM) gemm_list[g++] = j;
+    gemm_list[g] = gemm_list[g + 1] = -1;
   }
   __syncthreads();
 
@@ -65,8 +66,10 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
   // W[16 wave + l15][kc + 4 lg .. +3] for the 16-k chunks kc = 0, 16, .. (K <= 128 -> 8 float4)
   float4 bcur[8], bnext[8];
   // Weight distribution is the slow resource of this kernel: every CU pulls the same 64 KB per op and the
-  // L2 -> CU path delivers it in ~8-14 k cycles when all CUs ask at once (traced with -DGN_CHAIN_TRACE), longer
-  // than one op's MFMA phase.  Fragments are therefore prefetched TWO GEMM ops ahead (bn1, bn2).
+  // L2 -> CU path delivers it in ~8-14 k cycles when all CUs ask at once (traced with -DGN_CHAIN_TRACE), about
+  // one op's MFMA phase.  The next GEMM's fragments are in flight during the current op (bnext); the first GEMM's
+  // are requested before the program's LOAD ops.  (Two-deep prefetch was tried: a register rotation by copies
+  // waits on the youngest loads, a static 3-buffer rotation triples the MFMA code and spills at RT >= 4.)
   auto wload = [&](float4 (&dst)[8], const float* __restrict__ W, int N, int K) {
     const int n = wave * 16 + l15;
     const float* __restrict__ row = W + (size_t)n * K + (lg << 2);
@@ -76,8 +79,12 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
       if (n < N && c * 16 < K) dst[c] = *reinterpret_cast<const float4*>(row + c * 16);
     }
   };
-  float4 bn2[8];
-  int pf = 0;   // how many of (bnext, bn2) hold the fragments of the upcoming GEMM ops
+  auto wload_op = [&](float4 (&dst)[8], int ord) {
+    const int j = __builtin_amdgcn_readfirstlane(gemm_list[ord]);
+    if (j >= 0) wload(dst, P.ops[j].W, P.ops[j].N, P.ops[j].K);
+  };
+  wload_op(bnext, 0);   // in flight under the LOAD op(s) that start every program
+  int gord = 0;         // ordinal of the next GEMM op
 
   for (int oi = 0; oi < P.n_ops; ++oi) {
     const gn_chain_op& op = P.ops[oi];
@@ -141,35 +148,31 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
       const float* __restrict__ const res_g = op.res_g;
       const float* __restrict__ const res2_g = op.res2_g;
       const int32_t* __restrict__ const res_rows = op.res_rows;
-      const int nj = __builtin_amdgcn_readfirstlane(next_gemm[oi]);
-      const int nj2 = nj >= 0 ? __builtin_amdgcn_readfirstlane(next_gemm[nj]) : -1;
       GN_STAMP(0);
-      if (pf >= 1) {
+      const bool active = wave * 16 < N;   // this wave's 16 output columns exist
+      // RT = 1 has a single 16x16 tile per wave: its 32 MFMAs would form one dependent chain, so even and odd
+      // K-chunks accumulate separately (two independent chains, summed at the end)
+      constexpr int KSP = RT == 1 ? 2 : 1;
+      v4f accs[KSP][RT];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) bcur[c] = bnext[c];
-        if (pf == 2) {
+      for (int q = 0; q < KSP; ++q)
 #pragma unroll
-          for (int c = 0; c < 8; ++c) bnext[c] = bn2[c];
-        }
-        --pf;
-      } else {
-        wload(bcur, W, N, K);
-      }
-      if (pf == 0 && nj >= 0) { wload(bnext, P.ops[nj].W, P.ops[nj].N, P.ops[nj].K); pf = 1; }
-      if (pf == 1 && nj2 >= 0) { wload(bn2, P.ops[nj2].W, P.ops[nj2].N, P.ops[nj2].K); pf = 2; }
+        for (int t = 0; t < RT; ++t) accs[q][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+      // lanes of group lg supply k = kc + 4 lg + j to MFMA j (same permutation for A and B)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bcur[c] = bnext[c];   // requested one GEMM ago (or at kernel start)
+      wload_op(bnext, gord + 1);                          // the next GEMM's fragments fly in under this op
+      ++gord;
 #ifdef GN_CHAIN_TRACE
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // bcur landed (up to 16 newer loads: bnext, bn2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // bcur landed (the 8 newer loads are bnext)
 #endif
       GN_STAMP(1);
-      const bool active = wave * 16 < N;   // this wave's 16 output columns exist
-      v4f acc[RT];
-#pragma unroll
-      for (int t = 0; t < RT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-      if (active) {
+      auto mfma_phase = [&]() {
+        if (!active) return;
         const int kq = lg << 2;
-        // lanes of group lg supply k = kc + 4 lg + j to MFMA j (same permutation for A and B)
         auto chunk = [&](int c, const float4 (&a)[RT]) {
           const float4 b = bcur[c];
+          v4f (&acc)[RT] = accs[c & (KSP - 1)];
 #pragma unroll
           for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -204,7 +207,11 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
             }
           }
         }
-      }
+      };
+      mfma_phase();
+      v4f acc[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = KSP == 2 ? accs[0][t] + accs[KSP - 1][t] : accs[0][t];
 #ifdef GN_CHAIN_TRACE
       if (active) { float sink = 0.f; for (int t = 0; t < RT; ++t) sink += acc[t][0]; if (sink == 1.2345e30f) S[0][0][0] = sink; }
 #endif

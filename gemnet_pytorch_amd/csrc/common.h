@@ -26,7 +26,9 @@ static inline int gn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b);
 // v_exp_f32 + v_rcp_f32 (about 1 ulp each; |rel err| of s below ~3e-7 for |x| < 30) instead of the
 // ~40-instruction IEEE expf + division: the activation epilogue of the LDS-resident layer chain was
 // VALU-bound (4.5 k cycles per op for 20 values per lane, traced with -DGN_CHAIN_TRACE).
-__device__ __forceinline__ float gn_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// (`__frcp_rn` still expands to the IEEE div_scale / div_fmas / div_fixup sequence; the builtin is the bare
+// v_rcp_f32.)
+__device__ __forceinline__ float gn_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float gn_ssilu(float x) { return x * gn_sigmoid(x) * GN_INV_06; }
 
