@@ -334,7 +334,7 @@ extern "C" int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const fl
   if (S <= 0 || C <= 0 || (C % 4) != 0 || I <= 0) return (int)hipErrorInvalidValue;
   const size_t smem = ((size_t)(I + 2 * S) * (C + 4) + (size_t)S * I) * sizeof(float);
   if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(bil_project_bwd_kernel, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bil_project_bwd_kernel, dim3((unsigned)E), dim3(128), smem, static_cast<hipStream_t>(stream),
                      dP, Sm, B, x, expand_idx, seg_off, gB, dSm, dY, S, C, I);
   GN_LAUNCH_CHECK();
   return 0;
