@@ -418,6 +418,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 is still measuring the roofline pass: leave together
         dist.destroy_process_group()
 
 

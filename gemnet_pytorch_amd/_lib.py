@@ -75,6 +75,7 @@ SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_index_gpu_stage2": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gn_pm_f32": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i64, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],

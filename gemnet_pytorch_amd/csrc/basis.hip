@@ -73,6 +73,48 @@ __global__ void dact_mul_kernel(const float* __restrict__ g, const float* __rest
   }
 }
 
+// out = c * f^(k)(z) * a * b * d  (k = -1: no activation factor; a, b, d optional), float4 body + scalar tail
+__device__ __forceinline__ float pm_act(float v, int k) {
+  return k == 0 ? gn_ssilu(v) : (k == 1 ? gn_dssilu(v) : (k == 2 ? gn_d2ssilu(v) : gn_d3ssilu(v)));
+}
+__global__ void pm_kernel(const float* __restrict__ z, int k, const float* __restrict__ a,
+                          const float* __restrict__ b, const float* __restrict__ d, float c,
+                          float* __restrict__ out, int64_t n, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = i0; i < n4; i += stride) {
+      float4 r = make_float4(c, c, c, c);
+      if (k >= 0) {
+        const float4 v = reinterpret_cast<const float4*>(z)[i];
+        r.x *= pm_act(v.x, k); r.y *= pm_act(v.y, k); r.z *= pm_act(v.z, k); r.w *= pm_act(v.w, k);
+      }
+      if (a) { const float4 v = reinterpret_cast<const float4*>(a)[i]; r.x *= v.x; r.y *= v.y; r.z *= v.z; r.w *= v.w; }
+      if (b) { const float4 v = reinterpret_cast<const float4*>(b)[i]; r.x *= v.x; r.y *= v.y; r.z *= v.z; r.w *= v.w; }
+      if (d) { const float4 v = reinterpret_cast<const float4*>(d)[i]; r.x *= v.x; r.y *= v.y; r.z *= v.z; r.w *= v.w; }
+      reinterpret_cast<float4*>(out)[i] = r;
+    }
+    for (int64_t i = (n4 << 2) + i0; i < n; i += stride) {
+      float r = c;
+      if (k >= 0) r *= pm_act(z[i], k);
+      if (a) r *= a[i];
+      if (b) r *= b[i];
+      if (d) r *= d[i];
+      out[i] = r;
+    }
+  } else {
+    for (int64_t i = i0; i < n; i += stride) {
+      float r = c;
+      if (k >= 0) r *= pm_act(z[i], k);
+      if (a) r *= a[i];
+      if (b) r *= b[i];
+      if (d) r *= d[i];
+      out[i] = r;
+    }
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -138,5 +180,17 @@ extern "C" int gn_dact_mul_f32(const float* g, const float* z, int act, const fl
   return 0;
 }
 
-extern "C" int gn_abi_version(void) { return 4; }
+extern "C" int gn_pm_f32(const float* z, int k, const float* a, const float* b, const float* d, float c, float* out,
+                         int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (k < -1 || k > 3 || (k >= 0 && !z)) return (int)hipErrorInvalidValue;
+  auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  const int vec = al(z) && al(a) && al(b) && al(d) && al(out);
+  hipLaunchKernelGGL(pm_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     z, k, a, b, d, c, out, n, vec);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_abi_version(void) { return 5; }
 extern "C" const char* gn_error_string(int code) { return hipGetErrorString((hipError_t)code); }

@@ -167,6 +167,19 @@ def ssilu(x, k):
     return out
 
 
+def pm(z, k, a=None, b=None, d=None, c=1.0):
+    """c * ssilu^(k)(z) * a * b * d  (k = -1: no activation factor; a, b, d optional, all of one shape)."""
+    ref = z if z is not None else a
+    require_device(ref)
+    ts = [None if t is None else _f32c(t) for t in (z, a, b, d)]
+    for t in ts:
+        assert t is None or t.shape == ref.shape, "pm operands must share one shape"
+    out = torch.empty(ref.shape, device=ref.device, dtype=torch.float32)
+    check(_lib.load().gn_pm_f32(ptr(ts[0]), int(k), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), float(c), ptr(out),
+                                out.numel(), stream()), "gn_pm_f32")
+    return out
+
+
 def dact_mul(g, z, act, mul, c, want_gmul=False):
     """dz = g*c*(mul or 1)*(ssilu'(z) if act else 1); gmul = g*c*(ssilu(z) if act else z)."""
     require_device(g)

@@ -133,7 +133,7 @@ class AtomUpdateBlock(torch.nn.Module):
 
     def _aggregate(self, m, rbf, id_a):
         """scale * sum_{edges into atom} m * dense_rbf(rbf)   (atom_update_block.py:60-68)."""
-        if ops.is_fused():  # Hadamard and scale in the GEMM epilogue (linear: scale before the sum)
+        if ops.is_fused() or not AutomaticFit.fitting_mode:  # Hadamard and scale in the GEMM epilogue (linear: scale before the sum)
             x = self.dense_rbf(rbf, mul=m, alpha=self.scale_sum.value())
             return ops.segsum_rows(x, id_a), x
         x = m * self.dense_rbf(rbf)
@@ -211,7 +211,7 @@ class OutputBlock(AtomUpdateBlock):
                 x_E = layer(x_E)
         x_E = self.out_energy(x_E)
         if self.direct_forces:
-            if ops.is_fused():  # x already carries scale_sum: rescale to scale_rbf
+            if ops.is_fused() or not AutomaticFit.fitting_mode:  # x already carries scale_sum: rescale to scale_rbf
                 x_F = x * (self.scale_rbf.value() / self.scale_sum.value())
             else:
                 x_F = self.scale_rbf(m, x)
@@ -381,7 +381,7 @@ class TripletInteraction(torch.nn.Module):
     def forward(self, m, rbf3, cbf3, plan):
         rbf_W1, sph = cbf3
         x_ba = self.dense_ba(m)
-        if ops.is_fused():
+        if ops.is_fused() or not AutomaticFit.fitting_mode:
             x_ba = self.mlp_rbf(rbf3, mul=x_ba, alpha=self.scale_rbf.value())
             x_ba = self.down_projection(x_ba)
             x = self.mlp_cbf(rbf_W1, sph, x_ba, plan.trip, alpha=self.scale_cbf_sum.value())
@@ -417,7 +417,7 @@ class QuadrupletInteraction(torch.nn.Module):
     def forward(self, m, rbf, cbf, sbf, plan):
         rbf_W1, sph = sbf
         x_db = self.dense_db(m)
-        if ops.is_fused():
+        if ops.is_fused() or not AutomaticFit.fitting_mode:
             x_db = self.mlp_rbf(rbf, mul=x_db, alpha=self.scale_rbf.value())
             x_db = ops.gather_rows(self.down_projection(x_db), plan.intm_db)
             x_db = self.mlp_cbf(cbf, mul=x_db, alpha=self.scale_cbf.value())

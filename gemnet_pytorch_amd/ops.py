@@ -141,24 +141,57 @@ def bmm(A, B, ta=False, tb=False):
 
 
 # ----------------------------------------------------------------------------- activation
-class _SSiLU(torch.autograd.Function):
+class _PM(torch.autograd.Function):
+    """y = c * ssilu^(k)(z) * a * b   (k = -1: no activation factor; a, b optional) as ONE launch (gn_pm_f32).
+
+    Closed under differentiation: d/dz is the same form with k+1 and one more factor, d/da is the same form with a
+    replaced by the incoming gradient.  The kernel takes three factors, which is exactly what the double backward
+    of `ssilu(z) * mul` needs (f''(z) * mul * g * gg); a third derivative is never taken on this path."""
+
     @staticmethod
-    def forward(ctx, x, k):
-        ctx.save_for_backward(x)
-        ctx.k = k
-        return K.ssilu(x, k)
+    def forward(ctx, k, c, z, *factors):
+        ctx.k, ctx.c = k, c
+        ctx.n_f = len(factors)
+        ctx.save_for_backward(z, *factors)
+        f = list(factors) + [None] * (3 - len(factors))
+        return K.pm(z, k, f[0], f[1], f[2], c)
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        if ctx.k >= 3:
-            raise NotImplementedError("ssilu derivative order > 3")
-        return g * _SSiLU.apply(x, ctx.k + 1), None
+        z, *factors = ctx.saved_tensors
+        k, c = ctx.k, ctx.c
+        need = ctx.needs_input_grad  # (k, c, z, *factors)
+        gz = None
+        if k >= 0 and need[2]:
+            if len(factors) >= 3:
+                raise NotImplementedError("pm: more than three tensor factors (third derivative of the activation)")
+            if k >= 3:
+                raise NotImplementedError("ssilu derivative order > 3")
+            gz = _PM.apply(k + 1, c, z, *factors, g)
+        gf = []
+        for i in range(len(factors)):
+            if need[3 + i]:
+                others = [f for j, f in enumerate(factors) if j != i]
+                gf.append(_PM.apply(k, c, z, *others, g))
+            else:
+                gf.append(None)
+        return (None, None, gz, *gf)
+
+
+def pm(z, k=0, *factors, c=1.0):
+    """c * ssilu^(k)(z) * prod(factors); k = -1 drops the activation factor (then z may be None)."""
+    factors = [f for f in factors if f is not None]
+    if k < 0:
+        if not factors:
+            raise ValueError("pm without activation needs at least one factor")
+        if len(factors) == 1 and c == 1.0:
+            return factors[0]
+    return _PM.apply(int(k), float(c), z if k >= 0 else None, *factors)
 
 
 def ssilu(x, k=0):
     """k-th derivative of ScaledSiLU (base_layers.py:51-58)."""
-    return _SSiLU.apply(x, k)
+    return _PM.apply(int(k), 1.0, x)
 
 
 # ------------------------------------------------------------------- bilinear aggregation
@@ -454,15 +487,18 @@ def dense(x, W, act=False, *, mul=None, alpha=1.0, res=None, res_rows=None, beta
         z = z + gather_rows(g1, i1)
     if g2 is not None:
         z = z + gather_rows(g2, i2)
-    y = ssilu(z) if act else z
-    if mul is not None:
-        y = y * mul
-    if alpha != 1.0:
-        y = y * alpha
+    # ((f(z) * mul * alpha + res) * beta + res2) * beta2 with the scalars folded: one fused pointwise launch for the
+    # activation / Hadamard / scale and one `add` per residual
+    c = alpha * (beta if res is not None else 1.0) * (beta2 if res2 is not None else 1.0)
+    if act or mul is not None or c != 1.0:
+        y = pm(z, 0 if act else -1, *((z,) if not act else ()), mul, c=c)
+    else:
+        y = z
     if res is not None:
-        y = (y + (res if res_rows is None else gather_rows(res, res_rows))) * beta
+        r = res if res_rows is None else gather_rows(res, res_rows)
+        y = torch.add(y, r, alpha=beta * (beta2 if res2 is not None else 1.0))
     if res2 is not None:
-        y = (y + res2) * beta2
+        y = torch.add(y, res2, alpha=beta2)
     return y
 
 

@@ -234,6 +234,12 @@ int gn_quad_basis_bwd_f32(const float* gY, const float* R, const int32_t* qc, co
 /* ---- pointwise -------------------------------------------------------------------------
  * out[i] = d^k/dx^k ssilu(x[i]), k in {0,1,2,3}   (base_layers.py:51-58) */
 int gn_ssilu_f32(const float* x, float* out, int64_t n, int k, void* stream);
+/* the pointwise product the composite (twice differentiable) path is built from:
+ *   out[i] = c * (k >= 0 ? d^k/dz^k ssilu(z[i]) : 1) * (a ? a[i] : 1) * (b ? b[i] : 1) * (d ? d[i] : 1)
+ * ScaledSiLU, its Hadamard / scale-factor epilogues (interaction_block.py:531-552,670-683) and every term of their
+ * first and second derivatives are single launches of this form. */
+int gn_pm_f32(const float* z, int k, const float* a, const float* b, const float* d, float c, float* out,
+              int64_t n, void* stream);
 /* backward glue of a fused Dense: with a = act ? ssilu'(z) : 1 and y0 = act ? ssilu(z) : z,
  *   dz[i] = g[i] * c * (mul ? mul[i] : 1) * a      gmul[i] = g[i] * c * y0   (if gmul != NULL) */
 int gn_dact_mul_f32(const float* g, const float* z, int act, const float* mul, float c, float* dz,

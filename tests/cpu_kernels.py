@@ -79,6 +79,14 @@ def ssilu(x, k):
     return _act(x, k)
 
 
+def pm(z, k, a=None, b=None, d=None, c=1.0):
+    out = _act(z, k) if k >= 0 else torch.ones_like(a)
+    for t in (a, b, d):
+        if t is not None:
+            out = out * t
+    return out * c
+
+
 def bil_reduce(Y, x, sp):
     xt = x[sp.expand.idx32.long()]
     out = torch.zeros((sp.n_reduce, Y.shape[1], x.shape[1]), dtype=x.dtype)
@@ -319,7 +327,7 @@ def quad_basis_bwd(gY, R, qc, qa, qb, qd, S):
     return Gc, Gb, Gd
 
 
-_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -389,3 +389,21 @@ def test_gemm_k_major_weight_operand(M, N, Kd):
     y, z = K.gemm(f32(A), f32(Bm), False, True, a_dact_pre=f32(pre), mul=f32(mul), res=f32(res), **kw)
     close(z, ref_z, atol=1e-4)
     close(y, ref_y, atol=1e-4)
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 1000, 128 * 1001 + 3])
+@pytest.mark.parametrize("k", [-1, 0, 1, 2, 3])
+def test_pointwise_product_primitive(n, k):
+    """gn_pm_f32: c * ssilu^(k)(z) * a * b * d with optional factors (the composite path's only pointwise op)."""
+    g = torch.Generator().manual_seed(n + k)
+    z, a, b, d = (rnd(g, n) * 2 for _ in range(4))
+    for fs in ((a,), (a, b), (a, b, d)) + (((),) if k >= 0 else ()):
+        ref = CK.pm(z, k, *fs, c=0.7) if fs else CK.pm(z, k, c=0.7)
+        out = K.pm(f32(z), k, *[f32(t) for t in fs], c=0.7)
+        # f'' and f''' change sign: compare against the magnitude of the factors, not of the (cancelling) result
+        scale = float(torch.stack([t.abs() for t in fs]).prod(0).max()) if fs else 1.0
+        close(out, ref, rtol=2e-5, atol=3e-6 * max(1.0, scale))
+    # unaligned views take the scalar path
+    if n > 8:
+        zz, aa = f32(z)[1:], f32(a)[1:]
+        close(K.pm(zz, max(k, 0), aa), CK.pm(z[1:], max(k, 0), a[1:]), rtol=2e-5, atol=3e-6 * max(1.0, float(a.abs().max())))
