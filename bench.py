@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--model", choices=["T", "Q"], default="T",
                     help="T = GemNet-T (the headline metric); Q = GemNet-Q (BASELINE.json configs[2], reported as a side case)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--torch-optimizer", action="store_true",
+                    help="train mode: torch.optim.AdamW + clip_grad_norm_ instead of the fused two-launch optimizer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -319,7 +321,7 @@ def main():
             return model(inputs)
     else:
         from gemnet_pytorch_amd.training.ddp import TrainStep
-        ts = TrainStep(model, world_size=world)
+        ts = TrainStep(model, world_size=world, fused_optimizer=not args.torch_optimizer)
         if use_graph:
             try:
                 ts.capture(inputs, targets)

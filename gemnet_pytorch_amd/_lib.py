@@ -76,6 +76,7 @@ SIGNATURES = {
     "gn_index_gpu_stage2": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_pm_f32": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i64, _vp],
+    "gn_adamw_ema_step_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
@@ -112,6 +113,8 @@ def load():
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     lib.gn_abi_version.restype = _i
+    lib.gn_optim_blocks.restype = _i
+    lib.gn_optim_blocks.argtypes = [_i64]
     lib.gn_index_gpu_ws_bytes.restype = _i64
     lib.gn_index_gpu_ws_bytes.argtypes = [_i, _i64, _i]
     lib.gn_error_string.restype = ctypes.c_char_p

@@ -1,0 +1,95 @@
+// Trainer-step fusion: what Trainer.train_on_batch does after loss.backward()
+// (gemnet/training/trainer.py:250-278 shared-gradient rescale, :353-356 global-norm clip, :115-160,:358 AdamW/Adam
+// with amsgrad and eps 1e-7, gemnet/training/ema_decay.py:68-93 EMA update) — ~100 small launches over ~60
+// parameter tensors in the reference — as TWO launches over one flat fp32 buffer (the same buffer the gradient
+// all-reduce uses):
+//   sqnorm_kernel   partial sums of (g * gscale)^2 per block (deterministic two-stage reduction, no atomics)
+//   adamw_ema_kernel every block folds the partials (fixed order) into the clip coefficient, then one pass:
+//                    p, m, v, vmax, ema updated in place.
+// Per-element vectors `gscale` (1/num_blocks for the shared basis projections, 1 elsewhere) and `wd` (weight decay
+// of the AdamW group, 0 for embeddings / frequencies / biases) encode the parameter groups.
+#include "common.h"
+
+namespace {
+
+constexpr int OPT_NT = 256;
+
+__global__ __launch_bounds__(OPT_NT) void sqnorm_kernel(const float* __restrict__ g, const float* __restrict__ gscale,
+                                                       int64_t n, double* __restrict__ partial) {
+  __shared__ double sh[OPT_NT / 64];
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)OPT_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * OPT_NT) {
+    const double v = (double)g[i] * (double)gscale[i];
+    acc += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < OPT_NT / 64; ++w) s += sh[w];
+    partial[blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(OPT_NT) void adamw_ema_kernel(
+    float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ gscale, const float* __restrict__ wd,
+    float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax, float* __restrict__ ema, int64_t n,
+    const double* __restrict__ partial, int n_partial, float max_norm, float lr, float beta1, float beta2, float eps,
+    float bias1, float bias2_sqrt, float ema_decay, float* __restrict__ norm_out) {
+  __shared__ float clip_s;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n_partial; ++i) s += partial[i];   // same fixed order in every block
+    const float norm = (float)sqrt(s);
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+    const float coef = max_norm / (norm + 1e-6f);
+    clip_s = coef < 1.0f ? coef : 1.0f;
+    if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+  }
+  __syncthreads();
+  const float clip = clip_s;
+  const float step = lr / bias1;
+  const float omd = 1.0f - ema_decay;
+  for (int64_t i = blockIdx.x * (int64_t)OPT_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * OPT_NT) {
+    const float gi = g[i] * gscale[i] * clip;
+    float pi = p[i];
+    pi *= 1.0f - lr * wd[i];                               // decoupled weight decay (0 in the Adam group)
+    const float mi = m[i] + (1.0f - beta1) * (gi - m[i]);   // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float vm = fmaxf(vmax[i], vi);                    // amsgrad
+    const float denom = sqrtf(vm) / bias2_sqrt + eps;
+    pi -= step * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    vmax[i] = vm;
+    if (ema) ema[i] -= omd * (ema[i] - pi);
+  }
+}
+
+}  // namespace
+
+extern "C" int gn_optim_blocks(int64_t n) {
+  int64_t b = (n + OPT_NT * 8 - 1) / (OPT_NT * 8);
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int gn_adamw_ema_step_f32(float* p, const float* g, const float* gscale, const float* wd, float* m, float* v,
+                                     float* vmax, float* ema, int64_t n, double* partial, float max_norm, float lr,
+                                     float beta1, float beta2, float eps, int step, float ema_decay, float* norm_out,
+                                     void* stream) {
+  if (n <= 0) return 0;
+  if (step < 1 || !partial) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nb = gn_optim_blocks(n);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nb), dim3(OPT_NT), 0, st, g, gscale, n, partial);
+  GN_LAUNCH_CHECK();
+  const float bias1 = 1.0f - powf(beta1, (float)step);
+  const float bias2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(nb), dim3(OPT_NT), 0, st, p, g, gscale, wd, m, v, vmax, ema, n, partial, nb,
+                     max_norm, lr, beta1, beta2, eps, bias1, bias2_sqrt, ema_decay, norm_out);
+  GN_LAUNCH_CHECK();
+  return 0;
+}

@@ -84,13 +84,22 @@ class TrainStep:
     """fwd + force + loss + backward + (all-reduce) + shared-grad rescale + clip + optimizer step."""
 
     def __init__(self, model, world_size=1, rho_force=0.999, grad_clip_max=10.0, optimizer=None,
-                 global_counts=None):
+                 global_counts=None, fused_optimizer=False):
         self.model = model
         self.world_size = world_size
         self.rho = rho_force
         self.clip = grad_clip_max
-        self.buf = FlatGradBuffer(model.parameters())
-        self.opt = optimizer if optimizer is not None else make_optimizer(model)
+        self.fused = None
+        if fused_optimizer:
+            # rescale + clip + AdamW + EMA in two launches over the flat buffer (training/fused_optim.py)
+            from .fused_optim import FusedAdamWEMA
+            self.fused = FusedAdamWEMA(model, grad_clip_max=grad_clip_max)
+            self.buf = FlatGradBuffer.__new__(FlatGradBuffer)
+            self.buf.params, self.buf.flat = self.fused.params, self.fused.flat_g
+            self.opt = None
+        else:
+            self.buf = FlatGradBuffer(model.parameters())
+            self.opt = optimizer if optimizer is not None else make_optimizer(model)
         self.global_counts = global_counts  # (B_global, A_global) if known statically
         self.last_loss = None
 
@@ -147,9 +156,13 @@ class TrainStep:
         else:
             loss = self._forward_backward(inputs, targets)
         self.buf.all_reduce()
-        scale_shared_grads(self.model)
-        torch.nn.utils.clip_grad_norm_(self.buf.params, max_norm=self.clip)
-        if step_optimizer:
-            self.opt.step()
+        if self.fused is not None:
+            if step_optimizer:
+                self.fused.step()
+        else:
+            scale_shared_grads(self.model)
+            torch.nn.utils.clip_grad_norm_(self.buf.params, max_norm=self.clip)
+            if step_optimizer:
+                self.opt.step()
         self.last_loss = loss
         return self.last_loss

@@ -245,6 +245,18 @@ int gn_pm_f32(const float* z, int k, const float* a, const float* b, const float
 int gn_dact_mul_f32(const float* g, const float* z, int act, const float* mul, float c, float* dz,
                     float* gmul, int64_t n, void* stream);
 
+/* ---- trainer-step fusion ---------------------------------------------------------------------
+ * Everything Trainer.train_on_batch does between loss.backward() and the next forward (trainer.py:250-278 shared-
+ * gradient rescale, :353-356 clip_grad_norm_, :115-160 AdamW / Adam (amsgrad, eps) step, ema_decay.py:68-93) over ONE
+ * flat fp32 parameter buffer in two launches.  gscale[i]: gradient rescale (1/num_blocks for shared projections);
+ * wd[i]: decoupled weight decay of the element's group (0 = plain Adam).  `partial`: caller-owned workspace of
+ * gn_optim_blocks(n) doubles.  ema may be NULL.  norm_out (device float, optional) <- pre-clip global gradient norm.
+ * step >= 1 is the Adam step count (bias correction computed on the host in fp32 like torch.optim). */
+int gn_optim_blocks(int64_t n);
+int gn_adamw_ema_step_f32(float* p, const float* g, const float* gscale, const float* wd, float* m, float* v,
+                          float* vmax, float* ema, int64_t n, double* partial, float max_norm, float lr, float beta1,
+                          float beta2, float eps, int step, float ema_decay, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

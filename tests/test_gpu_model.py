@@ -146,3 +146,33 @@ def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch):
     fs = max(1.0, float(F0.abs().mean()))
     assert float((F1 - F0).abs().mean()) <= 1e-5 * fs
     assert float((E1 - E0).abs().max()) <= 2e-5 * max(1.0, float(E0.abs().max()))
+
+
+def test_fused_trainer_step_matches_torch_optimizers(golden_model):
+    """N3: rescale + clip + AdamW/Adam(amsgrad) + EMA in two launches == the reference sequence built from
+    scale_shared_grads, clip_grad_norm_, torch.optim and ExponentialMovingAverage (three steps)."""
+    import copy
+    from gemnet_pytorch_amd.training.ddp import TrainStep, make_optimizer
+    from gemnet_pytorch_amd.training.ema_decay import ExponentialMovingAverage
+    g = golden_model
+    cfg, params, inputs = load_case(g, "t1")
+    dev = to_dev(inputs)
+    targets = {"E": torch.tensor(g["t1.Et"], device=DEV)[:, None], "F": torch.tensor(g["t1.Ft"], device=DEV)}
+    a = build(cfg, params).train()
+    b = copy.deepcopy(a)
+    clip = 0.5  # active clipping
+    ref = TrainStep(a, grad_clip_max=clip, optimizer=make_optimizer(a, learning_rate=2e-3, weight_decay=0.01))
+    ema = ExponentialMovingAverage([p for p in a.parameters() if p.requires_grad], 0.9)
+    fused = TrainStep(b, grad_clip_max=clip, fused_optimizer=True)
+    fused.fused.lr, fused.fused.wd[fused.fused.wd > 0], fused.fused.ema_decay = 2e-3, 0.01, 0.9
+    for _ in range(3):
+        la = ref(dev, targets)
+        ema.update()
+        lb = fused(dict(dev), targets)
+        assert abs(float(la) - float(lb)) <= 2e-5 * abs(float(la))
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        if pa.requires_grad:
+            scale = max(1e-3, float(pa.abs().max()))
+            assert float((pa - pb).abs().max()) <= 2e-4 * scale, n
+    for sa, sb in zip(ema.shadow_params, fused.fused.ema_parameters()):
+        assert float((sa - sb).abs().max()) <= 2e-4 * max(1e-3, float(sa.abs().max()))
