@@ -107,6 +107,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
     } else if (kind == GN_OP_SCALE) {
       const int w4 = op.width >> 2, slot = op.slot, a_slot = op.a_slot, ld = op.ld;
       const float alpha = op.alpha;
+      const int mode = op.act;   // factor taken from src: 0 ssilu'(src), 1 src, 2 ssilu(src)
       const float* __restrict__ const src = op.src;
       float* __restrict__ const out = op.out;
       for (int f = tid; f < BM * w4; f += NT) {
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
         v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
         if (src && gr < M) {
           const float4 z = *reinterpret_cast<const float4*>(src + gr * ld + c);
-          v.x *= gn_dssilu(z.x); v.y *= gn_dssilu(z.y); v.z *= gn_dssilu(z.z); v.w *= gn_dssilu(z.w);
+          if (mode == 0) { v.x *= gn_dssilu(z.x); v.y *= gn_dssilu(z.y); v.z *= gn_dssilu(z.z); v.w *= gn_dssilu(z.w); }
+          else if (mode == 1) { v.x *= z.x; v.y *= z.y; v.z *= z.z; v.w *= z.w; }
+          else { v.x *= gn_ssilu(z.x); v.y *= gn_ssilu(z.y); v.z *= gn_ssilu(z.z); v.w *= gn_ssilu(z.w); }
         }
         *reinterpret_cast<float4*>(&S[slot][r][c]) = v;
         if (out && gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = v;

@@ -339,8 +339,10 @@ class ChainProgram:
     def load(self, slot, src, rows=None):
         self.ops.append(dict(kind="load", slot=slot, src=src, rows=rows))
 
-    def scale(self, dst, a, alpha=1.0, Z=None, out=None, width=None):
-        self.ops.append(dict(kind="scale", slot=dst, a_slot=a, alpha=float(alpha), Z=Z, out=out, width=width))
+    def scale(self, dst, a, alpha=1.0, Z=None, out=None, width=None, mode=0):
+        """dst <- a * alpha * phi(Z): mode 0 phi = ssilu', 1 identity (Hadamard with Z), 2 ssilu."""
+        self.ops.append(dict(kind="scale", slot=dst, a_slot=a, alpha=float(alpha), Z=Z, out=out, width=width,
+                             mode=int(mode)))
 
     def gemm(self, W, a_slot, y_slot=-1, act=False, alpha=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
              pre_out=None, mul=None, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0, out=None):
@@ -389,6 +391,7 @@ def chain(prog):
             Z, out = o["Z"], o["out"]
             w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
             c.kind, c.slot, c.a_slot, c.width, c.ld, c.alpha = GN_OP_SCALE, o["slot"], o["a_slot"], w, w, o["alpha"]
+            c.act = o.get("mode", 0)
             c.src = ptr(mat(Z, w)) if Z is not None else None
             c.out = ptr(mat(out, w)) if out is not None else None
         elif o["kind"] == "store":

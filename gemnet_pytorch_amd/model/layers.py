@@ -378,8 +378,20 @@ class TripletInteraction(torch.nn.Module):
         self.up_projection_ca = Dense(emb_size_bilinear, emb_size_edge, activation=activation, bias=False)
         self.up_projection_ac = Dense(emb_size_bilinear, emb_size_edge, activation=activation, bias=False)
 
+    def _head_ok(self):
+        ws = (self.dense_ba, self.mlp_rbf, self.down_projection)
+        return (ops.is_fused() and ops.stacks_enabled() and not AutomaticFit.fitting_mode
+                and all(d.bias is None and d.weight.shape[0] <= 128 and d.weight.shape[1] <= 128
+                        and d.weight.shape[1] % 16 == 0 for d in ws) and not self.mlp_rbf.act)
+
     def forward(self, m, rbf3, cbf3, plan):
         rbf_W1, sph = cbf3
+        if self._head_ok():  # dense_ba, radial Hadamard, down projection: one LDS-resident launch
+            x_ba = ops.dense_hadamard_down(m, rbf3, self.dense_ba.weight, self.mlp_rbf.weight,
+                                           self.down_projection.weight, self.dense_ba.act,
+                                           self.down_projection.act, self.scale_rbf.value())
+            x = self.mlp_cbf(rbf_W1, sph, x_ba, plan.trip, alpha=self.scale_cbf_sum.value())
+            return self.up_projection_ca(x, res=self.up_projection_ac(x), res_rows=plan.id_swap, beta=INV_SQRT_2)
         x_ba = self.dense_ba(m)
         if ops.is_fused() or not AutomaticFit.fitting_mode:
             x_ba = self.mlp_rbf(rbf3, mul=x_ba, alpha=self.scale_rbf.value())
@@ -416,6 +428,17 @@ class QuadrupletInteraction(torch.nn.Module):
 
     def forward(self, m, rbf, cbf, sbf, plan):
         rbf_W1, sph = sbf
+        ws = (self.dense_db, self.mlp_rbf, self.down_projection)
+        if (ops.is_fused() and ops.stacks_enabled() and not AutomaticFit.fitting_mode and not self.mlp_rbf.act
+                and all(d.bias is None and d.weight.shape[0] <= 128 and d.weight.shape[1] <= 128
+                        and d.weight.shape[1] % 16 == 0 for d in ws)):
+            x_db = ops.dense_hadamard_down(m, rbf, self.dense_db.weight, self.mlp_rbf.weight,
+                                           self.down_projection.weight, self.dense_db.act,
+                                           self.down_projection.act, self.scale_rbf.value())
+            x_db = ops.gather_rows(x_db, plan.intm_db)
+            x_db = self.mlp_cbf(cbf, mul=x_db, alpha=self.scale_cbf.value())
+            x = self.mlp_sbf(rbf_W1, sph, x_db, plan.quad, alpha=self.scale_sbf_sum.value())
+            return self.up_projection_ca(x, res=self.up_projection_ac(x), res_rows=plan.id_swap, beta=INV_SQRT_2)
         x_db = self.dense_db(m)
         if ops.is_fused() or not AutomaticFit.fitting_mode:
             x_db = self.mlp_rbf(rbf, mul=x_db, alpha=self.scale_rbf.value())

@@ -782,6 +782,67 @@ def stack(x, first=None, layers=(), s=0.7071067811865475):
     return _Stack.apply(spec, x, res, res2, g1, g2, *skips)
 
 
+class _DenseHadamardDown(torch.autograd.Function):
+    """x -> Dense_a(x) (.) (rbf W_r^T) * alpha -> Dense_d(.) as ONE launch forward and ONE backward (gn_chain_f32):
+    the head of TripletInteraction / QuadrupletInteraction (interaction_block.py:667-675, :531-541: dense_ba/db,
+    the radial Hadamard with its scale factor, down_projection).  Constant weights (see constant_weights())."""
+
+    @staticmethod
+    def forward(ctx, x, rbf, Wa, Wr, Wd, cfg):
+        act_a, act_d, alpha = cfg
+        M = x.shape[0]
+        dev, dt = x.device, x.dtype
+        x, rbf = x.contiguous(), rbf.contiguous()
+        Wa_c, Wr_c, Wd_c = contiguous_weight(Wa), contiguous_weight(Wr), contiguous_weight(Wd)
+        z1 = torch.empty((M, Wa_c.shape[0]), device=dev, dtype=dt)
+        r = torch.empty((M, Wr_c.shape[0]), device=dev, dtype=dt)
+        z3 = torch.empty((M, Wd_c.shape[0]), device=dev, dtype=dt)
+        y = torch.empty((M, Wd_c.shape[0]), device=dev, dtype=dt)
+        prog = K.ChainProgram(M)
+        prog.load(0, x)
+        prog.gemm(Wa_c, a_slot=0, y_slot=1, act=act_a, pre_out=z1)            # x_a = act(x Wa^T)
+        prog.load(0, rbf)
+        prog.gemm(Wr_c, a_slot=0, y_slot=0, pre_out=r, mul=1, alpha=alpha)     # (rbf Wr^T) * x_a * alpha
+        prog.gemm(Wd_c, a_slot=0, y_slot=1, act=act_d, pre_out=z3, out=y)
+        K.chain(prog)
+        ctx.cfg = cfg
+        ctx.save_for_backward(z1, r, z3, Wa, Wr, Wd)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        z1, r, z3, Wa, Wr, Wd = ctx.saved_tensors
+        act_a, act_d, alpha = ctx.cfg
+        need = ctx.needs_input_grad
+        M, dev, dt = g.shape[0], g.device, g.dtype
+        g = g.contiguous()
+        nd, nh = Wd.shape[0], Wa.shape[0]
+        gx = torch.empty((M, Wa.shape[1]), device=dev, dtype=dt) if need[0] else None
+        grbf = torch.empty((M, Wr.shape[1]), device=dev, dtype=dt) if need[1] else None
+        prog = K.ChainProgram(M)
+        prog.load(0, g)
+        if act_d:
+            prog.scale(0, 0, 1.0, Z=z3, width=nd)                               # dz3
+        prog.gemm(transposed(Wd), a_slot=0, y_slot=1)                            # d(hadamard) in slot 1
+        if need[1]:
+            # d r = dh * x_a * alpha, x_a = act(z1) recomputed;  d rbf = d r @ Wr
+            prog.scale(0, 1, alpha, Z=z1, width=nh, mode=2 if act_a else 1)
+            prog.gemm(transposed(Wr), a_slot=0, y_slot=-1, out=grbf)
+        if need[0]:
+            prog.scale(1, 1, alpha, Z=r, width=nh, mode=1)                       # d x_a = dh * r * alpha
+            if act_a:
+                prog.scale(1, 1, 1.0, Z=z1, width=nh, mode=0)                    # dz1
+            prog.gemm(transposed(Wa), a_slot=1, y_slot=-1, out=gx)
+        K.chain(prog)
+        return gx, grbf, None, None, None, None
+
+
+def dense_hadamard_down(x, rbf, Wa, Wr, Wd, act_a, act_d, alpha):
+    assert constant_weights(), "the fused interaction head is the constant-weight inference path"
+    return _DenseHadamardDown.apply(x, rbf, Wa, Wr, Wd, (bool(act_a), bool(act_d), float(alpha)))
+
+
 class _QuadBasis(torch.autograd.Function):
     """(R) -> real Y_lm(Phi_cab, Theta_cabd) of every quadruplet in one launch (first-order adjoint)."""
 

@@ -76,7 +76,8 @@ int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream);
  * and only pre-activations / the final result go back to memory.  A chain is a short program of ops
  * over LDS "slots" (32 rows x up to 128 columns each):
  *   GN_OP_LOAD   slot <- src[(rows ? rows[m] : m), 0:width]                       (global -> LDS)
- *   GN_OP_SCALE  dst_slot <- a_slot * alpha * (src ? ssilu'(src[m, :]) : 1); optional copy to `out`
+ *   GN_OP_SCALE  dst_slot <- a_slot * alpha * (src ? phi(src[m, :]) : 1); optional copy to `out`;
+ *                phi selected by `act`: 0 ssilu'(x) (adjoint of an activation), 1 x (Hadamard), 2 ssilu(x)
  *   GN_OP_GEMM   z = slot[a_slot] (32 x K) @ W^T (W is (N,K), k-contiguous) + gadd1[gidx1[m]] + gadd2[gidx2[m]]
  *                pre_out <- z;  y = act ? ssilu(z) : z;  y *= mul;  y *= alpha;
  *                y = (y + res) * beta;  y = (y + res2) * beta2      (mul/res/res2: an LDS slot or a global (M,N))

@@ -249,7 +249,8 @@ def chain(prog):
             w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
             v = slots[o["a_slot"]][:, :w] * o["alpha"]
             if Z is not None:
-                v = v * _act(Z, 1)
+                mode = o.get("mode", 0)
+                v = v * (_act(Z, 1) if mode == 0 else (Z if mode == 1 else _act(Z, 0)))
             new = slots[o["slot"]].clone()
             new[:, :w] = v
             slots[o["slot"]] = new
