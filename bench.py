@@ -126,7 +126,7 @@ class LaunchTimer:
         outs = out if isinstance(out, tuple) else (out,)
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
-    FAMILIES = ["gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "dact_mul", "chain", "bil_reduce",
+    FAMILIES = ["gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
                 "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd", "bessel_rbf", "sph_radial", "ylm0",
                 "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
                 "quad_basis_bwd"]

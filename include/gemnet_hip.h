@@ -72,18 +72,19 @@ int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream);
 
 /* ---- LDS-resident layer chains ----------------------------------------------------------------
  * One launch runs a whole stack of Dense / ResidualLayer (base_layers.py:44-89) — or its adjoint —
- * for a 32-row tile whose activations stay in LDS between layers; only the weights stream (from L2)
- * and only pre-activations / the final result go back to memory.  A chain is a short program of ops
- * over LDS "slots" (32 rows x up to 128 columns each):
+ * for a tile of 16..80 rows (chosen so that the launch is one round of <= 256 workgroups) whose activations
+ * stay in LDS between layers; only the weights stream (from L2, straight into MFMA fragment registers) and
+ * only pre-activations / the final result go back to memory.  A chain is a short program of ops over two
+ * LDS "slots" (tile rows x up to 128 columns each):
  *   GN_OP_LOAD   slot <- src[(rows ? rows[m] : m), 0:width]                       (global -> LDS)
  *   GN_OP_SCALE  dst_slot <- a_slot * alpha * (src ? phi(src[m, :]) : 1); optional copy to `out`;
  *                phi selected by `act`: 0 ssilu'(x) (adjoint of an activation), 1 x (Hadamard), 2 ssilu(x)
- *   GN_OP_GEMM   z = slot[a_slot] (32 x K) @ W^T (W is (N,K), k-contiguous) + gadd1[gidx1[m]] + gadd2[gidx2[m]]
+ *   GN_OP_GEMM   z = slot[a_slot] (rows x K) @ W^T (W is (N,K), k-contiguous) + gadd1[gidx1[m]] + gadd2[gidx2[m]]
  *                pre_out <- z;  y = act ? ssilu(z) : z;  y *= mul;  y *= alpha;
  *                y = (y + res) * beta;  y = (y + res2) * beta2      (mul/res/res2: an LDS slot or a global (M,N))
  *                slot[y_slot] <- y (may alias a_slot / res slots);  out <- y
  *   GN_OP_STORE  out[m, 0:width] <- slot                                           (LDS -> global)
- * Constraints: N, K <= 128, K % 8 == 0, every global matrix row-major with row length N (resp. `ld` for
+ * Constraints: M <= 2^24, N, K <= 128, K % 16 == 0, W contiguous and 16-byte aligned, every global matrix row-major with row length N (resp. `ld` for
  * LOAD/SCALE/STORE), W rows 16-byte aligned. */
 enum { GN_OP_LOAD = 0, GN_OP_SCALE = 1, GN_OP_GEMM = 2, GN_OP_STORE = 3 };
 #define GN_CHAIN_MAX_OPS 20
