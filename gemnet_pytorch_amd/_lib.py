@@ -71,6 +71,7 @@ SIGNATURES = {
     "gn_chain_f32": [ctypes.POINTER(ChainArgs), _vp],
     "gn_gemm_tn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "gn_gemm_tn_splitk": [_i, _i, _i],
+    "gn_gemm_tn_grouped_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
     "gn_index_gpu_stage1": [_vp, _i, _vp, _vp, _i, _i, _i, _i64, ctypes.c_double, ctypes.c_double, _i, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_index_gpu_stage2": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64,

@@ -54,18 +54,15 @@ __device__ __forceinline__ void tn_store(float (*Ts)[TBM], int tid, const float 
   }
 }
 
+// One 64x64 tile of out = alpha * A^T B over rows [kbeg, kend) of the operands (one workgroup).
 template <bool VA, bool VB>
-__global__ __launch_bounds__(TNT) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                      float* __restrict__ out, int M, int N, int K, int lda,
-                                                      int ldb, int ldo, int kchunk, float alpha) {
-  __shared__ __attribute__((aligned(16))) float As[2][TKS][TBM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][TKS][TBN];
+__device__ __forceinline__ void tn_tile(const float* __restrict__ A, const float* __restrict__ B,
+                                        float* __restrict__ o, int M, int N, int lda, int ldb, int ldo, int row0,
+                                        int col0, int kbeg, int kend, float alpha, float (*As)[TKS][TBM],
+                                        float (*Bs)[TKS][TBN]) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 1, wc = wave & 1;
-  const int row0 = blockIdx.x * TBM, col0 = blockIdx.y * TBN;
-  const int kbeg = blockIdx.z * kchunk;
-  const int kend = min(K, kbeg + kchunk);
   const int l31 = lane & 31, kh = lane >> 5;
   const int am = wr * 32 + l31, bn = wc * 32 + l31;
 
@@ -96,7 +93,6 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const float* __restrict__ 
     buf ^= 1;
   }
   // acc[r]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31 of the wave's 32x32 tile
-  float* __restrict__ o = out + (gridDim.z > 1 ? (size_t)blockIdx.z * M * ldo : 0);
   const int col = col0 + wc * 32 + l31;
   if (col < N) {
 #pragma unroll
@@ -104,6 +100,74 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const float* __restrict__ 
       const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (row < M) o[(size_t)row * ldo + col] = acc[r] * alpha;
     }
+  }
+}
+
+template <bool VA, bool VB>
+__global__ __launch_bounds__(TNT) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ out, int M, int N, int K, int lda,
+                                                      int ldb, int ldo, int kchunk, float alpha) {
+  __shared__ __attribute__((aligned(16))) float As[2][TKS][TBM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TKS][TBN];
+  const int kbeg = blockIdx.z * kchunk;
+  float* __restrict__ o = out + (gridDim.z > 1 ? (size_t)blockIdx.z * M * ldo : 0);
+  tn_tile<VA, VB>(A, B, o, M, N, lda, ldb, ldo, blockIdx.x * TBM, blockIdx.y * TBN, kbeg, min(K, kbeg + kchunk), alpha,
+                  As, Bs);
+}
+
+// Grouped form: every workgroup looks up its problem (binary search over the prefix of workgroup counts) — all
+// weight-gradient products of one training step in ONE launch (training/wgrad_queue.py).  Partials go to
+// ws + ws_off as [z][M][N].
+__global__ __launch_bounds__(TNT) void gemm_tn_grouped_kernel(const gn_tn_problem* __restrict__ probs, int n_prob,
+                                                              float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float As[2][TKS][TBM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TKS][TBN];
+  const int wg = blockIdx.x;
+  int lo = 0, hi = n_prob - 1;
+  while (lo < hi) {   // last problem with wg_begin <= wg
+    const int mid = (lo + hi + 1) >> 1;
+    if (probs[mid].wg_begin <= wg) lo = mid; else hi = mid - 1;
+  }
+  const gn_tn_problem p = probs[lo];
+  int local = wg - p.wg_begin;
+  const int tiles_n = (p.N + TBN - 1) / TBN, tiles_m = (p.M + TBM - 1) / TBM;
+  const int z = local / (tiles_m * tiles_n);
+  local -= z * tiles_m * tiles_n;
+  const int tm = local / tiles_n, tn = local - tm * tiles_n;
+  const int kbeg = z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  float* __restrict__ o = ws + p.ws_off + (size_t)z * p.M * p.N;
+  const bool va = (p.ldx % 4 == 0) && (p.M % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+  const bool vb = (p.ldy % 4 == 0) && (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0);
+  if (va && vb) tn_tile<true, true>(p.X, p.Y, o, p.M, p.N, p.ldx, p.ldy, p.N, tm * TBM, tn * TBN, kbeg, kend, 1.0f, As, Bs);
+  else tn_tile<false, false>(p.X, p.Y, o, p.M, p.N, p.ldx, p.ldy, p.N, tm * TBM, tn * TBN, kbeg, kend, 1.0f, As, Bs);
+}
+
+// Grouped fold: target t owns elements [0, n_t) and a list of partial slices (offsets into ws); one workgroup
+// folds 64 consecutive elements over all its slices in list order and ADDS the sum to the target (param.grad).
+__global__ __launch_bounds__(1024) void tn_fold_grouped_kernel(const gn_tn_target* __restrict__ targets, int n_target,
+                                                               const int64_t* __restrict__ slice_off,
+                                                               const float* __restrict__ ws) {
+  __shared__ float part[16][64];
+  const int wg = blockIdx.x;
+  int lo = 0, hi = n_target - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (targets[mid].wg_begin <= wg) lo = mid; else hi = mid - 1;
+  }
+  const gn_tn_target t = targets[lo];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)(wg - t.wg_begin) * 64 + lane;
+  float s = 0.f;
+  if (i < t.n)
+    for (int k = t.slice_begin + g; k < t.slice_end; k += 16) s += ws[slice_off[k] + i];
+  part[g][lane] = s;
+  __syncthreads();
+  if (g == 0 && i < t.n) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += part[j][lane];
+    t.out[i] += acc;
   }
 }
 
@@ -163,6 +227,20 @@ extern "C" int gn_gemm_tn_f32(const float* A, const float* B, float* C, int M, i
     const int64_t n = (int64_t)M * N;
     hipLaunchKernelGGL(tn_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, ws, C, n, N, ldc, splitk,
                        alpha);
+    GN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int gn_gemm_tn_grouped_f32(const gn_tn_problem* probs, int n_prob, int total_wg, const gn_tn_target* targets,
+                                      int n_target, int total_fold_wg, const int64_t* slice_off, float* ws,
+                                      void* stream) {
+  if (n_prob <= 0 || total_wg <= 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total_wg), dim3(TNT), 0, st, probs, n_prob, ws);
+  GN_LAUNCH_CHECK();
+  if (n_target > 0 && total_fold_wg > 0) {
+    hipLaunchKernelGGL(tn_fold_grouped_kernel, dim3(total_fold_wg), dim3(1024), 0, st, targets, n_target, slice_off, ws);
     GN_LAUNCH_CHECK();
   }
   return 0;

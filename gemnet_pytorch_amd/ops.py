@@ -39,6 +39,26 @@ def param_grads(enabled: bool):
         _PARAM_GRADS = old
 
 
+# Weight-gradient queue (training/wgrad_queue.py): in the final, non-differentiable backward of a training step the
+# dW = X^T Y products are leaves of the graph; with a queue set they are deferred into one grouped launch.
+_WGRAD_QUEUE = None
+
+
+@contextlib.contextmanager
+def wgrad_queue(queue):
+    global _WGRAD_QUEUE
+    prev, _WGRAD_QUEUE = _WGRAD_QUEUE, queue
+    try:
+        yield
+    finally:
+        _WGRAD_QUEUE = prev
+
+
+def _queueable(P):
+    return (_WGRAD_QUEUE is not None and not torch.is_grad_enabled() and P.is_leaf and P.requires_grad
+            and P.grad is not None and P.is_cuda and P.dim() == 2)
+
+
 # ------------------------------------------------------------------------ gather <-> segsum
 class _Gather(torch.autograd.Function):
     @staticmethod
@@ -98,7 +118,12 @@ class _MM(torch.autograd.Function):
             else:
                 gA = _MM.apply(B, g, not tb, False)   # (g b^T)^T = b @ g^T
         if ctx.needs_input_grad[1] and _PARAM_GRADS:
-            if tb:
+            if not ta and _queueable(B):
+                if tb:
+                    _WGRAD_QUEUE.add(B, A, g)         # B.grad += A^T @ g
+                else:
+                    _WGRAD_QUEUE.add(B, g, A)         # B.grad += g^T @ A
+            elif tb:
                 gB = _MM.apply(A, g, not ta, True)    # a^T @ g
             else:
                 gB = _MM.apply(g, A, True, not ta)    # (a^T g)^T = g^T @ a

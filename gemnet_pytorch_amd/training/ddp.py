@@ -102,6 +102,10 @@ class TrainStep:
             self.opt = optimizer if optimizer is not None else make_optimizer(model)
         self.global_counts = global_counts  # (B_global, A_global) if known statically
         self.last_loss = None
+        self.wgrad = None
+        if self.buf.params[0].is_cuda:
+            from .wgrad_queue import WeightGradQueue
+            self.wgrad = WeightGradQueue()  # all weight-gradient GEMMs of the final backward as one grouped launch
 
     def _counts(self, n_mol, n_atoms, device):
         if self.global_counts is not None:
@@ -126,7 +130,13 @@ class TrainStep:
         loss = self.loss(E, F, targets)
         self.buf.zero()
         # restrict the double backward to the parameters: no gradient w.r.t. the positions
-        torch.autograd.backward(loss, inputs=self.buf.params)
+        if self.wgrad is None:
+            torch.autograd.backward(loss, inputs=self.buf.params)
+        else:
+            from .. import ops
+            with ops.wgrad_queue(self.wgrad):
+                torch.autograd.backward(loss, inputs=self.buf.params)
+            self.wgrad.flush()
         return loss.detach()
 
     def capture(self, inputs, targets):

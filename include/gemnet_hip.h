@@ -122,6 +122,27 @@ int gn_gemm_tn_f32(const float* A, const float* B, float* C, int M, int N, int K
                    float alpha, float* ws, int splitk, void* stream);
 int gn_gemm_tn_splitk(int M, int N, int K);
 
+/* Grouped form: ALL weight-gradient products of one training step (the ~300 dW = X^T Y leaves of the double
+ * backward, trainer.py:346) as one launch + one fold launch.  Device-resident tables built by the caller:
+ *   probs[p]    one product: out_p (M,N) = X^T Y, X (K,M) row pitch ldx, Y (K,N) row pitch ldy, split over `splitk`
+ *               slices of `kchunk` rows (multiple of 16); its workgroups are [wg_begin, wg_begin +
+ *               ceil(M/64)*ceil(N/64)*splitk); partial z lands at ws + ws_off + z*M*N
+ *   targets[t]  one accumulator (a parameter's .grad, n contiguous floats): out[i] += sum of ws[slice_off[k] + i]
+ *               for k in [slice_begin, slice_end) in list order (deterministic); workgroups [wg_begin, +ceil(n/64))
+ * probs and targets are sorted by wg_begin (first entry 0). */
+typedef struct {
+  const float* X; const float* Y;
+  int M, N, K, ldx, ldy, splitk, kchunk, wg_begin;
+  int64_t ws_off;
+} gn_tn_problem;
+typedef struct {
+  float* out;
+  int64_t n;
+  int slice_begin, slice_end, wg_begin, pad_;
+} gn_tn_target;
+int gn_gemm_tn_grouped_f32(const gn_tn_problem* probs, int n_prob, int total_wg, const gn_tn_target* targets,
+                           int n_target, int total_fold_wg, const int64_t* slice_off, float* ws, void* stream);
+
 /* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
  * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */
 int gn_bmm_f32(const float* A, const float* B, float* C, int batch, int m, int n, int k,
