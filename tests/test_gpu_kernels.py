@@ -82,7 +82,8 @@ def test_gemm_strided_weight_slices():
     close(K.gemm(f32(h), Wd[:, 32:64], False, False), h @ W[:, 32:64].t())
 
 
-@pytest.mark.parametrize("b,m,n,k", [(100, 16, 64, 7), (33, 32, 32, 49), (7, 5, 3, 2)])
+@pytest.mark.parametrize("b,m,n,k", [(100, 16, 64, 7), (33, 32, 32, 49), (7, 5, 3, 2), (50, 7, 16, 64), (18122, 16, 64, 7),
+                                     (31, 49, 32, 32)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
 def test_bmm(b, m, n, k, ta, tb):
     g = torch.Generator().manual_seed(b + m)
