@@ -139,7 +139,7 @@ class AtomUpdateBlock(torch.nn.Module):
         x = m * self.dense_rbf(rbf)
         return self.scale_sum(m, ops.segsum_rows(x, id_a)), x
 
-    def _mlp_stack(self, x, layers, res2=None, beta2=1.0):
+    def _mlp_stack(self, x, layers, res2=None, beta2=1.0, tails=()):
         """Dense + ResidualLayers of the atom MLP as one LDS-resident launch (ops.stack)."""
         first = dict(W=layers[0].weight, act=layers[0].act)
         res_layers = [l.as_stack_layer() for l in layers[1:]]
@@ -148,17 +148,19 @@ class AtomUpdateBlock(torch.nn.Module):
                 res_layers[-1].update(skip=res2, skip_beta=beta2)
             else:
                 first.update(res=res2, beta=beta2)
-        return ops.stack(x, first=first, layers=res_layers, s=INV_SQRT_2)
+        return ops.stack(x, first=first, layers=res_layers, s=INV_SQRT_2, tails=tails)
 
     @staticmethod
     def _stackable(layers):
         return (ops.stacks_enabled() and isinstance(layers[0], Dense) and layers[0].bias is None
                 and all(isinstance(l, ResidualLayer) and l.stackable() for l in layers[1:]))
 
-    def forward(self, h, m, rbf, id_a, res2=None, beta2=1.0):
+    def forward(self, h, m, rbf, id_a, res2=None, beta2=1.0, tails=()):
+        """`tails`: weights Wt whose projections h_new @ Wt^T are wanted too (returned after h_new)."""
         x, _ = self._aggregate(m, rbf, id_a)
         if self._stackable(self.layers):
-            return self._mlp_stack(x, self.layers, res2, beta2)
+            return self._mlp_stack(x, self.layers, res2, beta2, tails)
+        assert not tails, "tail projections ride on the stacked path only"
         n = len(self.layers)
         for i, layer in enumerate(self.layers):
             if i + 1 == n and res2 is not None and isinstance(layer, ResidualLayer):
@@ -500,11 +502,16 @@ class _InteractionBase(torch.nn.Module):
         layers[-1].update(skip=m, skip_beta=INV_SQRT_2)
         layers += [l.as_stack_layer() for l in self.layers_after_skip]
         m = ops.stack(m, first=first, layers=layers, s=INV_SQRT_2)
-        h = self.atom_update(h, m, rbf_h, plan.id_a, res2=h, beta2=INV_SQRT_2)
         A = self.concat_layer.atom_features
         W = self.concat_layer.dense.weight
-        first = dict(W=W[:, 2 * A:], act=self.concat_layer.dense.act,
-                     g1=ops.dense(h, W[:, :A]), i1=plan.id_c, g2=ops.dense(h, W[:, A:2 * A]), i2=plan.id_a)
+        if self.atom_update._stackable(self.atom_update.layers):
+            # the two atom terms of the concat-Dense are tail projections of the atom stack (same launch)
+            h, g1, g2 = self.atom_update(h, m, rbf_h, plan.id_a, res2=h, beta2=INV_SQRT_2,
+                                         tails=(W[:, :A], W[:, A:2 * A]))
+        else:
+            h = self.atom_update(h, m, rbf_h, plan.id_a, res2=h, beta2=INV_SQRT_2)
+            g1, g2 = ops.dense(h, W[:, :A]), ops.dense(h, W[:, A:2 * A])
+        first = dict(W=W[:, 2 * A:], act=self.concat_layer.dense.act, g1=g1, i1=plan.id_c, g2=g2, i2=plan.id_a)
         layers = [l.as_stack_layer() for l in self.residual_m]
         layers[-1].update(skip=m, skip_beta=INV_SQRT_2)
         m = ops.stack(m, first=first, layers=layers, s=INV_SQRT_2)

@@ -715,30 +715,49 @@ class _Stack(torch.autograd.Function):
             prog.gemm(W2, a_slot=oth, y_slot=cur, act=True, pre_out=z2, res=cur, beta=s,
                       res2=skips[k], beta2=L["skip_beta"], out=y if last else None)
             zs += [z1, z2]
+        # tail projections y @ Wt^T of the final rows while they are still in LDS (the concat-Dense atom terms,
+        # embedding_block.py:70-72, ride on the atom stack instead of being two more launches)
+        tails = []
+        for Wt in spec.get("tails", ()):
+            Wt_c = contiguous_weight(Wt)
+            t = torch.empty((M, Wt_c.shape[0]), device=dev, dtype=dt)
+            prog.gemm(Wt_c, a_slot=cur, y_slot=-1, out=t)
+            tails.append(t)
         K.chain(prog)
+        ctx.set_materialize_grads(False)
         ctx.spec = spec
         ctx.has = (res is not None, res2 is not None, g1 is not None, g2 is not None,
                    tuple(sk is not None for sk in skips))
         ctx.save_for_backward(*[z for z in zs if z is not None])
         ctx.z_mask = [z is not None for z in zs]
         ctx.in_width = x.shape[1]
-        return y
+        ctx.out_shape = (M, n_out)
+        return (y, *tails) if tails else y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, *g_tails):
         spec = ctx.spec
         first, layers, s = spec["first"], spec["layers"], spec["s"]
         has_res, has_res2, has_g1, has_g2, has_skips = ctx.has
         need = ctx.needs_input_grad  # (spec, x, res, res2, g1, g2, *skips)
         saved = list(ctx.saved_tensors)
         zs = [saved.pop(0) if m else None for m in ctx.z_mask]
+        live = [t for t in (g, *g_tails) if t is not None]
+        if not live:
+            return (None,) * (6 + len(layers))
+        M, width = ctx.out_shape
+        dev, dt = live[0].device, live[0].dtype
+        if g is None:
+            g = torch.zeros((M, width), device=dev, dtype=dt)
         g = g.contiguous()
-        M, dev, dt = g.shape[0], g.device, g.dtype
         prog = K.ChainProgram(M)
         prog.load(0, g)
         cur, oth = 0, 1
-        width = g.shape[1]
+        for Wt, gt in zip(spec.get("tails", ()), g_tails):
+            if gt is not None:   # dL/dy += gt @ Wt
+                prog.load(oth, gt.contiguous())
+                prog.gemm(transposed(Wt), a_slot=oth, y_slot=cur, res=cur, beta=1.0)
         g_skips = [None] * len(layers)
         zi = len(zs)
         for k in range(len(layers) - 1, -1, -1):
@@ -792,12 +811,13 @@ class _Stack(torch.autograd.Function):
         return (None, gx, g_res, g_res2, gg1, gg2) + tuple(g_skips)
 
 
-def stack(x, first=None, layers=(), s=0.7071067811865475):
+def stack(x, first=None, layers=(), s=0.7071067811865475, tails=()):
     """first: dict(W, act, res=None, beta=1, res2=None, beta2=1, g1=None, i1=None, g2=None, i2=None) or None;
-    layers: sequence of dict(W1, W2, skip=None, skip_beta=1).  Requires constant_weights()."""
+    layers: sequence of dict(W1, W2, skip=None, skip_beta=1); tails: weights Wt -> extra outputs y @ Wt^T.
+    Returns y, or (y, *tail outputs).  Requires constant_weights()."""
     assert constant_weights(), "ops.stack is the constant-weight inference path"
     spec = dict(first=None, layers=[dict(W1=L["W1"], W2=L["W2"], skip_beta=float(L.get("skip_beta", 1.0)))
-                                    for L in layers], s=float(s))
+                                    for L in layers], s=float(s), tails=tuple(tails))
     res = res2 = g1 = g2 = None
     if first is not None:
         spec["first"] = dict(W=first["W"], act=bool(first.get("act", False)), beta=float(first.get("beta", 1.0)),
