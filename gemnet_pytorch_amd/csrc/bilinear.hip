@@ -90,6 +90,70 @@ __global__ __launch_bounds__(256) void bil_reduce_t_kernel(const float* __restri
   dx[j * C + c] = acc + acc2;
 }
 
+// Same adjoint, grouped by REDUCE edge instead of by expand row:  dxt[t,c] = sum_s Y[t,s] * dSm[r(t),s,c].
+// For the tensor basis (S = 49) the expand-row form above re-reads the 6 KB block dSm[r(t)] for every quadruplet
+// (9 M x 6.3 KB = 56 GB of L2 traffic per launch at B = 32: 3.8 ms).  Quadruplets are sorted by reduce edge, so
+// here a group of C lanes owns one edge, keeps dSm[e,:,c] in S registers, streams its segment of Y through LDS
+// (coalesced load, broadcast ds_read_b128) and writes the per-quadruplet rows; the sum over each expand row is
+// then one ordinary CSR segmented sum (gn_segsum_rows_f32).  Traffic: Y + dSm once + 2 x (Q x C) floats.
+template <int S, int CH>
+__global__ __launch_bounds__(256) void bil_expand_kernel(const float* __restrict__ Y, const float* __restrict__ dSm,
+                                                         const int32_t* __restrict__ seg_off,
+                                                         float* __restrict__ dxt, int64_t E, int C) {
+  constexpr int SP = (S + 3) / 4 * 4;            // padded row (16-B aligned rows in LDS)
+  extern __shared__ __attribute__((aligned(16))) float ys[];   // [groups][CH][SP]
+  __shared__ int nchunk_s;
+  const int gpb = blockDim.x / C;                 // edge groups per block
+  const int g = threadIdx.x / C;
+  const int c = threadIdx.x - g * C;
+  const int64_t e = (int64_t)blockIdx.x * gpb + g;
+  const bool live = g < gpb && e < E;
+  const int t0 = live ? seg_off[e] : 0;
+  const int t1 = live ? seg_off[e + 1] : 0;
+  if (threadIdx.x == 0) nchunk_s = 0;
+  __syncthreads();
+  if (live && c == 0) atomicMax(&nchunk_s, (t1 - t0 + CH - 1) / CH);
+  __syncthreads();
+  const int nchunk = nchunk_s;                    // uniform trip count: barriers below are unconditional
+  float d[S];
+  if (live) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) d[s] = dSm[(e * S + s) * C + c];
+  }
+  float* __restrict__ yg = ys + (size_t)g * CH * SP;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int tb = t0 + ch * CH;
+    const int nt = min(CH, t1 - tb);              // <= 0 when this group is done
+    __syncthreads();                               // previous chunk fully consumed
+    if (live && nt > 0) {
+      const float* __restrict__ src = Y + (int64_t)tb * S;
+      for (int i = c; i < nt * S; i += C) {
+        const int r = i / S;
+        yg[r * SP + (i - r * S)] = src[i];
+      }
+      if (SP > S)
+        for (int r = c; r < nt; r += C)
+          for (int p = S; p < SP; ++p) yg[r * SP + p] = 0.f;
+    }
+    __syncthreads();
+    if (live && nt > 0) {
+      for (int tt = 0; tt < nt; ++tt) {
+        const float4* __restrict__ row = reinterpret_cast<const float4*>(yg + tt * SP);
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < SP / 4; ++q) {
+          const float4 y = row[q];
+          acc = fmaf(y.x, d[4 * q], acc);
+          if (4 * q + 1 < S) acc = fmaf(y.y, d[4 * q + 1], acc);
+          if (4 * q + 2 < S) acc = fmaf(y.z, d[4 * q + 2], acc);
+          if (4 * q + 3 < S) acc = fmaf(y.w, d[4 * q + 3], acc);
+        }
+        dxt[(int64_t)(tb + tt) * C + c] = acc;
+      }
+    }
+  }
+}
+
 // dY[t,s] = sum_c dSm[r(t),s,c] * x[g(t),c]; one block per reduce edge, dSm[e] staged in LDS
 // with row stride C+4 (lanes of different s hit different 16-B slots; same s broadcasts).
 __global__ __launch_bounds__(256) void bil_dot_kernel(const float* __restrict__ dSm,
@@ -285,6 +349,28 @@ extern "C" int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32
     hipLaunchKernelGGL(bil_reduce_t_kernel<7>, grid, block, 0, st, Y, dSm, reduce_idx, permT, segT_off, dx, J, C);
   } else if (S == 49) {
     hipLaunchKernelGGL(bil_reduce_t_kernel<49>, grid, block, 0, st, Y, dSm, reduce_idx, permT, segT_off, dx, J, C);
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_expand_f32(const float* Y, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S,
+                                 int C, void* stream) {
+  if (E <= 0) return 0;
+  if (!ok_channels(C)) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int gpb = 256 / C;
+  dim3 grid(gn_cdiv(E, gpb)), block(256);
+  if (S == 49) {
+    constexpr int CH = 32;
+    hipLaunchKernelGGL((bil_expand_kernel<49, CH>), grid, block, (size_t)gpb * CH * 52 * sizeof(float), st, Y, dSm,
+                       seg_off, dxt, E, C);
+  } else if (S == 7) {
+    constexpr int CH = 32;
+    hipLaunchKernelGGL((bil_expand_kernel<7, CH>), grid, block, (size_t)gpb * CH * 8 * sizeof(float), st, Y, dSm,
+                       seg_off, dxt, E, C);
   } else {
     return (int)hipErrorInvalidValue;
   }

@@ -210,6 +210,12 @@ def bil_reduce_t(Y, D, sp):
     Y, D = _f32c(Y), _f32c(D)
     S, C = Y.shape[1], D.shape[2]
     permT, segT = sp.expand.csr
+    if S > 8:
+        # tensor basis: per-quadruplet rows grouped by reduce edge (dSm[e] read once per edge), then one CSR sum
+        dxt = torch.empty((sp.size, C), device=Y.device, dtype=torch.float32)
+        check(_lib.load().gn_bil_expand_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(dxt), sp.n_reduce, S, C, stream()),
+              "gn_bil_expand_f32")
+        return segsum(dxt, permT, segT, sp.n_expand)
     dx = torch.empty((sp.n_expand, C), device=Y.device, dtype=torch.float32)
     check(_lib.load().gn_bil_reduce_t_f32(ptr(Y), ptr(D), ptr(sp.reduce.idx32), ptr(permT), ptr(segT),
                                           ptr(dx), sp.n_expand, S, C, stream()), "gn_bil_reduce_t_f32")

@@ -193,6 +193,11 @@ int gn_bil_reduce_f32(const float* Y, const float* x, const int32_t* expand_idx,
 int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32_t* reduce_idx,
                         const int32_t* permT, const int32_t* segT_off, float* dx,
                         int64_t J, int S, int C, void* stream);
+/* dxt[t,c] = sum_s Y[t,s] * dSm[r(t),s,c]: the per-triplet/quadruplet rows of the adjoint above (dx[j] = sum of
+ * dxt over the transposed segment of j: gn_segsum_rows_f32), grouped by reduce edge so that dSm[e] is read once
+ * per edge instead of once per quadruplet (the S = 49 tensor basis: 56 GB -> 4 GB of traffic at B = 32). */
+int gn_bil_expand_f32(const float* Y, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,
+                      void* stream);
 /* dY[t,s] = sum_c dSm[r(t),s,c] * x[g(t),c] */
 int gn_bil_dot_f32(const float* dSm, const float* x, const int32_t* expand_idx,
                    const int32_t* seg_off, float* dY, int64_t E, int S, int C, void* stream);
