@@ -253,6 +253,103 @@ __global__ __launch_bounds__(256) void bil_reduce_project_kernel(
   }
 }
 
+// Tensor-basis (S = 49, C = I = 32) form of the fused K1 + K2 on the matrix cores.  For one reduce edge
+//   Sm[e] (S x C) = Yseg^T (S x K4) @ Xseg (K4 x C),   Xseg[t] = x[g(t)],   K4 ~ 500 quadruplets,
+// is a GEMM with M = S (padded to 64), N = C, K = K4: one wave per edge, v_mfma_f32_16x16x4_f32 with the operand
+// fragments loaded straight from global memory in fragment layout — lane (l15, lg) of a K-step of 4 quadruplets
+// reads Y[t + lg][16 mt + l15] (16 lanes = 64 contiguous bytes of one Y row) and x[g(t + lg)][16 nt + l15] — so the
+// per-quadruplet cost drops from 49 scalar loads + 49 FMAs per lane to 7 loads + 8 MFMAs per 4 quadruplets.
+// K2 (P = B[e]^T Sm, 32 x 49 x 32) runs on the same cores with Sm passed through LDS.
+typedef float v4f_b __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void bil_reduce_project_mfma49_kernel(
+    const float* __restrict__ Y, const float* __restrict__ x, const int32_t* __restrict__ expand_idx,
+    const int32_t* __restrict__ seg_off, const float* __restrict__ B, float* __restrict__ Sm,
+    float* __restrict__ P, int64_t E) {
+  constexpr int S = 49, C = 32, I = 32, LD = C + 4;
+  __shared__ __attribute__((aligned(16))) float sml[4][52][LD];   // Sm of this wave's edge, rows 49..51 zero
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  v4f_b acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
+  const bool s3 = l15 == 0;   // tile mt = 3 holds only s = 48
+  auto load = [&](int t, float (&a)[4], float (&b)[2]) {
+    const int tq = t + lg;
+    const bool ok = tq < t1;
+    const float* __restrict__ yr = Y + (int64_t)tq * S + l15;
+    a[0] = ok ? yr[0] : 0.f;
+    a[1] = ok ? yr[16] : 0.f;
+    a[2] = ok ? yr[32] : 0.f;
+    a[3] = (ok && s3) ? yr[48] : 0.f;
+    const int g = ok ? expand_idx[tq] : 0;
+    const float* __restrict__ xr = x + (int64_t)g * C + l15;
+    b[0] = ok ? xr[0] : 0.f;
+    b[1] = ok ? xr[16] : 0.f;
+  };
+  float a0[4], b0[2], a1[4], b1[2];
+  load(t0, a0, b0);
+  for (int t = t0; t < t1; t += 8) {
+    load(t + 4, a1, b1);               // next K-step in flight under this one's MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mt], b0[nt], acc[mt][nt], 0, 0, 0);
+    load(t + 8, a0, b0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b1[nt], acc[mt][nt], 0, 0, 0);
+  }
+  // D layout: col = l15 (c within tile), row = 4 lg + r (s within tile)
+  float* __restrict__ so = Sm + e * (int64_t)S * C;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int srow = 16 * mt + 4 * lg + r;
+        const float v = acc[mt][nt][r];
+        if (srow < S) so[srow * C + 16 * nt + l15] = v;
+        if (srow < 52) sml[wave][srow][16 * nt + l15] = srow < S ? v : 0.f;
+      }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+  __builtin_amdgcn_wave_barrier();
+  // K2: P[i,c] = sum_s B[e,s,i] Sm[s,c]:  A[m = i][k = s] = B[e][s][i],  Bop[k = s][n = c] = Sm[s][c]
+  v4f_b pacc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) pacc[mt][nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ be = B + e * (int64_t)S * I;
+#pragma unroll
+  for (int kk = 0; kk < 13; ++kk) {
+    const int sk = 4 * kk + lg;
+    const bool ok = sk < S;
+    const float a_0 = ok ? be[sk * I + l15] : 0.f;
+    const float a_1 = ok ? be[sk * I + 16 + l15] : 0.f;
+    const float b_0 = sml[wave][sk][l15];
+    const float b_1 = sml[wave][sk][16 + l15];
+    pacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_0, pacc[0][0], 0, 0, 0);
+    pacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_1, pacc[0][1], 0, 0, 0);
+    pacc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_0, pacc[1][0], 0, 0, 0);
+    pacc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_1, pacc[1][1], 0, 0, 0);
+  }
+  float* __restrict__ po = P + e * (int64_t)I * C;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) po[(16 * mt + 4 * lg + r) * C + 16 * nt + l15] = pacc[mt][nt][r];
+}
+
 // Adjoint of K2 fused with the K1 adjoint w.r.t. Y, one workgroup per reduce edge:
 //   gB[e,s,i]  = sum_c Sm[e,s,c] dP[e,i,c]
 //   dSm[e,s,c] = sum_i B[e,s,i] dP[e,i,c]                  (written: bil_reduce_t consumes it)
@@ -404,6 +501,9 @@ extern "C" int gn_bil_reduce_project_f32(const float* Y, const float* x, const i
   dim3 grid(gn_cdiv(E, epb)), block(256);
   if (S == 7) {
     hipLaunchKernelGGL(bil_reduce_project_kernel<7>, grid, block, smem, st, Y, x, expand_idx, seg_off, B, Sm, P, E, C, I);
+  } else if (S == 49 && C == 32 && I == 32) {
+    hipLaunchKernelGGL(bil_reduce_project_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, Y, x, expand_idx, seg_off, B,
+                       Sm, P, E);
   } else if (S == 49) {
     hipLaunchKernelGGL(bil_reduce_project_kernel<49>, grid, block, smem, st, Y, x, expand_idx, seg_off, B, Sm, P, E, C, I);
   } else {
