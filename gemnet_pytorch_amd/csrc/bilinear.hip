@@ -410,6 +410,146 @@ __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
   }
 }
 
+// Tensor-basis (S = 49, C = I = 32) form of the fused bilinear adjoint on the matrix cores, one wave per reduce edge:
+//   gB[s,i]  = sum_c Sm[s,c] dP[i,c]       (64 x 32 x 32)
+//   dSm[s,c] = sum_i B[s,i]  dP[i,c]       (64 x 32 x 32)     -> global + LDS
+//   dY[t,s]  = sum_c x[g(t),c] dSm[s,c]    (K4 x 64 x 32, 16 quadruplets per MFMA row tile)
+// Operands whose contraction index is contiguous are fetched as float4 and consumed component-wise: in K-step
+// (j, comp) lane group lg supplies k = 16 j + 4 lg + comp for BOTH operands, so the sum over k is complete.
+__global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
+    const float* __restrict__ dP, const float* __restrict__ Sm, const float* __restrict__ B,
+    const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
+    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int64_t E) {
+  constexpr int S = 49, C = 32, I = 32, LD = C + 4;
+  __shared__ __attribute__((aligned(16))) float dsl[4][64][LD];   // dSm of this wave's edge (rows >= 49 zero)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+  const float* __restrict__ dPe = dP + e * (int64_t)I * C;
+  const float* __restrict__ Sme = Sm + e * (int64_t)S * C;
+  const float* __restrict__ Be = B + e * (int64_t)S * I;
+  // ---- (1) gB and (2) dSm share the row-fragments of dP
+  float4 dprow[2][2];   // dP[16 nt + l15][16 j + 4 lg ..]   (k = c contiguous)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      dprow[nt][j] = *reinterpret_cast<const float4*>(dPe + (16 * nt + l15) * C + 16 * j + 4 * lg);
+  v4f_b acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int srow = 16 * mt + l15;
+    const bool ok = srow < S;
+    float4 a[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a[j] = ok ? *reinterpret_cast<const float4*>(Sme + srow * C + 16 * j + 4 * lg) : z4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      v4f_b c4 = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(a[j], q), comp(dprow[nt][j], q), c4, 0, 0, 0);
+      acc[mt][nt] = c4;
+    }
+  }
+  float* __restrict__ gBe = gB + e * (int64_t)S * I;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int srow = 16 * mt + 4 * lg + r;
+        if (srow < S) gBe[srow * I + 16 * nt + l15] = acc[mt][nt][r];
+      }
+  // (2) dSm[s,c] = sum_i B[s,i] dP[i,c]: A rows of B (k = i contiguous), Bop[k = i][n = c] = dP[i][c] (scalar loads)
+  float dpcol[2][2][4];   // dP[16 j + 4 lg + q][16 nt + l15]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dpcol[nt][j][q] = dPe[(16 * j + 4 * lg + q) * C + 16 * nt + l15];
+  float* __restrict__ dSe = dSm + e * (int64_t)S * C;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int srow = 16 * mt + l15;
+    const bool ok = srow < S;
+    float4 a[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a[j] = ok ? *reinterpret_cast<const float4*>(Be + srow * I + 16 * j + 4 * lg) : z4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      v4f_b c4 = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(a[j], q), dpcol[nt][j][q], c4, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int sr = 16 * mt + 4 * lg + r;
+        const float v = sr < S ? c4[r] : 0.f;
+        if (sr < S) dSe[sr * C + 16 * nt + l15] = v;
+        dsl[wave][sr][16 * nt + l15] = v;
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  // ---- (3) dY[t,s] = sum_c x[g(t),c] dSm[s,c]: Bop fragments (rows of dSm, k = c contiguous) once per edge
+  float4 bd[4][2];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      bd[nt][j] = *reinterpret_cast<const float4*>(&dsl[wave][16 * nt + l15][16 * j + 4 * lg]);
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  auto loadx = [&](int tb, float4 (&ax)[2]) {
+    const int tq = tb + l15;
+    if (tq < t1) {
+      const float* __restrict__ xr = x + (int64_t)expand_idx[tq] * C + 4 * lg;
+      ax[0] = *reinterpret_cast<const float4*>(xr);
+      ax[1] = *reinterpret_cast<const float4*>(xr + 16);
+    } else {
+      ax[0] = z4; ax[1] = z4;
+    }
+  };
+  float4 ax[2], an[2];
+  loadx(t0, ax);
+  for (int tb = t0; tb < t1; tb += 16) {
+    loadx(tb + 16, an);
+    v4f_b y4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      v4f_b c4 = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ax[j], q), comp(bd[nt][j], q), c4, 0, 0, 0);
+      y4[nt] = c4;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tq = tb + 4 * lg + r;
+      if (tq < t1) {
+        float* __restrict__ yo = dY + (int64_t)tq * S + l15;
+        yo[0] = y4[0][r];
+        yo[16] = y4[1][r];
+        yo[32] = y4[2][r];
+        if (l15 == 0) yo[48] = y4[3][r];
+      }
+    }
+    ax[0] = an[0]; ax[1] = an[1];
+  }
+}
+
 inline bool ok_channels(int C) { return C > 0 && C <= 256 && (256 % C) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -518,6 +658,12 @@ extern "C" int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const fl
                                       float* dY, int64_t E, int S, int C, int I, void* stream) {
   if (E <= 0) return 0;
   if (S <= 0 || C <= 0 || (C % 4) != 0 || I <= 0) return (int)hipErrorInvalidValue;
+  if (S == 49 && C == 32 && I == 32 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)) {
+    hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dP, Sm, B, x, expand_idx, seg_off, gB, dSm, dY, E);
+    GN_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = ((size_t)(I + 2 * S) * (C + 4) + (size_t)S * I) * sizeof(float);
   if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(bil_project_bwd_kernel, dim3((unsigned)E), dim3(128), smem, static_cast<hipStream_t>(stream),
