@@ -550,6 +550,59 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
   }
 }
 
+// Matrix-core form of bil_expand for the tensor basis (S = 49, C = 32): per reduce edge
+//   dxt[seg(e)] (K4 x C) = Yseg (K4 x S) @ dSm[e] (S x C),
+// one wave per edge, 16 quadruplets per MFMA row tile, the 26 B-operand fragments of dSm[e] held in registers.
+__global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __restrict__ Y,
+                                                                const float* __restrict__ dSm,
+                                                                const int32_t* __restrict__ seg_off,
+                                                                float* __restrict__ dxt, int64_t E) {
+  constexpr int S = 49, C = 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  const float* __restrict__ De = dSm + e * (int64_t)S * C;
+  float bd[13][2];   // dSm[4 kk + lg][16 nt + l15]
+#pragma unroll
+  for (int kk = 0; kk < 13; ++kk) {
+    const int sr = 4 * kk + lg;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bd[kk][nt] = sr < S ? De[sr * C + 16 * nt + l15] : 0.f;
+  }
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  auto loady = [&](int tb, float (&a)[13]) {
+    const int tq = tb + l15;
+    const bool ok = tq < t1;
+    const float* __restrict__ yr = Y + (int64_t)tq * S + lg;
+#pragma unroll
+    for (int kk = 0; kk < 12; ++kk) a[kk] = ok ? yr[4 * kk] : 0.f;
+    a[12] = (ok && lg == 0) ? yr[48] : 0.f;
+  };
+  float a[13], an[13];
+  loady(t0, a);
+  for (int tb = t0; tb < t1; tb += 16) {
+    loady(tb + 16, an);
+    v4f_b c0 = (v4f_b){0.f, 0.f, 0.f, 0.f}, c1 = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 13; ++kk) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bd[kk][0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bd[kk][1], c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tq = tb + 4 * lg + r;
+      if (tq < t1) {
+        float* __restrict__ o = dxt + (int64_t)tq * C + l15;
+        o[0] = c0[r];
+        o[16] = c1[r];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 13; ++kk) a[kk] = an[kk];
+  }
+}
+
 inline bool ok_channels(int C) { return C > 0 && C <= 256 && (256 % C) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -600,7 +653,9 @@ extern "C" int gn_bil_expand_f32(const float* Y, const float* dSm, const int32_t
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int gpb = 256 / C;
   dim3 grid(gn_cdiv(E, gpb)), block(256);
-  if (S == 49) {
+  if (S == 49 && C == 32) {
+    hipLaunchKernelGGL(bil_expand_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, Y, dSm, seg_off, dxt, E);
+  } else if (S == 49) {
     constexpr int CH = 32;
     hipLaunchKernelGGL((bil_expand_kernel<49, CH>), grid, block, (size_t)gpb * CH * 52 * sizeof(float), st, Y, dSm,
                        seg_off, dxt, E, C);
