@@ -147,47 +147,104 @@ GN_HD void ylm0_row(double theta, int S, int k, float* out) {
   }
 }
 
-// Visit every real Y_j(theta, phi), j < S*S, with its kt-th theta / kp-th phi derivative:
-// emit(slot, value).  Per degree l the slots hold m = 0, +1..+l, -l..-1 (negative list indices at
-// basis_utils.py:237).  Y_l,+m = sqrt2 N_lm Q_l^m cos(m phi), Y_l,-m = sqrt2 N_lm Q_l^m sin(m phi),
-// Q_l^m = phase-free associated Legendre in (cos theta, sin theta)  (basis_utils.py:137-159,226-243).
-template <typename F>
-GN_HD void ylm_visit(double theta, double ph, int S, int kt, int kp, F emit) {
+// ylm_prefactor(l, m) for l, m < 7 (the loop + sqrt per (l, m) per quadruplet was a third of the tensor-basis kernels)
+GN_HD double ylm_prefactor_tab(int l, int m) {
+  constexpr double T[7][7] = {
+    {0.28209479177387814, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {0.4886025119029199, 0.3454941494713355, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {0.6307831305050401, 0.2575161346821264, 0.1287580673410632, 0.0, 0.0, 0.0, 0.0},
+    {0.7463526651802308, 0.21545345607610045, 0.06813236509555216, 0.02781492157551894, 0.0, 0.0, 0.0},
+    {0.8462843753216345, 0.18923493915151202, 0.044603102903819275, 0.011920680675222404, 0.004214597070904597, 0.0, 0.0},
+    {0.9356025796273888, 0.17081687924064806, 0.03228135587163618, 0.006589404174225528, 0.0015531374585246046, 0.000491145188826305, 0.0},
+    {1.0171072362820548, 0.156943053829006, 0.024814875652103455, 0.00413581260868391, 0.0007550926197968212, 0.0001609862874555169, 4.6472738199140574e-05}};
+  return (l < 7 && m < 7) ? T[l][m] : ylm_prefactor(l, m);
+}
+
+// Jet arithmetic that only carries the derivative orders <= JO (the unused components fold away)
+template <int JO> GN_HD Jet jmul_o(const Jet& a, const Jet& b) {
+  Jet r = {a.v * b.v, 0.0, 0.0};
+  if (JO >= 1) r.d1 = a.d1 * b.v + a.v * b.d1;
+  if (JO >= 2) r.d2 = a.d2 * b.v + 2.0 * a.d1 * b.d1 + a.v * b.d2;
+  return r;
+}
+
+// Core recurrence over (m, l): visit(l, m, base, ql, cos(m phi), sin(m phi), prefactor) with the theta-jet of the
+// phase-free associated Legendre Q_l^m carried to order JO.  cos/sin(m phi) by the angle-addition recurrence from
+// one sincos (error ~ m eps) instead of one f64 sincos per m.
+template <int JO, typename F>
+GN_HD void ylm_core(double theta, double ph, int S, F visit) {
   double sn, cs;
   sincos(theta, &sn, &cs);
   const Jet js = {sn, cs, -sn};
   const Jet jc = {cs, -sn, -cs};
+  double s1, c1;
+  sincos(ph, &s1, &c1);
+  double cm = 1.0, sm = 0.0;   // cos(m phi), sin(m phi)
   Jet qmm = {1.0, 0.0, 0.0};
   for (int m = 0; m < S; ++m) {
-    if (m > 0) qmm = jscale(jmul(js, qmm), (double)(2 * m - 1));
-    double fc, fs;  // phi factors of +m (cos) and -m (sin), kp-th derivative
-    {
-      double smp, cmp;
-      sincos(m * ph, &smp, &cmp);
-      if (kp == 0) { fc = cmp; fs = smp; }
-      else if (kp == 1) { fc = -m * smp; fs = m * cmp; }
-      else { fc = -(double)m * m * cmp; fs = -(double)m * m * smp; }
+    if (m > 0) {
+      qmm = jscale(jmul_o<JO>(js, qmm), (double)(2 * m - 1));
+      const double cn = cm * c1 - sm * s1;
+      sm = sm * c1 + cm * s1;
+      cm = cn;
     }
     Jet qa = qmm;              // q[l-1][m]
     Jet qb = {0.0, 0.0, 0.0};  // q[l-2][m]
     for (int l = m; l < S; ++l) {
       Jet ql;
       if (l == m) ql = qmm;
-      else if (l == m + 1) ql = jscale(jmul(jc, qa), (double)(2 * m + 1));
-      else ql = jscale(jsub(jscale(jmul(jc, qa), (double)(2 * l - 1)), jscale(qb, (double)(l + m - 1))),
+      else if (l == m + 1) ql = jscale(jmul_o<JO>(jc, qa), (double)(2 * m + 1));
+      else ql = jscale(jsub(jscale(jmul_o<JO>(jc, qa), (double)(2 * l - 1)), jscale(qb, (double)(l + m - 1))),
                        1.0 / (l - m));
       if (l > m) { qb = qa; qa = ql; }
-      const double tv = (kt == 0) ? ql.v : (kt == 1 ? ql.d1 : ql.d2);
-      const int base = l * l;  // first slot of degree l
-      if (m == 0) {
-        emit(base, kp == 0 ? ylm_prefactor(l, 0) * tv : 0.0);
-      } else {
-        const double pf = 1.4142135623730951 * ylm_prefactor(l, m) * tv;
-        emit(base + m, pf * fc);              // +m
-        emit(base + 2 * l + 1 - m, pf * fs);  // -m
-      }
+      visit(l, m, l * l, ql, cm, sm, (m == 0 ? 1.0 : 1.4142135623730951) * ylm_prefactor_tab(l, m));
     }
   }
+}
+
+// Visit every real Y_j(theta, phi), j < S*S, with its kt-th theta / kp-th phi derivative:
+// emit(slot, value).  Per degree l the slots hold m = 0, +1..+l, -l..-1 (negative list indices at
+// basis_utils.py:237).  Y_l,+m = sqrt2 N_lm Q_l^m cos(m phi), Y_l,-m = sqrt2 N_lm Q_l^m sin(m phi),
+// Q_l^m = phase-free associated Legendre in (cos theta, sin theta)  (basis_utils.py:137-159,226-243).
+template <int KT, typename F>
+GN_HD void ylm_visit_t(double theta, double ph, int S, int kp, F emit) {
+  ylm_core<KT>(theta, ph, S, [&](int l, int m, int base, const Jet& ql, double cm, double sm, double pf) {
+    const double tv = pf * (KT == 0 ? ql.v : (KT == 1 ? ql.d1 : ql.d2));
+    if (m == 0) {
+      emit(base, kp == 0 ? tv : 0.0);
+    } else {
+      double fc, fs;  // phi factors of +m (cos) and -m (sin), kp-th derivative
+      if (kp == 0) { fc = cm; fs = sm; }
+      else if (kp == 1) { fc = -m * sm; fs = m * cm; }
+      else { fc = -(double)m * m * cm; fs = -(double)m * m * sm; }
+      emit(base + m, tv * fc);              // +m
+      emit(base + 2 * l + 1 - m, tv * fs);  // -m
+    }
+  });
+}
+
+template <typename F>
+GN_HD void ylm_visit(double theta, double ph, int S, int kt, int kp, F emit) {
+  if (kt == 0) ylm_visit_t<0>(theta, ph, S, kp, emit);
+  else if (kt == 1) ylm_visit_t<1>(theta, ph, S, kp, emit);
+  else ylm_visit_t<2>(theta, ph, S, kp, emit);
+}
+
+// Both first derivatives contracted with g in one pass (the geometry adjoint needs exactly these two):
+//   g_theta = sum_j g[j] dY_j/dtheta,   g_phi = sum_j g[j] dY_j/dphi
+GN_HD void ylm_dot_grad(double theta, double ph, int S, const float* g, double& g_theta, double& g_phi) {
+  double at = 0.0, ap = 0.0;
+  ylm_core<1>(theta, ph, S, [&](int l, int m, int base, const Jet& ql, double cm, double sm, double pf) {
+    if (m == 0) {
+      at += (double)g[base] * pf * ql.d1;
+    } else {
+      const double gp = (double)g[base + m], gm = (double)g[base + 2 * l + 1 - m];
+      at += pf * ql.d1 * (gp * cm + gm * sm);
+      ap += pf * ql.v * (double)m * (gm * cm - gp * sm);
+    }
+  });
+  g_theta = at;
+  g_phi = ap;
 }
 
 // out[j] = d^kt/dtheta^kt d^kp/dphi^kp Y_j(theta, phi), j < S*S

@@ -203,8 +203,9 @@ __global__ void quad_basis_bwd_kernel(const float* __restrict__ gY, const float*
     const float phi_cab = angle_uv(uab, uac);
     const float theta = angle_uv(p1, p2);
     const float* g = gY + q * (int64_t)S * S;
-    const float g_phi = (float)ylm_dot((double)phi_cab, (double)theta, S, 1, 0, g);   // d/d(first angle)
-    const float g_th = (float)ylm_dot((double)phi_cab, (double)theta, S, 0, 1, g);    // d/d(second angle)
+    double g_first, g_second;   // d/d(polar angle = Phi_cab), d/d(azimuth = Theta_cabd)
+    ylm_dot_grad((double)phi_cab, (double)theta, S, g, g_first, g_second);
+    const float g_phi = (float)g_first, g_th = (float)g_second;
     V3 g_ab, g_ac, gp1, gp2, t1, t2, g_bd, g_ba;
     angle_uv_bwd(uab, uac, g_phi, g_ab, g_ac);
     angle_uv_bwd(p1, p2, g_th, gp1, gp2);
