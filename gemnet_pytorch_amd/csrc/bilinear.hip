@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma49_kernel(
 __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
     const float* __restrict__ dP, const float* __restrict__ Sm, const float* __restrict__ B,
     const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
-    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int S, int C, int I) {
+    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int S, int C, int I, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ld = C + 4;
   float* dPl = sm;                 // [I][ld]
@@ -406,7 +406,8 @@ __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
       const float4 b = *reinterpret_cast<const float4*>(xr + c);
       acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
     }
-    dY[(int64_t)t * S + s] = acc;
+    if (accumulate) dY[(int64_t)t * S + s] += acc;
+    else dY[(int64_t)t * S + s] = acc;
   }
 }
 
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
 //   dY[t,s]  = sum_c x[g(t),c] dSm[s,c]    (K4 x 64 x 32, 16 quadruplets per MFMA row tile)
 // Operands whose contraction index is contiguous are fetched as float4 and consumed component-wise: in K-step
 // (j, comp) lane group lg supplies k = 16 j + 4 lg + comp for BOTH operands, so the sum over k is complete.
+template <bool ACC>
 __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
     const float* __restrict__ dP, const float* __restrict__ Sm, const float* __restrict__ B,
     const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
@@ -540,10 +542,17 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
       const int tq = tb + 4 * lg + r;
       if (tq < t1) {
         float* __restrict__ yo = dY + (int64_t)tq * S + l15;
-        yo[0] = y4[0][r];
-        yo[16] = y4[1][r];
-        yo[32] = y4[2][r];
-        if (l15 == 0) yo[48] = y4[3][r];
+        if (ACC) {   // dY is the running sum over the interaction blocks that share this basis
+          yo[0] += y4[0][r];
+          yo[16] += y4[1][r];
+          yo[32] += y4[2][r];
+          if (l15 == 0) yo[48] += y4[3][r];
+        } else {
+          yo[0] = y4[0][r];
+          yo[16] = y4[1][r];
+          yo[32] = y4[2][r];
+          if (l15 == 0) yo[48] = y4[3][r];
+        }
       }
     }
     ax[0] = an[0]; ax[1] = an[1];
@@ -708,21 +717,32 @@ extern "C" int gn_bil_reduce_project_f32(const float* Y, const float* x, const i
   return 0;
 }
 
-extern "C" int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,
-                                      const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm,
-                                      float* dY, int64_t E, int S, int C, int I, void* stream) {
+extern "C" int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, const float* B, const float* x,
+                                          const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm,
+                                          float* dY, int64_t E, int S, int C, int I, int accumulate, void* stream) {
   if (E <= 0) return 0;
   if (S <= 0 || C <= 0 || (C % 4) != 0 || I <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
   if (S == 49 && C == 32 && I == 32 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)) {
-    hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       dP, Sm, B, x, expand_idx, seg_off, gB, dSm, dY, E);
+    if (accumulate)
+      hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, dP, Sm, B, x,
+                         expand_idx, seg_off, gB, dSm, dY, E);
+    else
+      hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel<false>, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, dP, Sm, B, x,
+                         expand_idx, seg_off, gB, dSm, dY, E);
     GN_LAUNCH_CHECK();
     return 0;
   }
   const size_t smem = ((size_t)(I + 2 * S) * (C + 4) + (size_t)S * I) * sizeof(float);
   if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(bil_project_bwd_kernel, dim3((unsigned)E), dim3(128), smem, static_cast<hipStream_t>(stream),
-                     dP, Sm, B, x, expand_idx, seg_off, gB, dSm, dY, S, C, I);
+  hipLaunchKernelGGL(bil_project_bwd_kernel, dim3((unsigned)E), dim3(128), smem, st, dP, Sm, B, x, expand_idx, seg_off,
+                     gB, dSm, dY, S, C, I, accumulate);
   GN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,
+                                      const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm,
+                                      float* dY, int64_t E, int S, int C, int I, void* stream) {
+  return gn_bil_project_bwd_acc_f32(dP, Sm, B, x, expand_idx, seg_off, gB, dSm, dY, E, S, C, I, 0, stream);
 }

@@ -434,18 +434,21 @@ def bil_reduce_project(Y, x, B, sp):
     return Sm, P
 
 
-def bil_project_bwd(dP, Sm, B, x, sp):
-    """Fused adjoint of K2 and of K1 w.r.t. Y -> (gB (E,S,I), dSm (E,S,C), dY (T,S))."""
+def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None):
+    """Fused adjoint of K2 and of K1 w.r.t. Y -> (gB (E,S,I), dSm (E,S,C), dY (T,S)); with `dY_accum` the Y
+    gradient is ADDED into that (T,S) buffer (and returned) instead of written to a fresh one."""
     require_device(dP, Sm, B, x)
     dP, Sm, B, x = _f32c(dP), _f32c(Sm), _f32c(B), _f32c(x)
     E, S, C = Sm.shape
     I = B.shape[2]
     gB = torch.empty((E, S, I), device=x.device, dtype=torch.float32)
     dSm = torch.empty((E, S, C), device=x.device, dtype=torch.float32)
-    dY = torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
-    check(_lib.load().gn_bil_project_bwd_f32(ptr(dP), ptr(Sm), ptr(B), ptr(x), ptr(sp.expand.idx32),
-                                             ptr(sp.seg_off), ptr(gB), ptr(dSm), ptr(dY), E, S, C, I, stream()),
-          "gn_bil_project_bwd_f32")
+    if dY_accum is not None:
+        assert dY_accum.shape == (sp.size, S) and dY_accum.is_contiguous() and dY_accum.dtype == torch.float32
+    dY = dY_accum if dY_accum is not None else torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_project_bwd_acc_f32(ptr(dP), ptr(Sm), ptr(B), ptr(x), ptr(sp.expand.idx32),
+                                                 ptr(sp.seg_off), ptr(gB), ptr(dSm), ptr(dY), E, S, C, I,
+                                                 int(dY_accum is not None), stream()), "gn_bil_project_bwd_acc_f32")
     return gB, dSm, dY
 
 

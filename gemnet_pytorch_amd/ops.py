@@ -527,11 +527,32 @@ def dense(x, W, act=False, *, mul=None, alpha=1.0, res=None, res_rows=None, beta
     return y
 
 
+class GradSink:
+    """Running sum of the gradient of one tensor that several fused ops consume (the angular basis is shared by all
+    interaction blocks).  Each consumer adds its contribution into `buf` inside its own kernel and returns None to
+    autograd, except the consumer whose backward runs last, which returns the buffer — so autograd's own
+    accumulation (three (T,S)-sized adds per step: 1.8 GB each for the quadruplet basis) never happens."""
+
+    def __init__(self):
+        self.uses = 0
+        self.buf = None
+
+
+def share_gradient(t):
+    """Mark tensor `t` (a non-leaf that requires grad) as shared between fused bilinear layers of one forward."""
+    if t.requires_grad and _FUSED:
+        t._gn_sink = GradSink()
+    return t
+
+
 class _FusedBilinear(torch.autograd.Function):
     """out = alpha * K3(K2(rbf_W1, K1(sph, x)))  (SURVEY.md Appendix D), first-order backward."""
 
     @staticmethod
     def forward(ctx, rbf_W1, sph, x, W, sp, alpha):
+        ctx.sink = getattr(sph, "_gn_sink", None)
+        if ctx.sink is not None:
+            ctx.sink.uses += 1
         C, I, O = W.shape
         Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)
         W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)  # rows (i,c)
@@ -551,7 +572,16 @@ class _FusedBilinear(torch.autograd.Function):
         g = g.contiguous()
         W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)
         dP = K.gemm(g, W2, alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is already (N=I*C, K=O)
-        gB, dSm, gsph = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp)      # 2 bmm + bil_dot in one launch
+        sink = ctx.sink
+        if sink is not None and need[1]:
+            # the Y gradient is summed across the consumers of `sph` inside the kernel (see GradSink)
+            gB, dSm, sink.buf = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, dY_accum=sink.buf)
+            sink.uses -= 1
+            gsph = sink.buf if sink.uses == 0 else None
+            if sink.uses == 0:
+                sink.buf = None
+        else:
+            gB, dSm, gsph = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp)      # 2 bmm + bil_dot in one launch
         gx = gW = None
         if not need[0]:
             gB = None

@@ -212,6 +212,11 @@ int gn_bil_reduce_project_f32(const float* Y, const float* x, const int32_t* exp
 int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,
                            const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
                            int64_t E, int S, int C, int I, void* stream);
+/* Same with `accumulate != 0`: dY += (the Y gradient summed over the interaction blocks that share one basis tensor
+ * — saves a (T,S)-sized add per block: 1.8 GB for the quadruplet basis at B = 32). */
+int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, const float* B, const float* x,
+                               const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
+                               int64_t E, int S, int C, int I, int accumulate, void* stream);
 
 /* ---- basis functions (P6-P8; closed forms of SURVEY.md Appendix A, evaluated in f64 in-kernel) */
 /* out[e,n] = d^kd/dd^kd d^kf/df_n^kf [ u(d/c) sqrt(2/c) sin(f_n d/c)/d ]   (basis_layers.py:45-49);

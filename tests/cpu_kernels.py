@@ -294,10 +294,14 @@ def bil_reduce_project(Y, x, Bm, sp):
     return Sm, torch.bmm(Bm.transpose(1, 2), Sm)
 
 
-def bil_project_bwd(dP, Sm, Bm, x, sp):
+def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None):
     gB = torch.bmm(Sm, dP.transpose(1, 2))
     dSm = torch.bmm(Bm, dP)
-    return gB, dSm, bil_dot(dSm, x, sp)
+    dY = bil_dot(dSm, x, sp)
+    if dY_accum is not None:
+        dY_accum += dY
+        dY = dY_accum
+    return gB, dSm, dY
 
 
 def _quad_angles(Rc, Ra, Rb, Rd):

@@ -408,3 +408,21 @@ def test_pointwise_product_primitive(n, k):
     if n > 8:
         zz, aa = f32(z)[1:], f32(a)[1:]
         close(K.pm(zz, max(k, 0), aa), CK.pm(z[1:], max(k, 0), a[1:]), rtol=2e-5, atol=3e-6 * max(1.0, float(a.abs().max())))
+
+
+@pytest.mark.parametrize("S,C,I,E,J,mk", [(7, 64, 16, 300, 300, 12), (49, 32, 32, 40, 200, 70)])
+def test_bilinear_adjoint_accumulates_y_gradient(S, C, I, E, J, mk):
+    """gn_bil_project_bwd_acc_f32: the Y gradient of a second consumer is added into the first one's buffer."""
+    g = torch.Generator().manual_seed(S + E)
+    seg = torch.randint(0, mk, (E,), generator=g)
+    T = int(seg.sum())
+    red = torch.repeat_interleave(torch.arange(E), seg)
+    exp = torch.randint(0, J, (T,), generator=g)
+    from gemnet_pytorch_amd.graph import SegmentPlan
+    dev, cpu = SegmentPlan(red.to(DEV), exp.to(DEV), E, J), SegmentPlan(red, exp, E, J)
+    dP1, dP2, Sm, Bm, x = rnd(g, E, I, C), rnd(g, E, I, C), rnd(g, E, S, C), rnd(g, E, S, I), rnd(g, J, C)
+    _, _, dY = K.bil_project_bwd(f32(dP1), f32(Sm), f32(Bm), f32(x), dev)
+    _, _, dY2 = K.bil_project_bwd(f32(dP2), f32(Sm), f32(Bm), f32(x), dev, dY_accum=dY)
+    assert dY2.data_ptr() == dY.data_ptr()
+    ref = CK.bil_project_bwd(dP1, Sm, Bm, x, cpu)[2] + CK.bil_project_bwd(dP2, Sm, Bm, x, cpu)[2]
+    close(dY2, ref, atol=2e-4 * max(1.0, float(ref.abs().max())))
