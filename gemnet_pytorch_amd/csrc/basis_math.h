@@ -172,13 +172,9 @@ template <int JO> GN_HD Jet jmul_o(const Jet& a, const Jet& b) {
 // phase-free associated Legendre Q_l^m carried to order JO.  cos/sin(m phi) by the angle-addition recurrence from
 // one sincos (error ~ m eps) instead of one f64 sincos per m.
 template <int JO, typename F>
-GN_HD void ylm_core(double theta, double ph, int S, F visit) {
-  double sn, cs;
-  sincos(theta, &sn, &cs);
+GN_HD void ylm_core_sc(double sn, double cs, double s1, double c1, int S, F visit) {
   const Jet js = {sn, cs, -sn};
   const Jet jc = {cs, -sn, -cs};
-  double s1, c1;
-  sincos(ph, &s1, &c1);
   double cm = 1.0, sm = 0.0;   // cos(m phi), sin(m phi)
   Jet qmm = {1.0, 0.0, 0.0};
   for (int m = 0; m < S; ++m) {
@@ -200,6 +196,14 @@ GN_HD void ylm_core(double theta, double ph, int S, F visit) {
       visit(l, m, l * l, ql, cm, sm, (m == 0 ? 1.0 : 1.4142135623730951) * ylm_prefactor_tab(l, m));
     }
   }
+}
+
+template <int JO, typename F>
+GN_HD void ylm_core(double theta, double ph, int S, F visit) {
+  double sn, cs, s1, c1;
+  sincos(theta, &sn, &cs);
+  sincos(ph, &s1, &c1);
+  ylm_core_sc<JO>(sn, cs, s1, c1, S, visit);
 }
 
 // Visit every real Y_j(theta, phi), j < S*S, with its kt-th theta / kp-th phi derivative:
@@ -232,9 +236,11 @@ GN_HD void ylm_visit(double theta, double ph, int S, int kt, int kp, F emit) {
 
 // Both first derivatives contracted with g in one pass (the geometry adjoint needs exactly these two):
 //   g_theta = sum_j g[j] dY_j/dtheta,   g_phi = sum_j g[j] dY_j/dphi
-GN_HD void ylm_dot_grad(double theta, double ph, int S, const float* g, double& g_theta, double& g_phi) {
+// (sin, cos) of both angles given directly: angles that come from atan2(y, x) never need the atan2 nor the sincos)
+GN_HD void ylm_dot_grad_sc(double sn, double cs, double s1, double c1, int S, const float* g, double& g_theta,
+                           double& g_phi) {
   double at = 0.0, ap = 0.0;
-  ylm_core<1>(theta, ph, S, [&](int l, int m, int base, const Jet& ql, double cm, double sm, double pf) {
+  ylm_core_sc<1>(sn, cs, s1, c1, S, [&](int l, int m, int base, const Jet& ql, double cm, double sm, double pf) {
     if (m == 0) {
       at += (double)g[base] * pf * ql.d1;
     } else {
@@ -245,6 +251,26 @@ GN_HD void ylm_dot_grad(double theta, double ph, int S, const float* g, double& 
   });
   g_theta = at;
   g_phi = ap;
+}
+
+GN_HD void ylm_dot_grad(double theta, double ph, int S, const float* g, double& g_theta, double& g_phi) {
+  double sn, cs, s1, c1;
+  sincos(theta, &sn, &cs);
+  sincos(ph, &s1, &c1);
+  ylm_dot_grad_sc(sn, cs, s1, c1, S, g, g_theta, g_phi);
+}
+
+// values only, from (sin, cos) of both angles
+GN_HD void ylm_row_sc(double sn, double cs, double s1, double c1, int S, float* o) {
+  ylm_core_sc<0>(sn, cs, s1, c1, S, [o](int l, int m, int base, const Jet& ql, double cm, double sm, double pf) {
+    const double tv = pf * ql.v;
+    if (m == 0) {
+      o[base] = (float)tv;
+    } else {
+      o[base + m] = (float)(tv * cm);
+      o[base + 2 * l + 1 - m] = (float)(tv * sm);
+    }
+  });
 }
 
 // out[j] = d^kt/dtheta^kt d^kp/dphi^kp Y_j(theta, phi), j < S*S

@@ -154,6 +154,17 @@ __device__ __forceinline__ float angle_uv(V3 u, V3 v) {
   const float yn = sqrtf(dot(w, w));
   return atan2f(yn < 1e-9f ? 1e-9f : yn, dot(u, v));
 }
+// (sin, cos) of that angle without atan2 / sincos: with y = max(|u x v|, 1e-9), x = u.v: sin = y / hypot(x, y),
+// cos = x / hypot(x, y)  (exactly the sine and cosine of atan2(y, x))
+__device__ __forceinline__ void angle_uv_sc(V3 u, V3 v, double& sn, double& cs) {
+  const V3 w = cross(u, v);
+  const float yn = sqrtf(dot(w, w));
+  const double y = yn < 1e-9f ? 1e-9 : (double)yn;
+  const double x = (double)dot(u, v);
+  const double ir = 1.0 / sqrt(x * x + y * y);
+  sn = y * ir;
+  cs = x * ir;
+}
 __device__ __forceinline__ void angle_uv_bwd(V3 u, V3 v, float gth, V3& gu, V3& gv) {
   const V3 w = cross(u, v);
   const float x = dot(u, v);
@@ -183,9 +194,10 @@ __global__ void quad_basis_fwd_kernel(const float* __restrict__ R, const int32_t
     const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
     const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
     const V3 uba = (-1.0f) * uab;
-    const float phi_cab = angle_uv(uab, uac);
-    const float theta = angle_uv(reject(uac, uab), reject(ubd, uba));
-    ylm_row((double)phi_cab, (double)theta, S, 0, 0, Y + q * (int64_t)S * S);
+    double sn, cs, s1, c1;   // polar angle Phi_cab, azimuth Theta_cabd
+    angle_uv_sc(uab, uac, sn, cs);
+    angle_uv_sc(reject(uac, uab), reject(ubd, uba), s1, c1);
+    ylm_row_sc(sn, cs, s1, c1, S, Y + q * (int64_t)S * S);
   }
 }
 
@@ -200,11 +212,12 @@ __global__ void quad_basis_bwd_kernel(const float* __restrict__ gY, const float*
     const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
     const V3 uba = (-1.0f) * uab;
     const V3 p1 = reject(uac, uab), p2 = reject(ubd, uba);
-    const float phi_cab = angle_uv(uab, uac);
-    const float theta = angle_uv(p1, p2);
+    double sn, cs, s1, c1;
+    angle_uv_sc(uab, uac, sn, cs);
+    angle_uv_sc(p1, p2, s1, c1);
     const float* g = gY + q * (int64_t)S * S;
     double g_first, g_second;   // d/d(polar angle = Phi_cab), d/d(azimuth = Theta_cabd)
-    ylm_dot_grad((double)phi_cab, (double)theta, S, g, g_first, g_second);
+    ylm_dot_grad_sc(sn, cs, s1, c1, S, g, g_first, g_second);
     const float g_phi = (float)g_first, g_th = (float)g_second;
     V3 g_ab, g_ac, gp1, gp2, t1, t2, g_bd, g_ba;
     angle_uv_bwd(uab, uac, g_phi, g_ab, g_ac);
