@@ -186,51 +186,77 @@ __device__ __forceinline__ void reject_bwd(V3 x, V3 n, V3 gr, V3& gx, V3& gn) {
   gn = (-a) * gr - gn_dot * ((1.0f / q) * x - (2.0f * s / (q * q)) * n);
 }
 
-// Y[q, :] = Y_lm(Phi_cab, Theta_cabd)
-__global__ void quad_basis_fwd_kernel(const float* __restrict__ R, const int32_t* __restrict__ qc,
-                                      const int32_t* __restrict__ qa, const int32_t* __restrict__ qb,
-                                      const int32_t* __restrict__ qd, float* __restrict__ Y, int64_t Q, int S) {
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {
-    const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
-    const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
-    const V3 uba = (-1.0f) * uab;
-    double sn, cs, s1, c1;   // polar angle Phi_cab, azimuth Theta_cabd
-    angle_uv_sc(uab, uac, sn, cs);
-    angle_uv_sc(reject(uac, uab), reject(ubd, uba), s1, c1);
-    ylm_row_sc(sn, cs, s1, c1, S, Y + q * (int64_t)S * S);
+// Y[q, :] = Y_lm(Phi_cab, Theta_cabd).  One thread per quadruplet; a thread's S^2 = 49 outputs are 196 B apart from
+// its neighbour's, so rows go through LDS (row stride 49 words: conflict-free) and leave as one contiguous,
+// coalesced block per workgroup (the direct 4-byte stores ran at a quarter of the write bandwidth).
+__global__ __launch_bounds__(256) void quad_basis_fwd_kernel(const float* __restrict__ R, const int32_t* __restrict__ qc,
+                                                             const int32_t* __restrict__ qa,
+                                                             const int32_t* __restrict__ qb,
+                                                             const int32_t* __restrict__ qd, float* __restrict__ Y,
+                                                             int64_t Q, int S) {
+  extern __shared__ float rows[];   // [256][S*S]
+  const int SS = S * S;
+  for (int64_t q0 = (int64_t)blockIdx.x * 256; q0 < Q; q0 += (int64_t)gridDim.x * 256) {
+    const int64_t q = q0 + threadIdx.x;
+    if (q < Q) {
+      const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
+      const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
+      const V3 uba = (-1.0f) * uab;
+      double sn, cs, s1, c1;   // polar angle Phi_cab, azimuth Theta_cabd
+      angle_uv_sc(uab, uac, sn, cs);
+      angle_uv_sc(reject(uac, uab), reject(ubd, uba), s1, c1);
+      ylm_row_sc(sn, cs, s1, c1, S, rows + threadIdx.x * SS);
+    }
+    __syncthreads();
+    const int64_t n = (Q - q0 < 256 ? Q - q0 : 256) * SS;
+    float* __restrict__ dst = Y + q0 * SS;
+    for (int64_t i = threadIdx.x; i < n; i += 256) dst[i] = rows[i];
+    __syncthreads();
   }
 }
 
-// Gc, Gb, Gd (Q,3): dE/dR of atoms c, b, d per quadruplet (dE/dR_a = -(Gc+Gb+Gd)) given gY (Q,S^2)
-__global__ void quad_basis_bwd_kernel(const float* __restrict__ gY, const float* __restrict__ R,
-                                      const int32_t* __restrict__ qc, const int32_t* __restrict__ qa,
-                                      const int32_t* __restrict__ qb, const int32_t* __restrict__ qd,
-                                      float* __restrict__ Gc, float* __restrict__ Gb, float* __restrict__ Gd,
-                                      int64_t Q, int S) {
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {
-    const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
-    const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
-    const V3 uba = (-1.0f) * uab;
-    const V3 p1 = reject(uac, uab), p2 = reject(ubd, uba);
-    double sn, cs, s1, c1;
-    angle_uv_sc(uab, uac, sn, cs);
-    angle_uv_sc(p1, p2, s1, c1);
-    const float* g = gY + q * (int64_t)S * S;
-    double g_first, g_second;   // d/d(polar angle = Phi_cab), d/d(azimuth = Theta_cabd)
-    ylm_dot_grad_sc(sn, cs, s1, c1, S, g, g_first, g_second);
-    const float g_phi = (float)g_first, g_th = (float)g_second;
-    V3 g_ab, g_ac, gp1, gp2, t1, t2, g_bd, g_ba;
-    angle_uv_bwd(uab, uac, g_phi, g_ab, g_ac);
-    angle_uv_bwd(p1, p2, g_th, gp1, gp2);
-    reject_bwd(uac, uab, gp1, t1, t2);   // d p1 / d(uac, uab)
-    g_ac = g_ac + t1; g_ab = g_ab + t2;
-    reject_bwd(ubd, uba, gp2, g_bd, g_ba);
-    g_ab = g_ab - g_ba;                   // uba = -uab
-    // uac = Rc - Ra, uab = Rb - Ra, ubd = Rd - Rb
-    const V3 gc = g_ac, gd = g_bd, gb = g_ab - g_bd;
-    Gc[3 * q] = gc.x; Gc[3 * q + 1] = gc.y; Gc[3 * q + 2] = gc.z;
-    Gb[3 * q] = gb.x; Gb[3 * q + 1] = gb.y; Gb[3 * q + 2] = gb.z;
-    Gd[3 * q] = gd.x; Gd[3 * q + 1] = gd.y; Gd[3 * q + 2] = gd.z;
+// Gc, Gb, Gd (Q,3): dE/dR of atoms c, b, d per quadruplet (dE/dR_a = -(Gc+Gb+Gd)) given gY (Q,S^2); the gY rows of
+// a workgroup are fetched coalesced into LDS first
+__global__ __launch_bounds__(256) void quad_basis_bwd_kernel(const float* __restrict__ gY, const float* __restrict__ R,
+                                                             const int32_t* __restrict__ qc,
+                                                             const int32_t* __restrict__ qa,
+                                                             const int32_t* __restrict__ qb,
+                                                             const int32_t* __restrict__ qd, float* __restrict__ Gc,
+                                                             float* __restrict__ Gb, float* __restrict__ Gd, int64_t Q,
+                                                             int S) {
+  extern __shared__ float rows[];   // [256][S*S]
+  const int SS = S * S;
+  for (int64_t q0 = (int64_t)blockIdx.x * 256; q0 < Q; q0 += (int64_t)gridDim.x * 256) {
+    const int64_t n = (Q - q0 < 256 ? Q - q0 : 256) * SS;
+    const float* __restrict__ src = gY + q0 * SS;
+    for (int64_t i = threadIdx.x; i < n; i += 256) rows[i] = src[i];
+    __syncthreads();
+    const int64_t q = q0 + threadIdx.x;
+    if (q < Q) {
+      const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
+      const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
+      const V3 uba = (-1.0f) * uab;
+      const V3 p1 = reject(uac, uab), p2 = reject(ubd, uba);
+      double sn, cs, s1, c1;
+      angle_uv_sc(uab, uac, sn, cs);
+      angle_uv_sc(p1, p2, s1, c1);
+      double g_first, g_second;   // d/d(polar angle = Phi_cab), d/d(azimuth = Theta_cabd)
+      ylm_dot_grad_sc(sn, cs, s1, c1, S, rows + threadIdx.x * SS, g_first, g_second);
+      const float g_phi = (float)g_first, g_th = (float)g_second;
+      V3 g_ab, g_ac, gp1, gp2, t1, t2, g_bd, g_ba;
+      angle_uv_bwd(uab, uac, g_phi, g_ab, g_ac);
+      angle_uv_bwd(p1, p2, g_th, gp1, gp2);
+      reject_bwd(uac, uab, gp1, t1, t2);   // d p1 / d(uac, uab)
+      g_ac = g_ac + t1; g_ab = g_ab + t2;
+      reject_bwd(ubd, uba, gp2, g_bd, g_ba);
+      g_ab = g_ab - g_ba;                   // uba = -uab
+      // uac = Rc - Ra, uab = Rb - Ra, ubd = Rd - Rb
+      const V3 gc = g_ac, gd = g_bd, gb = g_ab - g_bd;
+      Gc[3 * q] = gc.x; Gc[3 * q + 1] = gc.y; Gc[3 * q + 2] = gc.z;
+      Gb[3 * q] = gb.x; Gb[3 * q + 1] = gb.y; Gb[3 * q + 2] = gb.z;
+      Gd[3 * q] = gd.x; Gd[3 * q + 1] = gd.y; Gd[3 * q + 2] = gd.z;
+    }
+    __syncthreads();
   }
 }
 
@@ -290,8 +316,8 @@ extern "C" int gn_quad_basis_fwd_f32(const float* R, const int32_t* qc, const in
                                      const int32_t* qd, float* Y, int64_t Q, int S, void* stream) {
   if (Q <= 0) return 0;
   if (S > 7) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(quad_basis_fwd_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     R, qc, qa, qb, qd, Y, Q, S);
+  hipLaunchKernelGGL(quad_basis_fwd_kernel, dim3(grid_for(Q)), dim3(256), (size_t)256 * S * S * sizeof(float),
+                     static_cast<hipStream_t>(stream), R, qc, qa, qb, qd, Y, Q, S);
   GN_LAUNCH_CHECK();
   return 0;
 }
@@ -301,8 +327,8 @@ extern "C" int gn_quad_basis_bwd_f32(const float* gY, const float* R, const int3
                                      int64_t Q, int S, void* stream) {
   if (Q <= 0) return 0;
   if (S > 7) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(quad_basis_bwd_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     gY, R, qc, qa, qb, qd, Gc, Gb, Gd, Q, S);
+  hipLaunchKernelGGL(quad_basis_bwd_kernel, dim3(grid_for(Q)), dim3(256), (size_t)256 * S * S * sizeof(float),
+                     static_cast<hipStream_t>(stream), gY, R, qc, qa, qb, qd, Gc, Gb, Gd, Q, S);
   GN_LAUNCH_CHECK();
   return 0;
 }
