@@ -98,6 +98,7 @@ SIGNATURES = {
     "gn_trip_basis_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_quad_basis_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_quad_basis_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "gn_quad_basis_bwd_ld_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp],
     "gn_ssilu_f32": [_vp, _vp, _i64, _i, _vp],
     "gn_dact_mul_f32": [_vp, _vp, _i, _vp, _f, _vp, _vp, _i64, _vp],
 }

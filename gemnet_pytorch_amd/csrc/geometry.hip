@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void quad_basis_bwd_kernel(const float* __rest
                                                              const int32_t* __restrict__ qb,
                                                              const int32_t* __restrict__ qd, float* __restrict__ Gc,
                                                              float* __restrict__ Gb, float* __restrict__ Gd, int64_t Q,
-                                                             int S) {
+                                                             int S, int ldc, int ldb, int ldd) {
   extern __shared__ float rows[];   // [256][S*S]
   const int SS = S * S;
   for (int64_t q0 = (int64_t)blockIdx.x * 256; q0 < Q; q0 += (int64_t)gridDim.x * 256) {
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256) void quad_basis_bwd_kernel(const float* __rest
       g_ab = g_ab - g_ba;                   // uba = -uab
       // uac = Rc - Ra, uab = Rb - Ra, ubd = Rd - Rb
       const V3 gc = g_ac, gd = g_bd, gb = g_ab - g_bd;
-      Gc[3 * q] = gc.x; Gc[3 * q + 1] = gc.y; Gc[3 * q + 2] = gc.z;
-      Gb[3 * q] = gb.x; Gb[3 * q + 1] = gb.y; Gb[3 * q + 2] = gb.z;
-      Gd[3 * q] = gd.x; Gd[3 * q + 1] = gd.y; Gd[3 * q + 2] = gd.z;
+      Gc[ldc * q] = gc.x; Gc[ldc * q + 1] = gc.y; Gc[ldc * q + 2] = gc.z;
+      Gb[ldb * q] = gb.x; Gb[ldb * q + 1] = gb.y; Gb[ldb * q + 2] = gb.z;
+      Gd[ldd * q] = gd.x; Gd[ldd * q + 1] = gd.y; Gd[ldd * q + 2] = gd.z;
     }
     __syncthreads();
   }
@@ -325,10 +325,16 @@ extern "C" int gn_quad_basis_fwd_f32(const float* R, const int32_t* qc, const in
 extern "C" int gn_quad_basis_bwd_f32(const float* gY, const float* R, const int32_t* qc, const int32_t* qa,
                                      const int32_t* qb, const int32_t* qd, float* Gc, float* Gb, float* Gd,
                                      int64_t Q, int S, void* stream) {
+  return gn_quad_basis_bwd_ld_f32(gY, R, qc, qa, qb, qd, Gc, 3, Gb, 3, Gd, 3, Q, S, stream);
+}
+
+extern "C" int gn_quad_basis_bwd_ld_f32(const float* gY, const float* R, const int32_t* qc, const int32_t* qa,
+                                        const int32_t* qb, const int32_t* qd, float* Gc, int ldc, float* Gb, int ldb,
+                                        float* Gd, int ldd, int64_t Q, int S, void* stream) {
   if (Q <= 0) return 0;
-  if (S > 7) return (int)hipErrorInvalidValue;
+  if (S > 7 || ldc < 3 || ldb < 3 || ldd < 3) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(quad_basis_bwd_kernel, dim3(grid_for(Q)), dim3(256), (size_t)256 * S * S * sizeof(float),
-                     static_cast<hipStream_t>(stream), gY, R, qc, qa, qb, qd, Gc, Gb, Gd, Q, S);
+                     static_cast<hipStream_t>(stream), gY, R, qc, qa, qb, qd, Gc, Gb, Gd, Q, S, ldc, ldb, ldd);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -472,3 +472,16 @@ def quad_basis_bwd(gY, R, qc, qa, qb, qd, S):
     check(_lib.load().gn_quad_basis_bwd_f32(ptr(gY), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), ptr(Gb),
                                             ptr(Gd), Q, S, stream()), "gn_quad_basis_bwd_f32")
     return Gc, Gb, Gd
+
+
+def quad_basis_bwd_packed(gY, R, qc, qa, qb, qd, S):
+    """-> Gc (Q,3) and Gbd (Q,8) = [Gb xyz, 0, Gd xyz, 0] (one float4 segmented sum reduces both)."""
+    require_device(gY, R)
+    gY, R = _f32c(gY), _f32c(R)
+    Q = qc.shape[0]
+    Gc = torch.empty((Q, 3), device=R.device, dtype=torch.float32)
+    Gbd = torch.zeros((Q, 8), device=R.device, dtype=torch.float32)
+    base = Gbd.data_ptr()
+    check(_lib.load().gn_quad_basis_bwd_ld_f32(ptr(gY), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), 3,
+                                               base, 8, base + 16, 8, Q, S, stream()), "gn_quad_basis_bwd_ld_f32")
+    return Gc, Gbd

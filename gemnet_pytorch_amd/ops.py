@@ -935,19 +935,26 @@ class _QuadBasis(torch.autograd.Function):
         ri_c, ri_a, ri_b, ri_d, S, plan = ctx.cfg
         if not ctx.needs_input_grad[0]:
             return (None,) * 7
-        Gc, Gb, Gd = K.quad_basis_bwd(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
         if plan is None:
+            Gc, Gb, Gd = K.quad_basis_bwd(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
             gR = (K.segsum(Gc, *ri_c.csr, ri_c.n_rows) + K.segsum(Gb, *ri_b.csr, ri_b.n_rows)
                   + K.segsum(Gd, *ri_d.csr, ri_d.n_rows) - K.segsum(Gc + Gb + Gd, *ri_a.csr, ri_a.n_rows))
         else:
             # two-level sums: the quadruplets of one reduce edge (c -> a) are contiguous and share c and a, so their
             # contributions are first summed per edge with coalesced reads (9 M x 12 B gathered through a
             # permutation by atom ran at 180 GB/s), then the 18 k edge rows go to the atoms
+            # b and d are shared by the quadruplets of one intermediate triplet (a, b, d): [Gb | Gd] rows of 32 B
+            # are summed per intermediate triplet in one float4 pass, then the 0.6 M rows go to the atoms
+            Gc, Gbd = K.quad_basis_bwd_packed(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
             seg, E = plan.quad.seg_off, plan.n_edges
             Ec = K.segsum(Gc, None, seg, E)
-            Ea = Ec + K.segsum(Gb, None, seg, E) + K.segsum(Gd, None, seg, E)
+            Ebd = K.segsum(Gbd, None, seg, E)
+            Ea = Ec + Ebd[:, 0:3] + Ebd[:, 4:7]
+            Ibd = K.segsum(Gbd, *plan.quad.expand.csr, plan.quad.n_expand)
+            rb, rd = plan.quad_geom["b_of_exp"], plan.quad_geom["d_of_exp"]
             gR = (K.segsum(Ec, *plan.id_c.csr, plan.id_c.n_rows) - K.segsum(Ea, *plan.id_a.csr, plan.id_a.n_rows)
-                  + K.segsum(Gb, *ri_b.csr, ri_b.n_rows) + K.segsum(Gd, *ri_d.csr, ri_d.n_rows))
+                  + K.segsum(Ibd[:, 0:3].contiguous(), *rb.csr, rb.n_rows)
+                  + K.segsum(Ibd[:, 4:7].contiguous(), *rd.csr, rd.n_rows))
         return (gR,) + (None,) * 6
 
 

@@ -263,6 +263,11 @@ int gn_quad_basis_fwd_f32(const float* R, const int32_t* qc, const int32_t* qa, 
 int gn_quad_basis_bwd_f32(const float* gY, const float* R, const int32_t* qc, const int32_t* qa,
                           const int32_t* qb, const int32_t* qd, float* Gc, float* Gb, float* Gd, int64_t Q,
                           int S, void* stream);
+/* Same with explicit row pitches of the three outputs (Gb and Gd interleaved in one (Q,8) array let the sum over
+ * the quadruplets of an intermediate triplet run as ONE float4 segmented sum). */
+int gn_quad_basis_bwd_ld_f32(const float* gY, const float* R, const int32_t* qc, const int32_t* qa, const int32_t* qb,
+                             const int32_t* qd, float* Gc, int ldc, float* Gb, int ldb, float* Gd, int ldd, int64_t Q,
+                             int S, void* stream);
 
 /* ---- pointwise -------------------------------------------------------------------------
  * out[i] = d^k/dx^k ssilu(x[i]), k in {0,1,2,3}   (base_layers.py:51-58) */

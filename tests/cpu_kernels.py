@@ -332,7 +332,14 @@ def quad_basis_bwd(gY, R, qc, qa, qb, qd, S):
     return Gc, Gb, Gd
 
 
-_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+def quad_basis_bwd_packed(gY, R, qc, qa, qb, qd, S):
+    Gc, Gb, Gd = quad_basis_bwd(gY, R, qc, qa, qb, qd, S)
+    Gbd = torch.zeros((Gb.shape[0], 8), dtype=Gb.dtype)
+    Gbd[:, 0:3], Gbd[:, 4:7] = Gb, Gd
+    return Gc, Gbd
+
+
+_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 
