@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __r
                                                                 const float* __restrict__ dSm,
                                                                 const int32_t* __restrict__ seg_off,
                                                                 float* __restrict__ dxt, int64_t E) {
-  constexpr int S = 49, C = 32;
+  constexpr int S = 49, C = 32, TT = 16, LDY = 53;   // 16 quadruplets per row tile; LDS row pitch 53 (odd: no conflicts)
+  __shared__ float ysm[4][2][TT * LDY];               // per wave, double buffered
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, lg = lane >> 4;
   const int64_t e = (int64_t)blockIdx.x * 4 + wave;
@@ -580,23 +581,42 @@ __global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __r
     for (int nt = 0; nt < 2; ++nt) bd[kk][nt] = sr < S ? De[sr * C + 16 * nt + l15] : 0.f;
   }
   const int t0 = seg_off[e], t1 = seg_off[e + 1];
-  auto loady = [&](int tb, float (&a)[13]) {
-    const int tq = tb + l15;
-    const bool ok = tq < t1;
-    const float* __restrict__ yr = Y + (int64_t)tq * S + lg;
+  // the 16 x 49 block of Y of a row tile is one contiguous run of 784 floats: 13 coalesced loads per lane, parked in
+  // this wave's LDS buffer in [t][s] layout, then read back as MFMA A fragments (lane (l15, lg) <- Y[t = l15][4 kk + lg])
+  float st[13];
+  auto fetch = [&](int tb) {
+    const int n = (t1 - tb < TT ? t1 - tb : TT) * S;
+    const float* __restrict__ src = Y + (int64_t)tb * S;
 #pragma unroll
-    for (int kk = 0; kk < 12; ++kk) a[kk] = ok ? yr[4 * kk] : 0.f;
-    a[12] = (ok && lg == 0) ? yr[48] : 0.f;
+    for (int j = 0; j < 13; ++j) {
+      const int i = lane + 64 * j;
+      st[j] = i < n ? src[i] : 0.f;
+    }
   };
-  float a[13], an[13];
-  loady(t0, a);
-  for (int tb = t0; tb < t1; tb += 16) {
-    loady(tb + 16, an);
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      const int i = lane + 64 * j;
+      if (i < TT * S) {
+        const int r = i / S;
+        ysm[wave][buf][r * LDY + (i - r * S)] = st[j];
+      }
+    }
+  };
+  int buf = 0;
+  if (t0 < t1) { fetch(t0); park(0); }
+  for (int tb = t0; tb < t1; tb += TT) {
+    const bool more = tb + TT < t1;
+    if (more) fetch(tb + TT);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's parked rows are visible to its own reads
+    __builtin_amdgcn_wave_barrier();
+    const float* __restrict__ yb = ysm[wave][buf] + l15 * LDY + lg;
     v4f_b c0 = (v4f_b){0.f, 0.f, 0.f, 0.f}, c1 = (v4f_b){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 13; ++kk) {
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bd[kk][0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bd[kk][1], c1, 0, 0, 0);
+      const float a = (kk < 12 || lg == 0) ? yb[4 * kk] : 0.f;
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bd[kk][0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bd[kk][1], c1, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -607,8 +627,8 @@ __global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __r
         o[16] = c1[r];
       }
     }
-#pragma unroll
-    for (int kk = 0; kk < 13; ++kk) a[kk] = an[kk];
+    if (more) park(buf ^ 1);
+    buf ^= 1;
   }
 }
 
