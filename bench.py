@@ -113,8 +113,12 @@ class LaunchTimer:
             b, m, n = o.shape
             k = args[0].numel() // (b * m)
             return 2.0 * b * m * n * k, (args[0].numel() + args[1].numel() + o.numel()) * f32
+        if name == "bil_dy_multi":
+            sp, nb = args[2], len(args[0])
+            S, C = args[0][0].shape[1], args[0][0].shape[2]
+            return 2.0 * nb * sp.size * S * C, nb * (sp.n_reduce * S * C + sp.n_expand * C) * f32 + sp.size * (S * f32 + 4)
         if name in ("bil_reduce", "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd"):
-            sp = args[-1]
+            sp = next(a for a in reversed(args) if hasattr(a, "n_reduce"))
             if name == "bil_project_bwd":
                 S, C = args[1].shape[1], args[1].shape[2]
             else:
@@ -127,7 +131,7 @@ class LaunchTimer:
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
     FAMILIES = ["gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
-                "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd", "bessel_rbf", "sph_radial", "ylm0",
+                "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "bessel_rbf", "sph_radial", "ylm0",
                 "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
                 "quad_basis_bwd"]
 

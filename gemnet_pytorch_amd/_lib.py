@@ -79,6 +79,7 @@ SIGNATURES = {
     "gn_pm_f32": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i64, _vp],
     "gn_adamw_ema_step_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp],
     "gn_bil_expand_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bil_dy_multi_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
     dSm[e * (int64_t)S * C + o] = acc;
   }
   __syncthreads();
+  if (!dY) return;
   const int t0 = seg_off[e], t1 = seg_off[e + 1];
   const int n = (t1 - t0) * S;
   for (int p = tid; p < n; p += nt) {
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
       }
     }
   }
+  if (!dY) return;   // deferred: the caller sums the Y gradient of several blocks in gn_bil_dy_multi_f32
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   // ---- (3) dY[t,s] = sum_c x[g(t),c] dSm[s,c]: Bop fragments (rows of dSm, k = c contiguous) once per edge
@@ -632,6 +634,85 @@ __global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __r
   }
 }
 
+// dY[t,s] = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c] over the nb <= 4 interaction blocks that share one tensor basis:
+// written ONCE instead of written by the first block and read-modify-written by every further one (the (Q,49) array is
+// 1.8 GB at B = 32).  One wave per reduce edge; the B fragments of all nb blocks stay in registers.
+struct gn_dy_multi_args {
+  const float* dS[4];
+  const float* x[4];
+  int nb;
+};
+
+__global__ __launch_bounds__(256) void bil_dy_multi_mfma49_kernel(const gn_dy_multi_args a,
+                                                                  const int32_t* __restrict__ expand_idx,
+                                                                  const int32_t* __restrict__ seg_off,
+                                                                  float* __restrict__ dY, int64_t E) {
+  constexpr int S = 49, C = 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+  const int nb = a.nb;
+  float4 bd[4][4][2];   // [block][s tile][j]: dSm_b[e][16 nt + l15][16 j + 4 lg ..]
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int sr = 16 * nt + l15;
+        bd[b][nt][j] = (b < nb && sr < S)
+                           ? *reinterpret_cast<const float4*>(a.dS[b] + (e * S + sr) * C + 16 * j + 4 * lg)
+                           : z4;
+      }
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  for (int tb = t0; tb < t1; tb += 16) {
+    const int tq = tb + l15;
+    const bool ok = tq < t1;
+    const int64_t g = ok ? expand_idx[tq] : 0;
+    float4 ax[4][2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < nb && ok) {
+        const float* __restrict__ xr = a.x[b] + g * C + 4 * lg;
+        ax[b][0] = *reinterpret_cast<const float4*>(xr);
+        ax[b][1] = *reinterpret_cast<const float4*>(xr + 16);
+      } else {
+        ax[b][0] = z4; ax[b][1] = z4;
+      }
+    }
+    v4f_b y4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      v4f_b c4 = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b < nb) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ax[b][j], q), comp(bd[b][nt][j], q), c4, 0, 0, 0);
+        }
+      }
+      y4[nt] = c4;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tr = tb + 4 * lg + r;
+      if (tr < t1) {
+        float* __restrict__ yo = dY + (int64_t)tr * S + l15;
+        yo[0] = y4[0][r];
+        yo[16] = y4[1][r];
+        yo[32] = y4[2][r];
+        if (l15 == 0) yo[48] = y4[3][r];
+      }
+    }
+  }
+}
+
 inline bool ok_channels(int C) { return C > 0 && C <= 256 && (256 % C) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -757,6 +838,24 @@ extern "C" int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, cons
   if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(bil_project_bwd_kernel, dim3((unsigned)E), dim3(128), smem, st, dP, Sm, B, x, expand_idx, seg_off,
                      gB, dSm, dY, S, C, I, accumulate);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_dy_multi_f32(const float* const* dSm_list, const float* const* x_list, int nb,
+                                   const int32_t* expand_idx, const int32_t* seg_off, float* dY, int64_t E, int S, int C,
+                                   void* stream) {
+  if (E <= 0 || nb <= 0) return 0;
+  if (nb > 4 || S != 49 || C != 32) return (int)hipErrorInvalidValue;   // tensor basis of GemNet-Q only
+  gn_dy_multi_args a;
+  a.nb = nb;
+  for (int b = 0; b < 4; ++b) {
+    a.dS[b] = b < nb ? dSm_list[b] : nullptr;
+    a.x[b] = b < nb ? x_list[b] : nullptr;
+    if (b < nb && (!aligned16(a.dS[b]) || !aligned16(a.x[b]))) return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(bil_dy_multi_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                     expand_idx, seg_off, dY, E);
   GN_LAUNCH_CHECK();
   return 0;
 }

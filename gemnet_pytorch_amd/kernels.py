@@ -434,7 +434,22 @@ def bil_reduce_project(Y, x, B, sp):
     return Sm, P
 
 
-def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None):
+def bil_dy_multi(dSm_list, x_list, sp):
+    """dY (T,S) = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c] for the blocks b that share one tensor basis (one pass)."""
+    require_device(*dSm_list, *x_list)
+    dSm_list = [_f32c(t) for t in dSm_list]
+    x_list = [_f32c(t) for t in x_list]
+    nb = len(dSm_list)
+    E, S, C = dSm_list[0].shape
+    dY = torch.empty((sp.size, S), device=x_list[0].device, dtype=torch.float32)
+    arr = ctypes.c_void_p * nb
+    check(_lib.load().gn_bil_dy_multi_f32(arr(*[t.data_ptr() for t in dSm_list]), arr(*[t.data_ptr() for t in x_list]),
+                                          nb, ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(dY), E, S, C, stream()),
+          "gn_bil_dy_multi_f32")
+    return dY
+
+
+def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True):
     """Fused adjoint of K2 and of K1 w.r.t. Y -> (gB (E,S,I), dSm (E,S,C), dY (T,S)); with `dY_accum` the Y
     gradient is ADDED into that (T,S) buffer (and returned) instead of written to a fresh one."""
     require_device(dP, Sm, B, x)
@@ -445,7 +460,10 @@ def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None):
     dSm = torch.empty((E, S, C), device=x.device, dtype=torch.float32)
     if dY_accum is not None:
         assert dY_accum.shape == (sp.size, S) and dY_accum.is_contiguous() and dY_accum.dtype == torch.float32
-    dY = dY_accum if dY_accum is not None else torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
+    if not want_dY:
+        dY = None
+    else:
+        dY = dY_accum if dY_accum is not None else torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
     check(_lib.load().gn_bil_project_bwd_acc_f32(ptr(dP), ptr(Sm), ptr(B), ptr(x), ptr(sp.expand.idx32),
                                                  ptr(sp.seg_off), ptr(gB), ptr(dSm), ptr(dY), E, S, C, I,
                                                  int(dY_accum is not None), stream()), "gn_bil_project_bwd_acc_f32")

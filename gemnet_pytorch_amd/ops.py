@@ -536,6 +536,7 @@ class GradSink:
     def __init__(self):
         self.uses = 0
         self.buf = None
+        self.pending = []   # (dSm_b, x_b) of the consumers whose Y gradient is deferred to one combined pass
 
 
 def share_gradient(t):
@@ -573,7 +574,16 @@ class _FusedBilinear(torch.autograd.Function):
         W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)
         dP = K.gemm(g, W2, alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is already (N=I*C, K=O)
         sink = ctx.sink
-        if sink is not None and need[1]:
+        if sink is not None and need[1] and Sm.shape[1] == 49 and Sm.shape[2] == 32 and sink.uses + len(sink.pending) <= 4:
+            # tensor basis: gB and dSm now, the Y gradient of all consumers in ONE pass when the last one arrives
+            gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False)
+            sink.pending.append((dSm, x))
+            sink.uses -= 1
+            gsph = None
+            if sink.uses == 0:
+                gsph = K.bil_dy_multi([d for d, _ in sink.pending], [xx for _, xx in sink.pending], sp)
+                sink.pending = []
+        elif sink is not None and need[1]:
             # the Y gradient is summed across the consumers of `sph` inside the kernel (see GradSink)
             gB, dSm, sink.buf = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, dY_accum=sink.buf)
             sink.uses -= 1

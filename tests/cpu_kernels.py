@@ -294,9 +294,15 @@ def bil_reduce_project(Y, x, Bm, sp):
     return Sm, torch.bmm(Bm.transpose(1, 2), Sm)
 
 
-def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None):
+def bil_dy_multi(dSm_list, x_list, sp):
+    return sum(bil_dot(d, x, sp) for d, x in zip(dSm_list, x_list))
+
+
+def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True):
     gB = torch.bmm(Sm, dP.transpose(1, 2))
     dSm = torch.bmm(Bm, dP)
+    if not want_dY:
+        return gB, dSm, None
     dY = bil_dot(dSm, x, sp)
     if dY_accum is not None:
         dY_accum += dY
@@ -339,7 +345,7 @@ def quad_basis_bwd_packed(gY, R, qc, qa, qb, qd, S):
     return Gc, Gbd
 
 
-_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -426,3 +426,30 @@ def test_bilinear_adjoint_accumulates_y_gradient(S, C, I, E, J, mk):
     assert dY2.data_ptr() == dY.data_ptr()
     ref = CK.bil_project_bwd(dP1, Sm, Bm, x, cpu)[2] + CK.bil_project_bwd(dP2, Sm, Bm, x, cpu)[2]
     close(dY2, ref, atol=2e-4 * max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("nb", [1, 2, 4])
+def test_bilinear_deferred_y_gradient_of_several_blocks(nb):
+    """gn_bil_project_bwd with dY == NULL + gn_bil_dy_multi_f32: the tensor-basis Y gradient of nb blocks in one pass."""
+    S, C, I, E, J, mk = 49, 32, 32, 50, 260, 75
+    g = torch.Generator().manual_seed(nb)
+    seg = torch.randint(0, mk, (E,), generator=g)
+    seg[3] = 0
+    T = int(seg.sum())
+    red = torch.repeat_interleave(torch.arange(E), seg)
+    exp = torch.randint(0, J, (T,), generator=g)
+    from gemnet_pytorch_amd.graph import SegmentPlan
+    dev, cpu = SegmentPlan(red.to(DEV), exp.to(DEV), E, J), SegmentPlan(red, exp, E, J)
+    ref = 0
+    dS_dev, x_dev = [], []
+    for _ in range(nb):
+        dP, Sm, Bm, x = rnd(g, E, I, C), rnd(g, E, S, C), rnd(g, E, S, I), rnd(g, J, C)
+        gB, dSm, dY = K.bil_project_bwd(f32(dP), f32(Sm), f32(Bm), f32(x), dev, want_dY=False)
+        rB, rS, rY = CK.bil_project_bwd(dP, Sm, Bm, x, cpu)
+        assert dY is None
+        close(gB, rB, atol=2e-4 * float(rB.abs().max()))
+        close(dSm, rS, atol=2e-4 * float(rS.abs().max()))
+        ref = ref + rY
+        dS_dev.append(dSm)
+        x_dev.append(f32(x))
+    close(K.bil_dy_multi(dS_dev, x_dev, dev), ref, atol=3e-4 * max(1.0, float(ref.abs().max())))
