@@ -85,6 +85,7 @@ SIGNATURES = {
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_bil_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_reduce_t_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bil_reduce_t_grouped_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_dot_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_reduce_project_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_project_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],

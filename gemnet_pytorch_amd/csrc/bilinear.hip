@@ -90,6 +90,89 @@ __global__ __launch_bounds__(256) void bil_reduce_t_kernel(const float* __restri
   dx[j * C + c] = acc + acc2;
 }
 
+// Same adjoint for index sets where r(t) and g(t) always fall in the same small GROUP of rows — the triplets
+// c->a<-b: reduce edge (c->a) and expand edge (b->a) both end in atom a, so the ~deg(a) blocks dSm[e] of the edges
+// into a serve all deg(a)^2 triplets around a.  The ungrouped kernel above pulls dSm[r(t)] (S*C floats) through
+// L2 once per triplet (332 k x 1.8 KB = 600 MB, 315 MB of it missing to HBM at B = 32); here one workgroup owns one
+// atom, parks its dSm blocks in LDS once (coalesced), and every expand row of the atom reads them from there.
+// Traffic: Y + dSm once + dx.
+// One wave per expand row (C = 64 lanes = channels), 16 waves per workgroup, two rows of a wave in flight.  The
+// entries of a row's transposed segment are fetched 64 at a time, one per lane (grp_kseg -> permT, rposT -> Y:
+// three dependent load rounds per ROW, overlapping the tile fill, instead of three per triplet) and handed to
+// the whole wave with v_readlane; the inner loop is then LDS reads and FMAs only.
+template <int S>
+struct grouped_row {
+  int j, k0, k1, p;
+  float y[S];
+};
+
+template <int S>
+__global__ __launch_bounds__(1024) void bil_reduce_t_grouped_kernel(
+    const float* __restrict__ Y, const float* __restrict__ dSm, const int32_t* __restrict__ grp_rows,
+    const int32_t* __restrict__ grp_off, const int2* __restrict__ grp_kseg, const int32_t* __restrict__ permT,
+    const int32_t* __restrict__ rposT, float* __restrict__ dx) {
+  constexpr int C = 64, SC = S * C, NV = SC / 4;
+  extern __shared__ float gtile[];  // [rows of the group][S*C]
+  const int g = blockIdx.x;
+  const int r0 = grp_off[g], n = grp_off[g + 1] - r0;
+  if (n <= 0) return;
+  for (int i = threadIdx.x; i < n * NV; i += 1024) {
+    const int l = i / NV, v = i - l * NV;
+    const float4 d = reinterpret_cast<const float4*>(dSm + (int64_t)grp_rows[r0 + l] * SC)[v];
+    reinterpret_cast<float4*>(gtile + l * SC)[v] = d;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto fetch = [&](grouped_row<S>& r, int kb) {  // lane i takes entry kb + i of the row's transposed segment
+    const bool on = kb + lane < r.k1;
+    const int t = on ? permT[kb + lane] : 0;
+    r.p = on ? rposT[kb + lane] * SC : 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) r.y[s] = on ? Y[(int64_t)t * S + s] : 0.f;
+  };
+  auto open_row = [&](grouped_row<S>& r, int l) {
+    r.j = -1, r.k0 = r.k1 = 0;
+    if (l >= n) return;
+    const int2 ks = grp_kseg[r0 + l];
+    r.j = __builtin_amdgcn_readfirstlane(grp_rows[r0 + l]);
+    r.k0 = __builtin_amdgcn_readfirstlane(ks.x);
+    r.k1 = __builtin_amdgcn_readfirstlane(ks.y);
+    fetch(r, r.k0);
+  };
+  auto finish_row = [&](grouped_row<S>& r) {
+    if (r.j < 0) return;
+    float acc = 0.f, acc2 = 0.f;
+    for (int kb = r.k0; kb < r.k1; kb += 64) {
+      if (kb != r.k0) fetch(r, kb);
+      const int m = min(64, r.k1 - kb);
+      int k = 0;
+      for (; k + 2 <= m; k += 2) {
+        const float* da = gtile + __builtin_amdgcn_readlane(r.p, k) + lane;
+        const float* db = gtile + __builtin_amdgcn_readlane(r.p, k + 1) + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.y[s]), k)), da[s * C], acc);
+          acc2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.y[s]), k + 1)), db[s * C], acc2);
+        }
+      }
+      if (k < m) {
+        const float* da = gtile + __builtin_amdgcn_readlane(r.p, k) + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+          acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.y[s]), k)), da[s * C], acc);
+      }
+    }
+    dx[(int64_t)r.j * C + lane] = acc + acc2;
+  };
+  grouped_row<S> ra, rb;
+  open_row(ra, w), open_row(rb, w + 16);  // index loads of the first rows overlap the tile fill
+  __syncthreads();
+  for (int l = w; l < n; l += 32) {
+    finish_row(ra), finish_row(rb);
+    open_row(ra, l + 32), open_row(rb, l + 48);
+  }
+}
+
 // Same adjoint, grouped by REDUCE edge instead of by expand row:  dxt[t,c] = sum_s Y[t,s] * dSm[r(t),s,c].
 // For the tensor basis (S = 49) the expand-row form above re-reads the 6 KB block dSm[r(t)] for every quadruplet
 // (9 M x 6.3 KB = 56 GB of L2 traffic per launch at B = 32: 3.8 ms).  Quadruplets are sorted by reduce edge, so
@@ -752,6 +835,28 @@ extern "C" int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32
   } else {
     return (int)hipErrorInvalidValue;
   }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_reduce_t_grouped_f32(const float* Y, const float* dSm, const int32_t* grp_rows,
+                                           const int32_t* grp_off, const int32_t* grp_kseg, const int32_t* permT,
+                                           const int32_t* rposT, float* dx, int64_t G, int max_rows, int S, int C,
+                                           void* stream) {
+  if (G <= 0) return 0;
+  if (C != 64 || S != 7 || max_rows < 1) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)max_rows * S * C * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static size_t lds_max = 0;
+  if (lds > 64 * 1024 && lds > lds_max) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_reduce_t_grouped_kernel<7>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    lds_max = 160 * 1024;
+  }
+  hipLaunchKernelGGL(bil_reduce_t_grouped_kernel<7>, dim3((unsigned)G), dim3(1024), lds, st, Y, dSm, grp_rows, grp_off,
+                     reinterpret_cast<const int2*>(grp_kseg), permT, rposT, dx);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -58,6 +58,30 @@ class SegmentPlan:
     def seg_off(self):
         return self.reduce.csr[1]
 
+    def set_row_groups(self, row_group: torch.Tensor, n_groups: int):
+        """Declare that r(t) and g(t) of every entry fall in the same group of rows (`row_group[row]`), as the
+        triplets c->a<-b do with the target atom a of both edges (data_container.py:262-300)."""
+        assert self.n_reduce == self.n_expand == int(row_group.shape[0])
+        self._row_group, self._n_groups, self._groups = row_group, int(n_groups), None
+
+    @property
+    def groups(self):
+        """(grp_rows, grp_off, grp_kseg, rposT, max_rows) for gn_bil_reduce_t_grouped_f32, or None."""
+        if getattr(self, "_row_group", None) is None:
+            return None
+        if self._groups is None:
+            key = self._row_group
+            rows = torch.argsort(key, stable=True)
+            off = _seg_offsets_sorted(key[rows], self._n_groups)
+            rank = torch.empty_like(rows)
+            rank[rows] = torch.arange(rows.shape[0], device=rows.device) - off.to(torch.int64)[key[rows]]
+            permT, segT = self.expand.csr
+            rposT = rank[self.reduce.idx64[permT.to(torch.int64)]].to(torch.int32).contiguous()
+            kseg = torch.stack([segT[:-1][rows], segT[1:][rows]], dim=1).to(torch.int32).contiguous()
+            max_rows = int((off[1:] - off[:-1]).max().item()) if rows.shape[0] else 0
+            self._groups = (rows.to(torch.int32).contiguous(), off, kseg, rposT, max_rows)
+        return self._groups
+
 
 class GraphPlan:
     """All index plans of one batch.  Built once per batch (`GraphPlan.from_inputs`), cached in the
@@ -80,6 +104,7 @@ class GraphPlan:
         self.id_swap.inverse = self.id_swap  # id_swap is an involution (data_container.py:303-308)
         self.batch_seg = RowIndex(inputs["batch_seg"], self.n_mol, is_sorted=True)
         self.trip = SegmentPlan(inputs["id3_reduce_ca"], inputs["id3_expand_ba"], self.n_edges, self.n_edges)
+        self.trip.set_row_groups(id_a, self.n_atoms)  # reduce c->a and expand b->a share the target atom
         # atom triples of each triplet for the angle c<-a->b (gemnet.py:442-444)
         r, x = inputs["id3_reduce_ca"], inputs["id3_expand_ba"]
         self.t_c, self.t_a, self.t_b = id_c[r], id_a[r], id_c[x]
@@ -137,6 +162,7 @@ class GraphPlan:
         """Materialise every lazily-built CSR (call before hipGraph capture)."""
         for ri in self.row_indices():
             ri.csr
+        self.trip.groups
         return self
 
     def to(self, *args, **kwargs):

@@ -216,6 +216,15 @@ def bil_reduce_t(Y, D, sp):
         check(_lib.load().gn_bil_expand_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(dxt), sp.n_reduce, S, C, stream()),
               "gn_bil_expand_f32")
         return segsum(dxt, permT, segT, sp.n_expand)
+    grp = sp.groups if S == 7 and C == 64 else None
+    if grp is not None and 0 < grp[4] * S * C * 4 <= 160 * 1024:
+        # triplets: both edges end in the same atom — that atom's dSm blocks are parked in LDS once
+        rows, off, kseg, rposT, max_rows = grp
+        dx = torch.empty((sp.n_expand, C), device=Y.device, dtype=torch.float32)
+        check(_lib.load().gn_bil_reduce_t_grouped_f32(ptr(Y), ptr(D), ptr(rows), ptr(off), ptr(kseg), ptr(permT),
+                                                      ptr(rposT), ptr(dx), off.shape[0] - 1, max_rows, S, C, stream()),
+              "gn_bil_reduce_t_grouped_f32")
+        return dx
     dx = torch.empty((sp.n_expand, C), device=Y.device, dtype=torch.float32)
     check(_lib.load().gn_bil_reduce_t_f32(ptr(Y), ptr(D), ptr(sp.reduce.idx32), ptr(permT), ptr(segT),
                                           ptr(dx), sp.n_expand, S, C, stream()), "gn_bil_reduce_t_f32")

@@ -193,6 +193,15 @@ int gn_bil_reduce_f32(const float* Y, const float* x, const int32_t* expand_idx,
 int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32_t* reduce_idx,
                         const int32_t* permT, const int32_t* segT_off, float* dx,
                         int64_t J, int S, int C, void* stream);
+/* The same adjoint when r(t) and g(t) always lie in one GROUP of rows (triplets c->a<-b: both edges end in atom a;
+ * data_container.py:262-300).  Group g owns rows grp_rows[grp_off[g]..grp_off[g+1]); grp_kseg[i] = {k0,k1} is the
+ * transposed segment (range of permT) of row grp_rows[i]; rposT[k] = position of r(permT[k]) inside its group.
+ * A workgroup parks the group's dSm blocks in LDS (max_rows*S*C*4 <= 160 KB, else hipErrorInvalidValue and the
+ * caller uses gn_bil_reduce_t_f32) so dSm is read from HBM once, not once per t.
+ * S = 7 and C = 64 only (else hipErrorInvalidValue).  Rows outside every group are not written. */
+int gn_bil_reduce_t_grouped_f32(const float* Y, const float* dSm, const int32_t* grp_rows, const int32_t* grp_off,
+                                const int32_t* grp_kseg, const int32_t* permT, const int32_t* rposT, float* dx,
+                                int64_t G, int max_rows, int S, int C, void* stream);
 /* dxt[t,c] = sum_s Y[t,s] * dSm[r(t),s,c]: the per-triplet/quadruplet rows of the adjoint above (dx[j] = sum of
  * dxt over the transposed segment of j: gn_segsum_rows_f32), grouped by reduce edge so that dSm[e] is read once
  * per edge instead of once per quadruplet (the S = 49 tensor basis: 56 GB -> 4 GB of traffic at B = 32). */

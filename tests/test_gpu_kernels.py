@@ -137,6 +137,39 @@ def test_bilinear_kernels(S, C, E, J, mk):
     close(K.bil_dot(f32(D), f32(x), dev), CK.bil_dot(D, x, cpu), atol=1e-4)
 
 
+@pytest.mark.parametrize("A,deg,C", [(40, 9, 64), (7, 30, 64), (25, 4, 32), (3, 80, 64), (2, 100, 64)])
+def test_bilinear_adjoint_grouped_by_target_atom(A, deg, C):
+    """Triplets c->a<-b: reduce and expand edge share the target atom, so gn_bil_reduce_t_grouped_f32 parks the
+    atom's dSm blocks in LDS; same result as the ungrouped adjoint (and the >160 KB case falls back to it)."""
+    g = torch.Generator().manual_seed(A * deg)
+    S = 7
+    # ragged in-degrees, edges of one atom NOT contiguous in edge order
+    degs = torch.randint(0, deg + 1, (A,), generator=g)
+    degs[0] = deg
+    tgt = torch.repeat_interleave(torch.arange(A), degs)
+    tgt = tgt[torch.randperm(tgt.shape[0], generator=g)]
+    E = int(tgt.shape[0])
+    red, exp = [], []
+    for a in range(A):
+        es = torch.nonzero(tgt == a).flatten().tolist()
+        for r in es:
+            for x in es:
+                if r != x:
+                    red.append(r), exp.append(x)
+    red, exp = torch.tensor(red, dtype=torch.int64), torch.tensor(exp, dtype=torch.int64)
+    order = torch.argsort(red, stable=True)
+    red, exp = red[order], exp[order]
+    cpu = SegmentPlan(red, exp, E, E)
+    dev = SegmentPlan(red.to(DEV), exp.to(DEV), E, E)
+    dev.set_row_groups(tgt.to(DEV), A)
+    assert dev.groups[4] == deg
+    Y, D = rnd(g, cpu.size, S), rnd(g, E, S, C)
+    got = K.bil_reduce_t(f32(Y), f32(D), dev)
+    close(got, CK.bil_reduce_t(Y, D, cpu), atol=1e-4)
+    plain = SegmentPlan(red.to(DEV), exp.to(DEV), E, E)
+    close(got, K.bil_reduce_t(f32(Y), f32(D), plain).double().cpu(), atol=1e-5)
+
+
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 def test_ssilu(k):
     x = torch.linspace(-12, 12, 1001, dtype=torch.float64)

@@ -122,3 +122,36 @@ def test_basis_ops_first_and_second_order():
     nrm = torch.tensor(B.sph_bessel_normalizer(3, 2))
     assert gradcheck(lambda t: ops.sph_radial(t, z, nrm, 5.0, 5), (d,))
     assert gradgradcheck(lambda t: ops.sph_radial(t, z, nrm, 5.0, 5), (d,))
+
+
+def test_triplet_groups_by_target_atom():
+    """SegmentPlan.groups (consumed by gn_bil_reduce_t_grouped_f32): every triplet's reduce and expand edge sit in the
+    group of their common target atom, and rposT / grp_kseg address them."""
+    from gemnet_pytorch_amd.graph import GraphPlan
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    from gemnet_pytorch_amd.training import data_container as DC
+    ds = make_dataset(3, 20, config=2)
+    idx = DC.build_indices(ds["R"], ds["N"], 5.0, 10.0, True)
+    inputs = {k: torch.as_tensor(v) for k, v in idx.items()}
+    inputs["Z"] = torch.as_tensor(ds["Z"]).long()
+    inputs["N"] = torch.as_tensor(ds["N"]).long()
+    inputs["batch_seg"] = torch.repeat_interleave(torch.arange(len(ds["N"])), inputs["N"])
+    plan = GraphPlan(inputs, True)
+    rows, off, kseg, rposT, max_rows = plan.trip.groups
+    permT, segT = plan.trip.expand.csr
+    id_a, red, exp = inputs["id_a"], inputs["id3_reduce_ca"], inputs["id3_expand_ba"]
+    assert torch.equal(id_a[red], id_a[exp])
+    assert sorted(rows.tolist()) == list(range(plan.n_edges))
+    assert max_rows == int(torch.bincount(id_a, minlength=plan.n_atoms).max())
+    seen = 0
+    for g in range(plan.n_atoms):
+        for i in range(int(off[g]), int(off[g + 1])):
+            j = int(rows[i])
+            assert int(id_a[j]) == g
+            k0, k1 = kseg[i].tolist()
+            assert (k0, k1) == (int(segT[j]), int(segT[j + 1]))
+            for k in range(k0, k1):
+                t = int(permT[k])
+                assert int(exp[t]) == j and int(rows[int(off[g]) + int(rposT[k])]) == int(red[t])
+                seen += 1
+    assert seen == plan.trip.size
