@@ -433,6 +433,81 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma49_kernel(
       for (int r = 0; r < 4; ++r) po[(16 * mt + 4 * lg + r) * C + 16 * nt + l15] = pacc[mt][nt][r];
 }
 
+// Spherical-basis (S = 7, C = 64, I = 16: GemNet-T / the triplet branch) form of the fused K1 + K2 on the matrix cores,
+// one wave per reduce edge.  The scalar kernel above issues 7 FMAs per (triplet, lane) plus 112 per lane for K2 and
+// is instruction-bound (52 us for 18 k edges / 332 k triplets against 21 us of HBM traffic); here
+//   K1  Sm[s,c] = sum_t Y[t,s] x[g(t),c]   M = s (7 of 16 rows), N = c (4 tiles), K = t (4 triplets per MFMA):
+//       lane (l15, lg) reads Y[t + lg][l15] and x[g(t + lg)][16 nt + l15] straight into fragment layout;
+//   K2  P[i,c] = sum_s B[s,i] Sm[s,c]      consumed from the K1 accumulators in place: in K-step r lane group lg
+//       supplies s = 4 lg + r for BOTH operands (its own D row r), so Sm never passes through LDS.
+__global__ __launch_bounds__(256) void bil_reduce_project_mfma7_kernel(
+    const float* __restrict__ Y, const float* __restrict__ x, const int32_t* __restrict__ expand_idx,
+    const int32_t* __restrict__ seg_off, const float* __restrict__ B, float* __restrict__ Sm,
+    float* __restrict__ P, int64_t E) {
+  constexpr int S = 7, C = 64, I = 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  const bool srow = l15 < S;
+  const float* __restrict__ be = B + e * (int64_t)S * I;
+  // Loads are UNCONDITIONAL at clamped (always valid) addresses and masked with a select afterwards: a load inside
+  // `cond ? *p : 0` becomes a branch per dword (and splits float4 loads into four of them).
+  float bk[4];   // B[s = 4 lg + r][i = l15]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = be[min(4 * lg + r, S - 1) * I + l15];
+    bk[r] = (4 * lg + r) < S ? v : 0.f;
+  }
+  v4f_b acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
+  const int tlast = max(t1 - 1, t0), scl = min(l15, S - 1);
+  auto load = [&](int t, float& a, float (&b)[4]) {
+    const int tq = t + lg;
+    const bool ok = tq < t1;
+    const int tc = min(tq, tlast);
+    const float yv = Y[(int64_t)tc * S + scl];
+    a = (ok && srow) ? yv : 0.f;
+    const float* __restrict__ xr = x + (int64_t)expand_idx[tc] * C + l15;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float v = xr[16 * nt];
+      b[nt] = ok ? v : 0.f;
+    }
+  };
+  float a0 = 0.f, b0[4] = {0.f, 0.f, 0.f, 0.f}, a1, b1[4];
+  if (t0 < t1) load(t0, a0, b0);   // (an edge without triplets touches neither Y nor x: they may be empty)
+  for (int t = t0; t < t1; t += 8) {
+    load(t + 4, a1, b1);               // next K-step in flight under this one's MFMAs
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[nt], acc[nt], 0, 0, 0);
+    load(t + 8, a0, b0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[nt], acc[nt], 0, 0, 0);
+  }
+  // D layout: col = l15 (c within tile), row = 4 lg + r (s)
+  float* __restrict__ so = Sm + e * (int64_t)S * C;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * lg + r < S) so[(4 * lg + r) * C + 16 * nt + l15] = acc[nt][r];
+  v4f_b pacc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) pacc[nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bk[r], acc[nt][r], pacc[nt], 0, 0, 0);
+  float* __restrict__ po = P + e * (int64_t)I * C;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) po[(4 * lg + r) * C + 16 * nt + l15] = pacc[nt][r];
+}
+
 // Adjoint of K2 fused with the K1 adjoint w.r.t. Y, one workgroup per reduce edge:
 //   gB[e,s,i]  = sum_c Sm[e,s,c] dP[e,i,c]
 //   dSm[e,s,c] = sum_i B[e,s,i] dP[e,i,c]                  (written: bil_reduce_t consumes it)
@@ -495,6 +570,111 @@ __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
   }
 }
 
+// Spherical-basis (S = 7, C = 64, I = 16) form of the fused bilinear adjoint on the matrix cores, one wave per reduce
+// edge (the scalar kernel above spends ~700 instructions per lane and edge: 91 us against 28 us of HBM traffic):
+//   gB[s,i]  = sum_c Sm[s,c] dP[i,c]       (7/16 x 16 x 64)
+//   dSm[s,c] = sum_i B[s,i]  dP[i,c]       (7/16 x 64 x 16)   -> global + LDS
+//   dY[t,s]  = sum_c x[g(t),c] dSm[s,c]    (16 triplets per row tile x 7/16 x 64)
+// Contiguous contraction indices are fetched as float4 and consumed component-wise (K-step (j, comp): lane group lg
+// supplies k = 16 j + 4 lg + comp for both operands).
+template <bool ACC>
+__global__ __launch_bounds__(256) void bil_project_bwd_mfma7_kernel(
+    const float* __restrict__ dP, const float* __restrict__ Sm, const float* __restrict__ B,
+    const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
+    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int64_t E) {
+  constexpr int S = 7, C = 64, I = 16, LD = C + 4;
+  __shared__ __attribute__((aligned(16))) float dsl[4][8][LD];   // dSm of this wave's edge (row 7: MFMA padding)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+  const float* __restrict__ dPe = dP + e * (int64_t)I * C;
+  const float* __restrict__ Sme = Sm + e * (int64_t)S * C;
+  const float* __restrict__ Be = B + e * (int64_t)S * I;
+  const bool srow = l15 < S;
+  const int t0 = dY ? seg_off[e] : 0, t1 = dY ? seg_off[e + 1] : 0;
+  // Every load below is UNCONDITIONAL at a clamped (valid) address: `cond ? *p : 0` compiles to one branch per dword
+  // and splits the float4 loads.  Rows that only exist as MFMA padding (s >= 7, t >= t1) may hold duplicates: each
+  // padded row / column only feeds outputs that are never stored.
+  const int tlast = t1 - 1, scl = min(l15, S - 1);
+  auto loadx = [&](int tb, float4 (&xa)[4]) {   // x rows of the 16 triplets tb.., one per l15, k = c contiguous
+    if (tb >= t1) return;                       // (wave-uniform)
+    const float* __restrict__ xr = x + (int64_t)expand_idx[min(tb + l15, tlast)] * C + 4 * lg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const float4*>(xr + 16 * j);
+  };
+  float4 smf[4], dpf[4], xa[4], xb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xa[j] = xb[j] = z4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    smf[j] = *reinterpret_cast<const float4*>(Sme + scl * C + 16 * j + 4 * lg);
+    dpf[j] = *reinterpret_cast<const float4*>(dPe + l15 * C + 16 * j + 4 * lg);
+  }
+  const float4 bf = *reinterpret_cast<const float4*>(Be + scl * I + 4 * lg);
+  float dpk[4][4];   // dP[i = 4 lg + comp][c = 16 nt + l15]
+#pragma unroll
+  for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) dpk[cp][nt] = dPe[(4 * lg + cp) * C + 16 * nt + l15];
+  loadx(t0, xa), loadx(t0 + 16, xb);   // first two row tiles of the Y gradient in flight under the two products
+  // ---- (1) gB = Sm dP^T
+  v4f_b g = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) g = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(smf[j], cp), comp(dpf[j], cp), g, 0, 0, 0);
+  float* __restrict__ gbo = gB + e * (int64_t)S * I;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (4 * lg + r < S) gbo[(4 * lg + r) * I + l15] = g[r];
+  // ---- (2) dSm = B dP
+  v4f_b d[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) d[nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(bf, cp), dpk[cp][nt], d[nt], 0, 0, 0);
+  float* __restrict__ dso = dSm + e * (int64_t)S * C;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int srw = 4 * lg + r;
+      if (srw < S) dso[srw * C + 16 * nt + l15] = d[nt][r];
+      if (srw < 8) dsl[wave][srw][16 * nt + l15] = d[nt][r];   // row 7: padding, feeds the unstored column s = 7
+    }
+  if (!dY) return;
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+  __builtin_amdgcn_wave_barrier();
+  // ---- (3) dY = Xseg dSm^T
+  float4 bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bs[j] = *reinterpret_cast<const float4*>(&dsl[wave][min(l15, 7)][16 * j + 4 * lg]);
+  for (int tb = t0; tb < t1; tb += 16) {
+    float4 xn[4] = {z4, z4, z4, z4};
+    loadx(tb + 32, xn);
+    v4f_b y = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) y = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(xa[j], cp), comp(bs[j], cp), y, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = tb + 4 * lg + r;
+      if (srow && t < t1) {
+        float* o = dY + (int64_t)t * S + l15;
+        *o = ACC ? *o + y[r] : y[r];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = xb[j], xb[j] = xn[j];
+  }
+}
+
 // Tensor-basis (S = 49, C = I = 32) form of the fused bilinear adjoint on the matrix cores, one wave per reduce edge:
 //   gB[s,i]  = sum_c Sm[s,c] dP[i,c]       (64 x 32 x 32)
 //   dSm[s,c] = sum_i B[s,i]  dP[i,c]       (64 x 32 x 32)     -> global + LDS
@@ -531,7 +711,10 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
     const bool ok = srow < S;
     float4 a[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) a[j] = ok ? *reinterpret_cast<const float4*>(Sme + srow * C + 16 * j + 4 * lg) : z4;
+    for (int j = 0; j < 2; ++j) {   // unconditional at a clamped row, then masked (a load under `?:` is split per dword)
+      const float4 v = *reinterpret_cast<const float4*>(Sme + min(srow, S - 1) * C + 16 * j + 4 * lg);
+      a[j] = ok ? v : z4;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       v4f_b c4 = (v4f_b){0.f, 0.f, 0.f, 0.f};
@@ -568,7 +751,10 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
     const bool ok = srow < S;
     float4 a[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) a[j] = ok ? *reinterpret_cast<const float4*>(Be + srow * I + 16 * j + 4 * lg) : z4;
+    for (int j = 0; j < 2; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(Be + min(srow, S - 1) * I + 16 * j + 4 * lg);
+      a[j] = ok ? v : z4;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       v4f_b c4 = (v4f_b){0.f, 0.f, 0.f, 0.f};
@@ -746,9 +932,11 @@ __global__ __launch_bounds__(256) void bil_dy_multi_mfma49_kernel(const gn_dy_mu
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int sr = 16 * nt + l15;
-        bd[b][nt][j] = (b < nb && sr < S)
-                           ? *reinterpret_cast<const float4*>(a.dS[b] + (e * S + sr) * C + 16 * j + 4 * lg)
-                           : z4;
+        bd[b][nt][j] = z4;
+        if (b < nb) {   // (uniform)  unconditional load at a clamped row, then masked
+          const float4 v = *reinterpret_cast<const float4*>(a.dS[b] + (e * S + min(sr, S - 1)) * C + 16 * j + 4 * lg);
+          bd[b][nt][j] = sr < S ? v : z4;
+        }
       }
   const int t0 = seg_off[e], t1 = seg_off[e + 1];
   for (int tb = t0; tb < t1; tb += 16) {
@@ -909,7 +1097,10 @@ extern "C" int gn_bil_reduce_project_f32(const float* Y, const float* x, const i
   const size_t smem = (size_t)epb * S * I * sizeof(float);
   if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
   dim3 grid(gn_cdiv(E, epb)), block(256);
-  if (S == 7) {
+  if (S == 7 && C == 64 && I == 16) {
+    hipLaunchKernelGGL(bil_reduce_project_mfma7_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, Y, x, expand_idx, seg_off, B,
+                       Sm, P, E);
+  } else if (S == 7) {
     hipLaunchKernelGGL(bil_reduce_project_kernel<7>, grid, block, smem, st, Y, x, expand_idx, seg_off, B, Sm, P, E, C, I);
   } else if (S == 49 && C == 32 && I == 32) {
     hipLaunchKernelGGL(bil_reduce_project_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, Y, x, expand_idx, seg_off, B,
@@ -936,6 +1127,17 @@ extern "C" int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, cons
     else
       hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel<false>, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, dP, Sm, B, x,
                          expand_idx, seg_off, gB, dSm, dY, E);
+    GN_LAUNCH_CHECK();
+    return 0;
+  }
+  if (S == 7 && C == 64 && I == 16 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)) {
+    const dim3 grid(gn_cdiv(E, 4));
+    if (accumulate)
+      hipLaunchKernelGGL(bil_project_bwd_mfma7_kernel<true>, grid, dim3(256), 0, st, dP, Sm, B, x, expand_idx, seg_off, gB,
+                         dSm, dY, E);
+    else
+      hipLaunchKernelGGL(bil_project_bwd_mfma7_kernel<false>, grid, dim3(256), 0, st, dP, Sm, B, x, expand_idx, seg_off, gB,
+                         dSm, dY, E);
     GN_LAUNCH_CHECK();
     return 0;
   }

@@ -359,6 +359,8 @@ def test_bilinear_fused_project_kernels(S, C, I, E, J, mk):
     rgB, rdSm, rdY = CK.bil_project_bwd(dP, rSm, Bm, x, cpu)
     close(gB, rgB, atol=2e-4 * float(rgB.abs().max())); close(dSm, rdSm, atol=1e-4)
     close(dY, rdY, atol=2e-4 * float(rdY.abs().max()))
+    gB2, dSm2, none = K.bil_project_bwd(f32(dP), f32(rSm), f32(Bm), f32(x), dev, want_dY=False)
+    assert none is None and torch.equal(gB2, gB) and torch.equal(dSm2, dSm)
 
 
 def test_quad_basis_fused_fwd_bwd():
