@@ -984,6 +984,64 @@ __global__ __launch_bounds__(256) void bil_dy_multi_mfma49_kernel(const gn_dy_mu
   }
 }
 
+// The same one-pass Y gradient for the spherical basis (S = 7, C = 64: the triplet branch of all nb blocks shares
+// `sph`): dY[t,s] = sum_b sum_c x_b[g(t),c] dSm_b[e,s,c], written once instead of written by the first block and
+// read-modify-written by each further one.  One wave per reduce edge, 16 triplets per MFMA row tile; the x rows of
+// block b + 1 are in flight under the 16 MFMAs of block b.
+__global__ __launch_bounds__(256) void bil_dy_multi_mfma7_kernel(const gn_dy_multi_args a,
+                                                                 const int32_t* __restrict__ expand_idx,
+                                                                 const int32_t* __restrict__ seg_off,
+                                                                 float* __restrict__ dY, int64_t E) {
+  constexpr int S = 7, C = 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  if (t0 >= t1) return;
+  auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+  const int nb = a.nb;
+  const int scl = min(l15, S - 1);   // columns s >= 7 are MFMA padding: duplicates, never stored
+  float4 bd[4][4];                   // [block][j]: dSm_b[e][s = l15][16 j + 4 lg ..]
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (b < nb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bd[b][j] = *reinterpret_cast<const float4*>(a.dS[b] + (e * S + scl) * C + 16 * j + 4 * lg);
+    }
+  auto loadx = [&](int b, int64_t g, float4 (&ax)[4]) {
+    if (b >= nb) return;
+    const float* __restrict__ xr = a.x[b] + g * C + 4 * lg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ax[j] = *reinterpret_cast<const float4*>(xr + 16 * j);
+  };
+  for (int tb = t0; tb < t1; tb += 16) {
+    const int64_t g = expand_idx[min(tb + l15, t1 - 1)];   // rows t >= t1: duplicates, never stored
+    float4 ax[4], an[4];
+    loadx(0, g, ax);
+    v4f_b y = (v4f_b){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < nb) {
+        loadx(b + 1, g, an);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            y = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ax[j], q), comp(bd[b][j], q), y, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ax[j] = an[j];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = tb + 4 * lg + r;
+      if (l15 < S && t < t1) dY[(int64_t)t * S + l15] = y[r];
+    }
+  }
+}
+
 inline bool ok_channels(int C) { return C > 0 && C <= 256 && (256 % C) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -1153,7 +1211,7 @@ extern "C" int gn_bil_dy_multi_f32(const float* const* dSm_list, const float* co
                                    const int32_t* expand_idx, const int32_t* seg_off, float* dY, int64_t E, int S, int C,
                                    void* stream) {
   if (E <= 0 || nb <= 0) return 0;
-  if (nb > 4 || S != 49 || C != 32) return (int)hipErrorInvalidValue;   // tensor basis of GemNet-Q only
+  if (nb > 4 || !((S == 49 && C == 32) || (S == 7 && C == 64))) return (int)hipErrorInvalidValue;
   gn_dy_multi_args a;
   a.nb = nb;
   for (int b = 0; b < 4; ++b) {
@@ -1161,8 +1219,12 @@ extern "C" int gn_bil_dy_multi_f32(const float* const* dSm_list, const float* co
     a.x[b] = b < nb ? x_list[b] : nullptr;
     if (b < nb && (!aligned16(a.dS[b]) || !aligned16(a.x[b]))) return (int)hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(bil_dy_multi_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
-                     expand_idx, seg_off, dY, E);
+  if (S == 7)
+    hipLaunchKernelGGL(bil_dy_multi_mfma7_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       expand_idx, seg_off, dY, E);
+  else
+    hipLaunchKernelGGL(bil_dy_multi_mfma49_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       expand_idx, seg_off, dY, E);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -445,6 +445,8 @@ class _FusedDense(torch.autograd.Function):
     def forward(ctx, x, W, mul, res, res2, g1, g2, cfg):
         act, alpha, beta, beta2, res_rows, i1, i2 = cfg
         need_z = act or mul is not None
+        if not W.requires_grad and (W.stride(0) % 4 or W.data_ptr() % 16) and W.shape[1] % 4 == 0:
+            W = contiguous_weight(W)   # column slice of a wider frozen matrix (edge embedding): copied once, not per call
         out = K.gemm(x, W, act=act, pre_out=need_z, mul=mul, alpha=alpha,
                      res=res, ridx=None if res_rows is None else res_rows.idx32, beta=beta,
                      res2=res2, beta2=beta2,
@@ -556,8 +558,7 @@ class _FusedBilinear(torch.autograd.Function):
             ctx.sink.uses += 1
         C, I, O = W.shape
         Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)
-        W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)  # rows (i,c)
-        out = K.gemm(P.reshape(-1, I * C), transposed_2d(W2, W), alpha=alpha)
+        out = K.gemm(P.reshape(-1, I * C), bilinear_weight(W, True), alpha=alpha)
         keep_p = W.requires_grad and _PARAM_GRADS
         ctx.save_for_backward(rbf_W1, sph, x, W, Sm, P if keep_p else None)
         ctx.sp, ctx.alpha = sp, alpha
@@ -571,11 +572,11 @@ class _FusedBilinear(torch.autograd.Function):
         sp, alpha = ctx.sp, ctx.alpha
         need = ctx.needs_input_grad
         g = g.contiguous()
-        W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)
-        dP = K.gemm(g, W2, alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is already (N=I*C, K=O)
+        dP = K.gemm(g, bilinear_weight(W, False), alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is (N=I*C, K=O)
         sink = ctx.sink
-        if sink is not None and need[1] and Sm.shape[1] == 49 and Sm.shape[2] == 32 and sink.uses + len(sink.pending) <= 4:
-            # tensor basis: gB and dSm now, the Y gradient of all consumers in ONE pass when the last one arrives
+        if (sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64))
+                and sink.uses + len(sink.pending) <= 4):
+            # gB and dSm now, the Y gradient of all consumers of this basis in ONE pass when the last one arrives
             gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False)
             sink.pending.append((dSm, x))
             sink.uses -= 1
@@ -605,11 +606,17 @@ class _FusedBilinear(torch.autograd.Function):
         return gB, gsph, gx, gW, None, None
 
 
-def transposed_2d(W2, owner):
-    """W2^T contiguous, cached on the owning (frozen) parameter's version."""
-    if owner.requires_grad:
-        return W2.t().contiguous()
-    return _cached(("bil", owner.data_ptr(), tuple(owner.shape)), owner._version, lambda: W2.t().contiguous())
+def bilinear_weight(W, transposed_form):
+    """The (C, I, O) weight of the bilinear layer as W2 (I*C, O) with rows (i, c) — or W2^T — contiguous; both are
+    permuted COPIES, cached on the owning parameter's version when it is frozen."""
+    C, I, O = W.shape
+
+    def make():
+        W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)
+        return W2.t().contiguous() if transposed_form else W2
+    if W.requires_grad:
+        return make()
+    return _cached(("bilT" if transposed_form else "bil", W.data_ptr(), tuple(W.shape)), W._version, make)
 
 
 def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):

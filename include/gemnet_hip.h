@@ -227,7 +227,7 @@ int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, const float* B,
                                const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
                                int64_t E, int S, int C, int I, int accumulate, void* stream);
 /* gn_bil_project_bwd*_f32 accept dY == NULL (gB and dSm only).  The deferred Y gradient of up to 4 blocks that
- * share one tensor basis (S = 49, C = 32) is then produced in one pass:
+ * share one basis tensor (S = 49, C = 32 or S = 7, C = 64; else hipErrorInvalidValue) is then produced in one pass:
  *   dY[t,s] = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c]        (dSm_list / x_list: host arrays of nb device pointers) */
 int gn_bil_dy_multi_f32(const float* const* dSm_list, const float* const* x_list, int nb, const int32_t* expand_idx,
                         const int32_t* seg_off, float* dY, int64_t E, int S, int C, void* stream);

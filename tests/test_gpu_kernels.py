@@ -463,10 +463,12 @@ def test_bilinear_adjoint_accumulates_y_gradient(S, C, I, E, J, mk):
     close(dY2, ref, atol=2e-4 * max(1.0, float(ref.abs().max())))
 
 
+@pytest.mark.parametrize("shape", [(49, 32, 32, 50, 260, 75), (7, 64, 16, 90, 90, 40)])
 @pytest.mark.parametrize("nb", [1, 2, 4])
-def test_bilinear_deferred_y_gradient_of_several_blocks(nb):
-    """gn_bil_project_bwd with dY == NULL + gn_bil_dy_multi_f32: the tensor-basis Y gradient of nb blocks in one pass."""
-    S, C, I, E, J, mk = 49, 32, 32, 50, 260, 75
+def test_bilinear_deferred_y_gradient_of_several_blocks(nb, shape):
+    """gn_bil_project_bwd with dY == NULL + gn_bil_dy_multi_f32: the Y gradient of nb blocks that share one basis
+    (tensor basis of the quadruplets, spherical basis of the triplets) in one pass."""
+    S, C, I, E, J, mk = shape
     g = torch.Generator().manual_seed(nb)
     seg = torch.randint(0, mk, (E,), generator=g)
     seg[3] = 0

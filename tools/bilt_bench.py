@@ -101,3 +101,6 @@ for mode, name in ((0, "full"), (1, "no x loads"), (2, "no dY stores"), (3, "no 
     print(f"bwd7 variant {name:18s}: {timeit(run):7.2f} us")
 print(f"edge order, no atom grouping: fwd {timeit(lambda: K.bil_reduce_project(Y, x, Bm, plain)):7.2f} us   "
       f"bwd {timeit(lambda: K.bil_project_bwd(dP, Sm, Bm, x, plain)):7.2f} us")
+dS4 = [torch.randn(E, 7, 64, device="cuda", generator=g) for _ in range(4)]
+x4 = [torch.randn(E, 64, device="cuda", generator=g) for _ in range(4)]
+print(f"bil_dy_multi (7,64) 4 blocks: {timeit(lambda: K.bil_dy_multi(dS4, x4, sp)):7.2f} us")
