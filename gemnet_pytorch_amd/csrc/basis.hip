@@ -60,16 +60,39 @@ __global__ void ssilu_kernel(const float* __restrict__ x, float* __restrict__ ou
   }
 }
 
+__device__ __forceinline__ void dact_mul_one(float g, float z, int act, float m, float c, bool want_gmul, float& dz,
+                                             float& gm) {
+  const float gv = g * c;
+  const float a = act ? gn_dssilu(z) : 1.0f;
+  dz = gv * m * a;
+  if (want_gmul) gm = gv * (act ? gn_ssilu(z) : z);
+}
+
+// dz = c g f'(z) mul,  gmul = c g f(z)   (z, mul, gmul optional); float4 body + scalar tail when everything is aligned
 __global__ void dact_mul_kernel(const float* __restrict__ g, const float* __restrict__ z, int act,
                                 const float* __restrict__ mul, float c, float* __restrict__ dz,
-                                float* __restrict__ gmul, int64_t n) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const float gv = g[i] * c;
-    const float zv = z ? z[i] : 0.f;
-    const float a = act ? gn_dssilu(zv) : 1.0f;
-    dz[i] = gv * (mul ? mul[i] : 1.0f) * a;
-    if (gmul) gmul[i] = gv * (act ? gn_ssilu(zv) : zv);
+                                float* __restrict__ gmul, int64_t n, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t n4 = vec ? (n >> 2) : 0;
+  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = i0; i < n4; i += stride) {
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    const float4 zv = z ? reinterpret_cast<const float4*>(z)[i] : zero;
+    const float4 mv = mul ? reinterpret_cast<const float4*>(mul)[i] : one;
+    float4 d, m = zero;
+    dact_mul_one(gv.x, zv.x, act, mv.x, c, gmul, d.x, m.x);
+    dact_mul_one(gv.y, zv.y, act, mv.y, c, gmul, d.y, m.y);
+    dact_mul_one(gv.z, zv.z, act, mv.z, c, gmul, d.z, m.z);
+    dact_mul_one(gv.w, zv.w, act, mv.w, c, gmul, d.w, m.w);
+    reinterpret_cast<float4*>(dz)[i] = d;
+    if (gmul) reinterpret_cast<float4*>(gmul)[i] = m;
+  }
+  for (int64_t i = (n4 << 2) + i0; i < n; i += stride) {
+    float d, m = 0.f;
+    dact_mul_one(g[i], z ? z[i] : 0.f, act, mul ? mul[i] : 1.0f, c, gmul, d, m);
+    dz[i] = d;
+    if (gmul) gmul[i] = m;
   }
 }
 
@@ -174,8 +197,10 @@ extern "C" int gn_dact_mul_f32(const float* g, const float* z, int act, const fl
                                float* dz, float* gmul, int64_t n, void* stream) {
   if (n <= 0) return 0;
   if ((act || gmul) && !z) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(dact_mul_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     g, z, act, mul, c, dz, gmul, n);
+  auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  const int vec = al(g) && al(z) && al(mul) && al(dz) && al(gmul);
+  hipLaunchKernelGGL(dact_mul_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     g, z, act, mul, c, dz, gmul, n, vec);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -73,6 +73,46 @@ __global__ __launch_bounds__(256) void segsum_wave(const VT* __restrict__ y, con
   }
 }
 
+// Few output rows (the per-atom sums: 1024 rows at B = 32) leave most CUs without a wave and each wave walking its
+// segment alone (9 dependent perm -> row round trips: 9.6 us for 9 MB).  Here a whole workgroup owns a row: wave w
+// takes entries k0 + w*EPL + slot, stride 4*EPL; the 4*EPL partial sums are combined in a fixed order.
+template <typename VT>
+__global__ __launch_bounds__(256) void segsum_block(const VT* __restrict__ y, const int32_t* __restrict__ perm,
+                                                    const int32_t* __restrict__ seg_off, VT* __restrict__ x, int CW) {
+  __shared__ VT part[4][64];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = blockIdx.x;
+  const int k0 = seg_off[r], k1 = seg_off[r + 1];
+  for (int cb = 0; cb < CW; cb += 64) {
+    const int cw = min(64, CW - cb);
+    const int epl = 64 / cw;
+    const int slot = lane / cw;
+    const int c = cb + lane - slot * cw;
+    VT acc = vzero<VT>(), acc2 = vzero<VT>();
+    if (slot < epl) {
+      const int step = 4 * epl;
+      int k = k0 + wave * epl + slot;
+      for (; k + step < k1; k += 2 * step) {   // two entries in flight
+        const int64_t sa = perm ? perm[k] : k, sb = perm ? perm[k + step] : k + step;
+        const VT va = y[sa * CW + c], vb = y[sb * CW + c];
+        vadd(acc, va), vadd(acc2, vb);
+      }
+      if (k < k1) vadd(acc, y[(int64_t)(perm ? perm[k] : k) * CW + c]);
+      vadd(acc, acc2);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < cw) {
+      VT t = vzero<VT>();
+      for (int w = 0; w < 4; ++w)
+        for (int s2 = 0; s2 < epl; ++s2) vadd(t, part[w][s2 * cw + lane]);
+      x[r * CW + cb + lane] = t;
+    }
+    __syncthreads();
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
@@ -100,7 +140,14 @@ extern "C" int gn_segsum_rows_f32(const float* y, const int32_t* perm, const int
   if (N <= 0 || C <= 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid((unsigned)((N + 3) / 4)), block(256);
-  if (C % 4 == 0 && aligned16(x) && aligned16(y)) {
+  const bool v4 = C % 4 == 0 && aligned16(x) && aligned16(y);
+  if (N <= 4096) {   // fewer rows than the chip has wave slots: a workgroup per row
+    if (v4)
+      hipLaunchKernelGGL(segsum_block<float4>, dim3((unsigned)N), block, 0, st, reinterpret_cast<const float4*>(y), perm,
+                         seg_off, reinterpret_cast<float4*>(x), C / 4);
+    else
+      hipLaunchKernelGGL(segsum_block<float>, dim3((unsigned)N), block, 0, st, y, perm, seg_off, x, C);
+  } else if (v4) {
     hipLaunchKernelGGL(segsum_wave<float4>, grid, block, 0, st, reinterpret_cast<const float4*>(y), perm,
                        seg_off, reinterpret_cast<float4*>(x), N, C / 4);
   } else {

@@ -92,10 +92,10 @@ def test_bmm(b, m, n, k, ta, tb):
     close(K.bmm(f32(A), f32(Bm), ta, tb), CK.bmm(A, Bm, ta, tb))
 
 
-@pytest.mark.parametrize("C", [1, 3, 32, 128, 7 * 6])
-def test_gather_segsum(C):
+@pytest.mark.parametrize("N,T", [(97, 1000), (5000, 30000)])   # workgroup-per-row (N <= 4096) / wave-per-row kernels
+@pytest.mark.parametrize("C", [1, 3, 32, 128, 7 * 6, 320])
+def test_gather_segsum(C, N, T):
     g = torch.Generator().manual_seed(C)
-    N, T = 97, 1000
     idx = torch.randint(0, N, (T,), generator=g)
     x, y = rnd(g, N, C), rnd(g, T, C)
     ri = RowIndex(idx.to(DEV), N)
@@ -247,6 +247,15 @@ def test_dact_mul(act, has_mul):
     dz, gm = K.dact_mul(f32(gr), f32(z), act, f32(mul) if has_mul else None, 0.37, want_gmul=True)
     close(dz, ref_dz, atol=1e-5)
     close(gm, ref_gm, atol=1e-5)
+    # float4 body + scalar tail (n % 4 = 3), and the all-scalar path of a misaligned operand
+    gr, z, mul = rnd(g, 333, 7), rnd(g, 333, 7), rnd(g, 333, 7)
+    ref_dz, _ = CK.dact_mul(gr, z, act, mul if has_mul else None, 1.5, want_gmul=False)
+    dz, none = K.dact_mul(f32(gr), f32(z), act, f32(mul) if has_mul else None, 1.5, want_gmul=False)
+    assert none is None
+    close(dz, ref_dz, atol=1e-5)
+    gz = f32(torch.cat([z.flatten()[:1], z.flatten()]))[1:].reshape(333, 7)   # same values, 4-byte aligned only
+    dz, _ = K.dact_mul(f32(gr), gz, act, f32(mul) if has_mul else None, 1.5, want_gmul=False)
+    close(dz, ref_dz, atol=1e-5)
 
 
 def _rand_geometry(g, n_atoms=40, n_edges=300, n_trip=900):
