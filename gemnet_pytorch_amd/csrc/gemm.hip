@@ -539,6 +539,72 @@ void launch(const gn_gemm_args& p, bool fast, int vecA, int vecB, hipStream_t st
   else hipLaunchKernelGGL((gemm_generic<BM, BN, WR, WC>), grid, block, 0, st, p, vecA, vecB);
 }
 
+// ---- shapes the MFMA tiles do not fit -----------------------------------------------------------------------------
+// K <= 64 that is tiny or not a multiple of 4 (the 6 radial basis functions -> 16 / 128, the 42-column circular basis,
+// the K = 1 outer product of the energy head's input gradient): these are write-bound row operations, but the generic
+// tile kernel stages both operands through LDS dword by dword (42 us for the (18 k, 6) x (6, 128) edge embedding
+// against 9 MB of output).  Here the B tile (K x 128) sits in LDS, a thread owns one row and 4 columns 32 apart
+// (row-contiguous 128-byte stores), the row of A is a broadcast load, and the usual fused epilogue applies.
+__global__ __launch_bounds__(256) void gemm_smallk(const gn_gemm_args p) {
+  extern __shared__ float Bs[];   // [K][128]
+  const int K = p.K, N = p.N, M = p.M;
+  const int tid = threadIdx.x;
+  const int col0 = blockIdx.y * 128, row0 = blockIdx.x * 32;
+  const float* __restrict__ const B = p.B;
+  if (p.trans_b) {   // B is (K,N)
+    for (int i = tid; i < K * 128; i += 256) {
+      const int k = i >> 7, n = i & 127;
+      Bs[i] = col0 + n < N ? B[(size_t)k * p.ldb + col0 + n] : 0.f;
+    }
+  } else {           // B is (N,K): walk it in memory order
+    for (int i = tid; i < K * 128; i += 256) {
+      const int n = i / K, k = i - n * K;
+      Bs[k * 128 + n] = col0 + n < N ? B[(size_t)(col0 + n) * p.ldb + k] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int l32 = tid & 31, rg = tid >> 5;
+  const bool full = col0 + 128 <= N;
+  for (int rr = rg; rr < 32; rr += 8) {
+    const int r = row0 + rr;
+    if (r >= M) break;
+    const float* __restrict__ a = p.A + (size_t)r * p.lda;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+      const float av = a[k];
+      const float* b = Bs + k * 128 + l32;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) v[n] = fmaf(av, b[32 * n], v[n]);
+    }
+    int row[4], col[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) row[n] = r, col[n] = col0 + l32 + 32 * n;
+    if (full) epilogue_vals<4, true>(p, v, row, col);
+    else epilogue_vals<4, false>(p, v, row, col);
+  }
+}
+
+// N = 1 (the energy / scalar heads): C[m] = alpha * <A[m,:], b>, one wave per row, no epilogue stages.
+__global__ __launch_bounds__(256) void gemm_n1(const float* __restrict__ A, int lda, const float* __restrict__ b,
+                                               float* __restrict__ C, int ldc, int M, int K, float alpha, int vec) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const float* __restrict__ a = A + (size_t)r * lda;
+  float acc = 0.f;
+  if (vec) {
+    for (int k = 4 * lane; k < K; k += 256) {
+      const float4 u = *reinterpret_cast<const float4*>(a + k), w = *reinterpret_cast<const float4*>(b + k);
+      acc = fmaf(u.x, w.x, fmaf(u.y, w.y, fmaf(u.z, w.z, fmaf(u.w, w.w, acc))));
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) acc = fmaf(a[k], b[k], acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) C[(size_t)r * ldc] = acc * alpha;
+}
+
 }  // namespace
 
 // cfg < 0: automatic tile selection; cfg >= 0: explicit variant (tuning / tests).
@@ -549,6 +615,19 @@ extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) 
   const int vecA = (p.lda % 4 == 0) && aligned16(p.A) && (!p.a_dact_pre || aligned16(p.a_dact_pre));
   const int vecB = (p.ldb % 4 == 0) && aligned16(p.B);
   const bool fast = !p.trans_a && !p.trans_b && vecA && vecB && (p.K % 4 == 0) && p.splitk <= 1;
+  const bool plain = !p.a_dact_pre && !p.act && !p.pre_out && !p.mul && !p.res && !p.res2 && !p.gadd1 && !p.gadd2;
+  if (cfg < 0 && !p.trans_a && p.splitk <= 1 && p.N == 1 && plain && (p.trans_b ? p.ldb == 1 : true)) {
+    const int vec = vecA && aligned16(p.B) && (p.K % 4 == 0);
+    hipLaunchKernelGGL(gemm_n1, dim3(gn_cdiv(p.M, 4)), dim3(256), 0, st, p.A, p.lda, p.B, p.C, p.ldc, p.M, p.K, p.alpha, vec);
+    GN_LAUNCH_CHECK();
+    return 0;
+  }
+  if (cfg < 0 && !p.trans_a && !p.a_dact_pre && p.splitk <= 1 && p.K >= 1 && p.K <= 64 && (p.K % 4 != 0 || p.K < 8)) {
+    hipLaunchKernelGGL(gemm_smallk, dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(256), (size_t)p.K * 128 * sizeof(float),
+                       st, p);
+    GN_LAUNCH_CHECK();
+    return 0;
+  }
   // x @ B with B (K,N): k-major staging in the 8-wave kernel (any N; rows of B 16-byte aligned)
   if (cfg < 0 && !p.trans_a && p.trans_b && vecA && vecB && (p.K % 4 == 0) && (p.N % 4 == 0) && p.splitk <= 1 &&
       p.M >= 512) {

@@ -35,7 +35,7 @@ def f32(t):
 
 @pytest.mark.parametrize("M,N,Kd", [(64, 128, 32), (300, 128, 128), (1000, 64, 128), (257, 32, 64),
                                     (130, 16, 6), (77, 1, 128), (513, 128, 384), (95, 100, 42),
-                                    (2048, 64, 1024), (5, 7, 3)])
+                                    (2048, 64, 1024), (5, 7, 3), (1024, 128, 1), (300, 200, 6), (1000, 1, 130)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 def test_gemm_plain(M, N, Kd, ta, tb):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + Kd)
@@ -70,6 +70,29 @@ def test_gemm_fused_epilogue_and_prologue():
                   gidx1=i1.to(DEV), gadd2=f32(g2), gidx2=i2.to(DEV), **kw)
     close(z, ref_z, atol=5e-5)
     close(y, ref_y, atol=5e-5)
+
+
+@pytest.mark.parametrize("Kd,N,tb", [(6, 128, False), (6, 100, True), (42, 112, True), (1, 128, False)])
+def test_gemm_small_k_row_kernel_with_fused_epilogue(Kd, N, tb):
+    """K <= 64 and tiny / not a multiple of 4 (edge embedding: 6 radial functions + two gathered atom rows + ScaledSiLU;
+    the 42-column circular basis; K = 1 outer products) run the row kernel gemm_smallk with the same epilogue stages."""
+    g = torch.Generator().manual_seed(Kd * N)
+    M, A_rows = 1037, 60
+    A = rnd(g, M, Kd)
+    W = rnd(g, *((Kd, N) if tb else (N, Kd)))
+    mul, res, res2 = rnd(g, M, N), rnd(g, M, N), rnd(g, M, N)
+    g1, g2 = rnd(g, A_rows, N), rnd(g, A_rows, N)
+    i1 = torch.randint(0, A_rows, (M,), generator=g, dtype=torch.int32)
+    i2 = torch.randint(0, A_rows, (M,), generator=g, dtype=torch.int32)
+    kw = dict(act=True, pre_out=True, alpha=0.7, beta=0.5, beta2=1.25)
+    ref_y, ref_z = CK.gemm(A, W, False, tb, mul=mul, res=res, res2=res2, gadd1=g1, gidx1=i1, gadd2=g2, gidx2=i2, **kw)
+    y, z = K.gemm(f32(A), f32(W), False, tb, mul=f32(mul), res=f32(res), res2=f32(res2), gadd1=f32(g1),
+                  gidx1=i1.to(DEV), gadd2=f32(g2), gidx2=i2.to(DEV), **kw)
+    close(z, ref_z, atol=5e-5)
+    close(y, ref_y, atol=5e-5)
+    Wb = rnd(g, N, 262)   # a K-column slice of a wider weight (row pitch 262: the edge-embedding matrix)
+    if not tb:
+        close(K.gemm(f32(A), f32(Wb)[:, 256:256 + Kd]), CK.gemm(A, Wb[:, 256:256 + Kd]), atol=5e-5)
 
 
 def test_gemm_strided_weight_slices():
