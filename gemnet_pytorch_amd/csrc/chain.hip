@@ -19,7 +19,8 @@
 //   * only pre-activations (needed by the adjoint) and final rows touch memory.
 // The adjoint of a stack is another chain program (SCALE ops apply ssilu'(z) in LDS, GEMMs use the
 // transposed weights), so forward and backward share this kernel.
-// LDS: 2 slots x (16 RT) x 132 floats = 84 KB at RT = 5 (dynamic, opt-in above 64 KB).
+// LDS: 3 slots x (16 RT) x 132 floats = 127 KB at RT = 5 (dynamic, opt-in above 64 KB).  Two slots carry the
+// alternating activations; the third parks a tensor across several ops (the gradient of a skip connection).
 #include "common.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -37,7 +38,7 @@ namespace {
 
 constexpr int SW = 128;           // max slot width / max N, K of a GEMM op
 constexpr int SLD = SW + 4;       // slot leading dimension (floats): rows 528 B apart
-constexpr int NSLOT = 2;
+constexpr int NSLOT = 3;
 constexpr int NT = 512;
 
 template <int RT>

@@ -343,7 +343,7 @@ def trip_basis_bwd(gY, R, tc, ta, tb):
 
 
 class ChainProgram:
-    """A program for gn_chain_f32: ops over the two LDS slots of a row tile (see include/gemnet_hip.h).
+    """A program for gn_chain_f32: ops over the three LDS slots of a row tile (see include/gemnet_hip.h).
     Operands named `mul/res/res2` are either an int (LDS slot) or a tensor (global (M,N))."""
     NSLOT = 2
 

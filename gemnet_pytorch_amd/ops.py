@@ -779,6 +779,9 @@ class _Stack(torch.autograd.Function):
         ctx.z_mask = [z is not None for z in zs]
         ctx.in_width = x.shape[1]
         ctx.out_shape = (M, n_out)
+        # a skip connection fed by the stack's own input (m -> ... + m): its gradient joins dL/dx inside the backward
+        # program (parked in LDS slot 2) instead of as a second (M,128) tensor that autograd then adds to gx
+        ctx.skip_is_x = spec.get("skip_is_x", -1) if first is not None else -1
         return (y, *tails) if tails else y
 
     @staticmethod
@@ -806,6 +809,7 @@ class _Stack(torch.autograd.Function):
                 prog.load(oth, gt.contiguous())
                 prog.gemm(transposed(Wt), a_slot=oth, y_slot=cur, res=cur, beta=1.0)
         g_skips = [None] * len(layers)
+        park = ctx.skip_is_x if ctx.in_width == width else -1
         zi = len(zs)
         for k in range(len(layers) - 1, -1, -1):
             L = layers[k]
@@ -813,7 +817,10 @@ class _Stack(torch.autograd.Function):
             zi -= 2
             c = s
             if has_skips[k]:
-                if need[6 + k]:
+                if need[6 + k] and k == park and need[1]:
+                    prog.scale(2, cur, L["skip_beta"], width=width)   # joins dL/dx in the last GEMM below
+                    c = s * L["skip_beta"]
+                elif need[6 + k]:
                     g_skips[k] = torch.empty((M, width), device=dev, dtype=dt)
                     prog.scale(cur, cur, L["skip_beta"], out=g_skips[k], width=width)
                 else:
@@ -845,7 +852,8 @@ class _Stack(torch.autograd.Function):
                 prog.scale(cur, cur, c, Z=z0, out=dz0, width=width)
             if need[1]:
                 gx = torch.empty((M, ctx.in_width), device=dev, dtype=dt)
-                prog.gemm(transposed(first["W"]), a_slot=cur, y_slot=-1, out=gx)
+                parked = park >= 0 and has_skips[park] and need[6 + park]
+                prog.gemm(transposed(first["W"]), a_slot=cur, y_slot=-1, out=gx, res=2 if parked else None, beta=1.0)
             K.chain(prog)
             if has_g1 and need[4]:
                 gg1 = K.segsum(dz0, *first["i1"].csr, first["i1"].n_rows)
@@ -871,6 +879,7 @@ def stack(x, first=None, layers=(), s=0.7071067811865475, tails=()):
                              beta2=float(first.get("beta2", 1.0)), i1=first.get("i1"), i2=first.get("i2"))
         res, res2, g1, g2 = first.get("res"), first.get("res2"), first.get("g1"), first.get("g2")
     skips = [L.get("skip") for L in layers]
+    spec["skip_is_x"] = next((k for k, sk in enumerate(skips) if sk is x), -1)
     return _Stack.apply(spec, x, res, res2, g1, g2, *skips)
 
 

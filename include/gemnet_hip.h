@@ -75,7 +75,7 @@ int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream);
  * for a tile of 16..80 rows (chosen so that the launch is one round of <= 256 workgroups) whose activations
  * stay in LDS between layers; only the weights stream (from L2, straight into MFMA fragment registers) and
  * only pre-activations / the final result go back to memory.  A chain is a short program of ops over two
- * LDS "slots" (tile rows x up to 128 columns each):
+ * LDS "slots" 0..2 (tile rows x up to 128 columns each):
  *   GN_OP_LOAD   slot <- src[(rows ? rows[m] : m), 0:width]                       (global -> LDS)
  *   GN_OP_SCALE  dst_slot <- a_slot * alpha * (src ? phi(src[m, :]) : 1); optional copy to `out`;
  *                phi selected by `act`: 0 ssilu'(x) (adjoint of an activation), 1 x (Hadamard), 2 ssilu(x)

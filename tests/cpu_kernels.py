@@ -232,7 +232,7 @@ def chain(prog):
         for k in ("src", "W"):
             if o.get(k) is not None:
                 dt = o[k].dtype
-    slots = [torch.zeros(M, 128, dtype=dt) for _ in range(2)]
+    slots = [torch.zeros(M, 128, dtype=dt) for _ in range(3)]
 
     def sel(x, N):
         if x is None:

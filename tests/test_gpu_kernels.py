@@ -347,8 +347,9 @@ def _stack_programs(M, width, g, dev):
         p.gemm(t["W1"], a_slot=1, y_slot=0, act=True, pre_out=outs["z1"])
         p.gemm(t["W2"], a_slot=0, y_slot=1, act=True, pre_out=outs["z2"], res=1, beta=0.7, res2=t["skip"], beta2=0.6,
                out=outs["y"], mul=None)
+        p.scale(2, 1, 0.25, width=width)                      # park a scaled copy in the third slot ...
         p.scale(0, 1, 0.3, Z=t["Z"], out=outs["sc"])
-        p.gemm(t["W1"], a_slot=0, y_slot=0, act=False, mul=1, alpha=1.5)
+        p.gemm(t["W1"], a_slot=0, y_slot=0, act=False, mul=1, alpha=1.5, res=2, beta=1.0)   # ... and add it back here
         p.store(0, outs["st"])
         return p, outs
     return build
