@@ -20,3 +20,8 @@ for c in (-1, 0, 1, 7, 13, 14, 15):
     out = K.gemm(g, W2, cfg=c)
     t = timeit(lambda: K.gemm(g, W2, cfg=c))
     print(f"bwd cfg {c:3d}: {t:7.2f} us ({2.0 * M * 64 * 1024 / t / 1e6:5.1f} TF) err {float((out - ref).abs().max()):.1e}")
+W2 = W2t.t().contiguous()     # (K = 1024, N = 64): the k-major 8-wave kernel (x @ B with B (K,N))
+ref = P @ W2
+out = K.gemm(P, W2, False, True)
+t = timeit(lambda: K.gemm(P, W2, False, True))
+print(f"fwd k-major (B as (K,N)): {t:7.2f} us ({2.0 * M * 64 * 1024 / t / 1e6:5.1f} TF) err {float((out - ref).abs().max()):.1e}")
