@@ -361,22 +361,26 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma49_kernel(
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
-  const bool s3 = l15 == 0;   // tile mt = 3 holds only s = 48
+  // Loads are unconditional at clamped (valid) addresses and masked afterwards: `cond ? *p : 0` costs a branch per
+  // load.  Tile mt = 3 holds only s = 48: its other rows read the same element (they feed rows >= 49, zeroed below).
+  const int tlast = max(t1 - 1, t0);
   auto load = [&](int t, float (&a)[4], float (&b)[2]) {
     const int tq = t + lg;
     const bool ok = tq < t1;
-    const float* __restrict__ yr = Y + (int64_t)tq * S + l15;
-    a[0] = ok ? yr[0] : 0.f;
-    a[1] = ok ? yr[16] : 0.f;
-    a[2] = ok ? yr[32] : 0.f;
-    a[3] = (ok && s3) ? yr[48] : 0.f;
-    const int g = ok ? expand_idx[tq] : 0;
-    const float* __restrict__ xr = x + (int64_t)g * C + l15;
-    b[0] = ok ? xr[0] : 0.f;
-    b[1] = ok ? xr[16] : 0.f;
+    const int tc = min(tq, tlast);
+    const float* __restrict__ yr = Y + (int64_t)tc * S;
+    const float y0 = yr[l15], y1 = yr[16 + l15], y2 = yr[32 + l15], y3 = yr[48];
+    a[0] = ok ? y0 : 0.f;
+    a[1] = ok ? y1 : 0.f;
+    a[2] = ok ? y2 : 0.f;
+    a[3] = ok ? y3 : 0.f;
+    const float* __restrict__ xr = x + (int64_t)expand_idx[tc] * C + l15;
+    const float x0 = xr[0], x1 = xr[16];
+    b[0] = ok ? x0 : 0.f;
+    b[1] = ok ? x1 : 0.f;
   };
-  float a0[4], b0[2], a1[4], b1[2];
-  load(t0, a0, b0);
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, b0[2] = {0.f, 0.f}, a1[4], b1[2];
+  if (t0 < t1) load(t0, a0, b0);   // (an edge without quadruplets touches neither Y nor x)
   for (int t = t0; t < t1; t += 8) {
     load(t + 4, a1, b1);               // next K-step in flight under this one's MFMAs
 #pragma unroll
@@ -849,7 +853,10 @@ __global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __r
   for (int kk = 0; kk < 13; ++kk) {
     const int sr = 4 * kk + lg;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bd[kk][nt] = sr < S ? De[sr * C + 16 * nt + l15] : 0.f;
+    for (int nt = 0; nt < 2; ++nt) {   // unconditional at a clamped row, then masked (rows >= 49 pad the contraction)
+      const float v = De[min(sr, S - 1) * C + 16 * nt + l15];
+      bd[kk][nt] = sr < S ? v : 0.f;
+    }
   }
   const int t0 = seg_off[e], t1 = seg_off[e + 1];
   // the 16 x 49 block of Y of a row tile is one contiguous run of 784 floats: 13 coalesced loads per lane, parked in
@@ -859,10 +866,7 @@ __global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __r
     const int n = (t1 - tb < TT ? t1 - tb : TT) * S;
     const float* __restrict__ src = Y + (int64_t)tb * S;
 #pragma unroll
-    for (int j = 0; j < 13; ++j) {
-      const int i = lane + 64 * j;
-      st[j] = i < n ? src[i] : 0.f;
-    }
+    for (int j = 0; j < 13; ++j) st[j] = src[min(lane + 64 * j, n - 1)];   // rows past t1: duplicates, never stored
   };
   auto park = [&](int buf) {
 #pragma unroll
@@ -885,7 +889,8 @@ __global__ __launch_bounds__(256) void bil_expand_mfma49_kernel(const float* __r
     v4f_b c0 = (v4f_b){0.f, 0.f, 0.f, 0.f}, c1 = (v4f_b){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 13; ++kk) {
-      const float a = (kk < 12 || lg == 0) ? yb[4 * kk] : 0.f;
+      const float yv = yb[4 * kk];
+      const float a = (kk < 12 || lg == 0) ? yv : 0.f;
       c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bd[kk][0], c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bd[kk][1], c1, 0, 0, 0);
     }
