@@ -9,7 +9,12 @@ from gemnet_pytorch_amd.kernels import ptr, stream
 from tools.gemm_bench import timeit
 import bench
 
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "libbilt.so"))
+_exp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp")
+if not os.path.exists(os.path.join(_exp, "libbilt.so")):   # cross-compiles without a GPU: build before `gpurun`
+    import subprocess
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                           os.path.join(_exp, "bilt_variants.hip"), "-o", os.path.join(_exp, "libbilt.so")])
+lib = ctypes.CDLL(os.path.join(_exp, "libbilt.so"))
 vp, i32 = ctypes.c_void_p, ctypes.c_int
 lib.bilt_grouped.argtypes = [i32, i32] + [vp] * 8 + [i32, i32, vp]
 lib.bilt_staged.argtypes = [i32] + [vp] * 8 + [i32, i32, i32, vp]
