@@ -336,7 +336,55 @@ class GemNet(torch.nn.Module):
     def save_weights(self, path):
         torch.save(self.state_dict(), path)
 
+    def tf_variable_names(self):
+        """parameter name -> variable of the TensorFlow GemNet checkpoint (the copy list of gemnet.py:633-778 as rules;
+        pinned against the reference in tests/golden/tf_names.json): '.' -> '/', Dense `weight` -> `kernel`, the
+        ResidualLayer members `dense_mlp.<k>` -> `dense_mlp/layer_with_weights-<k>`, the embedding table without leaf."""
+        out = {}
+        for name, _ in self.named_parameters():
+            parts = name.split(".")
+            if name == "atom_emb.embeddings.weight":
+                parts = parts[:-1]
+            elif parts[-1] == "weight":
+                parts[-1] = "kernel"
+            parts = [f"layer_with_weights-{q}" if i > 0 and parts[i - 1] == "dense_mlp" else q
+                     for i, q in enumerate(parts)]
+            out[name] = "/".join(parts) + "/.ATTRIBUTES/VARIABLE_VALUE"
+        return out
+
     def load_tfmodel(self, path):
-        raise NotImplementedError(
-            "TensorFlow checkpoint import (gemnet.py:617-778) is out of scope: TensorFlow is not "
-            "available in this environment (SURVEY.md §2 row 10).")
+        """Import the weights of a TensorFlow GemNet checkpoint (gemnet.py:617-778): 2-D kernels are transposed
+        (TF Dense is (in, out)), the 3-D bilinear kernels and all other variables copied as they are.  `path` is a TF
+        checkpoint prefix (needs `tensorflow`, as in the reference) or a `.npz` holding the same variables under the
+        same names (`np.savez(f, **{n: reader.get_tensor(n) for n in names})` on a machine that has TensorFlow).
+        Unlike the reference — which raises AttributeError on `out_forces/bias` of its bias-free Dense — direct-force
+        models load as well."""
+        import numpy as np
+        if str(path).endswith(".npz"):
+            arrays = np.load(path)
+            get = lambda n: arrays[n]   # noqa: E731
+        else:
+            try:
+                import tensorflow as tf
+            except ImportError as e:
+                raise ImportError(
+                    "GemNet.load_tfmodel needs TensorFlow to read a TF checkpoint (as the reference does); without it, "
+                    "export the checkpoint's variables to a .npz with the same names and pass that file") from e
+            get = tf.train.load_checkpoint(path).get_tensor
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                tf_name = self.tf_variable_names_cached()[name]
+                W = torch.as_tensor(np.asarray(get(tf_name)))
+                if tf_name.endswith("kernel/.ATTRIBUTES/VARIABLE_VALUE") and W.dim() == 2:
+                    W = W.t()
+                if tuple(W.shape) != tuple(p.shape):
+                    raise ValueError(f"checkpoint variable {tf_name}: shape {tuple(W.shape)} does not fit "
+                                     f"parameter {name} {tuple(p.shape)}")
+                p.copy_(W.to(p.dtype))
+        self._wcache.clear()
+
+    def tf_variable_names_cached(self):
+        names = getattr(self, "_tf_names", None)
+        if names is None:
+            names = self._tf_names = self.tf_variable_names()
+        return names

@@ -10,7 +10,8 @@ with load_state_dict.
 
 Oracle-side shims (never shipped as product):
   torch_scatter.scatter -> index_add based;  numba.njit -> identity;  np.math -> math;
-  LambdaLR accepting (and dropping) the `verbose=` keyword torch >= 2.7 removed.
+  LambdaLR accepting (and dropping) the `verbose=` keyword torch >= 2.7 removed;
+  a recording stand-in for `tf.train.load_checkpoint` (golden_tfnames only: TensorFlow is not installed).
 """
 import math
 import os
@@ -446,8 +447,57 @@ def golden_scaling():
         json.dump(result, f, indent=1)
 
 
+# ----------------------------------------------------------------------------- N4: TF checkpoint variable names
+def golden_tfnames():
+    """Which TensorFlow checkpoint variable the reference's `GemNet.load_tfmodel` (gemnet.py:617-778) copies into
+    which parameter.  TensorFlow is not installed: the reference module's `tf` is replaced by a recorder whose reader
+    answers every `get_tensor(name)` with a 0-d array holding a serial number; after the call every parameter is
+    filled with the serial number of the variable it was loaded from (0-d arrays broadcast in `.data.copy_`)."""
+    import json
+    import gemnet.model.gemnet as ref_mod
+    out = {}
+    for tag, cfg in (("T", cfg_small(True)), ("Q", cfg_small(False)), ("dT", dict(cfg_small(True), direct_forces=True)),
+                     ("T3", cfg_full(True, 3))):
+        m = GemNet(**cfg, scale_file=SCALE_FILE)
+        for p_ in m.parameters():
+            p_.data.fill_(-1.0)
+        names = []
+
+        class Reader:
+            def get_tensor(self, name):
+                names.append(name)
+                return np.full((), len(names) - 1, dtype=np.float32)
+
+        ref_mod.tf = types.SimpleNamespace(train=types.SimpleNamespace(load_checkpoint=lambda path: Reader()))
+        error = None
+        try:
+            m.load_tfmodel("unused")
+        except AttributeError as e:   # direct-force models: the reference reads out_forces/bias of a bias-free Dense
+            error = f"{type(e).__name__}: {e}"
+        finally:
+            ref_mod.tf = None
+        mapping, not_loaded = {}, []
+        for n, p_ in m.named_parameters():
+            v = p_.detach().flatten()
+            assert bool((v == v[0]).all())
+            if float(v[0]) < 0:
+                not_loaded.append(n)
+            else:
+                mapping[n] = names[int(v[0])]
+        assert len(set(mapping.values())) == len(mapping)
+        assert error is not None or len(mapping) == len(names)
+        out[tag] = dict(cfg={k: v for k, v in cfg.items() if isinstance(v, (int, float, bool, str))},
+                        mapping=mapping, not_loaded=not_loaded, error=error,
+                        last_request=names[-1] if error else None)
+        print(tag, len(mapping), "variables;", "not loaded:", not_loaded)
+    with open(os.path.join(HERE, "tf_names.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["basis", "indices", "models", "keys", "trainer", "scaling"]
+    which = sys.argv[1:] or ["basis", "indices", "models", "keys", "trainer", "scaling", "tfnames"]
+    if "tfnames" in which:
+        golden_tfnames()
     if "scaling" in which:
         golden_scaling()
     if "trainer" in which:
