@@ -304,6 +304,14 @@ def golden_keys():
         m = GemNet(**cfg, scale_file=SCALE_FILE)
         out[name] = {"state_dict": {k: list(v.shape) for k, v in m.state_dict().items()},
                      "named_parameters": [n for n, _ in m.named_parameters()]}
+    # the published model configurations (pretrained/*/model_kwargs.json): what a `model.pth` of the reference holds
+    for name in ("GemNet-T", "GemNet-Q"):
+        with open(os.path.join(REF, "pretrained", name, "model_kwargs.json")) as f:
+            kw = json.load(f)
+        m = GemNet(**dict(kw, scale_file=SCALE_FILE))
+        out["pretrained/" + name] = {"model_kwargs": kw,
+                                     "state_dict": {k: list(v.shape) for k, v in m.state_dict().items()},
+                                     "named_parameters": [n for n, _ in m.named_parameters()]}
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("state_dict_keys.json", {k: len(v["state_dict"]) for k, v in out.items()})

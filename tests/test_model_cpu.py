@@ -124,6 +124,28 @@ def test_state_dict_keys_match_reference(variant, extra):
     assert [n for n, _ in model.named_parameters()] == ref["named_parameters"]
 
 
+@pytest.mark.parametrize("name", ["GemNet-T", "GemNet-Q"])
+def test_published_model_configurations_and_weight_files(name, tmp_path):
+    """pretrained/*/model_kwargs.json of the reference: the same keyword set builds the model, its
+    state_dict has the reference's keys and shapes, and a `model.pth` written in that format loads (load_weights)."""
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        ref = json.load(f)["pretrained/" + name]
+    kw = dict(ref["model_kwargs"], scale_file=SCALE_FILE)
+    model = GemNet(**kw)
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == ref["state_dict"]
+    assert [n for n, _ in model.named_parameters()] == ref["named_parameters"]
+    torch.manual_seed(7)
+    blob = {k: v.clone() for k, v in GemNet(**kw).state_dict().items()}   # (aliased keys stay consistent)
+    assert any(not torch.equal(v, blob[k]) for k, v in model.state_dict().items())
+    path = str(tmp_path / "model.pth")
+    torch.save(blob, path)
+    model.load_weights(path)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, blob[k]), k
+    model.save_weights(path)
+    assert set(torch.load(path)) == set(ref["state_dict"])
+
+
 def test_no_cpu_fallback():
     cfg = dict(num_spherical=7, num_radial=6, num_blocks=1, emb_size_atom=16, emb_size_edge=16,
                emb_size_trip=16, emb_size_quad=16, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=16,
