@@ -177,7 +177,7 @@ def test_bilinear_adjoint_grouped_by_target_atom(A, deg, C):
         es = torch.nonzero(tgt == a).flatten().tolist()
         for r in es:
             for x in es:
-                if r != x:
+                if r != x and (A > 5 or float(torch.rand((), generator=g)) < 0.85):   # small cases: incomplete pair sets
                     red.append(r), exp.append(x)
     red, exp = torch.tensor(red, dtype=torch.int64), torch.tensor(exp, dtype=torch.int64)
     order = torch.argsort(red, stable=True)
