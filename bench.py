@@ -117,6 +117,13 @@ class LaunchTimer:
             sp, nb = args[2], len(args[0])
             S, C = args[0][0].shape[1], args[0][0].shape[2]
             return 2.0 * nb * sp.size * S * C, nb * (sp.n_reduce * S * C + sp.n_expand * C) * f32 + sp.size * (S * f32 + 4)
+        if name == "bil_fused_fwd":
+            Y, x, B, W2T, sp = args[:5]
+            S, C, I, O = Y.shape[1], x.shape[1], B.shape[2], W2T.shape[0]
+            E = sp.n_reduce
+            fl = 2.0 * sp.size * S * C + 2.0 * E * S * I * C + 2.0 * E * I * C * O
+            by = sp.size * (S * f32 + 8) + (sp.n_expand * C + E * (S * C + S * I + O) + W2T.numel()) * f32
+            return fl, by
         if name in ("bil_reduce", "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd"):
             sp = next(a for a in reversed(args) if hasattr(a, "n_reduce"))
             if name == "bil_project_bwd":
@@ -131,7 +138,7 @@ class LaunchTimer:
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
     FAMILIES = ["gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
-                "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "bessel_rbf", "sph_radial", "ylm0",
+                "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_fused_fwd", "bil_project_bwd", "bil_dy_multi", "bessel_rbf", "sph_radial", "ylm0",
                 "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
                 "quad_basis_bwd"]
 

@@ -443,6 +443,24 @@ def bil_reduce_project(Y, x, B, sp):
     return Sm, P
 
 
+def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
+    """K1+K2+K3 in one launch -> (Sm (E,S,C), out (E,O)); W2T (O, I*C) = the bilinear weight, k-contiguous.
+    Spherical basis only (S, C, I, O) = (7, 64, 16, 64); see `bil_fused_fwd_supported`."""
+    require_device(Y, x, B, W2T)
+    Y, x, B, W2T = _f32c(Y), _f32c(x), _f32c(B), _f32c(W2T)
+    S, C, I, O = Y.shape[1], x.shape[1], B.shape[2], W2T.shape[0]
+    Sm = torch.empty((sp.n_reduce, S, C), device=x.device, dtype=torch.float32)
+    out = torch.empty((sp.n_reduce, O), device=x.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_fused_fwd_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B), ptr(W2T),
+                                           ptr(Sm), ptr(out), sp.n_reduce, S, C, I, O, float(alpha), stream()),
+          "gn_bil_fused_fwd_f32")
+    return Sm, out
+
+
+def bil_fused_fwd_supported(S, C, I, O):
+    return (S, C, I, O) == (7, 64, 16, 64)
+
+
 def bil_dy_multi(dSm_list, x_list, sp):
     """dY (T,S) = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c] for the blocks b that share one tensor basis (one pass)."""
     require_device(*dSm_list, *x_list)

@@ -557,9 +557,13 @@ class _FusedBilinear(torch.autograd.Function):
         if ctx.sink is not None:
             ctx.sink.uses += 1
         C, I, O = W.shape
-        Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)
-        out = K.gemm(P.reshape(-1, I * C), bilinear_weight(W, True), alpha=alpha)
         keep_p = W.requires_grad and _PARAM_GRADS
+        if not keep_p and K.bil_fused_fwd_supported(sph.shape[1], C, I, O):
+            Sm, out = K.bil_fused_fwd(sph, x, rbf_W1, bilinear_weight(W, True), sp, alpha)   # K1 + K2 + K3, P stays in LDS
+            P = None
+        else:
+            Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)
+            out = K.gemm(P.reshape(-1, I * C), bilinear_weight(W, True), alpha=alpha)
         ctx.save_for_backward(rbf_W1, sph, x, W, Sm, P if keep_p else None)
         ctx.sp, ctx.alpha = sp, alpha
         return out

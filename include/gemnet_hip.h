@@ -216,6 +216,14 @@ int gn_bil_dot_f32(const float* dSm, const float* x, const int32_t* expand_idx,
 int gn_bil_reduce_project_f32(const float* Y, const float* x, const int32_t* expand_idx,
                               const int32_t* seg_off, const float* B, float* Sm, float* P, int64_t E, int S,
                               int C, int I, void* stream);
+/* K1 + K2 + K3 in one launch (efficient.py:173-188 incl. the final `torch.matmul(..., self.weight)`), for callers that
+ * do not need P afterwards (inference / frozen weights):
+ *   Sm as above (written: the adjoint needs it);  out[e,o] = alpha * sum_{i,c} P[e,i,c] * W2T[o, i*C + c]
+ * W2T = the (C,I,O) bilinear weight permuted to (O, I*C), k-contiguous, 16-byte aligned.
+ * S = 7, C = 64, I = 16, O = 64 only (else hipErrorInvalidValue: use gn_bil_reduce_project_f32 + gn_gemm_f32). */
+int gn_bil_fused_fwd_f32(const float* Y, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
+                         const float* B, const float* W2T, float* Sm, float* out, int64_t E, int S, int C, int I, int O,
+                         float alpha, void* stream);
 /* Fused adjoint: gB[e,s,i] = sum_c Sm[e,s,c] dP[e,i,c]; dSm[e,s,c] = sum_i B[e,s,i] dP[e,i,c];
  * dY[t,s] = sum_c dSm[r(t),s,c] x[g(t),c].  x rows 16-byte aligned, C % 4 == 0. */
 int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,

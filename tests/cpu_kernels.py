@@ -345,7 +345,12 @@ def quad_basis_bwd_packed(gY, R, qc, qa, qb, qd, S):
     return Gc, Gbd
 
 
-_NAMES = ["quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
+    Sm, P = bil_reduce_project(Y, x, B, sp)
+    return Sm, (P.reshape(P.shape[0], -1) @ W2T.t()) * alpha
+
+
+_NAMES = ["bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

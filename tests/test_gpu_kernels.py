@@ -496,6 +496,24 @@ def test_bilinear_adjoint_accumulates_y_gradient(S, C, I, E, J, mk):
     close(dY2, ref, atol=2e-4 * max(1.0, float(ref.abs().max())))
 
 
+@pytest.mark.parametrize("E,mk", [(500, 18), (77, 5), (16, 30), (1, 3)])
+def test_bilinear_forward_fused_with_the_final_projection(E, mk):
+    """gn_bil_fused_fwd_f32: K1 + K2 + K3 in one launch (P parked in LDS) == gn_bil_reduce_project_f32 + gn_gemm_f32."""
+    S, C, I, O = 7, 64, 16, 64
+    g = torch.Generator().manual_seed(E)
+    cpu, dev = _segplan(g, E, E, mk)
+    Y, x, Bm = rnd(g, cpu.size, S), rnd(g, E, C), rnd(g, E, S, I)
+    W2T = rnd(g, O, I * C) / 32
+    Sm, out = K.bil_fused_fwd(f32(Y), f32(x), f32(Bm), f32(W2T), dev, alpha=0.6)
+    rSm, rout = CK.bil_fused_fwd(Y, x, Bm, W2T, cpu, alpha=0.6)
+    close(Sm, rSm, atol=1e-4)
+    close(out, rout, atol=3e-4 * max(1.0, float(rout.abs().max())))
+    Sm2, P2 = K.bil_reduce_project(f32(Y), f32(x), f32(Bm), dev)
+    assert torch.equal(Sm, Sm2)
+    with pytest.raises(RuntimeError):
+        K.bil_fused_fwd(f32(Y), f32(x)[:, :32].contiguous(), f32(Bm), f32(W2T)[:, :512].contiguous(), dev)
+
+
 @pytest.mark.parametrize("shape", [(49, 32, 32, 50, 260, 75), (7, 64, 16, 90, 90, 40)])
 @pytest.mark.parametrize("nb", [1, 2, 4])
 def test_bilinear_deferred_y_gradient_of_several_blocks(nb, shape):
