@@ -1,4 +1,4 @@
-"""Prototype check (next round: not yet run on a GPU): the adjoint of the bilinear tail in one launch
+"""Prototype check: the adjoint of the bilinear tail in one launch
 (tools/exp/k3fused_bwd.hip: dP kept in LDS) vs the two product launches gn_gemm_f32 + gn_bil_project_bwd_f32(dY = NULL)."""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
