@@ -533,12 +533,26 @@ class GradSink:
     """Running sum of the gradient of one tensor that several fused ops consume (the angular basis is shared by all
     interaction blocks).  Each consumer adds its contribution into `buf` inside its own kernel and returns None to
     autograd, except the consumer whose backward runs last, which returns the buffer — so autograd's own
-    accumulation (three (T,S)-sized adds per step: 1.8 GB each for the quadruplet basis) never happens."""
+    accumulation (three (T,S)-sized adds per step: 1.8 GB each for the quadruplet basis) never happens.
+
+    Re-entrant: `consumers` is fixed by the forward; every backward pass over the graph (one per target when
+    GemNet.forward differentiates several energies with retain_graph=True) counts its own `left` down from
+    `consumers` and clears the running state when it reaches zero."""
 
     def __init__(self):
-        self.uses = 0
+        self.consumers = 0  # fused bilinear layers that consumed the tensor in the forward
+        self.left = 0       # consumers whose backward has not run yet in the CURRENT backward pass
         self.buf = None
         self.pending = []   # (dSm_b, x_b) of the consumers whose Y gradient is deferred to one combined pass
+
+    def arrive(self):
+        """Called once per consumer backward; returns True for the last consumer of this pass."""
+        if self.left == 0:          # first consumer of a new pass
+            self.left = self.consumers
+            self.buf = None
+            self.pending = []
+        self.left -= 1
+        return self.left == 0
 
 
 def share_gradient(t):
@@ -555,7 +569,7 @@ class _FusedBilinear(torch.autograd.Function):
     def forward(ctx, rbf_W1, sph, x, W, sp, alpha):
         ctx.sink = getattr(sph, "_gn_sink", None)
         if ctx.sink is not None:
-            ctx.sink.uses += 1
+            ctx.sink.consumers += 1
         C, I, O = W.shape
         keep_p = W.requires_grad and _PARAM_GRADS
         if not keep_p and K.bil_fused_fwd_supported(sph.shape[1], C, I, O):
@@ -578,22 +592,21 @@ class _FusedBilinear(torch.autograd.Function):
         g = g.contiguous()
         dP = K.gemm(g, bilinear_weight(W, False), alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is (N=I*C, K=O)
         sink = ctx.sink
-        if (sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64))
-                and sink.uses + len(sink.pending) <= 4):
+        if sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64)) and sink.consumers <= 4:
             # gB and dSm now, the Y gradient of all consumers of this basis in ONE pass when the last one arrives
             gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False)
+            last = sink.arrive()
             sink.pending.append((dSm, x))
-            sink.uses -= 1
             gsph = None
-            if sink.uses == 0:
+            if last:
                 gsph = K.bil_dy_multi([d for d, _ in sink.pending], [xx for _, xx in sink.pending], sp)
                 sink.pending = []
         elif sink is not None and need[1]:
             # the Y gradient is summed across the consumers of `sph` inside the kernel (see GradSink)
+            last = sink.arrive()
             gB, dSm, sink.buf = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, dY_accum=sink.buf)
-            sink.uses -= 1
-            gsph = sink.buf if sink.uses == 0 else None
-            if sink.uses == 0:
+            gsph = sink.buf if last else None
+            if last:
                 sink.buf = None
         else:
             gB, dSm, gsph = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp)      # 2 bmm + bil_dot in one launch

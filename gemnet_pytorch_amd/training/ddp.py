@@ -102,19 +102,24 @@ class TrainStep:
             self.opt = optimizer if optimizer is not None else make_optimizer(model)
         self.global_counts = global_counts  # (B_global, A_global) if known statically
         self.last_loss = None
+        self._pinned_counts = None   # ((B_local, A_local), (B_global, A_global)) of the captured static batch
         self.wgrad = None
         if self.buf.params[0].is_cuda:
             from .wgrad_queue import WeightGradQueue
             self.wgrad = WeightGradQueue()  # all weight-gradient GEMMs of the final backward as one grouped launch
 
     def _counts(self, n_mol, n_atoms, device):
+        """(B_global, A_global).  Batches of a real loader vary in atom count and the last one is partial
+        (drop_last=False), so the counts are exchanged EVERY step unless the caller fixed them (`global_counts=`)
+        or the step was captured for one static batch (`capture()` pins them for that batch only)."""
         if self.global_counts is not None:
             return self.global_counts
+        if self._pinned_counts is not None and self._pinned_counts[0] == (n_mol, n_atoms):
+            return self._pinned_counts[1]
         if self.world_size > 1:
             t = torch.tensor([n_mol, n_atoms], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            self.global_counts = (float(t[0]), float(t[1]))  # static batch shape: exchange once
-            return self.global_counts
+            return float(t[0]), float(t[1])
         return float(n_mol), float(n_atoms)
 
     def loss(self, E, F, targets):
@@ -144,7 +149,9 @@ class TrainStep:
         hipGraph for this (static-shape) batch; the collective, clipping and optimizer stay eager.
         The graph reads the parameters in place, so optimizer updates are seen by every replay."""
         self.model.train()
-        self._counts(int(inputs["N"].shape[0]), int(inputs["Z"].shape[0]), inputs["Z"].device)
+        local = (int(inputs["N"].shape[0]), int(inputs["Z"].shape[0]))
+        self._pinned_counts = None
+        self._pinned_counts = (local, self._counts(*local, inputs["Z"].device))   # no collective inside the graph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

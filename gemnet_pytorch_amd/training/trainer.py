@@ -11,8 +11,10 @@ amsgrad, eps 1e-7 (:115-160); shared-gradient rescale (:250-278); global-norm or
 (:218-248,349-356); linear-warmup exponential decay + reduce-on-plateau; EMA of the parameters.
 
 Native differences: all gradients live in ONE flat buffer (`FlatGradBuffer`), so in a multi-process run
-(one process per GPU, `torch.distributed` initialised) the step issues exactly one RCCL all-reduce, with the
-loss terms normalised by the GLOBAL molecule / atom counts (see training/ddp.py); `loss.backward()` is
+(one process per GPU, `torch.distributed` initialised) the step issues exactly one RCCL all-reduce of the
+gradients, with the loss terms normalised by the GLOBAL molecule / atom counts (see training/ddp.py) and the
+returned / logged loss all-reduced to the global value (every rank must therefore run the same number of
+`train_on_batch` / `test_on_batch` calls — shard the validation set evenly or pad it); `loss.backward()` is
 restricted to the parameters (no gradient w.r.t. positions); `load_state_dict` works (upstream's iterates a
 bound method, trainer.py:508).
 """
@@ -164,28 +166,39 @@ class Trainer:
     def _world(self):
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    def _global_weights(self, n_mol, n_atoms, device, dtype):
+        """(B_r / B, A_r / A): this rank's share of the global molecule / atom counts (one small all-reduce)."""
+        counts = torch.tensor([n_mol, n_atoms], dtype=torch.float64, device=device)
+        local = counts.clone()
+        dist.all_reduce(counts)
+        return (local / counts).to(dtype)
+
     def _objective(self, targets, mean_energy, var_energy, mean_forces, var_forces):
-        """-> (loss for this rank, dict of metric tensors).  In a multi-process run the energy/force means are
-        taken over the GLOBAL batch: local sums divided by all-reduced counts, so summed gradients are exact."""
+        """-> (objective to differentiate on this rank, value to report, dict of metric tensors).
+
+        Single process: both are the reference's loss (trainer.py:284-343).  Multi-process (one rank per GPU): every
+        term is a mean over the rank's molecules / atoms, so the rank's objective weights it by its share of the
+        GLOBAL counts (B_r/B, A_r/A) and the SUM of the ranks' gradients is the gradient of the loss on the union
+        batch — for the MAE/RMSE terms and for the Gaussian NLL terms alike.  The REPORTED value is the all-reduced
+        sum of those weighted objectives, i.e. the global loss, identical on every rank (so `decay_maybe(val_loss)`
+        takes the same decision everywhere)."""
         out = {}
         if self.mve:
-            out["energy_nll"] = self.get_nll(targets["E"], mean_energy, var_energy)
-            out["force_nll"] = self.get_nll(targets["F"], mean_forces, var_forces)
-            loss = out["energy_nll"] * (1 - self.rho_force) + self.rho_force * out["force_nll"]
-            return loss, out
-        out["energy_mae"] = self.get_mae(targets["E"], mean_energy)
-        force_metric = self.get_mae(targets["F"], mean_forces) if self.loss == "mae" \
-            else self.get_rmse(targets["F"], mean_forces)
-        out["force_mae" if self.loss == "mae" else "force_rmse"] = force_metric
-        loss = out["energy_mae"] * (1 - self.rho_force) + self.rho_force * force_metric
-        if self._world() > 1:
-            counts = torch.tensor([mean_energy.shape[0], mean_forces.shape[0]], dtype=torch.float64,
-                                  device=mean_energy.device)
-            local = counts.clone()
-            dist.all_reduce(counts)
-            w = (local / counts).to(loss.dtype)  # B_r / B, A_r / A
-            loss = out["energy_mae"] * w[0] * (1 - self.rho_force) + self.rho_force * force_metric * w[1]
-        return loss, out
+            out["energy_nll"] = e_term = self.get_nll(targets["E"], mean_energy, var_energy)
+            out["force_nll"] = f_term = self.get_nll(targets["F"], mean_forces, var_forces)
+        else:
+            out["energy_mae"] = e_term = self.get_mae(targets["E"], mean_energy)
+            f_term = self.get_mae(targets["F"], mean_forces) if self.loss == "mae" \
+                else self.get_rmse(targets["F"], mean_forces)
+            out["force_mae" if self.loss == "mae" else "force_rmse"] = f_term
+        if self._world() == 1:
+            loss = e_term * (1 - self.rho_force) + self.rho_force * f_term
+            return loss, loss.detach(), out
+        w = self._global_weights(mean_energy.shape[0], mean_forces.shape[0], mean_energy.device, e_term.dtype)
+        loss = e_term * w[0] * (1 - self.rho_force) + self.rho_force * f_term * w[1]
+        report = loss.detach().clone()
+        dist.all_reduce(report)
+        return loss, report, out
 
     # ------------------------------------------------------------------------------------------ steps
     def train_on_batch(self, dataset_iter, metrics):
@@ -193,7 +206,7 @@ class Trainer:
         inputs, targets = next(dataset_iter)
         inputs, targets = self.dict2device(inputs), self.dict2device(targets)
         mean_energy, var_energy, mean_forces, var_forces = self.predict(inputs)
-        loss, parts = self._objective(targets, mean_energy, var_energy, mean_forces, var_forces)
+        loss, report, parts = self._objective(targets, mean_energy, var_energy, mean_forces, var_forces)
 
         if self._grads is None:
             self._grads = FlatGradBuffer(self.model.parameters())
@@ -209,10 +222,9 @@ class Trainer:
         self.schedulers.step()
         self.exp_decay.update()
 
-        loss = loss.detach()
         with torch.no_grad():
-            self._update_metrics(metrics, loss, targets, mean_energy, var_energy, mean_forces, var_forces, parts)
-        return loss
+            self._update_metrics(metrics, report, targets, mean_energy, var_energy, mean_forces, var_forces, parts)
+        return report
 
     def _update_metrics(self, metrics, loss, targets, mean_energy, var_energy, mean_forces, var_forces, parts):
         energy_mae = parts.get("energy_mae")
@@ -244,9 +256,9 @@ class Trainer:
             outs = self.predict(inputs)  # forces need dE/dR (first-order, fused path in eval mode)
         mean_energy, var_energy, mean_forces, var_forces = (None if o is None else o.detach() for o in outs)
         with torch.no_grad():
-            loss, parts = self._objective(targets, mean_energy, var_energy, mean_forces, var_forces)
-            self._update_metrics(metrics, loss, targets, mean_energy, var_energy, mean_forces, var_forces, parts)
-        return loss
+            _, report, parts = self._objective(targets, mean_energy, var_energy, mean_forces, var_forces)
+            self._update_metrics(metrics, report, targets, mean_energy, var_energy, mean_forces, var_forces, parts)
+        return report
 
     def eval_on_batch(self, dataset_iter):
         self.model.eval()

@@ -26,15 +26,52 @@ def _rowmajor(t):
     return t if (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
 
 
+class _TableSlot:
+    """One pinned host table + its device copy + the event that marks the copy's completion."""
+
+    def __init__(self, nbytes, dev):
+        self.host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.copied = torch.cuda.Event()
+        self.in_flight = False
+
+
 class WeightGradQueue:
+    """Eager steps rotate through `RING` table slots and wait on a slot's copy event before rewriting its pinned
+    host buffer (the CPU may run a step ahead of the GPU: rewriting the buffer of a copy that has not executed yet
+    would hand the earlier step the later step's operand addresses).  A slot used while a hipGraph is being captured
+    belongs to that graph — the captured memcpy re-reads its pinned buffer at every replay — so it is moved to
+    `_captured`, kept alive for the lifetime of the queue and never written again."""
+    RING = 3
+
     def __init__(self):
         self.items = []
-        self._host = self._dev = None
+        self._ring = []
+        self._next = 0
+        self._captured = []
         self._keep = None
 
     def add(self, param, X, Y):
         """param.grad (M,N) += X^T @ Y with X (K,M), Y (K,N)."""
         self.items.append((param, _rowmajor(X), _rowmajor(Y)))
+
+    def _slot(self, nbytes, dev, capturing):
+        if capturing:
+            slot = _TableSlot(nbytes, dev)   # allocated outside the pool of eager slots; owned by the graph
+            self._captured.append(slot)
+            return slot
+        if len(self._ring) < self.RING:
+            self._ring.append(_TableSlot(nbytes, dev))
+            return self._ring[-1]
+        i = self._next
+        self._next = (i + 1) % self.RING
+        slot = self._ring[i]
+        if slot.in_flight:
+            slot.copied.synchronize()       # the previous use of this pinned buffer has been read by the GPU
+            slot.in_flight = False
+        if slot.host.numel() < nbytes:
+            slot = self._ring[i] = _TableSlot(nbytes, dev)
+        return slot
 
     def flush(self):
         items, self.items = self.items, []
@@ -68,21 +105,21 @@ class WeightGradQueue:
         blob = probs.tobytes() + targets.tobytes() + slice_off.tobytes()
         nbytes = len(blob)
         capturing = torch.cuda.is_current_stream_capturing()
-        if self._host is None or self._host.numel() < nbytes or self._frozen:
-            # the table of a captured graph is read from the pinned buffer at every replay: never overwrite it
-            assert not capturing, "run one eager step before capturing (sizes the tables), capture only once"
-            self._host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
-            self._dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._frozen = False
-        self._host.numpy()[:nbytes] = np.frombuffer(blob, dtype=np.uint8)
-        self._dev[:nbytes].copy_(self._host[:nbytes], non_blocking=True)
+        slot = self._slot(nbytes, dev, capturing)
+        slot.host.numpy()[:nbytes] = np.frombuffer(blob, dtype=np.uint8)
+        slot.dev[:nbytes].copy_(slot.host[:nbytes], non_blocking=True)
+        if not capturing:
+            slot.copied.record()
+            slot.in_flight = True
         ws = torch.empty(ws_off, dtype=torch.float32, device=dev)
-        base = self._dev.data_ptr()
+        base = slot.dev.data_ptr()
         o_t = probs.nbytes
         o_s = o_t + targets.nbytes
         check(_lib.load().gn_gemm_tn_grouped_f32(base, len(items), wg, base + o_t, len(by_param), fold_wg, base + o_s,
                                                  ptr(ws), stream()), "gn_gemm_tn_grouped_f32")
-        self._keep = (items, ws)  # operands stay allocated until the launches (or the captured graph) no longer run
-        self._frozen = capturing
-
-    _frozen = False
+        # operands stay allocated until the launches have been enqueued after them in stream order (eager: the
+        # caching allocator is stream-ordered) or, for a captured graph, for as long as the graph may be replayed
+        if capturing:
+            slot.keep = (items, ws)
+        else:
+            self._keep = (items, ws)

@@ -102,3 +102,86 @@ def test_flat_buffer_views():
     lin(torch.ones(1, 3)).sum().backward()
     assert buf.flat.numel() == 8 and float(buf.flat.abs().sum()) > 0
     assert lin.weight.grad.data_ptr() == buf.flat.data_ptr()
+
+
+# ------------------------------------------------------------------ Trainer under world_size 2 (gloo)
+def _trainer_worker(rank, world, port, shards, out_dir, mve):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_kernels
+    from gemnet_pytorch_amd.training.metrics import Metrics
+    from gemnet_pytorch_amd.training.trainer import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with cpu_kernels.emulate():
+            model = _model_mve() if mve else _model()
+            tr = Trainer(model, learning_rate=1e-3, weight_decay=0.0, grad_clip_max=1e9, loss="rmse", mve=mve)
+            tr.dict2device = lambda d, device=None: d
+            dc = _make(4)
+
+            def it():
+                while True:
+                    yield _batch(dc, shards[rank])
+
+            train = Metrics("train", tr.tracked_metrics)
+            val = Metrics("val", tr.tracked_metrics)
+            stream = it()
+            loss = float(tr.train_on_batch(stream, train))
+            grads = tr._grads.flat.clone().numpy()
+            vloss = float(tr.test_on_batch(stream, val))
+        np.save(os.path.join(out_dir, f"tg_{rank}.npy"), grads)
+        np.save(os.path.join(out_dir, f"tl_{rank}.npy"), np.array([loss, vloss]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _model_mve():
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+    torch.manual_seed(3)
+    m = GemNet(**dict(CFG, num_targets=2), scale_file=SCALE_FILE).double()
+    m._check_inputs = lambda R: None
+    return m
+
+
+@pytest.mark.parametrize("mve", [False, True])
+def test_trainer_two_ranks_equal_single_process(tmp_path, mve):
+    """Trainer.train_on_batch / test_on_batch on two gloo ranks (uneven shards 3 + 1 molecules): the all-reduced
+    gradient is the single-process gradient of the union batch (MAE/RMSE and Gaussian-NLL objectives alike), and the
+    loss every rank returns and logs is the global loss — identical on both ranks — for training and validation."""
+    import cpu_kernels
+    from gemnet_pytorch_amd.training.metrics import Metrics
+    from gemnet_pytorch_amd.training.trainer import Trainer
+    dc = _make(4)
+    with cpu_kernels.emulate():
+        model = _model_mve() if mve else _model()
+        tr = Trainer(model, learning_rate=1e-3, weight_decay=0.0, grad_clip_max=1e9, loss="rmse", mve=mve)
+        tr.dict2device = lambda d, device=None: d
+
+        def it():
+            while True:
+                yield _batch(dc, [0, 1, 2, 3])
+
+        stream = it()
+        loss_ref = float(tr.train_on_batch(stream, Metrics("train", tr.tracked_metrics)))
+        grad_ref = tr._grads.flat.clone().numpy()
+        vloss_ref = float(tr.test_on_batch(stream, Metrics("val", tr.tracked_metrics)))
+    shards = [[0, 1, 3], [2]]
+    mp.spawn(_trainer_worker, args=(2, _free_port(), shards, str(tmp_path), mve), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "tg_0.npy"), np.load(tmp_path / "tg_1.npy")
+    l0, l1 = np.load(tmp_path / "tl_0.npy"), np.load(tmp_path / "tl_1.npy")
+    assert np.array_equal(g0, g1)
+    np.testing.assert_allclose(g0, grad_ref, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(l0, l1, rtol=1e-12)                      # same value on every rank
+    np.testing.assert_allclose(l0, [loss_ref, vloss_ref], rtol=1e-8)    # = the loss of the union batch
+
+
+def test_train_step_counts_follow_the_batch():
+    """Without `global_counts`, TrainStep exchanges the molecule/atom counts every step (batches of a real loader
+    vary); only a captured static batch pins them."""
+    ts = TrainStep.__new__(TrainStep)
+    ts.global_counts, ts._pinned_counts, ts.world_size = None, None, 1
+    assert ts._counts(4, 32, "cpu") == (4.0, 32.0)
+    assert ts._counts(3, 20, "cpu") == (3.0, 20.0)
+    ts._pinned_counts = ((4, 32), (8.0, 64.0))
+    assert ts._counts(4, 32, "cpu") == (8.0, 64.0) and ts._counts(3, 20, "cpu") == (3.0, 20.0)

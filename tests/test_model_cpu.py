@@ -181,3 +181,29 @@ def test_derived_weight_cache_is_owned_by_the_model(golden_model):
         assert c._wcache == {} and len(a._wcache) > 0
         a.double()
         assert a._wcache == {}
+
+
+@pytest.mark.parametrize("tag", ["t2", "q1"])
+def test_multi_target_forces_fused_equals_composite(golden_model, tag):
+    """num_targets = 2 with autograd forces: GemNet.forward differentiates once per target with retain_graph=True
+    (gemnet.py:605-611), so the shared-gradient sink of the fused bilinear layers sees several backward passes over
+    one graph.  Every target's force must equal the composite (force_graph=True) result."""
+    cfg, _, inputs = load_case(golden_model, tag)
+    cfg = dict(cfg, num_targets=2)
+    params = GO.make_params(cfg, 17, GO.load_scale_factors(SCALE_FILE))
+    inputs["R"] = inputs["R"].double()
+    res = {}
+    with cpu_kernels.emulate():
+        for mode in ("fused", "composite"):
+            model = build(cfg, params).eval()
+            model.force_graph = (mode == "composite")
+            E, F = model(dict(inputs))
+            assert F.shape == (inputs["R"].shape[0], 2, 3)
+            res[mode] = (E.detach(), F.detach())
+            E2, F2 = model(dict(inputs))           # the sink state must not leak into the next forward
+            assert torch.allclose(F2.detach(), F.detach(), rtol=1e-12, atol=1e-14)
+    scale = float(res["composite"][1].abs().mean())
+    for t in range(2):
+        d = float((res["fused"][1][:, t] - res["composite"][1][:, t]).abs().max())
+        assert d <= 1e-10 * max(1.0, scale), (t, d, scale)
+    assert torch.allclose(res["fused"][0], res["composite"][0], rtol=1e-10, atol=1e-12)

@@ -153,3 +153,34 @@ def test_reference_module_paths_resolve_to_native_classes():
         m = importlib.import_module(mod)
         for n in names:
             assert getattr(m, n).__module__.startswith("gemnet_pytorch_amd."), (mod, n)
+
+
+def test_ema_checkpoint_layout_matches_reference():
+    """ExponentialMovingAverage.state_dict uses the reference's keys (ema_decay.py:148-159: lists under
+    `shadow_params` / `collected_params`), loads such a dict by COPY, and still reads round-1 flat checkpoints."""
+    from gemnet_pytorch_amd.training.ema_decay import ExponentialMovingAverage
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(3, 2)
+    ema = ExponentialMovingAverage(lin.parameters(), 0.9)
+    with torch.no_grad():
+        lin.weight.add_(1.0)
+    ema.update()
+    ema.store()
+    sd = ema.state_dict()
+    assert set(sd) == {"decay", "num_updates", "shadow_params", "collected_params"}
+    assert [tuple(t.shape) for t in sd["shadow_params"]] == [(2, 3), (2,)]
+    assert [tuple(t.shape) for t in sd["collected_params"]] == [(2, 3), (2,)]
+    # a dict in the reference's format (independent tensors) loads by copy into two different trainers
+    ref_fmt = {"decay": 0.5, "num_updates": None, "shadow_params": [t.clone() for t in sd["shadow_params"]],
+               "collected_params": [t.clone() for t in sd["collected_params"]]}
+    a = ExponentialMovingAverage(torch.nn.Linear(3, 2).parameters(), 0.9)
+    b = ExponentialMovingAverage(torch.nn.Linear(3, 2).parameters(), 0.9)
+    a.load_state_dict(ref_fmt)
+    b.load_state_dict(ref_fmt)
+    assert a.decay == 0.5 and torch.equal(a.shadow, ema.shadow) and torch.equal(a.backup, ema.backup)
+    a.shadow.add_(1.0)                                     # in-place update of one must not leak into the other
+    assert torch.equal(b.shadow, ema.shadow) and torch.equal(ref_fmt["shadow_params"][0], sd["shadow_params"][0])
+    b.load_state_dict({"decay": 0.9, "num_updates": None, "shadow": ema.shadow, "backup": None})   # round-1 layout
+    assert torch.equal(b.shadow, ema.shadow) and b.shadow.data_ptr() != ema.shadow.data_ptr() and b.backup is None
+    with pytest.raises(ValueError):
+        a.load_state_dict(dict(ref_fmt, shadow_params=ref_fmt["shadow_params"][:1]))
