@@ -56,6 +56,7 @@ class ChainOp(ctypes.Structure):
         ("res_slot", _i), ("res_g", _vp), ("res_rows", _vp), ("beta", _f),
         ("res2_slot", _i), ("res2_g", _vp), ("beta2", _f),
         ("out", _vp),
+        ("mul_mode", _i), ("y2_slot", _i), ("y2_src", _i), ("mode2", _i), ("alpha2", _f), ("Z2", _vp), ("out2", _vp),
     ]
 
 
@@ -69,6 +70,8 @@ SIGNATURES = {
     "gn_gemm_f32": [ctypes.POINTER(GemmArgs), _vp],
     "gn_gemm_f32_cfg": [ctypes.POINTER(GemmArgs), _i, _vp],
     "gn_chain_f32": [ctypes.POINTER(ChainArgs), _vp],
+    "gn_chain_split_f32": [ctypes.POINTER(ChainArgs), _i, _vp],
+    "gn_pack_weight_split": [_vp, _i, _i, _i, _i, _vp, _vp],
     "gn_gemm_tn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "gn_gemm_tn_splitk": [_i, _i, _i],
     "gn_gemm_tn_grouped_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
@@ -124,6 +127,8 @@ def load():
     lib.gn_optim_blocks.argtypes = [_i64]
     lib.gn_index_gpu_ws_bytes.restype = _i64
     lib.gn_index_gpu_ws_bytes.argtypes = [_i, _i64, _i]
+    lib.gn_pack_weight_split_bytes.restype = _i64
+    lib.gn_pack_weight_split_bytes.argtypes = [_i, _i]
     lib.gn_error_string.restype = ctypes.c_char_p
     lib.gn_error_string.argtypes = [_i]
     for name, argtypes in SIGNATURES.items():

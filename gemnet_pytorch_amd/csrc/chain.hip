@@ -91,8 +91,10 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
     const gn_chain_op& op = P.ops[oi];
     const int kind = op.kind;
     if (kind == GN_OP_LOAD) {
-      const int w4 = op.width >> 2, slot = op.slot, ld = op.ld;
+      const int w4 = op.width >> 2, slot = op.slot, ld = op.ld, y2_slot = op.y2_slot, mode2 = op.mode2, width = op.width;
+      const float alpha = op.alpha, alpha2 = op.alpha2;
       const float* __restrict__ const src = op.src;
+      const float* __restrict__ const Z2 = op.Z2;
       const int32_t* __restrict__ const rows = op.rows;
       for (int f = tid; f < BM * w4; f += NT) {
         const int r = f / w4, c = (f - r * w4) << 2;
@@ -101,8 +103,19 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
         if (gr < M) {
           const int64_t sr = rows ? (int64_t)rows[gr] : gr;
           v = *reinterpret_cast<const float4*>(src + sr * ld + c);
+          v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
         }
         *reinterpret_cast<float4*>(&S[slot][r][c]) = v;
+        if (y2_slot >= 0) {   // second tensor derived from the loaded rows: v * alpha2 * phi2(Z2)
+          float4 u = make_float4(v.x * alpha2, v.y * alpha2, v.z * alpha2, v.w * alpha2);
+          if (Z2 && gr < M) {
+            const float4 z = *reinterpret_cast<const float4*>(Z2 + gr * width + c);
+            if (mode2 == 0) { u.x *= gn_dssilu(z.x); u.y *= gn_dssilu(z.y); u.z *= gn_dssilu(z.z); u.w *= gn_dssilu(z.w); }
+            else if (mode2 == 1) { u.x *= z.x; u.y *= z.y; u.z *= z.z; u.w *= z.w; }
+            else { u.x *= gn_ssilu(z.x); u.y *= gn_ssilu(z.y); u.z *= gn_ssilu(z.z); u.w *= gn_ssilu(z.w); }
+          }
+          *reinterpret_cast<float4*>(&S[y2_slot][r][c]) = u;
+        }
       }
       __syncthreads();
     } else if (kind == GN_OP_SCALE) {
@@ -152,6 +165,10 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
       const float* __restrict__ const res_g = op.res_g;
       const float* __restrict__ const res2_g = op.res2_g;
       const int32_t* __restrict__ const res_rows = op.res_rows;
+      const int mul_mode = op.mul_mode, y2_slot = op.y2_slot, y2_src = op.y2_src, mode2 = op.mode2;
+      const float alpha2 = op.alpha2;
+      const float* __restrict__ const Z2 = op.Z2;
+      float* __restrict__ const out2 = op.out2;
       GN_STAMP(0);
       const bool active = wave * 16 < N;   // this wave's 16 output columns exist
       // RT = 1 has a single 16x16 tile per wave: its 32 MFMAs would form one dependent chain, so even and odd
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
       if (active) { float sink = 0.f; for (int t = 0; t < RT; ++t) sink += acc[t][0]; if (sink == 1.2345e30f) S[0][0][0] = sink; }
 #endif
       GN_STAMP(2);
-      if (y_slot == a_slot) __syncthreads();   // all reads of a_slot must finish before it is overwritten
+      if (y_slot == a_slot || y2_slot == a_slot) __syncthreads();   // all reads of a_slot must finish before it is overwritten
       if (active) {
         // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg.  The epilogue is written
         // stage-major (one uniform branch per stage, the RT*4 values of a stage unrolled and independent) — the
@@ -251,8 +268,15 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
         if (gadd2) GN_EACH(if (ok[t][r]) v[t][r] += gadd2[(size_t)gidx2[row0 + row] * N + col];)
         if (pre_out) GN_EACH(if (ok[t][r]) pre_out[off] = v[t][r];)
         if (act) GN_EACH(v[t][r] = gn_ssilu(v[t][r]);)
+        const bool want2 = y2_slot >= 0 || out2;
+        float v2[RT][4];
+        if (want2 && y2_src) GN_EACH(v2[t][r] = v[t][r];)
         if (mul_slot >= 0) GN_EACH(v[t][r] *= S[mul_slot][row][col];)
-        else if (mul_g) GN_EACH(if (ok[t][r]) v[t][r] *= mul_g[off];)
+        else if (mul_g) {
+          if (mul_mode == 2) GN_EACH(if (ok[t][r]) v[t][r] *= gn_dssilu(mul_g[off]);)
+          else if (mul_mode == 3) GN_EACH(if (ok[t][r]) v[t][r] *= gn_ssilu(mul_g[off]);)
+          else GN_EACH(if (ok[t][r]) v[t][r] *= mul_g[off];)
+        }
         if (alpha != 1.0f) GN_EACH(v[t][r] *= alpha;)
         if (res_slot >= 0) GN_EACH(v[t][r] = (v[t][r] + S[res_slot][row][col]) * beta;)
         else if (res_g) {
@@ -264,6 +288,17 @@ __global__ __launch_bounds__(NT) void chain_kernel(const gn_chain_args P) {
         GN_STAMP(5);
         if (out) GN_EACH(if (ok[t][r]) out[off] = v[t][r];)
         if (y_slot >= 0) GN_EACH(S[y_slot][row][col] = ok[t][r] ? v[t][r] : 0.f;)
+        if (want2) {
+          if (!y2_src) GN_EACH(v2[t][r] = v[t][r];)
+          GN_EACH(v2[t][r] *= alpha2;)
+          if (Z2) {
+            if (mode2 == 0) GN_EACH(if (ok[t][r]) v2[t][r] *= gn_dssilu(Z2[off]);)
+            else if (mode2 == 1) GN_EACH(if (ok[t][r]) v2[t][r] *= Z2[off];)
+            else GN_EACH(if (ok[t][r]) v2[t][r] *= gn_ssilu(Z2[off]);)
+          }
+          if (out2) GN_EACH(if (ok[t][r]) out2[off] = v2[t][r];)
+          if (y2_slot >= 0) GN_EACH(S[y2_slot][row][col] = ok[t][r] ? v2[t][r] : 0.f;)
+        }
 #undef GN_EACH
       }
       GN_STAMP(3);
@@ -307,11 +342,14 @@ extern "C" int gn_chain_f32(const gn_chain_args* args, void* stream) {
     const gn_chain_op& o = args->ops[i];
     if (o.kind == GN_OP_GEMM) {
       if (o.N <= 0 || o.N > SW || o.K <= 0 || o.K > SW || (o.K % 16) != 0) return (int)hipErrorInvalidValue;
-      if (o.a_slot < 0 || o.a_slot >= NSLOT || o.slot >= NSLOT) return (int)hipErrorInvalidValue;
+      if (o.a_slot < 0 || o.a_slot >= NSLOT || o.slot >= NSLOT || o.y2_slot >= NSLOT) return (int)hipErrorInvalidValue;
+      if (o.y2_slot >= 0 && (o.y2_slot == o.slot || o.y2_slot == o.mul_slot || o.y2_slot == o.res_slot ||
+                             o.y2_slot == o.res2_slot)) return (int)hipErrorInvalidValue;
       if ((reinterpret_cast<uintptr_t>(o.W) & 15u) != 0) return (int)hipErrorInvalidValue;
     } else {
       if (o.width <= 0 || o.width > SW || (o.width % 4) != 0 || (o.ld % 4) != 0) return (int)hipErrorInvalidValue;
       if (o.slot < 0 || o.slot >= NSLOT) return (int)hipErrorInvalidValue;
+      if (o.kind == GN_OP_LOAD && (o.y2_slot >= NSLOT || o.y2_slot == o.slot)) return (int)hipErrorInvalidValue;
     }
   }
   hipStream_t st = static_cast<hipStream_t>(stream);

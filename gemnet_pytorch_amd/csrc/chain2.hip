@@ -1,0 +1,510 @@
+// LDS-resident layer chains on the bf16 matrix pipe with split operands (include/gemnet_hip.h, gn_chain_split_f32).
+//
+// Why: gfx950 runs f32-input MFMA at the f32 VECTOR rate (256 FLOP/clk/CU: 10.2 k cycles for one 80-row x 128 x 128
+// layer per CU) while `v_mfma_f32_16x16x32_bf16` runs 16x faster.  An fp32 value is EXACTLY the sum of three bf16
+// planes (8 + 8 + 8 significand bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)); keeping the six
+// largest of the nine cross products of two split operands,
+//       a b ~= ah bh + (ah bm + am bh) + (ah bl + al bh + am bm),             fp32 accumulation,
+// drops only terms below 2^-24 |a b|: the same order as fp32 rounding itself (measured on the full 4-block model,
+// tools/exp/split_precision_cpu.py: force MAE 2.8e-6 vs 3.6e-6 for plain fp32, 7.9e-5 with 3 products, 1.9e-2 with 1).
+// Six bf16 MFMAs cost 6/16 of one f32 MFMA pass.  `nprod` selects 6 (fp32-equivalent, default), 3 or 1 (plain bf16
+// operands, fp32 accumulate and fp32 everywhere else: the BASELINE "bf16" configuration).
+//
+// Layout of one row tile (BM = 16 RT rows, RT = 1..5 so that a launch is one round of <= 256 workgroups):
+//   * two LDS slots, each THREE bf16 planes [BM][128] with 288-byte rows (conflict-free ds_read_b128 in the b128 lane
+//     groups); a slot therefore holds exact fp32 values (residuals / Hadamard operands are rebuilt as hi + mid + lo);
+//     "slot 2" is a register-resident parking slot in accumulator layout (skip-connection gradient of the adjoint);
+//   * 8 waves; wave w owns output columns 16w..16w+15 for all RT row blocks and computes the TRANSPOSED tile
+//     (A operand = its 16 weight rows, B operand = the activations): lane (m = lane % 16, g = lane / 16) ends up with
+//     4 CONSECUTIVE columns 16w + 4g .. +3 of row 16t + m, so every epilogue access is a float4 / ds_write_b64;
+//   * weights arrive pre-split and pre-packed in fragment order (gn_pack_weight_split): one 1 KB contiguous load per
+//     (k-chunk, plane) and wave — the strided 16 x 64 B fragment loads of chain.hip pulled 64 KB in 4.0 k cycles with
+//     every CU asking at once, the packed form in 1.1 k (profiles/r2_wfetch.txt); next op's fragments are prefetched;
+//   * two accumulator sets per row block (hh | the five cross terms): the small terms are summed among themselves
+//     first; a third set (tried) pushed the RT = 5 kernel over 256 VGPRs.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#ifdef GN_CHAIN_TRACE
+// diagnosis build only (tools/chain2_trace.py): shader-clock stamps of wave 0 of two workgroups
+__device__ unsigned long long gn_chain2_trace_buf[2][GN_CHAIN_MAX_OPS][8];
+#define GN2_STAMP(i) do { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) \
+    gn_chain2_trace_buf[blockIdx.x == 100][oi][i] = clock64(); } while (0)
+#else
+#define GN2_STAMP(i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int SW = 128;            // max N, K
+constexpr int ROWB = 288;          // bytes per plane row: 128 bf16 + 32 B pad
+constexpr int NT = 512;
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  f32x2v v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));   // v_cvt_pk_bf16_f32, a in the low half
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// x (4 floats) -> three planes of 4 bf16 each; hi + mid + lo == x exactly (barring underflow)
+__device__ __forceinline__ void split4(const float4 x, uint2& H, uint2& M, uint2& L) {
+  H.x = pk_bf16(x.x, x.y); H.y = pk_bf16(x.z, x.w);
+  const float r0 = x.x - bf_lo(H.x), r1 = x.y - bf_hi(H.x), r2 = x.z - bf_lo(H.y), r3 = x.w - bf_hi(H.y);
+  M.x = pk_bf16(r0, r1); M.y = pk_bf16(r2, r3);
+  const float s0 = r0 - bf_lo(M.x), s1 = r1 - bf_hi(M.x), s2 = r2 - bf_lo(M.y), s3 = r3 - bf_hi(M.y);
+  L.x = pk_bf16(s0, s1); L.y = pk_bf16(s2, s3);
+}
+__device__ __forceinline__ float4 join4(const uint2 H, const uint2 M, const uint2 L) {
+  return make_float4((bf_lo(H.x) + bf_lo(M.x)) + bf_lo(L.x), (bf_hi(H.x) + bf_hi(M.x)) + bf_hi(L.x),
+                     (bf_lo(H.y) + bf_lo(M.y)) + bf_lo(L.y), (bf_hi(H.y) + bf_hi(M.y)) + bf_hi(L.y));
+}
+
+// NPL = planes that enter the MFMAs: 1 -> 1 product (bf16 operands), 2 -> 3 products, 3 -> 6 products
+// ADJ: the program uses the register parking slot or second outputs (the adjoint programs); plain forward stacks run the
+// leaner variant (park / y2 registers would push the RT = 5 kernel into scratch, and a kernel with a scratch segment pays
+// ~1 us more per launch).
+template <int RT, int NPL, bool ADJ>
+__global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) {
+  constexpr int BM = 16 * RT;
+  constexpr int PLANE = BM * ROWB;          // bytes of one plane
+  constexpr int SLOT = 3 * PLANE;           // bytes of one slot (always three planes: exact fp32 content)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int l15 = lane & 15;
+  const int lg = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * BM;
+  const int M = P.M;
+  // weight pointer / shape of the GEMM ops in program order, staged in LDS once: the next op's fragments are requested
+  // at the top of every GEMM op and must not wait for a scalar load of its descriptor from the kernarg segment
+  __shared__ const void* gemm_W[GN_CHAIN_MAX_OPS + 2];
+  __shared__ int gemm_NK[GN_CHAIN_MAX_OPS + 2];
+  if (tid == 0) {
+    int g = 0;
+    for (int j = 0; j < P.n_ops; ++j)
+      if (P.ops[j].kind == GN_OP_GEMM) {
+        gemm_W[g] = P.ops[j].W;
+        gemm_NK[g++] = (P.ops[j].N << 16) | P.ops[j].K;
+      }
+    gemm_W[g] = gemm_W[g + 1] = nullptr;
+    gemm_NK[g] = gemm_NK[g + 1] = 0;
+  }
+  __syncthreads();
+
+  // weight fragments of one GEMM op: [k-chunk c][plane p] -> 8 bf16 (A operand rows = this wave's 16 weight rows)
+  uint4 bcur[4][NPL];
+  auto wload_op = [&](uint4 (&dst)[4][NPL], int ord) {
+    // packed layout: [col tile][k-chunk][plane (3)][lane][8 bf16]
+    const int nk = __builtin_amdgcn_readfirstlane(gemm_NK[ord]);
+    const int N = nk >> 16, kc = ((nk & 0xffff) + 31) >> 5;
+    const uint4* __restrict__ base = reinterpret_cast<const uint4*>(gemm_W[ord]) + ((size_t)wave * kc * 3) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        dst[c][p] = make_uint4(0u, 0u, 0u, 0u);
+        if (wave * 16 < N && c < kc) dst[c][p] = base[(c * 3 + p) * 64];
+      }
+  };
+  // One fragment set: the NEXT GEMM's weights are requested right after the current op's MFMA phase (its fragments
+  // are dead then) and land under the epilogue + barrier (96 KB per CU arrive in ~2.2 k cycles with every CU asking,
+  // profiles/r2_wfetch.txt); a second set held across the MFMA phase pushed the RT = 5 kernel into scratch.
+  wload_op(bcur, 0);
+  int gord = 0;
+
+  float4 park[ADJ ? RT : 1];   // register slot 2 (accumulator layout)
+#pragma unroll
+  for (int t = 0; t < (ADJ ? RT : 1); ++t) park[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto plane_ptr = [&](int slot, int p) -> unsigned char* { return smem + slot * SLOT + p * PLANE; };
+  // accumulator-layout element block of this lane in row block t: row 16t + l15, columns 16 wave + 4 lg .. +3
+  auto slot_read_acc = [&](int slot, int t) -> float4 {
+    const int off = (16 * t + l15) * ROWB + (wave * 16 + (lg << 2)) * 2;
+    const uint2 H = *reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off);
+    const uint2 Mi = *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off);
+    const uint2 L = *reinterpret_cast<const uint2*>(plane_ptr(slot, 2) + off);
+    return join4(H, Mi, L);
+  };
+  auto slot_write = [&](int slot, int row, int col, const float4 v) {
+    uint2 H, Mi, L;
+    split4(v, H, Mi, L);
+    const int off = row * ROWB + col * 2;
+    *reinterpret_cast<uint2*>(plane_ptr(slot, 0) + off) = H;
+    *reinterpret_cast<uint2*>(plane_ptr(slot, 1) + off) = Mi;
+    *reinterpret_cast<uint2*>(plane_ptr(slot, 2) + off) = L;
+  };
+  auto slot_read = [&](int slot, int row, int col) -> float4 {
+    const int off = row * ROWB + col * 2;
+    return join4(*reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off),
+                 *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off),
+                 *reinterpret_cast<const uint2*>(plane_ptr(slot, 2) + off));
+  };
+
+  for (int oi = 0; oi < P.n_ops; ++oi) {
+    const gn_chain_op& op = P.ops[oi];
+    const int kind = op.kind;
+    GN2_STAMP(0);
+    if (kind == GN_OP_LOAD) {
+      // linear mapping (coalesced 512 B rows); columns up to the next multiple of 32 are zero-filled so that the
+      // zero-padded k-chunk of a K = 16 weight never multiplies stale LDS bits
+      const int width = op.width, slot = op.slot, ld = op.ld, y2_slot = op.y2_slot, mode2 = op.mode2;
+      const int w4 = ((width + 31) & ~31) >> 2;
+      const float alpha = op.alpha, alpha2 = op.alpha2;
+      const float* __restrict__ const src = op.src;
+      const float* __restrict__ const Z2 = op.Z2;
+      const int32_t* __restrict__ const rows = op.rows;
+      for (int f = tid; f < BM * w4; f += NT) {
+        const int r = f / w4, c = (f - r * w4) << 2;
+        const int64_t gr = row0 + r;
+        const bool in = gr < M && c < width;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+          const int64_t sr = rows ? (int64_t)rows[gr] : gr;
+          v = *reinterpret_cast<const float4*>(src + sr * ld + c);
+          v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        }
+        slot_write(slot, r, c, v);
+        if (ADJ && y2_slot >= 0) {   // second tensor derived from the loaded rows: v * alpha2 * phi2(Z2)
+          float4 u = make_float4(v.x * alpha2, v.y * alpha2, v.z * alpha2, v.w * alpha2);
+          if (Z2 && in) {
+            const float4 z = *reinterpret_cast<const float4*>(Z2 + gr * width + c);
+            if (mode2 == 0) { u.x *= gn_dssilu(z.x); u.y *= gn_dssilu(z.y); u.z *= gn_dssilu(z.z); u.w *= gn_dssilu(z.w); }
+            else if (mode2 == 1) { u.x *= z.x; u.y *= z.y; u.z *= z.z; u.w *= z.w; }
+            else { u.x *= gn_ssilu(z.x); u.y *= gn_ssilu(z.y); u.z *= gn_ssilu(z.z); u.w *= gn_ssilu(z.w); }
+          }
+          slot_write(y2_slot, r, c, u);
+        }
+      }
+      GN2_STAMP(3);
+      __syncthreads();
+      GN2_STAMP(4);
+    } else if (kind == GN_OP_SCALE) {
+      const int slot = op.slot, a_slot = op.a_slot, ld = op.ld, width = op.width;
+      const float alpha = op.alpha;
+      const int mode = op.act;   // factor taken from src: 0 ssilu'(src), 1 src, 2 ssilu(src)
+      const float* __restrict__ const src = op.src;
+      float* __restrict__ const out = op.out;
+      if (ADJ && slot == 2) {
+        // park: register slot in accumulator layout (plain scale only)
+        if (wave * 16 < width) {
+#pragma unroll
+          for (int t = 0; t < RT; ++t) {
+            float4 v = slot_read_acc(a_slot, t);
+            park[ADJ ? t : 0] = make_float4(v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha);
+          }
+        }
+        __syncthreads();   // the parked values are read before any later op (other thread mapping) rewrites a_slot
+      } else {
+        const int w4 = width >> 2;
+        for (int f = tid; f < BM * w4; f += NT) {
+          const int r = f / w4, c = (f - r * w4) << 2;
+          const int64_t gr = row0 + r;
+          float4 v = slot_read(a_slot, r, c);
+          v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+          if (src && gr < M) {
+            const float4 z = *reinterpret_cast<const float4*>(src + gr * ld + c);
+            if (mode == 0) { v.x *= gn_dssilu(z.x); v.y *= gn_dssilu(z.y); v.z *= gn_dssilu(z.z); v.w *= gn_dssilu(z.w); }
+            else if (mode == 1) { v.x *= z.x; v.y *= z.y; v.z *= z.z; v.w *= z.w; }
+            else { v.x *= gn_ssilu(z.x); v.y *= gn_ssilu(z.y); v.z *= gn_ssilu(z.z); v.w *= gn_ssilu(z.w); }
+          }
+          slot_write(slot, r, c, v);
+          if (out && gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = v;
+        }
+        __syncthreads();
+      }
+    } else if (kind == GN_OP_STORE) {
+      const int w4 = op.width >> 2, slot = op.slot, ld = op.ld;
+      float* __restrict__ const out = op.out;
+      for (int f = tid; f < BM * w4; f += NT) {
+        const int r = f / w4, c = (f - r * w4) << 2;
+        const int64_t gr = row0 + r;
+        if (gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = slot_read(slot, r, c);
+      }
+      __syncthreads();
+    } else {  // GN_OP_GEMM
+      const int N = op.N, K = op.K, a_slot = op.a_slot, y_slot = op.slot, act = op.act;
+      const float alpha = op.alpha, beta = op.beta, beta2 = op.beta2;
+      const float* __restrict__ const gadd1 = op.gadd1;
+      const float* __restrict__ const gadd2 = op.gadd2;
+      const int32_t* __restrict__ const gidx1 = op.gidx1;
+      const int32_t* __restrict__ const gidx2 = op.gidx2;
+      float* __restrict__ const pre_out = op.pre_out;
+      float* __restrict__ const out = op.out;
+      const int mul_slot = op.mul_slot, res_slot = op.res_slot, res2_slot = op.res2_slot;
+      const float* __restrict__ const mul_g = op.mul_g;
+      const float* __restrict__ const res_g = op.res_g;
+      const float* __restrict__ const res2_g = op.res2_g;
+      const int32_t* __restrict__ const res_rows = op.res_rows;
+      const int mul_mode = op.mul_mode, y2_slot = op.y2_slot, y2_src = op.y2_src, mode2 = op.mode2;
+      const float alpha2 = op.alpha2;
+      const float* __restrict__ const Z2 = op.Z2;
+      float* __restrict__ const out2 = op.out2;
+      const bool active = wave * 16 < N;
+      ++gord;
+#ifdef GN_CHAIN_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this op's fragments landed
+#endif
+      GN2_STAMP(1);
+
+      v4f a0[RT], a1[RT];   // hh | the cross terms hm + mh + hl + lh + mm (summed among themselves first)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        a0[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        a1[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+      }
+      if (active) {
+        const unsigned char* xb = smem + a_slot * SLOT + l15 * ROWB + (lg << 4);
+        const int kc = (K + 31) >> 5;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < kc) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, bcur[c][0]);
+            bf16x8 wm, wl;
+            if (NPL >= 2) wm = __builtin_bit_cast(bf16x8, bcur[c][NPL >= 2 ? 1 : 0]);
+            if (NPL >= 3) wl = __builtin_bit_cast(bf16x8, bcur[c][NPL >= 3 ? 2 : 0]);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+              const unsigned char* xp = xb + (16 * t) * ROWB + c * 64;
+              const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp));
+              bf16x8 xm, xl;
+              if (NPL >= 2) xm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp + PLANE));
+              if (NPL >= 3) xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp + 2 * PLANE));
+              if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, a1[t], 0, 0, 0);
+              a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, a0[t], 0, 0, 0);
+              if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, a1[t], 0, 0, 0);
+              if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, a1[t], 0, 0, 0);
+              if (NPL >= 2) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, a1[t], 0, 0, 0);
+              if (NPL >= 2) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, a1[t], 0, 0, 0);
+            }
+          }
+        }
+      }
+      float4 v[RT];            // the three partial sums collapse here: their registers are free for the prefetch below
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const v4f s = NPL >= 2 ? a0[t] + a1[t] : a0[t];
+        v[t] = make_float4(s[0], s[1], s[2], s[3]);
+      }
+      wload_op(bcur, gord);   // next GEMM's fragments (no-op after the last one): in flight under the epilogue
+#ifdef GN_CHAIN_TRACE
+      if (active) { float sink = 0.f; for (int t = 0; t < RT; ++t) sink += v[t].x; if (sink == 1.2345e30f) smem[0] = 1; }
+#endif
+      GN2_STAMP(2);
+      if (y_slot == a_slot || y2_slot == a_slot) __syncthreads();   // all reads of a_slot must finish before it is overwritten
+      if (active) {
+        // transposed tile: this lane holds columns n0 .. n0+3 of row 16 t + l15.  Written stage-major (one uniform
+        // branch per stage, the RT float4 of a stage unrolled and independent): the row-major form serialised ~25
+        // scalar branches and every dependent load per row block (5 k cycles per op at RT = 5, tools/chain2_trace.py).
+        const int n0 = wave * 16 + (lg << 2);
+        bool ok[RT];
+        uint32_t off[RT];        // element offset of (row, n0) in an (M, N) matrix: M * 128 < 2^32 (checked on the host)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const int64_t grow = row0 + 16 * t + l15;
+          ok[t] = grow < M;
+          off[t] = (uint32_t)grow * (uint32_t)N + (uint32_t)n0;
+        }
+#define GN2_EACH(body) _Pragma("unroll") for (int t = 0; t < RT; ++t) { body }
+#define GN2_ADD(q) v[t].x += q.x; v[t].y += q.y; v[t].z += q.z; v[t].w += q.w;
+#define GN2_MUL(q) v[t].x *= q.x; v[t].y *= q.y; v[t].z *= q.z; v[t].w *= q.w;
+#define GN2_RES(q, b) v[t].x = (v[t].x + q.x) * b; v[t].y = (v[t].y + q.y) * b; v[t].z = (v[t].z + q.z) * b; v[t].w = (v[t].w + q.w) * b;
+        if (gadd1) {
+          float4 q[RT];
+          GN2_EACH(q[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                   if (ok[t]) q[t] = *reinterpret_cast<const float4*>(gadd1 + (size_t)gidx1[row0 + 16 * t + l15] * N + n0);)
+          GN2_EACH(GN2_ADD(q[t]))
+        }
+        if (gadd2) {
+          float4 q[RT];
+          GN2_EACH(q[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                   if (ok[t]) q[t] = *reinterpret_cast<const float4*>(gadd2 + (size_t)gidx2[row0 + 16 * t + l15] * N + n0);)
+          GN2_EACH(GN2_ADD(q[t]))
+        }
+        if (pre_out) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(pre_out + off[t]) = v[t];)
+        if (act) GN2_EACH(v[t].x = gn_ssilu(v[t].x); v[t].y = gn_ssilu(v[t].y); v[t].z = gn_ssilu(v[t].z); v[t].w = gn_ssilu(v[t].w);)
+        const bool want2 = ADJ && (y2_slot >= 0 || out2);
+        // second output = v * alpha2 * phi2(Z2), written straight from the current value of v (no copy is kept):
+        // before the `mul` stage when y2_src = 1, after the last stage otherwise
+        auto emit_y2 = [&]() {
+          float4 q[RT];
+          if (Z2) {
+            GN2_EACH(q[t] = make_float4(0.f, 0.f, 0.f, 0.f); if (ok[t]) q[t] = *reinterpret_cast<const float4*>(Z2 + off[t]);)
+            if (mode2 == 0) GN2_EACH(q[t] = make_float4(gn_dssilu(q[t].x), gn_dssilu(q[t].y), gn_dssilu(q[t].z), gn_dssilu(q[t].w));)
+            else if (mode2 == 2) GN2_EACH(q[t] = make_float4(gn_ssilu(q[t].x), gn_ssilu(q[t].y), gn_ssilu(q[t].z), gn_ssilu(q[t].w));)
+            GN2_EACH(q[t].x *= v[t].x * alpha2; q[t].y *= v[t].y * alpha2; q[t].z *= v[t].z * alpha2; q[t].w *= v[t].w * alpha2;)
+          } else {
+            GN2_EACH(q[t] = make_float4(v[t].x * alpha2, v[t].y * alpha2, v[t].z * alpha2, v[t].w * alpha2);)
+          }
+          if (out2) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(out2 + off[t]) = q[t];)
+          if (y2_slot >= 0) GN2_EACH(slot_write(y2_slot, 16 * t + l15, n0, ok[t] ? q[t] : make_float4(0.f, 0.f, 0.f, 0.f));)
+        };
+        if (want2 && y2_src) emit_y2();
+        if (ADJ && mul_slot == 2) GN2_EACH(GN2_MUL(park[ADJ ? t : 0]))
+        else if (mul_slot >= 0) GN2_EACH(const float4 q = slot_read_acc(mul_slot, t); GN2_MUL(q))
+        else if (mul_g) {
+          float4 q[RT];
+          GN2_EACH(q[t] = make_float4(1.f, 1.f, 1.f, 1.f); if (ok[t]) q[t] = *reinterpret_cast<const float4*>(mul_g + off[t]);)
+          if (mul_mode == 2) GN2_EACH(q[t] = make_float4(gn_dssilu(q[t].x), gn_dssilu(q[t].y), gn_dssilu(q[t].z), gn_dssilu(q[t].w));)
+          else if (mul_mode == 3) GN2_EACH(q[t] = make_float4(gn_ssilu(q[t].x), gn_ssilu(q[t].y), gn_ssilu(q[t].z), gn_ssilu(q[t].w));)
+          GN2_EACH(GN2_MUL(q[t]))
+        }
+        if (alpha != 1.0f) GN2_EACH(v[t].x *= alpha; v[t].y *= alpha; v[t].z *= alpha; v[t].w *= alpha;)
+        if (ADJ && res_slot == 2) GN2_EACH(GN2_RES(park[ADJ ? t : 0], beta))
+        else if (res_slot >= 0) GN2_EACH(const float4 q = slot_read_acc(res_slot, t); GN2_RES(q, beta))
+        else if (res_g) {
+          float4 q[RT];
+          if (res_rows) GN2_EACH(q[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                 if (ok[t]) q[t] = *reinterpret_cast<const float4*>(res_g + (size_t)res_rows[row0 + 16 * t + l15] * N + n0);)
+          else GN2_EACH(q[t] = make_float4(0.f, 0.f, 0.f, 0.f); if (ok[t]) q[t] = *reinterpret_cast<const float4*>(res_g + off[t]);)
+          GN2_EACH(if (ok[t]) { GN2_RES(q[t], beta) })
+        }
+        if (ADJ && res2_slot == 2) GN2_EACH(GN2_RES(park[ADJ ? t : 0], beta2))
+        else if (res2_slot >= 0) GN2_EACH(const float4 q = slot_read_acc(res2_slot, t); GN2_RES(q, beta2))
+        else if (res2_g) {
+          float4 q[RT];
+          GN2_EACH(q[t] = make_float4(0.f, 0.f, 0.f, 0.f); if (ok[t]) q[t] = *reinterpret_cast<const float4*>(res2_g + off[t]);)
+          GN2_EACH(if (ok[t]) { GN2_RES(q[t], beta2) })
+        }
+        if (out) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(out + off[t]) = v[t];)
+        if (ADJ && y_slot == 2) GN2_EACH(park[ADJ ? t : 0] = v[t];)
+        else if (y_slot >= 0) GN2_EACH(slot_write(y_slot, 16 * t + l15, n0, ok[t] ? v[t] : make_float4(0.f, 0.f, 0.f, 0.f));)
+        if (want2 && !y2_src) emit_y2();
+#undef GN2_EACH
+#undef GN2_ADD
+#undef GN2_MUL
+#undef GN2_RES
+      } else if ((N & 16) && wave * 16 == N && y_slot >= 0 && y_slot < 2) {
+        // N = 16 (mod 32): the next GEMM reads k-chunks of 32 columns, so the 16 columns after N are zeroed
+        const int n0 = wave * 16 + (lg << 2);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) slot_write(y_slot, 16 * t + l15, n0, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+      GN2_STAMP(3);
+      __syncthreads();
+      GN2_STAMP(4);
+    }
+  }
+}
+
+template <int RT, int NPL, bool ADJ>
+int launch_chain_split(const gn_chain_args* args, hipStream_t st) {
+  constexpr int BM = 16 * RT;
+  constexpr size_t smem = (size_t)2 * 3 * BM * ROWB;
+  static bool configured = false;   // idempotent attribute; a benign race sets it twice
+  if (!configured) {
+    if (smem > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_split_kernel<RT, NPL, ADJ>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+    }
+    configured = true;
+  }
+  hipLaunchKernelGGL((chain_split_kernel<RT, NPL, ADJ>), dim3(gn_cdiv(args->M, BM)), dim3(NT), smem, st, *args);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int NPL, bool ADJ>
+int dispatch_rt(const gn_chain_args* args, hipStream_t st) {
+  const int rt = gn_cdiv(args->M, 256 * 16);
+  switch (rt <= 1 ? 1 : (rt >= 5 ? 5 : rt)) {
+    case 1: return launch_chain_split<1, NPL, ADJ>(args, st);
+    case 2: return launch_chain_split<2, NPL, ADJ>(args, st);
+    case 3: return launch_chain_split<3, NPL, ADJ>(args, st);
+    case 4: return launch_chain_split<4, NPL, ADJ>(args, st);
+    default: return launch_chain_split<5, NPL, ADJ>(args, st);
+  }
+}
+
+template <int NPL>
+int dispatch_adj(const gn_chain_args* args, bool adj, hipStream_t st) {
+  return adj ? dispatch_rt<NPL, true>(args, st) : dispatch_rt<NPL, false>(args, st);
+}
+
+// W (N,K) row-major with pitch ldw (or, trans != 0, the (K,N) matrix whose transpose is the weight) -> fragment-major
+// planes [col tile][k-chunk][plane][lane][8]: lane (n = lane % 16, g = lane / 16) of (tile, chunk) holds
+// W[16 tile + n][32 chunk + 8 g + i], i = 0..7; rows >= N and columns >= K are zero.
+__global__ void pack_weight_split_kernel(const float* __restrict__ W, int N, int K, int ldw, int trans,
+                                         uint4* __restrict__ out, int n_tiles, int kc) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (tile, chunk, lane)
+  if (idx >= n_tiles * kc * 64) return;
+  const int lane = idx & 63, tc = idx >> 6, c = tc % kc, tile = tc / kc;
+  const int n = tile * 16 + (lane & 15), k0 = c * 32 + ((lane >> 4) << 3);
+  float x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    x[i] = (n < N && k < K) ? (trans ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k]) : 0.f;
+  }
+  uint2 H0, M0, L0, H1, M1, L1;
+  split4(make_float4(x[0], x[1], x[2], x[3]), H0, M0, L0);
+  split4(make_float4(x[4], x[5], x[6], x[7]), H1, M1, L1);
+  uint4* dst = out + ((size_t)tc * 3) * 64 + lane;
+  dst[0] = make_uint4(H0.x, H0.y, H1.x, H1.y);
+  dst[64] = make_uint4(M0.x, M0.y, M1.x, M1.y);
+  dst[128] = make_uint4(L0.x, L0.y, L1.x, L1.y);
+}
+
+}  // namespace
+
+#ifdef GN_CHAIN_TRACE
+extern "C" int gn_chain2_trace_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gn_chain2_trace_buf), sizeof(gn_chain2_trace_buf));
+}
+#endif
+
+extern "C" int64_t gn_pack_weight_split_bytes(int N, int K) {
+  return (int64_t)gn_cdiv(N, 16) * gn_cdiv(K, 32) * 3 * 64 * 16;
+}
+
+extern "C" int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream) {
+  if (N <= 0 || K <= 0) return 0;
+  const int n_tiles = gn_cdiv(N, 16), kc = gn_cdiv(K, 32);
+  const int total = n_tiles * kc * 64;
+  hipLaunchKernelGGL(pack_weight_split_kernel, dim3(gn_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), W, N, K, ldw, trans, static_cast<uint4*>(out), n_tiles, kc);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* stream) {
+  if (args->M <= 0 || args->n_ops <= 0) return 0;
+  if (args->n_ops > GN_CHAIN_MAX_OPS) return (int)hipErrorInvalidValue;
+  if (args->M > (1 << 24)) return (int)hipErrorInvalidValue;
+  if (nprod != 1 && nprod != 3 && nprod != 6) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < args->n_ops; ++i) {
+    const gn_chain_op& o = args->ops[i];
+    if (o.kind == GN_OP_GEMM) {
+      if (o.N <= 0 || o.N > SW || (o.N % 16) != 0 || o.K <= 0 || o.K > SW || (o.K % 4) != 0) return (int)hipErrorInvalidValue;
+      if (o.a_slot < 0 || o.a_slot > 1 || o.slot > 2) return (int)hipErrorInvalidValue;
+      if ((reinterpret_cast<uintptr_t>(o.W) & 15u) != 0) return (int)hipErrorInvalidValue;
+      if (o.mul_slot > 2 || o.res_slot > 2 || o.res2_slot > 2 || o.y2_slot > 1) return (int)hipErrorInvalidValue;
+      if (o.y2_slot >= 0 && (o.y2_slot == o.slot || o.y2_slot == o.mul_slot || o.y2_slot == o.res_slot ||
+                             o.y2_slot == o.res2_slot)) return (int)hipErrorInvalidValue;
+    } else {
+      if (o.width <= 0 || o.width > SW || (o.width % 4) != 0 || (o.ld % 4) != 0) return (int)hipErrorInvalidValue;
+      if (o.slot < 0 || o.slot > 2) return (int)hipErrorInvalidValue;
+      if (o.slot == 2 && (o.kind != GN_OP_SCALE || o.src || o.out)) return (int)hipErrorInvalidValue;
+      if (o.kind == GN_OP_LOAD && (o.y2_slot > 1 || o.y2_slot == o.slot)) return (int)hipErrorInvalidValue;
+      if (o.kind == GN_OP_SCALE && (o.a_slot < 0 || o.a_slot > 1)) return (int)hipErrorInvalidValue;
+    }
+  }
+  bool adj = false;   // does the program touch the parking slot or a second output?
+  for (int i = 0; i < args->n_ops; ++i) {
+    const gn_chain_op& o = args->ops[i];
+    if (o.kind == GN_OP_GEMM)
+      adj = adj || o.slot == 2 || o.mul_slot == 2 || o.res_slot == 2 || o.res2_slot == 2 || o.y2_slot >= 0 || o.out2;
+    else
+      adj = adj || o.slot == 2 || (o.kind == GN_OP_LOAD && o.y2_slot >= 0);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nprod == 6) return dispatch_adj<3>(args, adj, st);
+  if (nprod == 3) return dispatch_adj<2>(args, adj, st);
+  return dispatch_adj<1>(args, adj, st);
+}

@@ -351,8 +351,10 @@ class ChainProgram:
         self.M = int(M)
         self.ops = []
 
-    def load(self, slot, src, rows=None):
-        self.ops.append(dict(kind="load", slot=slot, src=src, rows=rows))
+    def load(self, slot, src, rows=None, alpha=1.0, y2=-1, alpha2=1.0, Z2=None, mode2=0):
+        """slot <- src[rows] * alpha; optional second tensor y2 (slot) <- that * alpha2 * phi2(Z2) (as for gemm)."""
+        self.ops.append(dict(kind="load", slot=slot, src=src, rows=rows, alpha=float(alpha), y2=int(y2),
+                             alpha2=float(alpha2), Z2=Z2, mode2=int(mode2)))
 
     def scale(self, dst, a, alpha=1.0, Z=None, out=None, width=None, mode=0):
         """dst <- a * alpha * phi(Z): mode 0 phi = ssilu', 1 identity (Hadamard with Z), 2 ssilu."""
@@ -360,13 +362,114 @@ class ChainProgram:
                              mode=int(mode)))
 
     def gemm(self, W, a_slot, y_slot=-1, act=False, alpha=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
-             pre_out=None, mul=None, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0, out=None):
-        self.ops.append(dict(kind="gemm", W=W, a_slot=a_slot, slot=y_slot, act=bool(act), alpha=float(alpha),
+             pre_out=None, mul=None, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0, out=None, packed=None,
+             mul_mode=1, y2=-1, y2_src=0, alpha2=1.0, Z2=None, mode2=0, out2=None):
+        """W: the (N,K) fp32 weight; `packed`: its split-bf16 fragment form (pack_weight_split(W)) if the caller
+        caches it — the split-operand kernel packs on the fly otherwise.
+        mul_mode (global `mul` only): 1 identity, 2 ssilu'(mul), 3 ssilu(mul).
+        Second output: y2 (slot) / out2 (global) <- (y2_src ? activation output : final y) * alpha2 * phi2(Z2),
+        phi2 by mode2: 0 ssilu', 1 identity, 2 ssilu (Z2 None: plain scale)."""
+        self.ops.append(dict(kind="gemm", W=W, packed=packed, a_slot=a_slot, slot=y_slot, act=bool(act), alpha=float(alpha),
+                             mul_mode=int(mul_mode), y2=int(y2), y2_src=int(y2_src), alpha2=float(alpha2), Z2=Z2,
+                             mode2=int(mode2), out2=out2,
                              gadd1=gadd1, gidx1=gidx1, gadd2=gadd2, gidx2=gidx2, pre_out=pre_out, mul=mul,
                              res=res, res_rows=res_rows, beta=float(beta), res2=res2, beta2=float(beta2), out=out))
 
     def store(self, slot, out):
         self.ops.append(dict(kind="store", slot=slot, out=out))
+
+
+def fuse_program(prog):
+    """Peephole pass over a ChainProgram: SCALE ops that directly follow the GEMM producing their operand move into
+    that GEMM's epilogue (every stand-alone SCALE is a full LDS round trip + barrier: 4-5 us at 18 k rows, and the
+    adjoint of a residual layer used to carry three of them per two GEMMs).  Rewrites, with g the GEMM writing slot y:
+      A  g; scale(y <- y * a * phi(Z))            ->  g(mul = Z, mul_mode = phi, alpha *= a)       [g: plain epilogue]
+      B  g; [park]; scale(y <- y * c) ...          ->  g(final factor * c); park alpha / c
+         g; scale(y <- y * c, out = T)             ->  g(final factor * c, out = T)
+      C  g; ...; scale(o <- y * a2 * phi2(Z2)[, out2])  ->  g(y2 = o, alpha2 = a2, Z2, mode2, out2)
+    The result computes the same values (tests/test_ops_cpu.py runs both forms through the interpreter)."""
+    ops = [dict(o) for o in prog.ops]
+    out = []
+    i = 0
+    while i < len(ops):
+        g = ops[i]
+        i += 1
+        out.append(g)
+        if g["kind"] == "load" and g["slot"] in (0, 1):
+            # a LOAD produces its slot like a GEMM does: [park]; y *= c; o = y * a2 * phi2(Z2) ride on it (B, C)
+            y, N = g["slot"], g["src"].shape[1]
+            parks = []
+            while i < len(ops) and ops[i]["kind"] == "scale" and ops[i]["slot"] == 2 and ops[i]["a_slot"] == y:
+                parks.append(ops[i])
+                i += 1
+            while (i < len(ops) and ops[i]["kind"] == "scale" and ops[i]["slot"] == y and ops[i]["a_slot"] == y
+                   and (ops[i]["width"] or N) == N and ops[i]["Z"] is None and ops[i]["out"] is None
+                   and ops[i]["alpha"] != 0.0 and g["y2"] < 0):
+                g["alpha"] *= ops[i]["alpha"]
+                for pk in parks:
+                    pk["alpha"] /= ops[i]["alpha"]
+                i += 1
+            if i < len(ops) and g["y2"] < 0:
+                sc = ops[i]
+                if (sc["kind"] == "scale" and sc["slot"] in (0, 1) and sc["slot"] != y and sc["a_slot"] == y
+                        and (sc["width"] or N) == N and sc["out"] is None):
+                    g.update(y2=sc["slot"], alpha2=sc["alpha"], Z2=sc["Z"], mode2=sc.get("mode", 0))
+                    i += 1
+            out.extend(parks)
+            continue
+        if g["kind"] != "gemm" or g["slot"] not in (0, 1):
+            continue
+        y, N = g["slot"], g["W"].shape[0]
+
+        def is_scale(o, dst, src):
+            return o["kind"] == "scale" and o["slot"] == dst and o["a_slot"] == src and (o["width"] or N) == N
+
+        def fold_factor(c):
+            if g["res2"] is not None:
+                g["beta2"] *= c
+            elif g["res"] is not None:
+                g["beta"] *= c
+            else:
+                g["alpha"] *= c
+
+        # A: activation-derivative / Hadamard factor of a plain GEMM
+        if (i < len(ops) and is_scale(ops[i], y, y) and ops[i]["Z"] is not None and ops[i]["out"] is None
+                and g["mul"] is None and g["res"] is None and g["res2"] is None and g["out"] is None and g["y2"] < 0
+                and g.get("out2") is None):
+            sc = ops[i]
+            g["mul"], g["mul_mode"] = sc["Z"], {0: 2, 1: 1, 2: 3}[sc.get("mode", 0)]
+            g["alpha"] *= sc["alpha"]
+            i += 1
+        parks = []
+        while i < len(ops) and ops[i]["kind"] == "scale" and ops[i]["slot"] == 2 and ops[i]["a_slot"] == y:
+            parks.append(ops[i])
+            i += 1
+        # B: in-place plain scales of y
+        while (i < len(ops) and is_scale(ops[i], y, y) and ops[i]["Z"] is None and ops[i]["alpha"] != 0.0
+               and g["y2"] < 0 and g.get("out2") is None):
+            sc = ops[i]
+            if sc["out"] is not None:
+                if g["out"] is not None:
+                    break
+                g["out"] = sc["out"]
+            elif g["out"] is not None:
+                break          # g already stores the unscaled value
+            fold_factor(sc["alpha"])
+            for pk in parks:
+                pk["alpha"] /= sc["alpha"]
+            i += 1
+        # C: a second tensor derived from y into the other slot
+        if i < len(ops) and g["y2"] < 0 and g.get("out2") is None:
+            sc = ops[i]
+            o = sc.get("slot")
+            used = {y} | {x for x in (g["mul"], g["res"], g["res2"]) if isinstance(x, int)}
+            if sc["kind"] == "scale" and o in (0, 1) and o not in used and sc["a_slot"] == y and (sc["width"] or N) == N:
+                g.update(y2=o, y2_src=0, alpha2=sc["alpha"], Z2=sc["Z"], mode2=sc.get("mode", 0), out2=sc["out"])
+                i += 1
+        out.extend(parks)
+    fused = ChainProgram(prog.M)
+    fused.ops = out
+    return fused
 
 
 def _sel(x):
@@ -378,11 +481,48 @@ def _sel(x):
     return -1, x
 
 
-def chain(prog):
+# Arithmetic of the chain GEMMs: "f32" = v_mfma_f32_16x16x4_f32 (csrc/chain.hip); "split6" / "split3" / "bf16" =
+# bf16 matrix pipe with 6 / 3 / 1 products of split operands (csrc/chain2.hip; split6 is fp32-equivalent).
+CHAIN_MODES = {"f32": 0, "split6": 6, "split3": 3, "bf16": 1}
+CHAIN_MODE = "split6"
+
+
+def pack_weight_split(W, trans=False):
+    """(N,K) fp32 weight (or, trans, the (K,N) matrix whose transpose is the weight) -> packed bf16 planes (uint8)."""
+    require_device(W)
+    W = _rowmajor(W)
+    N, Kd = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
+    nbytes = -(-N // 16) * -(-Kd // 32) * 3 * 64 * 16
+    out = torch.empty(nbytes, device=W.device, dtype=torch.uint8)
+    check(_lib.load().gn_pack_weight_split(ptr(W), N, Kd, W.stride(0), int(bool(trans)), ptr(out), stream()),
+          "gn_pack_weight_split")
+    return out
+
+
+def chain_split_supported(prog):
+    """What gn_chain_split_f32 accepts: N % 16 == 0, slot 2 only as a parking slot."""
+    for o in prog.ops:
+        if o["kind"] == "gemm":
+            N = o["W"].shape[0]
+            if N % 16 or o["a_slot"] > 1 or o["y2"] > 1:
+                return False
+        elif o["kind"] == "scale":
+            if o["a_slot"] > 1 or (o["slot"] == 2 and (o["Z"] is not None or o["out"] is not None)):
+                return False
+        elif o["slot"] > 1 or o.get("y2", -1) > 1:
+            return False
+    return True
+
+
+def chain(prog, mode=None):
     """Run a ChainProgram (one launch)."""
     from ._lib import ChainArgs, GN_CHAIN_MAX_OPS, GN_OP_GEMM, GN_OP_LOAD, GN_OP_SCALE, GN_OP_STORE
     if len(prog.ops) > GN_CHAIN_MAX_OPS:
         raise ValueError("chain program too long")
+    nprod = CHAIN_MODES[mode or CHAIN_MODE]
+    if nprod and not chain_split_supported(prog):
+        nprod = 0
+    keep = []
     a = ChainArgs()
     a.M, a.n_ops = prog.M, len(prog.ops)
     M = prog.M
@@ -396,12 +536,14 @@ def chain(prog):
 
     for i, o in enumerate(prog.ops):
         c = a.ops[i]
-        c.slot, c.a_slot, c.mul_slot, c.res_slot, c.res2_slot = -1, -1, -1, -1, -1
+        c.slot, c.a_slot, c.mul_slot, c.res_slot, c.res2_slot, c.y2_slot = -1, -1, -1, -1, -1, -1
         if o["kind"] == "load":
             src = mat(o["src"])
             assert o["rows"] is not None or src.shape[0] == M
             c.kind, c.slot, c.width, c.ld = GN_OP_LOAD, o["slot"], src.shape[1], src.stride(0)
             c.src, c.rows = ptr(src), ptr(o["rows"])
+            c.alpha, c.y2_slot, c.alpha2, c.mode2 = o.get("alpha", 1.0), o.get("y2", -1), o.get("alpha2", 1.0), o.get("mode2", 0)
+            c.Z2 = ptr(mat(o["Z2"], src.shape[1])) if o.get("Z2") is not None else None
         elif o["kind"] == "scale":
             Z, out = o["Z"], o["out"]
             w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
@@ -415,6 +557,12 @@ def chain(prog):
         else:
             W = mat(o["W"])
             N, Kd = W.shape
+            if nprod:
+                Wp = o.get("packed")
+                if Wp is None:
+                    Wp = pack_weight_split(W)
+                keep.append(Wp)
+                W = Wp
             c.kind, c.W, c.N, c.K, c.a_slot, c.slot = GN_OP_GEMM, ptr(W), N, Kd, o["a_slot"], o["slot"]
             c.act, c.alpha, c.beta, c.beta2 = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
             for name in ("gadd1", "gadd2"):
@@ -427,7 +575,15 @@ def chain(prog):
             c.res_slot, t = _sel(o["res"]); c.res_g = ptr(mat(t, N)) if t is not None else None
             c.res_rows = ptr(o["res_rows"])
             c.res2_slot, t = _sel(o["res2"]); c.res2_g = ptr(mat(t, N)) if t is not None else None
-    check(_lib.load().gn_chain_f32(ctypes.byref(a), stream()), "gn_chain_f32")
+            c.mul_mode, c.y2_slot, c.y2_src, c.mode2, c.alpha2 = o["mul_mode"], o["y2"], o["y2_src"], o["mode2"], o["alpha2"]
+            c.Z2 = ptr(mat(o["Z2"], N)) if o["Z2"] is not None else None
+            c.out2 = ptr(mat(o["out2"], N)) if o["out2"] is not None else None
+            if o["mul_mode"] > 1:
+                assert c.mul_slot < 0 and c.mul_g is not None, "mul_mode applies to a global mul operand"
+    if nprod:
+        check(_lib.load().gn_chain_split_f32(ctypes.byref(a), nprod, stream()), "gn_chain_split_f32")
+    else:
+        check(_lib.load().gn_chain_f32(ctypes.byref(a), stream()), "gn_chain_f32")
 
 
 def bil_reduce_project(Y, x, B, sp):

@@ -739,6 +739,25 @@ def contiguous_weight(W):
                    lambda: W.detach().contiguous())
 
 
+def packed_weight(W, trans):
+    """Split-bf16 fragment form (gn_pack_weight_split) of the weight W (trans: of W^T) for the split-operand chain
+    kernel.  Cached with the other derived forms when W is frozen; packed per call when W is trainable (a cache keyed
+    by the address of a per-call temporary would hand a later weight the earlier one's planes); None when the chain
+    runs on the f32 MFMA or on the host emulation."""
+    if K.CHAIN_MODE == "f32" or not W.is_cuda:
+        return None
+    if W.requires_grad:
+        return K.pack_weight_split(W.detach(), trans=trans)
+    return _cached(("pkt" if trans else "pk", W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version,
+                   lambda: K.pack_weight_split(W.detach(), trans=trans))
+
+
+def _gemm(prog, W, trans=False, **kw):
+    """Append `x @ W^T` (trans: `x @ W`) to a chain program: the fp32 (N,K) form for the f32-MFMA kernel / the host
+    emulation and the packed split form for the bf16 kernel."""
+    prog.gemm(transposed(W) if trans else contiguous_weight(W), packed=packed_weight(W, trans), **kw)
+
+
 class _Stack(torch.autograd.Function):
     """[Dense] + ResidualLayer* as ONE launch (gn_chain_f32), activations resident in LDS.
 
@@ -762,7 +781,7 @@ class _Stack(torch.autograd.Function):
         if first is not None:
             W0 = contiguous_weight(first["W"])
             z0 = torch.empty((M, W0.shape[0]), device=dev, dtype=dt) if first["act"] else None
-            prog.gemm(W0, a_slot=0, y_slot=1, act=first["act"],
+            _gemm(prog, first["W"], a_slot=0, y_slot=1, act=first["act"],
                       gadd1=g1, gidx1=None if g1 is None else first["i1"].idx32,
                       gadd2=g2, gidx2=None if g2 is None else first["i2"].idx32,
                       pre_out=z0, res=res, beta=first["beta"], res2=res2, beta2=first["beta2"],
@@ -775,8 +794,8 @@ class _Stack(torch.autograd.Function):
             z1 = torch.empty((M, width), device=dev, dtype=dt)
             z2 = torch.empty((M, width), device=dev, dtype=dt)
             last = k + 1 == len(layers)
-            prog.gemm(W1, a_slot=cur, y_slot=oth, act=True, pre_out=z1)
-            prog.gemm(W2, a_slot=oth, y_slot=cur, act=True, pre_out=z2, res=cur, beta=s,
+            _gemm(prog, L["W1"], a_slot=cur, y_slot=oth, act=True, pre_out=z1)
+            _gemm(prog, L["W2"], a_slot=oth, y_slot=cur, act=True, pre_out=z2, res=cur, beta=s,
                       res2=skips[k], beta2=L["skip_beta"], out=y if last else None)
             zs += [z1, z2]
         # tail projections y @ Wt^T of the final rows while they are still in LDS (the concat-Dense atom terms,
@@ -785,7 +804,7 @@ class _Stack(torch.autograd.Function):
         for Wt in spec.get("tails", ()):
             Wt_c = contiguous_weight(Wt)
             t = torch.empty((M, Wt_c.shape[0]), device=dev, dtype=dt)
-            prog.gemm(Wt_c, a_slot=cur, y_slot=-1, out=t)
+            _gemm(prog, Wt, a_slot=cur, y_slot=-1, out=t)
             tails.append(t)
         K.chain(prog)
         ctx.set_materialize_grads(False)
@@ -824,7 +843,7 @@ class _Stack(torch.autograd.Function):
         for Wt, gt in zip(spec.get("tails", ()), g_tails):
             if gt is not None:   # dL/dy += gt @ Wt
                 prog.load(oth, gt.contiguous())
-                prog.gemm(transposed(Wt), a_slot=oth, y_slot=cur, res=cur, beta=1.0)
+                _gemm(prog, Wt, trans=True, a_slot=oth, y_slot=cur, res=cur, beta=1.0)
         g_skips = [None] * len(layers)
         park = ctx.skip_is_x if ctx.in_width == width else -1
         zi = len(zs)
@@ -844,9 +863,9 @@ class _Stack(torch.autograd.Function):
                     c = s * L["skip_beta"]
             prog.scale(cur, cur, c, width=width)                  # G = dL/d(x + f(x))
             prog.scale(oth, cur, 1.0, Z=z2)                        # dz2
-            prog.gemm(transposed(L["W2"]), a_slot=oth, y_slot=oth)   # dh1 = dz2 @ W2
+            _gemm(prog, L["W2"], trans=True, a_slot=oth, y_slot=oth)   # dh1 = dz2 @ W2
             prog.scale(oth, oth, 1.0, Z=z1)                        # dz1
-            prog.gemm(transposed(L["W1"]), a_slot=oth, y_slot=cur, res=cur, beta=1.0)  # dx = dz1 @ W1 + G
+            _gemm(prog, L["W1"], trans=True, a_slot=oth, y_slot=cur, res=cur, beta=1.0)  # dx = dz1 @ W1 + G
         gx = g_res = g_res2 = gg1 = gg2 = None
         if first is not None:
             z0 = zs[0]
@@ -865,13 +884,16 @@ class _Stack(torch.autograd.Function):
                     c = 1.0
             want_dz = (has_g1 and need[4]) or (has_g2 and need[5])
             dz0 = torch.empty((M, width), device=dev, dtype=dt) if want_dz else None
+            src = cur
             if z0 is not None or c != 1.0 or want_dz:
-                prog.scale(cur, cur, c, Z=z0, out=dz0, width=width)
+                # into the other slot: the producing GEMM then emits it as its second output (K.fuse_program)
+                prog.scale(oth, cur, c, Z=z0, out=dz0, width=width)
+                src = oth
             if need[1]:
                 gx = torch.empty((M, ctx.in_width), device=dev, dtype=dt)
                 parked = park >= 0 and has_skips[park] and need[6 + park]
-                prog.gemm(transposed(first["W"]), a_slot=cur, y_slot=-1, out=gx, res=2 if parked else None, beta=1.0)
-            K.chain(prog)
+                _gemm(prog, first["W"], trans=True, a_slot=src, y_slot=-1, out=gx, res=2 if parked else None, beta=1.0)
+            K.chain(K.fuse_program(prog))
             if has_g1 and need[4]:
                 gg1 = K.segsum(dz0, *first["i1"].csr, first["i1"].n_rows)
             if has_g2 and need[5]:
@@ -879,7 +901,7 @@ class _Stack(torch.autograd.Function):
         else:
             gx = torch.empty((M, width), device=dev, dtype=dt)
             prog.store(cur, gx)
-            K.chain(prog)
+            K.chain(K.fuse_program(prog))
         return (None, gx, g_res, g_res2, gg1, gg2) + tuple(g_skips)
 
 
@@ -918,10 +940,10 @@ class _DenseHadamardDown(torch.autograd.Function):
         y = torch.empty((M, Wd_c.shape[0]), device=dev, dtype=dt)
         prog = K.ChainProgram(M)
         prog.load(0, x)
-        prog.gemm(Wa_c, a_slot=0, y_slot=1, act=act_a, pre_out=z1)            # x_a = act(x Wa^T)
+        _gemm(prog, Wa, a_slot=0, y_slot=1, act=act_a, pre_out=z1)            # x_a = act(x Wa^T)
         prog.load(0, rbf)
-        prog.gemm(Wr_c, a_slot=0, y_slot=0, pre_out=r, mul=1, alpha=alpha)     # (rbf Wr^T) * x_a * alpha
-        prog.gemm(Wd_c, a_slot=0, y_slot=1, act=act_d, pre_out=z3, out=y)
+        _gemm(prog, Wr, a_slot=0, y_slot=0, pre_out=r, mul=1, alpha=alpha)     # (rbf Wr^T) * x_a * alpha
+        _gemm(prog, Wd, a_slot=0, y_slot=1, act=act_d, pre_out=z3, out=y)
         K.chain(prog)
         ctx.cfg = cfg
         ctx.save_for_backward(z1, r, z3, Wa, Wr, Wd)
@@ -942,17 +964,27 @@ class _DenseHadamardDown(torch.autograd.Function):
         prog.load(0, g)
         if act_d:
             prog.scale(0, 0, 1.0, Z=z3, width=nd)                               # dz3
-        prog.gemm(transposed(Wd), a_slot=0, y_slot=1)                            # d(hadamard) in slot 1
-        if need[1]:
-            # d r = dh * x_a * alpha, x_a = act(z1) recomputed;  d rbf = d r @ Wr
-            prog.scale(0, 1, alpha, Z=z1, width=nh, mode=2 if act_a else 1)
-            prog.gemm(transposed(Wr), a_slot=0, y_slot=-1, out=grbf)
-        if need[0]:
-            prog.scale(1, 1, alpha, Z=r, width=nh, mode=1)                       # d x_a = dh * r * alpha
+        if need[0] and need[1]:
+            # dh = dz3 @ Wd feeds two products: d x_a = dh * r * alpha (the GEMM's own output, slot 1) and
+            # d r = dh * x_a * alpha with x_a = act(z1) recomputed (second output, taken before the `mul` stage, slot 0)
+            _gemm(prog, Wd, trans=True, a_slot=0, y_slot=1, mul=r, mul_mode=1, alpha=alpha,
+                  y2=0, y2_src=1, alpha2=alpha, Z2=z1, mode2=2 if act_a else 1)
+            _gemm(prog, Wr, trans=True, a_slot=0, y_slot=-1, out=grbf)           # d rbf = d r @ Wr
             if act_a:
                 prog.scale(1, 1, 1.0, Z=z1, width=nh, mode=0)                    # dz1
-            prog.gemm(transposed(Wa), a_slot=1, y_slot=-1, out=gx)
-        K.chain(prog)
+            _gemm(prog, Wa, trans=True, a_slot=1, y_slot=-1, out=gx)
+        else:
+            _gemm(prog, Wd, trans=True, a_slot=0, y_slot=1)                      # d(hadamard) in slot 1
+            if need[1]:
+                # d r = dh * x_a * alpha, x_a = act(z1) recomputed;  d rbf = d r @ Wr
+                prog.scale(0, 1, alpha, Z=z1, width=nh, mode=2 if act_a else 1)
+                _gemm(prog, Wr, trans=True, a_slot=0, y_slot=-1, out=grbf)
+            if need[0]:
+                prog.scale(1, 1, alpha, Z=r, width=nh, mode=1)                   # d x_a = dh * r * alpha
+                if act_a:
+                    prog.scale(1, 1, 1.0, Z=z1, width=nh, mode=0)                # dz1
+                _gemm(prog, Wa, trans=True, a_slot=1, y_slot=-1, out=gx)
+        K.chain(K.fuse_program(prog))
         return gx, grbf, None, None, None, None
 
 

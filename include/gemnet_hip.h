@@ -80,9 +80,13 @@ int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream);
  *   GN_OP_SCALE  dst_slot <- a_slot * alpha * (src ? phi(src[m, :]) : 1); optional copy to `out`;
  *                phi selected by `act`: 0 ssilu'(x) (adjoint of an activation), 1 x (Hadamard), 2 ssilu(x)
  *   GN_OP_GEMM   z = slot[a_slot] (rows x K) @ W^T (W is (N,K), k-contiguous) + gadd1[gidx1[m]] + gadd2[gidx2[m]]
- *                pre_out <- z;  y = act ? ssilu(z) : z;  y *= mul;  y *= alpha;
- *                y = (y + res) * beta;  y = (y + res2) * beta2      (mul/res/res2: an LDS slot or a global (M,N))
+ *                pre_out <- z;  a = act ? ssilu(z) : z;  y = a * phi_mul(mul);  y *= alpha;
+ *                y = (y + res) * beta;  y = (y + res2) * beta2      (mul/res/res2: an LDS slot or a global (M,N);
+ *                phi_mul by `mul_mode` for a GLOBAL mul: 1 identity (default 0 means identity too), 2 ssilu', 3 ssilu)
  *                slot[y_slot] <- y (may alias a_slot / res slots);  out <- y
+ *                second output (y2_slot >= 0 or out2): y2 = (y2_src ? a : y) * alpha2 * phi2(Z2[m, :]) with phi2 by
+ *                `mode2` as for SCALE (Z2 NULL: plain scale);  slot[y2_slot] <- y2;  out2 <- y2.   The adjoint of a
+ *                residual layer needs G = dz1 W1 + c G_old AND dz2' = G c' ssilu'(z2') of the next layer: one op.
  *   GN_OP_STORE  out[m, 0:width] <- slot                                           (LDS -> global)
  * Constraints: M <= 2^24, N, K <= 128, K % 16 == 0, W contiguous and 16-byte aligned, every global matrix row-major with row length N (resp. `ld` for
  * LOAD/SCALE/STORE), W rows 16-byte aligned. */
@@ -106,6 +110,13 @@ typedef struct {
   int res_slot; const float* res_g; const int32_t* res_rows; float beta;
   int res2_slot; const float* res2_g; float beta2;
   float* out;
+  int mul_mode;             /* GEMM: 0/1 mul as is, 2 ssilu'(mul_g), 3 ssilu(mul_g) (global mul only) */
+  int y2_slot;              /* GEMM: slot of the second output (-1 none) */
+  int y2_src;               /* 0: derived from the final y, 1: from a (after the activation, before mul) */
+  int mode2;                /* phi2: 0 ssilu'(Z2), 1 Z2, 2 ssilu(Z2) */
+  float alpha2;
+  const float* Z2;          /* (M,N) global or NULL */
+  float* out2;              /* (M,N) global or NULL */
 } gn_chain_op;
 typedef struct {
   int M;
@@ -113,6 +124,20 @@ typedef struct {
   gn_chain_op ops[GN_CHAIN_MAX_OPS];
 } gn_chain_args;
 int gn_chain_f32(const gn_chain_args* args, void* stream);
+
+/* The same chain programs on the bf16 matrix pipe with SPLIT operands (csrc/chain2.hip): every fp32 operand is the
+ * exact sum of three bf16 planes (hi + mid + lo); `nprod` = 6 keeps the six largest cross products per element
+ * (fp32-equivalent: dropped terms are below 2^-24 of the product; 6/16 of the f32-MFMA pipe time), 3 keeps
+ * hh + hm + mh, 1 is plain bf16 operands — always fp32 accumulation, fp32 epilogue, exact fp32 residual stream.
+ * Differences from gn_chain_f32: every GEMM op's `W` points at the PACKED weight produced by gn_pack_weight_split
+ * (not at the fp32 matrix); N % 16 == 0, K % 4 == 0; slots 0/1 live in LDS, slot 2 is a register-resident parking
+ * slot (written by a plain SCALE or as a GEMM's y_slot; readable as mul/res/res2 only).
+ * Replaces: Dense/ResidualLayer stacks (base_layers.py:44-89) exactly like gn_chain_f32. */
+int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* stream);
+/* W (N,K) fp32 with row pitch ldw — or, trans != 0, the (K,N) matrix whose transpose is the weight — -> three bf16
+ * planes in MFMA-fragment order; `out` holds gn_pack_weight_split_bytes(N,K) bytes (16-byte aligned). */
+int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream);
+int64_t gn_pack_weight_split_bytes(int N, int K);
 
 /* C (M,N) = alpha * A^T B with A (K,M), B (K,N) row-major: the weight-gradient product dW = dY^T X of every
  * Dense (base_layers.py:5-48; autograd of torch.nn.Linear in the reference) and the weight adjoints of the double

@@ -185,14 +185,23 @@ def seg_sum(src, index, n):
 
 
 def atom_update(P, prefix, c, nA, m, rbf, id_a, head):
-    x = m * dense(rbf, P[f"{prefix}.dense_rbf.weight"], False)
-    x = seg_sum(x, id_a, nA) * P[f"{prefix}.scale_sum.scale_factor"]
+    """AtomUpdateBlock (atom_update_block.py:55-72); with head=True the OutputBlock (:157-193), which returns
+    (E per atom, F per edge) — F is 0 unless direct_forces."""
+    xe = m * dense(rbf, P[f"{prefix}.dense_rbf.weight"], False)
+    x = seg_sum(xe, id_a, nA) * P[f"{prefix}.scale_sum.scale_factor"]
     x = dense(x, P[f"{prefix}.layers.0.weight"], True)
     for i in range(c["num_atom"]):
         x = residual(P, f"{prefix}.layers.{i + 1}", x)
-    if head:
-        x = dense(x, P[f"{prefix}.out_energy.weight"], False)
-    return x
+    if not head:
+        return x
+    x = dense(x, P[f"{prefix}.out_energy.weight"], False)
+    if not c["direct_forces"]:
+        return x, 0.0
+    f = xe * P[f"{prefix}.scale_rbf.scale_factor"]                      # atom_update_block.py:181-183
+    f = dense(f, P[f"{prefix}.seq_forces.0.weight"], True)
+    for i in range(c["num_atom"]):
+        f = residual(P, f"{prefix}.seq_forces.{i + 1}", f)
+    return x, dense(f, P[f"{prefix}.out_forces.weight"], False)            # (nEdges, num_targets)
 
 
 def edge_embedding(w, h, m_rbf, id_c, id_a):
@@ -205,7 +214,11 @@ def bilinear(rbfW1, sph, x_t, id_reduce, W, nE):
     out[e,o] = sum_{t in seg(e)} sum_s sum_i sum_c sph[t,s] rbfW1[e,i,s] x[t,c] W[c,i,o]."""
     S = sph.shape[1]
     C = x_t.shape[1]
-    sum_k = seg_sum(sph[:, :, None] * x_t[:, None, :], id_reduce, nE)  # (E,S,C)
+    sum_k = torch.zeros((nE, S, C), dtype=x_t.dtype)                     # (E,S,C), accumulated in chunks of triplets
+    step = max(1, (1 << 24) // (S * C))                                  # (a 32-atom GemNet-Q molecule has 3e5 quadruplets)
+    for lo in range(0, sph.shape[0], step):
+        hi = lo + step
+        sum_k = sum_k.index_add(0, id_reduce[lo:hi], sph[lo:hi, :, None] * x_t[lo:hi, None, :])
     P = torch.matmul(rbfW1, sum_k)  # (E,I,S)@(E,S,C) -> (E,I,C)
     return torch.einsum("eic,cio->eo", P, W)
 
@@ -230,7 +243,7 @@ def forward(cfg, P, inputs, need_forces=True, create_graph=False):
     S, Rn = c["num_spherical"], c["num_radial"]
     Z = inputs["Z"]
     R = inputs["R"].to(dt).detach().clone()
-    if need_forces:
+    if need_forces and not c["direct_forces"]:
         R.requires_grad_(True)
     id_a, id_c, id_swap = inputs["id_a"], inputs["id_c"], inputs["id_swap"]
     id3_exp, id3_red = inputs["id3_expand_ba"], inputs["id3_reduce_ca"]
@@ -282,7 +295,7 @@ def forward(cfg, P, inputs, need_forces=True, create_graph=False):
     rbf_h = dense(rbf, P["mlp_rbf_h.weight"], False)
     rbf_out = dense(rbf, P["mlp_rbf_out.weight"], False)
 
-    E_a = atom_update(P, "out_blocks.0", c, nA, m, rbf_out, id_a, head=True)
+    E_a, F_ca = atom_update(P, "out_blocks.0", c, nA, m, rbf_out, id_a, head=True)
     for i in range(c["num_blocks"]):
         pb = f"int_blocks.{i}"
         x_skip = dense(m, P[f"{pb}.dense_ca.weight"], True)
@@ -321,14 +334,26 @@ def forward(cfg, P, inputs, need_forces=True, create_graph=False):
         for j in range(c["num_concat"]):
             m2 = residual(P, f"{pb}.residual_m.{j}", m2)
         m = (m + m2) * INV_SQRT_2
-        E_a = E_a + atom_update(P, f"out_blocks.{i + 1}", c, nA, m, rbf_out, id_a, head=True)
+        E_i, F_i = atom_update(P, f"out_blocks.{i + 1}", c, nA, m, rbf_out, id_a, head=True)
+        E_a, F_ca = E_a + E_i, F_ca + F_i
 
     E_mol = seg_sum(E_a, batch_seg, nMol)
     if not c["extensive"]:
         cnt = seg_sum(torch.ones(nA, 1, dtype=dt), batch_seg, nMol).clamp(min=1)
         E_mol = E_mol / cnt
+    if c["direct_forces"]:                                                   # gemnet.py:586-597
+        if c["forces_coupled"]:
+            id_undir = inputs["id_undir"]
+            half = seg_sum(F_ca, id_undir, nE // 2) * 0.5                  # mean over the two directions
+            F_ca = half[id_undir]
+        F_ji = F_ca[:, :, None] * (V / D[:, None])[:, None, :]
+        return E_mol, seg_sum(F_ji, id_a, nA)                               # (nAtoms, num_targets, 3)
     if not need_forces:
         return E_mol, None
+    if c["num_targets"] > 1:                                                # gemnet.py:599-609
+        F = torch.stack([-torch.autograd.grad(E_mol[:, t].sum(), R, create_graph=create_graph, retain_graph=True)[0]
+                         for t in range(c["num_targets"])], dim=1)
+        return E_mol, F
     F = -torch.autograd.grad(E_mol.sum(), R, create_graph=create_graph)[0]
     return E_mol, F
 

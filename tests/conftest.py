@@ -42,3 +42,8 @@ def golden_indices():
 @pytest.fixture(scope="session")
 def golden_model():
     return dict(np.load(os.path.join(GOLDEN, "model.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_model2():
+    return dict(np.load(os.path.join(GOLDEN, "model2.npz")))

@@ -242,8 +242,16 @@ def chain(prog):
     for o in prog.ops:
         if o["kind"] == "load":
             src = o["src"] if o["rows"] is None else o["src"][o["rows"].long()]
+            src = src * o.get("alpha", 1.0)
             slots[o["slot"]] = torch.zeros(M, 128, dtype=dt)
             slots[o["slot"]][:, :src.shape[1]] = src
+            if o.get("y2", -1) >= 0:
+                y2 = src * o.get("alpha2", 1.0)
+                if o.get("Z2") is not None:
+                    m2 = o.get("mode2", 0)
+                    y2 = y2 * (_act(o["Z2"], 1) if m2 == 0 else (o["Z2"] if m2 == 1 else _act(o["Z2"], 0)))
+                slots[o["y2"]] = torch.zeros(M, 128, dtype=dt)
+                slots[o["y2"]][:, :src.shape[1]] = y2
         elif o["kind"] == "scale":
             Z, out = o["Z"], o["out"]
             w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
@@ -269,9 +277,11 @@ def chain(prog):
             if o["pre_out"] is not None:
                 o["pre_out"].copy_(z)
             y = _act(z, 0) if o["act"] else z
+            a_val = y
             mul = sel(o["mul"], N)
             if mul is not None:
-                y = y * mul
+                mm = o.get("mul_mode", 1)
+                y = y * (mul if mm <= 1 else _act(mul, 1 if mm == 2 else 0))
             y = y * o["alpha"]
             res = sel(o["res"], N)
             if res is not None:
@@ -283,10 +293,22 @@ def chain(prog):
                 y = (y + res2) * o["beta2"]
             if o["out"] is not None:
                 o["out"].copy_(y)
+            y2 = None
+            if o.get("y2", -1) >= 0 or o.get("out2") is not None:
+                y2 = (a_val if o.get("y2_src", 0) else y) * o.get("alpha2", 1.0)
+                if o.get("Z2") is not None:
+                    m2 = o.get("mode2", 0)
+                    y2 = y2 * (_act(o["Z2"], 1) if m2 == 0 else (o["Z2"] if m2 == 1 else _act(o["Z2"], 0)))
+                if o.get("out2") is not None:
+                    o["out2"].copy_(y2)
             if o["slot"] >= 0:
                 new = slots[o["slot"]].clone()
                 new[:, :N] = y
                 slots[o["slot"]] = new
+            if y2 is not None and o.get("y2", -1) >= 0:
+                new = slots[o["y2"]].clone()
+                new[:, :N] = y2
+                slots[o["y2"]] = new
 
 
 def bil_reduce_project(Y, x, Bm, sp):

@@ -296,6 +296,123 @@ def golden_models():
     print("model.npz", len(out), "arrays")
 
 
+# ------------------------------------------------------------ G4b / G3: round-2 model + layer fixtures
+HEAD_KEYS = ("out_energy.weight", "out_forces.weight")
+
+
+def scale_heads(params, factor):
+    """Multiply the output-head weights (E and direct F are linear in them) — used to bring mean|F| to 1 eV/A so the
+    1e-5 eV/A force bar can be asserted literally on the deep models."""
+    return {k: (v * factor if k.endswith(HEAD_KEYS) else v) for k, v in params.items()}
+
+
+def _flatten(prefix, obj, out):
+    if torch.is_tensor(obj):
+        out[prefix] = obj.detach().numpy()
+    elif isinstance(obj, (tuple, list)):
+        for i, o in enumerate(obj):
+            _flatten(f"{prefix}.{i}", o, out)
+    elif isinstance(obj, dict):
+        for k, o in obj.items():
+            _flatten(f"{prefix}.{k}", o, out)
+
+
+def run_model2(cfg, seed, Rlist, Zlist, tag, out, with_grads=False, unit_forces=True, layers=()):
+    """Like run_model, plus: (1) the output heads are rescaled so that mean|F| = 1 (`<tag>.out_scale`, applied by the
+    tests to the same generated weights); (2) direct-force / multi-target models; (3) forward hooks on `layers`
+    record every tensor entering and leaving those reference modules (`<tag>.L.<module>.in|kw|out...`)."""
+    to = cfg["triplets_only"]
+    N = np.array([len(r) for r in Rlist], dtype=np.int32)
+    R = np.concatenate(Rlist).astype(np.float32)
+    Z = np.concatenate(Zlist).astype(np.int32)
+    rs = np.random.RandomState(seed + 99)
+    Et = rs.standard_normal(len(N)).astype(np.float32)
+    Ft = rs.standard_normal(R.shape).astype(np.float32)
+    dc = _MemContainer(dict(N=N, Z=Z, R=R, E=Et, F=Ft), 5.0, 10.0, to)
+    batch = dc[list(range(len(N)))]
+    sf = GO.load_scale_factors(SCALE_FILE)
+    params = GO.make_params(cfg, seed, sf, dtype=torch.float64)
+    inputs = {k: v for k, v in batch.items() if k not in ("E", "F")}
+    inputs["R"] = inputs["R"].double()
+    model = GemNet(**cfg, scale_file=SCALE_FILE).double()
+    model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
+    model.train()
+    scale = 1.0
+    if unit_forces:
+        _, F0 = model(dict(inputs))
+        scale = 1.0 / float(F0.detach().abs().mean())
+        params = scale_heads(params, scale)
+        model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
+    store, hooks = {}, []
+    for name in layers:
+        def hook(mod, args, kwargs, output, name=name):
+            _flatten(f"{tag}.L.{name}.in", args, store)
+            _flatten(f"{tag}.L.{name}.kw", kwargs, store)
+            _flatten(f"{tag}.L.{name}.out", output, store)
+        hooks.append(model.get_submodule(name).register_forward_hook(hook, with_kwargs=True))
+    E, F = model(dict(inputs))
+    for h in hooks:
+        h.remove()
+    out.update(store)
+    out[f"{tag}.seed"], out[f"{tag}.cfg"], out[f"{tag}.out_scale"] = np.array(seed), np.array(repr(cfg)), np.array(scale)
+    out[f"{tag}.Z"], out[f"{tag}.R"], out[f"{tag}.N"] = Z, R, N
+    out[f"{tag}.Et"], out[f"{tag}.Ft"] = Et, Ft
+    for k in dc.index_keys:
+        out[f"{tag}.{k}"] = batch[k].numpy().astype(np.int32)
+    out[f"{tag}.E"], out[f"{tag}.F"] = E.detach().numpy(), F.detach().numpy()
+    if with_grads:
+        Fl = F[:, 0] if F.dim() == 3 else F
+        loss = GO.training_loss(E[:, :1], Fl, batch["E"].double()[:, None] if batch["E"].dim() == 1 else batch["E"].double(),
+                                batch["F"].double())
+        out[f"{tag}.loss"] = loss.detach().numpy()
+        loss.backward()
+        names, norms = [], []
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                norms.append(float(p.grad.norm()))
+        out[f"{tag}.grad_names"], out[f"{tag}.grad_norms"] = np.array(names), np.array(norms)
+        named = dict(model.named_parameters())
+        for n in ("mlp_cbf3.weight", "int_blocks.0.trip_interaction.mlp_cbf.weight", "int_blocks.0.dense_ca.weight",
+                  "out_blocks.1.out_forces.weight", "out_blocks.0.seq_forces.0.weight"):
+            if n in named and named[n].grad is not None:
+                out[f"{tag}.grad.{n}"] = named[n].grad.numpy()
+    print(tag, "E", E.detach().numpy().ravel()[:3], "mean|F|", float(F.detach().abs().mean()), "out_scale", scale,
+          {k: int(batch[k].shape[0]) for k in ("id_a", "id3_reduce_ca")}, flush=True)
+
+
+def golden_models2():
+    """-> model2.npz: unit-force deep models (T/Q, 2 and 4 blocks), direct-force models (GemNet-dT/dQ), a two-target
+    model, and per-layer inputs/outputs of the reference modules (P1/P2/P3/P4/P5/P10/P13)."""
+    out = {}
+    m12 = make_molecule(12, 1000 * 1 + 0)
+    m9 = make_molecule(9, 77, box=4.5)
+    m32 = make_molecule(32, 2000)
+    pair = ([m12["R"], m9["R"]], [m12["Z"], m9["Z"]])
+    Q_LAYERS = ("mlp_cbf3", "mlp_sbf4", "int_blocks.0", "int_blocks.0.trip_interaction",
+                "int_blocks.0.quad_interaction", "int_blocks.0.trip_interaction.mlp_cbf",
+                "int_blocks.0.quad_interaction.mlp_sbf", "int_blocks.0.atom_update", "out_blocks.1")
+    T_LAYERS = ("mlp_cbf3", "int_blocks.1", "int_blocks.1.trip_interaction", "int_blocks.1.trip_interaction.mlp_cbf",
+                "int_blocks.1.atom_update", "out_blocks.2")
+    # per-layer captures: small GemNet-Q (both interactions) and full-width GemNet-T (second block)
+    run_model2(cfg_small(False), 2, [m12["R"]], [m12["Z"]], "q1L", out, unit_forces=False, layers=Q_LAYERS)
+    run_model2(cfg_full(True, 2), 3, *pair, "t2s", out, with_grads=True, layers=T_LAYERS)
+    run_model2(cfg_full(False, 2), 4, *pair, "q2s", out)
+    # direct forces (gemnet.py:586-597, atom_update_block.py:181-188): small T uncoupled, small Q coupled, full-width T
+    run_model2(dict(cfg_small(True), direct_forces=True, forces_coupled=False), 41, [m12["R"]], [m12["Z"]], "dt1", out,
+               with_grads=True, unit_forces=False)
+    run_model2(dict(cfg_small(False), direct_forces=True, forces_coupled=True), 42, [m12["R"]], [m12["Z"]], "dq1", out,
+               with_grads=True, unit_forces=False)
+    run_model2(dict(cfg_full(True, 2), direct_forces=True, forces_coupled=True), 43, *pair, "dt2s", out, with_grads=True)
+    # two targets with autograd forces (one backward per target, gemnet.py:599-609)
+    run_model2(dict(cfg_small(True), num_targets=2), 44, [m12["R"]], [m12["Z"]], "t1m", out, unit_forces=False)
+    # the published configurations (pretrained/*/model_kwargs.json), 4 blocks, one 32-atom molecule, unit forces
+    run_model2(cfg_full(True, 4), 5, [m32["R"]], [m32["Z"]], "t4s", out)
+    run_model2(cfg_full(False, 4), 6, [m32["R"]], [m32["Z"]], "q4s", out)
+    np.savez_compressed(os.path.join(HERE, "model2.npz"), **out)
+    print("model2.npz", len(out), "arrays")
+
+
 def golden_keys():
     import json
     out = {}
@@ -503,7 +620,7 @@ def golden_tfnames():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["basis", "indices", "models", "keys", "trainer", "scaling", "tfnames"]
+    which = sys.argv[1:] or ["basis", "indices", "models", "models2", "keys", "trainer", "scaling", "tfnames"]
     if "tfnames" in which:
         golden_tfnames()
     if "scaling" in which:
@@ -516,5 +633,7 @@ if __name__ == "__main__":
         golden_indices()
     if "models" in which:
         golden_models()
+    if "models2" in which:
+        golden_models2()
     if "keys" in which:
         golden_keys()

@@ -1,0 +1,118 @@
+"""-m gpu: BASELINE.json's full sizes through size-independent properties (the float64 reference does not finish a
+32 x 32-atom GemNet-Q batch in test time): the published 4-block GemNet-T / GemNet-Q configurations on
+  * 32 molecules x 32 atoms (configs[1], configs[2]) and 8 molecules x 64 atoms (the molecule size of configs[4]),
+checked for
+  * sum of forces = 0 per molecule (translation invariance of E; F = -dE/dR),
+  * invariance of E and equivariance of F under a rigid rotation + translation of every molecule,
+  * invariance under a permutation of the molecules of the batch,
+  * batch additivity: E / F of the batch equal the per-molecule runs (the per-molecule size IS golden-covered: t4s / q4s),
+  * hipGraph replay == eager, bit for bit.
+Output heads are rescaled so that mean|F| = 1 eV/A on the batch: all force tolerances are absolute eV/A."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SCALE_FILE
+from gemnet_pytorch_amd.model.gemnet import GemNet
+from gemnet_pytorch_amd.synthetic import make_dataset
+from gemnet_pytorch_amd.training.data_container import DataContainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FULL = dict(num_spherical=7, num_radial=6, num_blocks=4, emb_size_atom=128, emb_size_edge=128, emb_size_trip=64,
+            emb_size_quad=32, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=32, emb_size_bil_trip=64,
+            emb_size_bil_quad=32, num_before_skip=1, num_after_skip=1, num_concat=1, num_atom=2)
+SIZES = [("T", 32, 32), ("Q", 32, 32), ("T", 8, 64), ("Q", 8, 64)]
+
+
+def batch_of(ds, ids, triplets_only, R=None):
+    data = dict(ds)
+    if R is not None:
+        data["R"] = R
+    dc = DataContainer.from_arrays(data, 5.0, 10.0, triplets_only=triplets_only)
+    b = dc[list(ids)]
+    return {k: v.to(DEV) for k, v in b.items() if k not in ("E", "F")}
+
+
+@pytest.fixture(scope="module", params=SIZES, ids=[f"{m}-{b}x{n}" for m, b, n in SIZES])
+def setup(request):
+    kind, n_mol, n_atoms = request.param
+    cfg = dict(FULL, triplets_only=kind == "T")
+    torch.manual_seed(11)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV).eval()
+    model.requires_grad_(False)
+    ds = make_dataset(n_mol, n_atoms, config=2)
+    inputs = batch_of(ds, range(n_mol), cfg["triplets_only"])
+    with torch.no_grad():
+        pass
+    E, F = model(inputs)
+    s = 1.0 / float(F.abs().mean())            # forces are linear in the output heads
+    with torch.no_grad():
+        for ob in model.out_blocks:
+            ob.out_energy.weight.mul_(s)
+    model._wcache.clear()
+    E, F = model(inputs)
+    assert abs(float(F.abs().mean()) - 1.0) < 1e-3
+    return dict(kind=kind, cfg=cfg, model=model, ds=ds, n_mol=n_mol, n_atoms=n_atoms, inputs=inputs,
+                E=E.detach().clone(), F=F.detach().clone())
+
+
+def test_forces_sum_to_zero_per_molecule(setup):
+    F = setup["F"].view(setup["n_mol"], setup["n_atoms"], 3)
+    net = F.sum(dim=1).abs().max()
+    print(f"{setup['kind']} {setup['n_mol']}x{setup['n_atoms']}: max |sum_atoms F| = {float(net):.3e} eV/A")
+    assert float(net) <= 2e-4       # a sum of n_atoms fp32 forces of O(1) eV/A
+
+
+def test_rigid_motion_invariance(setup):
+    g = torch.Generator().manual_seed(3)
+    ds, n, B = setup["ds"], setup["n_atoms"], setup["n_mol"]
+    R = torch.tensor(ds["R"], dtype=torch.float64).view(B, n, 3)
+    Q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g, dtype=torch.float64))
+    Q = Q * torch.sign(torch.linalg.det(Q))[:, None, None]
+    shift = torch.randn(B, 1, 3, generator=g, dtype=torch.float64)
+    R2 = (R @ Q.transpose(1, 2) + shift).reshape(-1, 3).float().numpy()
+    E2, F2 = setup["model"](batch_of(ds, range(B), setup["cfg"]["triplets_only"], R=R2))
+    F_rot = (setup["F"].double().cpu().view(B, n, 3) @ Q.transpose(1, 2)).reshape(-1, 3)
+    dF = float((F2.double().cpu() - F_rot).abs().mean())
+    dE = float((E2 - setup["E"]).abs().max())
+    print(f"{setup['kind']} {B}x{n}: rotated+shifted: force MAE {dF:.3e} eV/A, energy diff {dE:.3e}")
+    # the rotated positions are re-rounded to fp32 (1e-7 relative in R): allow 10x the parity bar
+    assert dF <= 1e-4 and dE <= 1e-3 * max(1.0, float(setup["E"].abs().max()))
+
+
+def test_molecule_permutation_and_additivity(setup):
+    ds, n, B = setup["ds"], setup["n_atoms"], setup["n_mol"]
+    model, to = setup["model"], setup["cfg"]["triplets_only"]
+    perm = list(np.random.RandomState(5).permutation(B))
+    E2, F2 = model(batch_of(ds, perm, to))
+    F_ref = setup["F"].view(B, n, 3)[perm].reshape(-1, 3)
+    dF = float((F2 - F_ref).abs().mean())
+    print(f"{setup['kind']} {B}x{n}: permuted batch: force MAE {dF:.3e}")
+    assert dF <= 1e-5 and float((E2 - setup["E"][perm]).abs().max()) <= 2e-5 * max(1.0, float(setup["E"].abs().max()))
+    # additivity: three molecules run alone (that size is covered by the reference goldens t4s / q4s)
+    for i in (0, B // 2, B - 1):
+        Ei, Fi = model(batch_of(ds, [i], to))
+        d = float((Fi - setup["F"].view(B, n, 3)[i]).abs().mean())
+        assert d <= 1e-5, (i, d)
+        assert float((Ei[0] - setup["E"][i]).abs().max()) <= 2e-5 * max(1.0, float(setup["E"].abs().max()))
+
+
+def test_hipgraph_replay_equals_eager_bitwise(setup):
+    model, inputs = setup["model"], setup["inputs"]
+    for _ in range(2):
+        model(inputs)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model(inputs)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        Eg, Fg = model(inputs)
+    graph.replay()
+    torch.cuda.synchronize()
+    E, F = model(inputs)
+    assert torch.equal(E, Eg) and torch.equal(F, Fg)
+    assert torch.equal(F, setup["F"])     # and run-to-run reproducible (no atomics)

@@ -355,16 +355,82 @@ def _stack_programs(M, width, g, dev):
     return build
 
 
-@pytest.mark.parametrize("M,width", [(1000, 128), (33, 64), (18122, 128)])
-def test_chain_kernel_vs_interpreter(M, width):
-    g = torch.Generator().manual_seed(M)
-    build = _stack_programs(M, width, g, DEV)
-    p_ref, o_ref = build(lambda t: t.clone(), lambda i: i)
-    CK.chain(p_ref)
-    p_dev, o_dev = build(lambda t: f32(t), lambda i: i.to(DEV))
-    K.chain(p_dev)
-    for k in o_ref:
-        close(o_dev[k], o_ref[k], rtol=1e-4, atol=2e-4 * max(1.0, float(o_ref[k].abs().max())))
+def _adjoint_programs(M, width, g, dev):
+    """The fused-epilogue features of the adjoint programs: LOAD with scale + second tensor, a global mul with
+    activation-derivative mode, second outputs (from the final value and from the pre-mul value, to a slot aliasing
+    the A operand and to global memory)."""
+    def mk(*shape):
+        return rnd(g, *shape)
+    gin, W1, W2 = mk(M, width), mk(width, width) / 11, mk(width, width) / 11
+    z1, z2, z3, r = mk(M, width), mk(M, width), mk(M, width), mk(M, width)
+
+    def build(conv, idx):
+        t = {k: conv(v) for k, v in dict(g=gin, W1=W1, W2=W2, z1=z1, z2=z2, z3=z3, r=r).items()}
+        outs = {k: conv(torch.zeros(M, width, dtype=torch.float64)) for k in ("a", "b", "o2", "c", "d")}
+        p = K.ChainProgram(M)
+        p.load(0, t["g"], alpha=0.7, y2=1, alpha2=1.3, Z2=t["z2"], mode2=0)         # G, dz2 = G * 1.3 * f'(z2)
+        p.scale(2, 0, 0.5, width=width)
+        p.gemm(t["W2"], a_slot=1, y_slot=1, mul=t["z1"], mul_mode=2, out=None)        # dz1 = (dz2 W2) f'(z1)
+        p.gemm(t["W1"], a_slot=1, y_slot=0, res=0, alpha=2.0, beta=0.5, y2=1, alpha2=0.9, Z2=t["z3"], mode2=2,
+               out2=outs["o2"])                                                       # G' and G' * 0.9 * f(z3)
+        p.store(0, outs["a"])
+        p.store(1, outs["b"])
+        p.gemm(t["W2"], a_slot=1, y_slot=1, mul=t["r"], mul_mode=1, alpha=1.1, res=2, beta=1.0,
+               y2=0, y2_src=1, alpha2=0.8, Z2=t["z1"], mode2=1)                      # two products of one GEMM
+        p.store(0, outs["c"])
+        p.store(1, outs["d"])
+        return p, outs
+    return build
+
+
+# relative error budget of one chain program per arithmetic: f32 MFMA and the six-product split are fp32-equivalent
+CHAIN_TOL = {"f32": 1e-4, "split6": 1e-4, "split3": 2e-3, "bf16": 1e-1}
+
+
+@pytest.mark.parametrize("mode", ["f32", "split6", "split3", "bf16"])
+@pytest.mark.parametrize("M,width", [(1000, 128), (33, 64), (18122, 128), (5000, 128), (9000, 64), (13000, 128)])
+def test_chain_kernel_vs_interpreter(M, width, mode):
+    """Every op kind, aliasing slots, slot / register / global operands, all five tile heights (RT = 1..5), on the f32
+    MFMA kernel and on the split-operand bf16 kernel (packed weights), against the float64 interpreter."""
+    tol = CHAIN_TOL[mode]
+    worst = 0.0
+    for maker in (_stack_programs, _adjoint_programs):
+        g = torch.Generator().manual_seed(M)
+        build = maker(M, width, g, DEV)
+        p_ref, o_ref = build(lambda t: t.clone(), lambda i: i)
+        CK.chain(p_ref)
+        p_dev, o_dev = build(lambda t: f32(t), lambda i: i.to(DEV))
+        K.chain(p_dev, mode=mode)
+        for k in o_ref:
+            scale = max(1.0, float(o_ref[k].abs().max()))
+            err = float((o_dev[k].double().cpu() - o_ref[k]).abs().max()) / scale
+            worst = max(worst, err)
+            assert err <= 2 * tol, (maker.__name__, k, err)
+    print(f"chain {mode} M={M} width={width}: max err / scale = {worst:.2e}")
+
+
+def test_split_six_products_is_fp32_equivalent():
+    """One 128x128 layer: the six-product split reproduces the f32-MFMA result to fp32 rounding level, and the plane
+    decomposition is exact (LOAD -> STORE round trip is bit-identical)."""
+    g = torch.Generator().manual_seed(5)
+    M = 4096
+    x, W = f32(rnd(g, M, 128)), f32(rnd(g, 128, 128) / 11)
+    ref = x.double() @ W.double().t()
+    outs = {}
+    for mode in ("f32", "split6"):
+        y = torch.empty(M, 128, device=DEV)
+        p = K.ChainProgram(M)
+        p.load(0, x)
+        p.gemm(W, a_slot=0, y_slot=1, out=y)
+        K.chain(p, mode=mode)
+        outs[mode] = float((y.double() - ref).abs().max())
+    assert outs["split6"] <= 2.0 * outs["f32"] + 1e-7, outs
+    rt = torch.empty(M, 128, device=DEV)
+    p = K.ChainProgram(M)
+    p.load(0, x)
+    p.store(0, rt)
+    K.chain(p, mode="split6")
+    assert torch.equal(rt, x)
 
 
 @pytest.mark.parametrize("M,N,Kd,ta,tb", [(128, 128, 18122, True, True), (64, 128, 5000, True, True),

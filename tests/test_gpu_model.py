@@ -1,11 +1,11 @@
 """-m gpu: GemNet on the HIP path (fp32, MI355X) against the reference's float64 goldens.
 
-Tolerance (BASELINE.json north_star): force MAE within 1e-5 eV/A for fp32.  The synthetic molecules
-are denser than COLL and the deterministic test weights are not trained, so |F| reaches 1e1..1e4
-in the deeper cases; the bar is therefore applied relative to the force scale:
-    mean|F_hip - F_ref| <= 1e-5 * max(1, mean|F_ref|).
-Second-order (training) gradients are compared per parameter by norm (rtol 2e-3) and elementwise
-for the stored ones."""
+Tolerance (BASELINE.json north_star): force MAE within 1e-5 eV/A for fp32 — asserted LITERALLY (absolute) on
+fixtures whose forces are O(1) eV/A: the shallow models t1/q1/dt1/dq1/t1m and the deep models whose output heads were
+rescaled to mean|F| = 1 (t2s, q2s, dt2s, t4s = pretrained GemNet-T configuration, q4s = pretrained GemNet-Q
+configuration; tests/golden/make_golden.py::run_model2).  The unscaled deep fixtures (|F| up to 3e4 with the untrained
+test weights) are kept as a RELATIVE-precision check under their own name.  Every test prints the measured MAE.
+Second-order (training) gradients are compared per parameter by norm (rtol 2e-3) and elementwise for the stored ones."""
 import numpy as np
 import pytest
 import torch
@@ -26,35 +26,104 @@ def build(cfg, params):
     return model.to(DEV)
 
 
+def test_multi_target_forces_fused_equals_composite(golden_model2):
+    """num_targets = 2: one backward pass per target over the same graph (retain_graph) through the shared-gradient
+    sink of the fused bilinear layers; both targets' forces equal the composite path and the reference."""
+    g = golden_model2
+    cfg, params, inputs = load_case(g, "t1m")
+    res = {}
+    for mode in ("fused", "composite"):
+        model = build(cfg, params).eval()
+        model.force_graph = (mode == "composite")
+        E, F = model(to_dev(inputs))
+        res[mode] = F.detach().cpu().numpy()
+        assert F.shape == (inputs["R"].shape[0], 2, 3)
+    for t in range(2):
+        d_ref = float(np.abs(res["fused"][:, t] - g["t1m.F"][:, t]).mean())
+        d_cmp = float(np.abs(res["fused"][:, t] - res["composite"][:, t]).mean())
+        print(f"target {t}: fused vs reference {d_ref:.3e}, fused vs composite {d_cmp:.3e}")
+        assert d_ref <= FORCE_TOL and d_cmp <= FORCE_TOL
+
+
 def to_dev(inputs):
     return {k: v.to(DEV) for k, v in inputs.items()}
 
 
-@pytest.mark.parametrize("tag", ["t1", "q1", "t2", "q2", "t4"])
-def test_energy_force_parity(golden_model, tag):
+def _case(golden_model, golden_model2, tag):
+    g = golden_model2 if f"{tag}.E" in golden_model2 else golden_model
+    return (g,) + load_case(g, tag)
+
+
+ABS_CASES = ["t1", "q1", "t2s", "q2s", "t4s", "q4s", "dt1", "dq1", "dt2s", "t1m"]
+
+
+@pytest.mark.parametrize("tag", ABS_CASES)
+def test_energy_force_parity(golden_model, golden_model2, tag):
+    """mean|F_hip - F_ref| <= 1e-5 eV/A, absolute, on fixtures with mean|F| in [0.4, 1.5] eV/A: autograd forces (T and
+    Q, 1 / 2 / 4 blocks incl. both published configurations), direct forces (dT, dQ; coupled and uncoupled), two targets."""
+    g, cfg, params, inputs = _case(golden_model, golden_model2, tag)
+    model = build(cfg, params).eval()
+    E, F = model(to_dev(inputs))
+    assert F.is_cuda and (cfg.get("direct_forces", False) or not F.requires_grad)
+    Eref, Fref = g[f"{tag}.E"], g[f"{tag}.F"]
+    assert tuple(F.shape) == Fref.shape
+    fmean = float(np.abs(Fref).mean())
+    assert 0.3 <= fmean <= 1.6, fmean          # the fixture itself is O(1) eV/A: the bar below is literal
+    f_mae = float(np.abs(F.detach().cpu().numpy() - Fref).mean())
+    f_max = float(np.abs(F.detach().cpu().numpy() - Fref).max())
+    e_err = float(np.abs(E.detach().cpu().numpy() - Eref).max())
+    print(f"{tag}: force MAE {f_mae:.3e} eV/A (max {f_max:.3e}; mean|F_ref| {fmean:.3f}), energy err {e_err:.3e} "
+          f"(max|E_ref| {float(np.abs(Eref).max()):.3f})")
+    assert f_mae <= FORCE_TOL
+    assert e_err <= 2e-5 * max(1.0, float(np.abs(Eref).max()))
+
+
+@pytest.mark.parametrize("tag", ["t2", "q2", "t4"])
+def test_relative_precision_on_unscaled_deep_fixtures(golden_model, tag):
+    """The same models with the raw test weights (mean|F| = 5 .. 3.9e3 eV/A): error relative to the force scale."""
     g = golden_model
     cfg, params, inputs = load_case(g, tag)
     model = build(cfg, params).eval()
     E, F = model(to_dev(inputs))
-    assert F.is_cuda and not F.requires_grad
     Eref, Fref = g[f"{tag}.E"], g[f"{tag}.F"]
-    fscale = max(1.0, float(np.abs(Fref).mean()))
-    escale = max(1.0, float(np.abs(Eref).max()))
+    fscale = float(np.abs(Fref).mean())
     f_mae = float(np.abs(F.detach().cpu().numpy() - Fref).mean())
-    e_err = float(np.abs(E.detach().cpu().numpy() - Eref).max())
-    print(f"{tag}: force MAE {f_mae:.3e} (scale {fscale:.2e}), energy err {e_err:.3e} (scale {escale:.2e})")
+    print(f"{tag}: force MAE / mean|F_ref| = {f_mae / fscale:.3e} (mean|F_ref| {fscale:.3e})")
     assert f_mae <= FORCE_TOL * fscale
-    assert e_err <= 2e-5 * escale
+    assert float(np.abs(E.detach().cpu().numpy() - Eref).max()) <= 2e-5 * max(1.0, float(np.abs(Eref).max()))
 
 
-@pytest.mark.parametrize("tag", ["t1", "q1", "t2"])
-def test_training_gradients_parity(golden_model, tag):
-    g = golden_model
+@pytest.mark.parametrize("mode,bar", [("f32", 1e-5), ("split6", 1e-5), ("split3", 1e-3), ("bf16", None)])
+@pytest.mark.parametrize("tag", ["t4s", "q4s"])
+def test_matmul_arithmetic_modes(golden_model2, tag, mode, bar, monkeypatch):
+    """The Dense stacks on the f32 MFMA, on the bf16 matrix pipe with 6 / 3 split-operand products, and with plain
+    bf16 operands (BASELINE configs[4] arithmetic; fp32 accumulate, fp32 everywhere else): measured force MAE of the
+    published 4-block configurations against the float64 reference.  bf16 is reported as measured (no bar: the
+    reference's own bf16 autocast is at 1e-2)."""
+    from gemnet_pytorch_amd import kernels as K
+    g = golden_model2
     cfg, params, inputs = load_case(g, tag)
+    monkeypatch.setattr(K, "CHAIN_MODE", mode)
+    model = build(cfg, params).eval()
+    E, F = model(to_dev(inputs))
+    f_mae = float(np.abs(F.detach().cpu().numpy() - g[f"{tag}.F"]).mean())
+    print(f"{tag} [{mode}]: force MAE {f_mae:.3e} eV/A at mean|F| = 1")
+    assert np.isfinite(f_mae)
+    if bar is not None:
+        assert f_mae <= bar
+    else:
+        assert f_mae <= 0.2
+
+
+@pytest.mark.parametrize("tag", ["t1", "q1", "t2", "t2s", "dt1", "dq1", "dt2s"])
+def test_training_gradients_parity(golden_model, golden_model2, tag):
+    """loss.backward() through the force (second order) resp. through the direct-force head (first order, fused
+    layers) against the reference's parameter gradients."""
+    g, cfg, params, inputs = _case(golden_model, golden_model2, tag)
     model = build(cfg, params).train()
     E, F = model(to_dev(inputs))
     assert F.requires_grad
-    loss = GO.training_loss(E, F, torch.tensor(g[f"{tag}.Et"], device=DEV)[:, None],
+    loss = GO.training_loss(E[:, :1], F[:, 0] if F.dim() == 3 else F, torch.tensor(g[f"{tag}.Et"], device=DEV)[:, None],
                             torch.tensor(g[f"{tag}.Ft"], device=DEV))
     np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=2e-5)
     loss.backward()
@@ -83,7 +152,7 @@ def test_repeatable_bitwise(golden_model):
 def test_native_library_loaded():
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
-    assert lib.gn_abi_version() == 6
+    assert lib.gn_abi_version() == 8
     with open("/proc/self/maps") as f:
         assert "libgemnet_hip.so" in f.read()
 

@@ -17,9 +17,8 @@ from test_oracle_model import load_case
 
 
 def build(cfg, params, dtype=torch.float64):
-    model = GemNet(**cfg, scale_file=SCALE_FILE)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(dtype)   # dtype first: rescaled heads are not fp32-representable
     model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
-    model = model.to(dtype)
     model._check_inputs = lambda R: None
     return model
 
@@ -207,3 +206,43 @@ def test_multi_target_forces_fused_equals_composite(golden_model, tag):
         d = float((res["fused"][1][:, t] - res["composite"][1][:, t]).abs().max())
         assert d <= 1e-10 * max(1.0, scale), (t, d, scale)
     assert torch.allclose(res["fused"][0], res["composite"][0], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("tag", ["t2s", "q2s", "dt1", "dq1", "dt2s", "t1m", "t4s"])
+def test_round2_fixtures_energy_force(golden_model2, tag, mode):
+    """Unit-force deep models, direct-force models (GemNet-dT/dQ, coupled and uncoupled) and the two-target model on
+    the emulated launchers, composite (train) and fused (eval) execution modes, ABSOLUTE 1e-9 against the reference."""
+    g = golden_model2
+    cfg, params, inputs = load_case(g, tag)
+    with cpu_kernels.emulate():
+        model = build(cfg, params)
+        model = model.train() if mode == "train" else model.eval()
+        inputs["R"] = inputs["R"].double()
+        E, F = model(inputs)
+    Eref, Fref = g[f"{tag}.E"], g[f"{tag}.F"]
+    assert F.shape == Fref.shape
+    assert np.abs(F.detach().numpy() - Fref).max() <= 1e-9 * max(1.0, float(np.abs(Fref).max()))
+    assert np.abs(E.detach().numpy() - Eref).max() <= 1e-9 * max(1.0, float(np.abs(Eref).max()))
+
+
+@pytest.mark.parametrize("tag", ["t2s", "dt1", "dq1", "dt2s"])
+def test_round2_training_gradients(golden_model2, tag):
+    g = golden_model2
+    cfg, params, inputs = load_case(g, tag)
+    with cpu_kernels.emulate():
+        model = build(cfg, params).train()
+        inputs["R"] = inputs["R"].double()
+        E, F = model(inputs)
+        loss = GO.training_loss(E[:, :1], F[:, 0] if F.dim() == 3 else F, torch.tensor(g[f"{tag}.Et"]).double()[:, None],
+                                torch.tensor(g[f"{tag}.Ft"]).double())
+        np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=1e-9)
+        loss.backward()
+    named = dict(model.named_parameters())
+    names = [str(n) for n in g[f"{tag}.grad_names"]]
+    norms = np.array([0.0 if named[n].grad is None else float(named[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(norms, g[f"{tag}.grad_norms"], rtol=1e-7, atol=1e-12)
+    for n in names:
+        key = f"{tag}.grad.{n}"
+        if key in g:
+            np.testing.assert_allclose(named[n].grad.numpy(), g[key], rtol=1e-6, atol=1e-10)

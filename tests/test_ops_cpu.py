@@ -155,3 +155,43 @@ def test_triplet_groups_by_target_atom():
                 assert int(exp[t]) == j and int(rows[int(off[g]) + int(rposT[k])]) == int(red[t])
                 seen += 1
     assert seen == plan.trip.size
+
+
+def test_fuse_program_preserves_semantics():
+    """K.fuse_program moves SCALE ops into the producing GEMM / LOAD epilogue: the fused program must compute the
+    same tensors (the adjoint of a Dense + two residual layers with a parked skip gradient and a residual output)."""
+    import gemnet_pytorch_amd.kernels as K
+    g = torch.Generator().manual_seed(0)
+    M, W = 37, 64
+
+    def mk(*s):
+        return torch.randn(*s, generator=g, dtype=torch.float64)
+    gin, Ws = mk(M, W), [mk(W, W) / 8 for _ in range(5)]
+    zs = [mk(M, W) for _ in range(5)]
+
+    def build():
+        outs = [torch.zeros(M, W, dtype=torch.float64) for _ in range(3)]
+        p = K.ChainProgram(M)
+        p.load(0, gin)
+        cur, oth = 0, 1
+        for k in (1, 0):
+            if k == 0:
+                p.scale(2, cur, 0.6, width=W)
+            p.scale(cur, cur, 0.7 if k else 0.42, width=W)
+            p.scale(oth, cur, 1.0, Z=zs[2 * k + 1])
+            p.gemm(Ws[2 * k + 1], a_slot=oth, y_slot=oth)
+            p.scale(oth, oth, 1.0, Z=zs[2 * k])
+            p.gemm(Ws[2 * k], a_slot=oth, y_slot=cur, res=cur, beta=1.0)
+        p.scale(cur, cur, 0.9, out=outs[0], width=W)
+        p.scale(oth, cur, 1.0, Z=zs[4], out=outs[1], width=W)
+        p.gemm(Ws[4], a_slot=oth, y_slot=-1, out=outs[2], res=2, beta=1.0)
+        return p, outs
+    p0, o0 = build()
+    cpu_kernels.chain(p0)
+    p1, o1 = build()
+    f = K.fuse_program(p1)
+    kinds = [o["kind"] for o in f.ops]
+    assert kinds.count("scale") == 1 and kinds.count("gemm") == 5, kinds       # only the park survives
+    cpu_kernels.chain(f)
+    for a, b in zip(o0, o1):
+        assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(a.abs().max()))
