@@ -11,6 +11,12 @@ synthetic batch of 32 molecules x 32 atoms per GPU (BASELINE.json configs[1]), f
   --mode train   times the full training step instead (fwd + force + loss.backward + RCCL gradient
                  all-reduce + AdamW), reported under the same JSON keys with metric suffix.
 
+Besides the headline, the same JSON line carries `extra` (never part of `value`):
+  extra.train_step                 the full training step (with N > 1 GPUs: including the RCCL gradient all-reduce)
+  extra.interaction_block_fwd_bwd  ONE InteractionBlock forward+backward, isolated: step/s and roofline fractions
+  extra.gemnet_q                   BASELINE configs[2]: GemNet-Q forward+force with its own roofline
+  extra.dynamic_shape              a new batch every step: device index build + plan + eager forward+force
+
 Extra objects on the JSON line:
   roofline      dominant kernel family of the step, measured live with HIP events around every launch
                 in one instrumented (eager) pass over the same batch
@@ -78,14 +84,14 @@ class LaunchTimer:
                     N, Kd = o["W"].shape
                     fl += 2.0 * prog.M * N * Kd
                     by += N * Kd * f32
-                    for k in ("pre_out", "out", "gadd1", "gadd2"):
+                    for k in ("pre_out", "out", "gadd1", "gadd2", "out2"):
                         if torch.is_tensor(o.get(k)):
                             by += prog.M * N * f32
-                    for k in ("mul", "res", "res2"):
+                    for k in ("mul", "res", "res2", "Z2"):
                         if torch.is_tensor(o.get(k)):
                             by += prog.M * N * f32
                 elif o["kind"] == "load":
-                    by += prog.M * o["src"].shape[1] * f32
+                    by += prog.M * o["src"].shape[1] * f32 * (2 if torch.is_tensor(o.get("Z2")) else 1)
                 elif o["kind"] == "store":
                     by += prog.M * o["out"].shape[1] * f32
                 else:
@@ -235,10 +241,9 @@ def roofline_from(fam):
                 share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
 
 
-def cpu_baseline(cfg, n_atoms, budget_s=20.0):
+def cpu_baseline(cfg, n_atoms, budget_s=14.0, n_mol=8):
     """Oracle (CPU restatement, fp32, all host cores) forward+force on a bounded sample."""
     from oracle import gemnet_oracle as GO
-    n_mol = 8
     inputs, _ = make_batch(cfg, n_mol, n_atoms, first=0, device="cpu")
     params = GO.make_params(cfg, 0, GO.load_scale_factors(SCALE_FILE), dtype=torch.float32)
     # pick the faster of two thread counts on this host (oversubscribing 128+ SMT threads hurts torch CPU)
@@ -267,6 +272,201 @@ def cpu_baseline(cfg, n_atoms, budget_s=20.0):
                 ms_per_step=round(dt / steps * 1e3, 1))
 
 
+# ------------------------------------------------------------------------------------------------ timing helpers
+def capture(step, warm=2):
+    """Warm `step` on a side stream and capture it into a hipGraph; returns (graph, outputs)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    return graph, out
+
+
+def time_steps(run, steps, warmup, world=1):
+    """`warmup` untimed + exactly `steps` timed calls between barrier + synchronize on both sides; max over ranks."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def family_roofline(step):
+    """Instrument one eager pass of `step` and return (roofline of the dominant family, per-family table)."""
+    with LaunchTimer() as lt:
+        step()
+    fam = lt.summary()
+    return roofline_from(fam), fam
+
+
+def log_families(title, fam):
+    tot = sum(v["ms"] for v in fam.values())
+    log(f"[bench] {title}: per-family kernel time of one step's launches, replayed back-to-back:")
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:14]:
+        log(f"    {k:16s} {v['ms']:8.3f} ms  {100 * v['ms'] / tot:5.1f} %  {v['launches']:5d} launches"
+            f"  {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.2f} TFLOP/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s")
+
+
+# ------------------------------------------------------------------------------------------------ extra measurements
+def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, warmup=3, want_roofline=True):
+    """The full training step (trainer.py:325-360): forward + force + loss + loss.backward() through the
+    force + ONE flat-buffer RCCL all-reduce (world > 1) + shared-gradient rescale + global-norm clip + AdamW(amsgrad) + EMA.
+    fwd/force/backward are one hipGraph; collective and optimizer launches follow it."""
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+    from gemnet_pytorch_amd.training.ddp import TrainStep
+    torch.manual_seed(model_seed)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(inputs["R"].device)
+    ts = TrainStep(model, world_size=world, fused_optimizer=True)
+    inputs = {k: v for k, v in inputs.items() if k != "_plan"}
+    graphed = True
+    try:
+        ts.capture(inputs, targets)
+    except Exception as ex:  # noqa: BLE001
+        log(f"[bench] training-step capture unavailable ({type(ex).__name__}: {ex}); eager")
+        ts._graph, graphed = None, False
+    elapsed = time_steps(lambda: ts(inputs, targets), steps, warmup, world)
+    out = dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(world * batch * steps / elapsed, 1),
+               steps=steps, warmup=warmup, hipgraph=graphed, rccl_world_size=world,
+               collective=("all_reduce(sum) of one flat %.1f MB fp32 gradient buffer per step over RCCL"
+                           % (ts.buf.flat.numel() * 4 / 1e6)) if world > 1 else "none (single process)",
+               optimizer="fused rescale + clip + AdamW(amsgrad) + EMA, 2 launches (csrc/optim.hip)",
+               loss=float(ts.last_loss))
+    if want_roofline:
+        held, ts._graph = getattr(ts, "_graph", None), None
+        roof, fam = family_roofline(lambda: ts(inputs, targets, step_optimizer=False))
+        ts._graph = held
+        log_families("training step", fam)
+        out["roofline"] = roof
+        out["launches_per_step"] = int(sum(v["launches"] for v in fam.values()))
+    del ts, model
+    return out
+
+
+def extra_interaction_block(model, plan, steps=50, warmup=10):
+    """ONE InteractionBlockTripletsOnly (interaction_block.py:158-234 / :363-422), forward + backward w.r.t. all its
+    inputs (what the force pass runs per block: weights constant), isolated, hipGraph replay."""
+    from gemnet_pytorch_amd import kernels as K
+    from gemnet_pytorch_amd import ops
+    dev = plan.device
+    g = torch.Generator(device="cpu").manual_seed(7)
+    A, E, T = plan.n_atoms, plan.n_edges, plan.trip.size
+    blk = model.int_blocks[1]
+    ea = blk.atom_update.layers[0].weight.shape[0]
+    ee = blk.dense_ca.weight.shape[0]
+    er = blk.trip_interaction.mlp_rbf.weight.shape[1]
+    S, I = model.num_spherical, blk.trip_interaction.mlp_cbf.weight.shape[1]
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dev).requires_grad_(True)
+    h, m = rnd(A, ea), rnd(E, ee)
+    rbf3, rbf_h, rbf_W1 = rnd(E, er, scale=0.3), rnd(E, er, scale=0.3), rnd(E, S, I, scale=0.3)
+    sph = rnd(T, S, scale=0.5)
+    gh, gm = torch.randn(A, ea, generator=g).to(dev), torch.randn(E, ee, generator=g).to(dev)
+    leaves = [h, m, rbf3, rbf_W1, sph, rbf_h]
+
+    def step():
+        with ops.weight_cache(model._wcache), ops.fused_first_order(True), ops.param_grads(False):
+            h2, m2 = blk(h=h, m=m, rbf3=rbf3, cbf3=(rbf_W1, sph), rbf_h=rbf_h, plan=plan)
+            return torch.autograd.grad([h2, m2], leaves, [gh, gm])
+    graph, _ = capture(step)
+    elapsed = time_steps(graph.replay, steps, warmup)
+    sec = elapsed / steps
+    # algorithmic cost (DESIGN.md section 5, SURVEY.md 8d): forward 2 (E 281 600 + T 448 + A 81 920) flop and
+    # E 1 612 + T 36 + A 1 024 + 1.43 MB bytes; the backward w.r.t. the inputs repeats both
+    flops = 2 * 2.0 * (E * 281600 + T * 448 + A * 81920)
+    byts = 2 * (E * 1612 + T * 36 + A * 1024 + 1.43e6)
+    return dict(steps_per_s=round(1.0 / sec, 1), ms_per_step=round(sec * 1e3, 4), steps=steps, warmup=warmup,
+                rows=dict(atoms=A, edges=E, triplets=T), arithmetic=K.CHAIN_MODE,
+                algorithmic_gflop=round(flops / 1e9, 2), algorithmic_mb=round(byts / 1e6, 1),
+                achieved_tflops=round(flops / sec / 1e12, 2), frac_f32_mfma_peak=round(flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                achieved_gbs=round(byts / sec / 1e9, 1), frac_hbm_roofline=round(byts / sec / 1e9 / PEAK_HBM_GBS, 4),
+                note="forward + backward w.r.t. (h, m, rbf3, rbf_W1, sph, rbf_h), constant weights, one hipGraph replay per step")
+
+
+def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3):
+    """BASELINE.json configs[2]: GemNet-Q (quadruplet interactions on) forward+force on the same batch."""
+    from gemnet_pytorch_amd.graph import GraphPlan
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+    cfg = dict(GEMNET_T, triplets_only=False)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(1234)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(dev).eval()
+    model.requires_grad_(False)
+    inputs, _ = make_batch(cfg, n_mol, n_atoms, first=rank * n_mol, device=dev)
+    plan = GraphPlan.from_inputs(inputs, False).warm()
+    sizes = dict(atoms=plan.n_atoms, edges=plan.n_edges, triplets=plan.trip.size, interaction_edges=plan.n_int,
+                 intermediate_triplets=plan.n_intm, quadruplets=plan.quad.size)
+    step = lambda: model(inputs)  # noqa: E731
+    for _ in range(2):
+        step()
+    graph, _ = capture(step)
+    elapsed = time_steps(graph.replay, steps, warmup)
+    roof, fam = family_roofline(step)
+    log_families("GemNet-Q forward+force", fam)
+    return dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / elapsed, 1),
+                steps=steps, warmup=warmup, per_gpu=sizes, hipgraph=True, roofline=roof)
+
+
+def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12, warmup=4):
+    """A NEW batch every step (data_provider.py:159-165; ase_calculator.py:155-158 rebuilds the graph every MD step):
+    positions resident in HBM -> device index construction (csrc/index_gpu.hip) -> GraphPlan (CSR groupings) -> eager
+    forward+force.  No hipGraph (shapes change); includes the host sync that returns the array sizes."""
+    from gemnet_pytorch_amd.index_device import DeviceGraphBuilder
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    dev = torch.device("cuda", torch.cuda.current_device())
+    data = []
+    for b in range(n_batches):
+        ds = make_dataset(n_mol, n_atoms, config=2, first=(rank * n_batches + b + 1) * n_mol)
+        data.append(dict(R=torch.tensor(ds["R"], device=dev), Z=torch.tensor(ds["Z"], device=dev).long(),
+                         N=torch.tensor(ds["N"], device=dev).long(), N_host=ds["N"]))
+    builders = [DeviceGraphBuilder(d["N_host"], cfg["cutoff"], cfg["int_cutoff"], cfg["triplets_only"], device=dev)
+                for d in data]
+    state = {"i": 0}
+    t_idx = [0.0]
+
+    def step():
+        b = state["i"] % n_batches
+        state["i"] += 1
+        d = data[b]
+        t0 = time.perf_counter()
+        idx = builders[b](d["R"])
+        t_idx[0] += time.perf_counter() - t0
+        return model(dict(Z=d["Z"], R=d["R"].clone(), N=d["N"], **idx))
+    for _ in range(warmup):
+        step()
+    t_idx[0] = 0.0
+    elapsed = time_steps(step, steps, 0)
+    return dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / elapsed, 1),
+                steps=steps, warmup=warmup, distinct_batches=n_batches,
+                host_ms_in_index_build=round(t_idx[0] / steps * 1e3, 3),
+                note="device index build (incl. its size read-back) + GraphPlan (CSR sorts) + eager forward+force per step; "
+                     "positions / Z / N resident in HBM")
+
+
 def main():
     import faulthandler
     faulthandler.enable(file=sys.stderr)
@@ -280,10 +480,12 @@ def main():
     ap.add_argument("--model", choices=["T", "Q"], default="T",
                     help="T = GemNet-T (the headline metric); Q = GemNet-Q (BASELINE.json configs[2], reported as a side case)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
-    ap.add_argument("--torch-optimizer", action="store_true",
-                    help="train mode: torch.optim.AdamW + clip_grad_norm_ instead of the fused two-launch optimizer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extra` object (training step, isolated InteractionBlock, GemNet-Q, dynamic shapes)")
+    ap.add_argument("--chain-mode", choices=["f32", "split6", "split3", "bf16"], default=None,
+                    help="arithmetic of the Dense stacks (default: kernels.CHAIN_MODE = split6, fp32-equivalent)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -307,8 +509,11 @@ def main():
             ge.build()
     if world > 1:
         dist.barrier()
+    from gemnet_pytorch_amd import kernels as K
     from gemnet_pytorch_amd.graph import GraphPlan
     from gemnet_pytorch_amd.model.gemnet import GemNet
+    if args.chain_mode:
+        K.CHAIN_MODE = args.chain_mode
 
     cfg = dict(GEMNET_T)
     if args.model == "Q":
@@ -320,99 +525,68 @@ def main():
     sizes = dict(atoms=plan.n_atoms, edges=plan.n_edges, triplets=plan.trip.size)
     if args.model == "Q":
         sizes.update(interaction_edges=plan.n_int, intermediate_triplets=plan.n_intm, quadruplets=plan.quad.size)
-    log(f"[bench] rank {rank}/{world}: {args.batch} molecules, {sizes}")
+    log(f"[bench] rank {rank}/{world}: {args.batch} molecules, {sizes}, Dense-stack arithmetic {K.CHAIN_MODE}")
 
-    use_graph = not args.no_graph
-    train_graph = False
-    if args.mode == "force":
+    extra = {}
+    if args.mode == "train":   # explicit request: the training step IS the timed region
+        tr = extra_train_step(cfg, 1234, inputs, targets, world, args.batch, steps=args.steps, warmup=args.warmup,
+                              want_roofline=not args.no_roofline and rank == 0)
+        elapsed = tr["ms_per_step"] * 1e-3 * args.steps
+        graph, roof = tr["hipgraph"], tr.pop("roofline", None)
+        extra["train_step"] = tr
+    else:
         model.eval()
         model.requires_grad_(False)  # inference: only dE/dR is needed, no parameter-gradient graph
-
-        def step():
-            return model(inputs)
-    else:
-        from gemnet_pytorch_amd.training.ddp import TrainStep
-        ts = TrainStep(model, world_size=world, fused_optimizer=not args.torch_optimizer)
-        if use_graph:
-            try:
-                ts.capture(inputs, targets)
-                train_graph = True
-            except Exception as ex:  # noqa: BLE001
-                log(f"[bench] training-step capture unavailable ({type(ex).__name__}: {ex}); eager")
-                ts._graph = None
-        use_graph = False
-
-        def step():
-            return ts(inputs, targets)
-
-    # eager warm-up (also validates the path before capture)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    graph = None
-    if use_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g_out = step()
-            torch.cuda.synchronize()
-            graph.replay()
-            torch.cuda.synchronize()
-            ref = step()
-            torch.cuda.synchronize()
-            if not (torch.allclose(g_out[0], ref[0]) and torch.allclose(g_out[1], ref[1])):
-                raise RuntimeError("hipGraph replay disagrees with eager")
-        except Exception as ex:  # noqa: BLE001
-            log(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches")
-            graph = None
-            torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
-
-    for _ in range(args.warmup):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    roof = None
-    if not args.no_roofline and rank == 0:
-        held = None
-        if args.mode == "train":  # the captured training step bypasses the launchers: instrument it eagerly
-            held, ts._graph = getattr(ts, "_graph", None), None
-        with LaunchTimer() as lt:
+        step = lambda: model(inputs)  # noqa: E731
+        for _ in range(2):  # eager warm-up (also validates the path before capture)
             step()
-        if held is not None:
-            ts._graph = held
-        fam = lt.summary()
-        roof = roofline_from(fam)
-        tot = sum(v["ms"] for v in fam.values())
-        log("[bench] per-family kernel time of one step's launches, replayed back-to-back:")
-        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
-            log(f"    {k:14s} {v['ms']:8.3f} ms  {100 * v['ms'] / tot:5.1f} %  {v['launches']:5d} launches"
-                f"  {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.2f} TFLOP/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s")
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            try:
+                graph, g_out = capture(step)
+                ref = step()
+                torch.cuda.synchronize()
+                if not (torch.allclose(g_out[0], ref[0]) and torch.allclose(g_out[1], ref[1])):
+                    raise RuntimeError("hipGraph replay disagrees with eager")
+            except Exception as ex:  # noqa: BLE001
+                log(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches")
+                graph = None
+                torch.cuda.synchronize()
+        elapsed = time_steps(graph.replay if graph is not None else step, args.steps, args.warmup, world)
+        roof = None
+        if not args.no_roofline and rank == 0:
+            roof, fam = family_roofline(step)
+            log_families("forward+force", fam)
+
+    # ---- the numbers SURVEY.md 8(d) asks for besides the headline (never part of `value`)
+    if not args.no_extras and args.mode == "force":
+        def guarded(name, fn):
+            try:
+                t0 = time.time()
+                extra[name] = fn()
+                log(f"[bench] extra.{name}: {json.dumps(extra[name])[:400]}  ({time.time() - t0:.1f} s)")
+            except Exception as ex:  # noqa: BLE001
+                extra[name] = {"error": f"{type(ex).__name__}: {ex}"}
+                log(f"[bench] extra.{name} failed: {extra[name]['error']}")
+            torch.cuda.synchronize()
+        if world > 1:
+            # multi-GPU: the training step, so that the RCCL gradient all-reduce is actually issued and timed (all ranks)
+            guarded("train_step", lambda: extra_train_step(cfg, 1234, inputs, targets, world, args.batch,
+                                                           want_roofline=False))
+        elif args.model == "T":
+            guarded("train_step", lambda: extra_train_step(cfg, 1234, inputs, targets, 1, args.batch))
+            guarded("interaction_block_fwd_bwd", lambda: extra_interaction_block(model, plan))
+            guarded("dynamic_shape", lambda: extra_dynamic_shape(cfg, model, args.batch, args.atoms, rank))
+            guarded("gemnet_q", lambda: extra_gemnet_q(args.batch, args.atoms, rank))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "force":
-        cpu = cpu_baseline(cfg, args.atoms)
+        cpu = cpu_baseline(cfg, args.atoms, n_mol=8)
+        try:
+            cpu["full_batch"] = cpu_baseline(cfg, args.atoms, budget_s=8.0, n_mol=args.batch)
+        except Exception as ex:  # noqa: BLE001
+            cpu["full_batch"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         mol_per_s = world * args.batch * args.steps / elapsed
@@ -425,9 +599,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"GemNet-{args.model} full (4 blocks, emb 128), batch {args.batch} molecules x "
                                    f"{args.atoms} atoms per GPU, forward+force, fp32 (BASELINE.json configs[{1 if args.model == 'T' else 2}])",
-                       "mode": args.mode, "hipgraph": graph is not None or train_graph, "per_gpu": sizes,
-                       "parallelism": f"dp{world} (independent molecule shards, no data-path collective)"},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "mode": args.mode, "hipgraph": bool(graph), "per_gpu": sizes,
+                       "dense_stack_arithmetic": {"f32": "v_mfma_f32_16x16x4_f32",
+                                                  "split6": "fp32 operands as 3 bf16 planes, 6 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (fp32-equivalent: dropped terms < 2^-24)",
+                                                  "split3": "3 bf16-plane products, fp32 accumulate",
+                                                  "bf16": "bf16 operands, fp32 accumulate"}[K.CHAIN_MODE],
+                       "parallelism": f"dp{world} (independent molecule shards, no data-path collective"
+                                      + ("; the RCCL gradient all-reduce is timed in extra.train_step)" if world > 1 else ")")},
+            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

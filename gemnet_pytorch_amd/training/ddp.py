@@ -165,13 +165,30 @@ class TrainStep:
         self._graph_key = id(inputs)
         return self
 
+    def _eager(self, inputs, targets):
+        """Eager forward/backward on a private stream: autograd ties every parameter's AccumulateGrad node to the
+        stream of its first backward, and nodes created on the DEFAULT stream make a later hipGraph capture of the
+        step fail inside hipStreamEndCapture (the engine then synchronises the capturing stream with the default
+        stream).  The caller's stream waits for the side stream, so the semantics are unchanged."""
+        dev_is_cuda = self.buf.params[0].is_cuda
+        if not dev_is_cuda or torch.cuda.is_current_stream_capturing():
+            return self._forward_backward(inputs, targets)
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream(device=self.buf.params[0].device)
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            loss = self._forward_backward(inputs, targets)
+        cur.wait_stream(self._stream)
+        return loss
+
     def __call__(self, inputs, targets, step_optimizer=True):
         self.model.train()
         if getattr(self, "_graph", None) is not None and self._graph_key == id(inputs):
             self._graph.replay()
             loss = self._graph_loss
         else:
-            loss = self._forward_backward(inputs, targets)
+            loss = self._eager(inputs, targets)
         self.buf.all_reduce()
         if self.fused is not None:
             if step_optimizer:

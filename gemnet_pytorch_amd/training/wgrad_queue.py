@@ -48,6 +48,7 @@ class WeightGradQueue:
         self.items = []
         self._ring = []
         self._next = 0
+        self._spare = None       # pre-allocated table for the next capture
         self._captured = []
         self._keep = None
 
@@ -57,9 +58,15 @@ class WeightGradQueue:
 
     def _slot(self, nbytes, dev, capturing):
         if capturing:
-            slot = _TableSlot(nbytes, dev)   # allocated outside the pool of eager slots; owned by the graph
+            # pinned memory cannot be allocated while a stream is capturing: the graph takes the spare slot that the
+            # last eager flush left behind (TrainStep.capture runs eager warm-up steps first), and owns it from now on
+            slot, self._spare = self._spare, None
+            if slot is None or slot.host.numel() < nbytes:
+                raise RuntimeError("WeightGradQueue: run one eager step of the same batch before capturing a hipGraph")
             self._captured.append(slot)
             return slot
+        if self._spare is None or self._spare.host.numel() < nbytes:
+            self._spare = _TableSlot(nbytes, dev)
         if len(self._ring) < self.RING:
             self._ring.append(_TableSlot(nbytes, dev))
             return self._ring[-1]
