@@ -11,8 +11,10 @@
 // operands, fp32 accumulate and fp32 everywhere else: the BASELINE "bf16" configuration).
 //
 // Layout of one row tile (BM = 16 RT rows, RT = 1..5 so that a launch is one round of <= 256 workgroups):
-//   * two LDS slots, each THREE bf16 planes [BM][128] with 288-byte rows (conflict-free ds_read_b128 in the b128 lane
-//     groups); a slot therefore holds exact fp32 values (residuals / Hadamard operands are rebuilt as hi + mid + lo);
+//   * two LDS slots, each THREE bf16 planes [BM][128]; the 16-byte unit u of row r lives at unit u ^ (r & 15): the
+//     ds_read_b128 fragment reads are conflict-free in the b128 lane groups and the ds_write_b64 of the transposed
+//     epilogue 2-way (4-way with padded rows; no 16-byte-aligned layout does better, tools/exp/lds_swizzle.py);
+//     a slot holds exact fp32 values (residuals / Hadamard operands are rebuilt as hi + mid + lo);
 //     "slot 2" is a register-resident parking slot in accumulator layout (skip-connection gradient of the adjoint);
 //   * 8 waves; wave w owns output columns 16w..16w+15 for all RT row blocks and computes the TRANSPOSED tile
 //     (A operand = its 16 weight rows, B operand = the activations): lane (m = lane % 16, g = lane / 16) ends up with
@@ -40,8 +42,16 @@ __device__ unsigned long long gn_chain2_trace_buf[2][GN_CHAIN_MAX_OPS][8];
 
 namespace {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every op would wait for its
+// pre-activation / output stores (and the weight prefetch) to complete before the next op may start.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int SW = 128;            // max N, K
-constexpr int ROWB = 288;          // bytes per plane row: 128 bf16 + 32 B pad
+constexpr int ROWB = 256;          // bytes per plane row: 128 bf16, no padding — 16-byte units are XOR-swizzled by the row
 constexpr int NT = 512;
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
@@ -124,8 +134,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
 
   auto plane_ptr = [&](int slot, int p) -> unsigned char* { return smem + slot * SLOT + p * PLANE; };
   // accumulator-layout element block of this lane in row block t: row 16t + l15, columns 16 wave + 4 lg .. +3
+  // byte offset of columns col .. col+3 (col % 4 == 0) of row `row` inside a plane
+  auto sw_off = [&](int row, int col) -> int { return row * ROWB + ((((col >> 3) ^ row) & 15) << 4) + ((col & 4) << 1); };
   auto slot_read_acc = [&](int slot, int t) -> float4 {
-    const int off = (16 * t + l15) * ROWB + (wave * 16 + (lg << 2)) * 2;
+    const int off = sw_off(16 * t + l15, wave * 16 + (lg << 2));
     const uint2 H = *reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off);
     const uint2 Mi = *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off);
     const uint2 L = *reinterpret_cast<const uint2*>(plane_ptr(slot, 2) + off);
@@ -134,20 +146,20 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
   auto slot_write = [&](int slot, int row, int col, const float4 v) {
     uint2 H, Mi, L;
     split4(v, H, Mi, L);
-    const int off = row * ROWB + col * 2;
+    const int off = sw_off(row, col);
     *reinterpret_cast<uint2*>(plane_ptr(slot, 0) + off) = H;
     *reinterpret_cast<uint2*>(plane_ptr(slot, 1) + off) = Mi;
     *reinterpret_cast<uint2*>(plane_ptr(slot, 2) + off) = L;
   };
   auto slot_read = [&](int slot, int row, int col) -> float4 {
-    const int off = row * ROWB + col * 2;
+    const int off = sw_off(row, col);
     return join4(*reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off),
                  *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off),
                  *reinterpret_cast<const uint2*>(plane_ptr(slot, 2) + off));
   };
 
   for (int oi = 0; oi < P.n_ops; ++oi) {
-    const gn_chain_op& op = P.ops[oi];
+    const gn_chain_op op = P.ops[oi];   // by value: the whole descriptor in one round of scalar loads, one wait
     const int kind = op.kind;
     GN2_STAMP(0);
     if (kind == GN_OP_LOAD) {
@@ -159,30 +171,45 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       const float* __restrict__ const src = op.src;
       const float* __restrict__ const Z2 = op.Z2;
       const int32_t* __restrict__ const rows = op.rows;
-      for (int f = tid; f < BM * w4; f += NT) {
+      // all global loads of the tile are issued before the first one is consumed (a tile is at most RT passes of the
+      // 512 threads): the serial load -> split -> write form took 6.7 k cycles for 40 KB (tools/chain2_trace.py)
+      float4 v[RT], zz[RT];
+      bool in[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int f = tid + i * NT;
         const int r = f / w4, c = (f - r * w4) << 2;
         const int64_t gr = row0 + r;
-        const bool in = gr < M && c < width;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) {
+        in[i] = f < BM * w4 && gr < M && c < width;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        zz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in[i]) {
           const int64_t sr = rows ? (int64_t)rows[gr] : gr;
-          v = *reinterpret_cast<const float4*>(src + sr * ld + c);
-          v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+          v[i] = *reinterpret_cast<const float4*>(src + sr * ld + c);
+          if (ADJ && y2_slot >= 0 && Z2) zz[i] = *reinterpret_cast<const float4*>(Z2 + gr * width + c);
         }
-        slot_write(slot, r, c, v);
-        if (ADJ && y2_slot >= 0) {   // second tensor derived from the loaded rows: v * alpha2 * phi2(Z2)
-          float4 u = make_float4(v.x * alpha2, v.y * alpha2, v.z * alpha2, v.w * alpha2);
-          if (Z2 && in) {
-            const float4 z = *reinterpret_cast<const float4*>(Z2 + gr * width + c);
-            if (mode2 == 0) { u.x *= gn_dssilu(z.x); u.y *= gn_dssilu(z.y); u.z *= gn_dssilu(z.z); u.w *= gn_dssilu(z.w); }
-            else if (mode2 == 1) { u.x *= z.x; u.y *= z.y; u.z *= z.z; u.w *= z.w; }
-            else { u.x *= gn_ssilu(z.x); u.y *= gn_ssilu(z.y); u.z *= gn_ssilu(z.z); u.w *= gn_ssilu(z.w); }
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int f = tid + i * NT;
+        if (f < BM * w4) {
+          const int r = f / w4, c = (f - r * w4) << 2;
+          v[i].x *= alpha; v[i].y *= alpha; v[i].z *= alpha; v[i].w *= alpha;
+          slot_write(slot, r, c, v[i]);
+          if (ADJ && y2_slot >= 0) {   // second tensor derived from the loaded rows: v * alpha2 * phi2(Z2)
+            float4 u = make_float4(v[i].x * alpha2, v[i].y * alpha2, v[i].z * alpha2, v[i].w * alpha2);
+            if (Z2 && in[i]) {
+              const float4 z = zz[i];
+              if (mode2 == 0) { u.x *= gn_dssilu(z.x); u.y *= gn_dssilu(z.y); u.z *= gn_dssilu(z.z); u.w *= gn_dssilu(z.w); }
+              else if (mode2 == 1) { u.x *= z.x; u.y *= z.y; u.z *= z.z; u.w *= z.w; }
+              else { u.x *= gn_ssilu(z.x); u.y *= gn_ssilu(z.y); u.z *= gn_ssilu(z.z); u.w *= gn_ssilu(z.w); }
+            }
+            slot_write(y2_slot, r, c, u);
           }
-          slot_write(y2_slot, r, c, u);
         }
       }
       GN2_STAMP(3);
-      __syncthreads();
+      lds_barrier();
       GN2_STAMP(4);
     } else if (kind == GN_OP_SCALE) {
       const int slot = op.slot, a_slot = op.a_slot, ld = op.ld, width = op.width;
@@ -199,7 +226,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
             park[ADJ ? t : 0] = make_float4(v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha);
           }
         }
-        __syncthreads();   // the parked values are read before any later op (other thread mapping) rewrites a_slot
+        lds_barrier();   // the parked values are read before any later op (other thread mapping) rewrites a_slot
       } else {
         const int w4 = width >> 2;
         for (int f = tid; f < BM * w4; f += NT) {
@@ -216,7 +243,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
           slot_write(slot, r, c, v);
           if (out && gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = v;
         }
-        __syncthreads();
+        lds_barrier();
       }
     } else if (kind == GN_OP_STORE) {
       const int w4 = op.width >> 2, slot = op.slot, ld = op.ld;
@@ -226,7 +253,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         const int64_t gr = row0 + r;
         if (gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = slot_read(slot, r, c);
       }
-      __syncthreads();
+      lds_barrier();
     } else {  // GN_OP_GEMM
       const int N = op.N, K = op.K, a_slot = op.a_slot, y_slot = op.slot, act = op.act;
       const float alpha = op.alpha, beta = op.beta, beta2 = op.beta2;
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         a1[t] = (v4f){0.f, 0.f, 0.f, 0.f};
       }
       if (active) {
-        const unsigned char* xb = smem + a_slot * SLOT + l15 * ROWB + (lg << 4);
+        const unsigned char* xb = smem + a_slot * SLOT + l15 * ROWB;   // row 16 t + l15: swizzle key = l15
         const int kc = (K + 31) >> 5;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
             if (NPL >= 3) wl = __builtin_bit_cast(bf16x8, bcur[c][NPL >= 3 ? 2 : 0]);
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-              const unsigned char* xp = xb + (16 * t) * ROWB + c * 64;
+              const unsigned char* xp = xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4);
               const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp));
               bf16x8 xm, xl;
               if (NPL >= 2) xm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp + PLANE));
@@ -296,7 +323,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       if (active) { float sink = 0.f; for (int t = 0; t < RT; ++t) sink += v[t].x; if (sink == 1.2345e30f) smem[0] = 1; }
 #endif
       GN2_STAMP(2);
-      if (y_slot == a_slot || y2_slot == a_slot) __syncthreads();   // all reads of a_slot must finish before it is overwritten
+      if (y_slot == a_slot || y2_slot == a_slot) lds_barrier();   // all reads of a_slot must finish before it is overwritten
       if (active) {
         // transposed tile: this lane holds columns n0 .. n0+3 of row 16 t + l15.  Written stage-major (one uniform
         // branch per stage, the RT float4 of a stage unrolled and independent): the row-major form serialised ~25
@@ -386,7 +413,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         for (int t = 0; t < RT; ++t) slot_write(y_slot, 16 * t + l15, n0, make_float4(0.f, 0.f, 0.f, 0.f));
       }
       GN2_STAMP(3);
-      __syncthreads();
+      lds_barrier();
       GN2_STAMP(4);
     }
   }

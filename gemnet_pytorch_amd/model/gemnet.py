@@ -68,6 +68,10 @@ class GemNet(torch.nn.Module):
         self.triplets_only = triplets_only
         self.num_spherical = num_spherical
         self.force_graph = None  # None: auto (training & grad enabled); True/False: forced
+        # arithmetic of the LDS-resident Dense stacks (kernels.CHAIN_MODES): None = the package default ("split6":
+        # fp32-equivalent split-bf16 products); "bf16" = plain bf16 MFMA operands with fp32 accumulation, fp32
+        # everywhere else (BASELINE configs[4]); "f32" = the f32-input MFMA
+        self.matmul_precision = None
         self.overlap_output_blocks = True
         self._side = None
         self._wcache = {}  # derived (transposed / contiguous) copies of frozen weights, see ops.weight_cache
@@ -264,7 +268,8 @@ class GemNet(torch.nn.Module):
         # force-by-autograd without a second-order graph: the graph of E is consumed right here, so
         # parameter gradients can never be requested -> weights are constants (enables ops.stack)
         const_w = fused and not self.direct_forces
-        with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w):
+        with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w), \
+                ops.chain_mode(self.matmul_precision):
             E_mol, F_ca, V_ca = self._energy(R, plan)
 
             if self.direct_forces:

@@ -398,6 +398,22 @@ def is_fused():
     return _FUSED
 
 
+@contextlib.contextmanager
+def chain_mode(mode):
+    """Select the arithmetic of the Dense stacks (kernels.CHAIN_MODES) for the enclosed launches; None keeps the
+    current one.  The packed-weight cache is keyed per weight, not per mode: all split modes share one packed form."""
+    if mode is None:
+        yield
+        return
+    if mode not in K.CHAIN_MODES:
+        raise ValueError(f"matmul_precision must be one of {sorted(K.CHAIN_MODES)}; got {mode!r}")
+    prev, K.CHAIN_MODE = K.CHAIN_MODE, mode
+    try:
+        yield
+    finally:
+        K.CHAIN_MODE = prev
+
+
 # Derived-weight cache (transposes / contiguous copies of FROZEN weights).  Entries are keyed by the address
 # of the source, so the dict must not outlive the tensors it was filled from: it is owned by a model
 # (GemNet._wcache, dropped on _apply / load_state_dict / deepcopy) and only active inside

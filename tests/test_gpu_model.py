@@ -272,3 +272,45 @@ def test_grouped_weight_gradients_match_autograd_accumulation(golden_model):
     tb(dict(dev), targets, step_optimizer=False)
     torch.cuda.synchronize()
     assert torch.equal(g1, tb.buf.flat)
+
+
+def test_model_matmul_precision_flag(golden_model2):
+    """GemNet.matmul_precision selects the Dense-stack arithmetic per model: "bf16" differs from the default by the
+    bf16 rounding of the operands, "f32" and the default (six split products) agree to fp32 rounding."""
+    g = golden_model2
+    cfg, params, inputs = load_case(g, "t2s")
+    model = build(cfg, params).eval()
+    dev = to_dev(inputs)
+    F = {}
+    for mode in (None, "f32", "bf16"):
+        model.matmul_precision = mode
+        F[mode] = model(dict(dev))[1].detach()
+    assert float((F[None] - F["f32"]).abs().mean()) <= 1e-5
+    d = float((F[None] - F["bf16"]).abs().mean())
+    assert 1e-4 < d < 0.2, d
+    with pytest.raises(ValueError):
+        model.matmul_precision = "fp8"
+        model(dict(dev))
+
+
+def test_force_graphs_runtime(golden_model2):
+    """runtime.ForceGraphs: sub-batches captured once into hipGraphs on their own streams reproduce the eager result;
+    set_positions feeds new coordinates to the captured buffers (MD with a fixed neighbour list)."""
+    from gemnet_pytorch_amd.runtime import ForceGraphs
+    g = golden_model2
+    cfg, params, inputs = load_case(g, "t2s")
+    model = build(cfg, params).eval()
+    model.requires_grad_(False)
+    a, b = to_dev(inputs), to_dev(inputs)
+    shift = torch.zeros_like(b["R"])
+    shift[:, 0] = 0.01 * torch.arange(b["R"].shape[0], device=DEV) / b["R"].shape[0]
+    E0, F0 = model(dict(a))
+    E1, F1 = model(dict(b, R=(b["R"] + shift)))
+    runner = ForceGraphs(model, [a, b])
+    runner.set_positions(1, b["R"] + shift)
+    runner()
+    torch.cuda.synchronize()
+    E, F = runner.energies_forces()
+    n = a["R"].shape[0]
+    assert torch.allclose(E[:E0.shape[0]], E0, atol=1e-6) and torch.allclose(F[:n], F0, atol=1e-6)
+    assert torch.allclose(E[E0.shape[0]:], E1, atol=1e-6) and torch.allclose(F[n:], F1, atol=1e-6)

@@ -1,0 +1,64 @@
+"""-m gpu: H2 on the device — the REFERENCE Trainer's recorded trajectory (tests/golden/trainer.npz: four
+train_on_batch steps, schedules, plateau decay, EMA evaluation; make_golden.py::golden_trainer) reproduced by
+gemnet_pytorch_amd.training.Trainer with the HIP kernels in fp32."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, SCALE_FILE
+from oracle import gemnet_oracle as GO
+from gemnet_pytorch_amd.model.gemnet import GemNet
+from gemnet_pytorch_amd.training.data_container import DataContainer
+from gemnet_pytorch_amd.training.metrics import Metrics
+from gemnet_pytorch_amd.training.trainer import Trainer
+
+pytestmark = pytest.mark.gpu
+
+
+def stream(dc, batches):
+    i = 0
+    while True:
+        b = dc[batches[i % len(batches)]]
+        yield {k: v for k, v in b.items() if k not in ("E", "F")}, {"E": b["E"], "F": b["F"]}
+        i += 1
+
+
+@pytest.mark.parametrize("tag", ["rmse", "mae_agc", "quad"])
+def test_training_trajectory_on_the_gpu(tag):
+    g = np.load(os.path.join(GOLDEN, "trainer.npz"))
+    cfg, kw = ast.literal_eval(str(g[f"{tag}.cfg"])), ast.literal_eval(str(g[f"{tag}.kw"]))
+    seed = int(g[f"{tag}.seed"])
+    data = dict(N=g[f"{tag}.N"], Z=g[f"{tag}.Z"], R=g[f"{tag}.R"], E=g[f"{tag}.Et"], F=g[f"{tag}.Ft"])
+    dc = DataContainer.from_arrays(data, 5.0, 10.0, triplets_only=cfg["triplets_only"])
+    batches = [[int(i) for i in str(b).split(",")] for b in g[f"{tag}.batches"]]
+    params = GO.make_params(cfg, seed, GO.load_scale_factors(SCALE_FILE))
+    model = GemNet(**cfg, scale_file=SCALE_FILE)
+    model.load_state_dict(GO.expand_to_reference_state_dict({k: v.float() for k, v in params.items()}), strict=True)
+    model = model.to("cuda")
+    trainer = Trainer(model, **kw)
+    metrics = Metrics("train", trainer.tracked_metrics)
+    it = stream(dc, batches)
+    losses, lrs = [], []
+    for _ in range(len(g[f"{tag}.losses"])):
+        losses.append(float(trainer.train_on_batch(it, metrics)))
+        lrs.append([s.get_last_lr()[0] for s in trainer.schedulers.wrapped])
+    print(tag, "losses", losses, "reference", g[f"{tag}.losses"].tolist())
+    # four optimizer steps in fp32 against the float64 reference run
+    np.testing.assert_allclose(losses, g[f"{tag}.losses"], rtol=2e-3)
+    np.testing.assert_allclose(lrs, g[f"{tag}.lrs"], rtol=1e-6)
+    res = metrics.result(append_tag=False)
+    np.testing.assert_allclose([float(res[k]) for k in sorted(res)], g[f"{tag}.metric_values"], rtol=2e-3)
+    named = dict(model.named_parameters())
+    names = [str(n) for n in g[f"{tag}.param_names"]]
+    np.testing.assert_allclose([float(named[n].detach().norm()) for n in names], g[f"{tag}.param_norms"], rtol=1e-3)
+    for v in (1.0, 1.0, 1.0):
+        trainer.decay_maybe(v)
+    trainer.save_variable_backups()
+    trainer.load_averaged_variables()
+    val_loss = float(trainer.test_on_batch(it, Metrics("val", trainer.tracked_metrics)))
+    np.testing.assert_allclose(val_loss, float(g[f"{tag}.val_loss"]), rtol=2e-3)
+    trainer.restore_variable_backups()
+    np.testing.assert_allclose([float(named[n].detach().norm()) for n in names], g[f"{tag}.restored_norms"], rtol=1e-3)
