@@ -21,7 +21,13 @@ class ForceGraphs:
         if not batches:
             raise ValueError("at least one sub-batch")
         self.model = model
-        self.batches = list(batches)
+        # Private position buffers: autograd ties a leaf's gradient accumulator to the stream of its first backward
+        # and keeps it on the tensor; positions that already went through an eager forward on the DEFAULT stream make
+        # the capture below crash inside hipStreamEndCapture (the engine synchronises the capturing stream with the
+        # default stream).  Fresh leaves see their first backward on this runner's own streams.
+        self.batches = [dict(b, R=b["R"].detach().clone()) for b in batches]
+        for b in self.batches:
+            b.pop("_plan", None)
         dev = self.batches[0]["R"].device
         if dev.type != "cuda":
             raise RuntimeError("ForceGraphs needs a HIP device (no CPU fallback)")
