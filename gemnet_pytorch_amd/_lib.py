@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgemnet_hip.so")
+LIB_PATH = os.environ.get("GEMNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libgemnet_hip.so")
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -84,6 +84,8 @@ SIGNATURES = {
     "gn_bil_expand_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_dy_multi_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gn_rbf_aggregate_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp],
+    "gn_rbf_aggregate_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_bil_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],

@@ -6,6 +6,7 @@ restatements to exercise the autograd/model logic on machines without a GPU; tha
 lives under tests/ and is never imported by the product.)
 """
 import ctypes
+import os
 
 import torch
 
@@ -145,6 +146,32 @@ def segsum(y, perm, seg_off, n_rows):
     check(_lib.load().gn_segsum_rows_f32(ptr(y), ptr(perm), ptr(seg_off), ptr(x), n_rows, _rowsize(y), stream()),
           "gn_segsum_rows_f32")
     return x
+
+
+def rbf_aggregate_supported(m, rbf, W):
+    return m.shape[1] == 128 and rbf.shape[1] == 16 and tuple(W.shape) == (128, 16)
+
+
+def rbf_aggregate_fwd(m, rbf, W, perm, seg_off, n_atoms, scale):
+    """out[a] = scale * sum_{e -> a} m[e] * (W rbf[e]) in one pass (gn_rbf_aggregate_fwd_f32)."""
+    require_device(m, rbf, W)
+    m, rbf, W = _f32c(m), _f32c(rbf), _f32c(W)
+    out = torch.empty((n_atoms, m.shape[1]), device=m.device, dtype=torch.float32)
+    check(_lib.load().gn_rbf_aggregate_fwd_f32(ptr(m), ptr(rbf), ptr(W), ptr(perm), ptr(seg_off), ptr(out), n_atoms,
+                                               m.shape[1], rbf.shape[1], float(scale), stream()), "gn_rbf_aggregate_fwd_f32")
+    return out
+
+
+def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=True):
+    """-> (g_m (E,C) or None, g_rbf (E,R) or None) (gn_rbf_aggregate_bwd_f32)."""
+    require_device(g_out, m, rbf, W)
+    g_out, m, rbf, W = _f32c(g_out), _f32c(m), _f32c(rbf), _f32c(W)
+    g_m = torch.empty_like(m) if want_m else None
+    g_rbf = torch.empty_like(rbf) if want_rbf else None
+    check(_lib.load().gn_rbf_aggregate_bwd_f32(ptr(g_out), ptr(m), ptr(rbf), ptr(W), ptr(id_a32), ptr(g_m), ptr(g_rbf),
+                                               m.shape[0], m.shape[1], rbf.shape[1], float(scale), stream()),
+          "gn_rbf_aggregate_bwd_f32")
+    return g_m, g_rbf
 
 
 def bmm(A, B, ta, tb):
@@ -484,7 +511,7 @@ def _sel(x):
 # Arithmetic of the chain GEMMs: "f32" = v_mfma_f32_16x16x4_f32 (csrc/chain.hip); "split6" / "split3" / "bf16" =
 # bf16 matrix pipe with 6 / 3 / 1 products of split operands (csrc/chain2.hip; split6 is fp32-equivalent).
 CHAIN_MODES = {"f32": 0, "split6": 6, "split3": 3, "bf16": 1}
-CHAIN_MODE = "split6"
+CHAIN_MODE = os.environ.get("GEMNET_CHAIN_MODE", "split6")
 
 
 def pack_weight_split(W, trans=False):

@@ -2,7 +2,8 @@
 with the InteractionBlock hot path running on hand-written gfx950 HIP kernels.
 
 Kept verbatim from the reference: constructor signature (:82-113), `forward(inputs) -> (E, F)`
-(:453-615) including the `inputs["R"].requires_grad` toggling (:494,:613), `predict` (:780-784),
+(:453-615; the force is differentiated w.r.t. a private leaf sharing `inputs["R"]`'s storage instead of toggling
+`inputs["R"].requires_grad` :494,:613 — the caller's tensor is left untouched), `predict` (:780-784),
 `load_weights`/`save_weights` (:786-790), attribute names the trainer reaches into
 (`mlp_rbf3/.mlp_cbf3/.mlp_rbf_h/.mlp_rbf4/.mlp_cbf4/.mlp_sbf4/.mlp_rbf_out`, `num_blocks`,
 `triplets_only`, `direct_forces`, trainer.py:263-278,417) and the state_dict key set.
@@ -15,6 +16,8 @@ Force graph policy: the reference always builds the force with `create_graph=Tru
 second-order graph is built when it can be used — `self.training and torch.is_grad_enabled()` —
 or when `self.force_graph` is set to True/False explicitly.
 """
+import contextlib
+
 import torch
 
 from .. import ops
@@ -23,6 +26,9 @@ from .layers import (AtomEmbedding, BesselBasisLayer, Dense, EdgeEmbedding,
                      EfficientInteractionDownProjection, InteractionBlock,
                      InteractionBlockTripletsOnly, OutputBlock, SphericalBasisLayer, TensorBasisLayer)
 from .scaling import AutomaticFit
+
+
+_nullcontext = contextlib.nullcontext
 
 
 class GemNet(torch.nn.Module):
@@ -256,7 +262,12 @@ class GemNet(torch.nn.Module):
         self._check_inputs(R)
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
         if not self.direct_forces:
-            inputs["R"].requires_grad = True
+            # The reference flips `inputs["R"].requires_grad` on the caller's tensor (gemnet.py:494,:613).  Here the
+            # force is differentiated w.r.t. a FRESH leaf that shares R's storage: autograd keeps a leaf's gradient
+            # accumulator — tied to the stream of its first backward — on the tensor object, and positions that once
+            # went through a forward on the default stream made later hipGraph captures of the same batch fail
+            # (the engine synchronised the capturing stream with the default stream).
+            R = R.detach().requires_grad_(True)
         # second-order graph only when it can be used (see module docstring)
         graph = self.force_graph
         if graph is None:
@@ -269,7 +280,7 @@ class GemNet(torch.nn.Module):
         # parameter gradients can never be requested -> weights are constants (enables ops.stack)
         const_w = fused and not self.direct_forces
         with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w), \
-                ops.chain_mode(self.matmul_precision):
+                ops.chain_mode(self.matmul_precision), torch.enable_grad() if not self.direct_forces else _nullcontext():
             E_mol, F_ca, V_ca = self._energy(R, plan)
 
             if self.direct_forces:
@@ -286,7 +297,6 @@ class GemNet(torch.nn.Module):
                              for i in range(self.num_targets)], dim=1)
                     else:
                         F_j = -torch.autograd.grad(E_mol.sum(), R, create_graph=graph)[0]
-                inputs["R"].requires_grad = False
         return E_mol, F_j
 
     def _side_stream(self, device):

@@ -125,15 +125,24 @@ class AtomUpdateBlock(torch.nn.Module):
         self.dense_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
         self.scale_sum = ScalingFactor(scale_file=scale_file, name=name + "_sum")
         self.layers = self.get_mlp(emb_size_atom, nHidden, activation)
+        # one-pass Dense(rbf) (.) m -> atom sum (csrc/aggregate.hip).  On for the AtomUpdateBlocks of the interaction
+        # blocks; OutputBlocks keep the GEMM + segmented-sum form while they run on the side stream: with the fused
+        # kernel there, hipGraph replays of the overlapped step stopped being bit-reproducible on MI355X (eager runs
+        # and the non-overlapped graph are; bisected in DESIGN.md section 9), so it is not used where streams overlap.
+        self.fuse_aggregate = True
 
     def get_mlp(self, units, nHidden, activation):
         dense1 = Dense(self.emb_size_edge, units, activation=activation, bias=False)
         res = [ResidualLayer(units, nLayers=2, activation=activation) for _ in range(nHidden)]
         return torch.nn.ModuleList([dense1] + res)
 
-    def _aggregate(self, m, rbf, id_a):
+    def _aggregate(self, m, rbf, id_a, want_x=False):
         """scale * sum_{edges into atom} m * dense_rbf(rbf)   (atom_update_block.py:60-68)."""
         if ops.is_fused() or not AutomaticFit.fitting_mode:  # Hadamard and scale in the GEMM epilogue (linear: scale before the sum)
+            if self.fuse_aggregate and not want_x and self.dense_rbf.bias is None and not self.dense_rbf.act:
+                fused = ops.rbf_aggregate(m, rbf, self.dense_rbf.weight, id_a, self.scale_sum.value())
+                if fused is not None:        # Dense + Hadamard + segmented sum in one pass (csrc/aggregate.hip)
+                    return fused, None
             x = self.dense_rbf(rbf, mul=m, alpha=self.scale_sum.value())
             return ops.segsum_rows(x, id_a), x
         x = m * self.dense_rbf(rbf)
@@ -184,6 +193,7 @@ class OutputBlock(AtomUpdateBlock):
         self.output_init = output_init
         self.direct_forces = direct_forces
         self.dense_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
+        self.fuse_aggregate = False
         self.seq_energy = self.layers  # alias (reference atom_update_block.py:130)
         self.out_energy = Dense(emb_size_atom, num_targets, bias=False, activation=None)
         if self.direct_forces:
@@ -205,7 +215,7 @@ class OutputBlock(AtomUpdateBlock):
             raise UserWarning(f"Unknown output_init: {self.output_init}")
 
     def forward(self, h, m, rbf, id_a):
-        x_E, x = self._aggregate(m, rbf, id_a)
+        x_E, x = self._aggregate(m, rbf, id_a, want_x=self.direct_forces)
         if self._stackable(self.seq_energy):
             x_E = self._mlp_stack(x_E, self.seq_energy)
         else:

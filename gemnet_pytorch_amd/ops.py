@@ -545,6 +545,36 @@ def dense(x, W, act=False, *, mul=None, alpha=1.0, res=None, res_rows=None, beta
     return y
 
 
+USE_AGGREGATE = os.environ.get("GEMNET_AGGREGATE", "1") == "1"
+
+
+class _RbfAggregate(torch.autograd.Function):
+    """out[a] = scale * sum_{e -> a} m[e] * (W rbf[e]): Dense(rbf) + Hadamard + scatter-add of AtomUpdateBlock /
+    OutputBlock (atom_update_block.py:60-68) as ONE pass forward and ONE pass backward; W constant (force pass)."""
+
+    @staticmethod
+    def forward(ctx, m, rbf, W, ri, scale):
+        perm, seg = ri.csr
+        ctx.save_for_backward(m, rbf, W)
+        ctx.ri, ctx.scale = ri, scale
+        return K.rbf_aggregate_fwd(m, rbf, W, perm, seg, ri.n_rows, scale)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        m, rbf, W = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g_m, g_rbf = K.rbf_aggregate_bwd(g.contiguous(), m, rbf, W, ctx.ri.idx32, ctx.scale, want_m=need[0], want_rbf=need[1])
+        return g_m, g_rbf, None, None, None
+
+
+def rbf_aggregate(m, rbf, W, ri, scale):
+    """Fused path of `AtomUpdateBlock._aggregate` for constant weights; None when the shapes are not the fused ones."""
+    if not (USE_AGGREGATE and constant_weights() and K.rbf_aggregate_supported(m, rbf, W)):
+        return None
+    return _RbfAggregate.apply(m, rbf, contiguous_weight(W), ri, float(scale))
+
+
 class GradSink:
     """Running sum of the gradient of one tensor that several fused ops consume (the angular basis is shared by all
     interaction blocks).  Each consumer adds its contribution into `buf` inside its own kernel and returns None to

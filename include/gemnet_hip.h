@@ -168,6 +168,18 @@ typedef struct {
 int gn_gemm_tn_grouped_f32(const gn_tn_problem* probs, int n_prob, int total_wg, const gn_tn_target* targets,
                            int n_target, int total_fold_wg, const int64_t* slice_off, float* ws, void* stream);
 
+/* ---- radial-weighted edge -> atom aggregation (csrc/aggregate.hip) ---------------------------------------------------
+ * AtomUpdateBlock / OutputBlock (atom_update_block.py:60-68,157-172):  out[a] = scale * sum_{e: id_a[e] = a} m[e] (.) (W rbf[e])
+ * in ONE pass (the reference: Dense over the edges, Hadamard product, torch_scatter.scatter(add)).
+ *   m (E,C) rbf (E,R) W (C,R) row-major; perm/seg_off = CSR of the edges by target atom (perm NULL: edges sorted);
+ *   out (n_atoms, C).  C == 128 and R == 16 (every published configuration); other shapes: hipErrorInvalidValue.
+ * Adjoint w.r.t. m and rbf (W constant: the force pass), one pass, deterministic:
+ *   g_m[e] = scale * g_out[id_a[e]] (.) (W rbf[e]);  g_rbf[e] = scale * W^T (g_out[id_a[e]] (.) m[e]);  either may be NULL. */
+int gn_rbf_aggregate_fwd_f32(const float* m, const float* rbf, const float* W, const int32_t* perm, const int32_t* seg_off,
+                             float* out, int64_t n_atoms, int C, int R, float scale, void* stream);
+int gn_rbf_aggregate_bwd_f32(const float* g_out, const float* m, const float* rbf, const float* W, const int32_t* id_a,
+                             float* g_m, float* g_rbf, int64_t E, int C, int R, float scale, void* stream);
+
 /* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
  * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */
 int gn_bmm_f32(const float* A, const float* B, float* C, int batch, int m, int n, int k,

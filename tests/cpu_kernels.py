@@ -372,7 +372,16 @@ def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
     return Sm, (P.reshape(P.shape[0], -1) @ W2T.t()) * alpha
 
 
-_NAMES = ["bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+def rbf_aggregate_fwd(m, rbf, W, perm, seg_off, n_atoms, scale):
+    return segsum(m * (rbf @ W.t()), perm, seg_off, n_atoms) * scale
+
+
+def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=True):
+    g = g_out[id_a32.long()] * scale
+    return (g * (rbf @ W.t()) if want_m else None), ((g * m) @ W if want_rbf else None)
+
+
+_NAMES = ["rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -607,3 +607,26 @@ def test_bilinear_deferred_y_gradient_of_several_blocks(nb, shape):
         dS_dev.append(dSm)
         x_dev.append(f32(x))
     close(K.bil_dy_multi(dS_dev, x_dev, dev), ref, atol=3e-4 * max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("n_atoms,deg", [(1024, 18), (37, 5), (3, 0)])
+def test_rbf_aggregate_fused_vs_reference_ops(n_atoms, deg):
+    """gn_rbf_aggregate_fwd/bwd (Dense over rbf + Hadamard + scatter-add of AtomUpdateBlock, one pass each) against the
+    float64 composition, including atoms without incoming edges and an unsorted target index."""
+    g = torch.Generator().manual_seed(n_atoms)
+    E = max(n_atoms * deg, 1)
+    id_a = torch.randint(0, n_atoms, (E,), generator=g)
+    if n_atoms > 5:
+        id_a[id_a == 2] = 3                       # atom 2 receives nothing
+    m, rbf, W, go = rnd(g, E, 128), rnd(g, E, 16), rnd(g, 128, 16) / 4, rnd(g, n_atoms, 128)
+    perm = torch.argsort(id_a, stable=True)
+    seg = torch.searchsorted(id_a[perm].contiguous(), torch.arange(n_atoms + 1)).to(torch.int32)
+    ref = torch.zeros(n_atoms, 128, dtype=torch.float64).index_add(0, id_a, m * (rbf @ W.t())) * 0.37
+    out = K.rbf_aggregate_fwd(f32(m), f32(rbf), f32(W), perm.to(torch.int32).to(DEV), seg.to(DEV), n_atoms, 0.37)
+    close(out, ref, rtol=1e-5, atol=1e-5 * max(1.0, float(ref.abs().max())))
+    gm, gr = K.rbf_aggregate_bwd(f32(go), f32(m), f32(rbf), f32(W), id_a.to(torch.int32).to(DEV), 0.37)
+    gsel = go[id_a] * 0.37
+    close(gm, gsel * (rbf @ W.t()), rtol=1e-5, atol=1e-5)
+    close(gr, (gsel * m) @ W, rtol=1e-5, atol=2e-5 * max(1.0, float(((gsel * m) @ W).abs().max())))
+    gm2, gr2 = K.rbf_aggregate_bwd(f32(go), f32(m), f32(rbf), f32(W), id_a.to(torch.int32).to(DEV), 0.37, want_m=False)
+    assert gm2 is None and torch.equal(gr2, gr)
