@@ -284,3 +284,88 @@ GN_HD double ylm_dot(double theta, double ph, int S, int kt, int kp, const float
   ylm_visit(theta, ph, S, kt, kp, [&acc, g](int slot, double v) { acc += (double)g[slot] * v; });
   return acc;
 }
+
+// ---- S = 7 rows with every loop bound a compile-time constant, in the scalar type T -----------------------------------
+// The generic visitors above run f64 jets through runtime loops (an f64 division and a table lookup per (l, m)): about
+// 10 k cycles per 64 quadruplets on gfx950.  The bilinear kernels that rebuild the tensor basis on the fly
+// (csrc/bilinear_ang.hip) evaluate a row per quadruplet per pass, so they use these fully unrolled forms in f32:
+// ~200 FMAs per row; deviation from the f64 row <= 2e-6 of the largest component (tests/test_host_math.py).
+template <typename T>
+GN_HD void ylm7_row_T(T sn, T cs, T s1, T c1, float* o) {
+  constexpr int L = 7;
+  T cm[L], sm[L];
+  cm[0] = T(1); sm[0] = T(0);
+#pragma unroll
+  for (int m = 1; m < L; ++m) {
+    cm[m] = cm[m - 1] * c1 - sm[m - 1] * s1;
+    sm[m] = sm[m - 1] * c1 + cm[m - 1] * s1;
+  }
+  T qmm = T(1);
+#pragma unroll
+  for (int m = 0; m < L; ++m) {
+    if (m > 0) qmm = qmm * sn * T(2 * m - 1);
+    T qa = qmm, qb = T(0);
+#pragma unroll
+    for (int l = m; l < L; ++l) {
+      T ql;
+      if (l == m) ql = qmm;
+      else if (l == m + 1) ql = cs * qa * T(2 * m + 1);
+      else ql = (T(2 * l - 1) * cs * qa - T(l + m - 1) * qb) * T(1.0 / (l - m));
+      if (l > m) { qb = qa; qa = ql; }
+      const T tv = ql * T((m == 0 ? 1.0 : 1.4142135623730951) * ylm_prefactor_tab(l, m));
+      if (m == 0) {
+        o[l * l] = (float)tv;
+      } else {
+        o[l * l + m] = (float)(tv * cm[m]);
+        o[l * l + 2 * l + 1 - m] = (float)(tv * sm[m]);
+      }
+    }
+  }
+}
+
+// g_theta = sum_j g[j] dY_j/dtheta, g_phi = sum_j g[j] dY_j/dphi for the 49 harmonics of S = 7 (ylm_dot_grad_sc in T)
+template <typename T>
+GN_HD void ylm7_dot_grad_T(T sn, T cs, T s1, T c1, const float* g, T& g_theta, T& g_phi) {
+  constexpr int L = 7;
+  T cm[L], sm[L];
+  cm[0] = T(1); sm[0] = T(0);
+#pragma unroll
+  for (int m = 1; m < L; ++m) {
+    cm[m] = cm[m - 1] * c1 - sm[m - 1] * s1;
+    sm[m] = sm[m - 1] * c1 + cm[m - 1] * s1;
+  }
+  T at = T(0), ap = T(0);
+  T qmm = T(1), dmm = T(0);          // Q_m^m and its theta derivative
+#pragma unroll
+  for (int m = 0; m < L; ++m) {
+    if (m > 0) {
+      const T nd = T(2 * m - 1) * (cs * qmm + sn * dmm);
+      qmm = T(2 * m - 1) * sn * qmm;
+      dmm = nd;
+    }
+    T qa = qmm, da = dmm, qb = T(0), db = T(0);
+#pragma unroll
+    for (int l = m; l < L; ++l) {
+      T ql, dl;
+      if (l == m) { ql = qmm; dl = dmm; }
+      else if (l == m + 1) { ql = T(2 * m + 1) * cs * qa; dl = T(2 * m + 1) * (cs * da - sn * qa); }
+      else {
+        const T a = T((2.0 * l - 1.0) / (l - m)), b = T((double)(l + m - 1) / (l - m));
+        ql = a * cs * qa - b * qb;
+        dl = a * (cs * da - sn * qa) - b * db;
+      }
+      if (l > m) { qb = qa; db = da; qa = ql; da = dl; }
+      const T pf = T((m == 0 ? 1.0 : 1.4142135623730951) * ylm_prefactor_tab(l, m));
+      if (m == 0) {
+        at += (T)g[l * l] * pf * dl;
+      } else {
+        const T gp = (T)g[l * l + m], gm = (T)g[l * l + 2 * l + 1 - m];
+        at += pf * dl * (gp * cm[m] + gm * sm[m]);
+        ap += pf * ql * T(m) * (gm * cm[m] - gp * sm[m]);
+      }
+    }
+  }
+  g_theta = at;
+  g_phi = ap;
+}
+

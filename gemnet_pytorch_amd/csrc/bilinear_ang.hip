@@ -1,0 +1,321 @@
+// Tensor-basis (GemNet-Q, S = 49, C = I = 32) bilinear kernels in ANGLE form (include/gemnet_hip.h, gn_bil_*_ang_f32).
+//
+// The reference materialises the real spherical harmonics of every quadruplet, Y (Q, 49) (basis_layers.py:239-295),
+// and every interaction block reads them again (efficient.py:173-177 and its autograd): at 9 M quadruplets that is
+// 1.76 GB per pass, 11 passes per forward+force step — 7 of 17 ms on MI355X (profiles/r1_final_*).  Here the per-quadruplet
+// input is 16 B: (sin, cos) of the polar angle Phi_cab and of the azimuth Theta_cabd (csrc/geometry.hip,
+// quad_angles_fwd_kernel).  Each wave rebuilds the Y_lm rows of 64 (resp. 16) quadruplets in its private LDS tile
+// — one lane per quadruplet, the shared recurrences of basis_math.h — and feeds the MFMA fragments from there:
+//   reduce_project_ang   Sm[e] = Yseg^T Xseg (K1) + P = B[e]^T Sm (K2)      replaces bil_reduce_project_mfma49
+//   expand_ang           dxt[seg(e)] = Yseg dSm[e]                          replaces bil_expand_mfma49
+//   dy_multi_ang         g_ang[t] = sum_s dY[t,s] dY_s/d(angles),  dY[t,s] = sum_b x_b[g(t)] . dSm_b[r(t),s]
+//                        — the (Q, 49) gradient array is never written either (was: written once, read back by the
+//                        geometry adjoint)
+// Numerics: rows by the fully unrolled f32 recurrences of basis_math.h (ylm7_row_T<float>: ~200 FMAs per row; the f64
+// jet visitors of the geometry kernels cost ~10 k cycles per 64 rows and made these kernels compute-bound), within 2e-6
+// of the f64 rows (tests/test_host_math.py).
+#include "common.h"
+#include "basis_math.h"
+
+typedef float v4f_a __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int S = 49, C = 32, I = 32;
+constexpr int LDY = 53;      // LDS row pitch of a Y row (odd: the per-lane row writes spread over the banks)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS traffic has landed
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- K1 + K2 ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bil_reduce_project_ang_kernel(
+    const float4* __restrict__ ang, const float* __restrict__ x, const int32_t* __restrict__ expand_idx,
+    const int32_t* __restrict__ seg_off, const float* __restrict__ B, float* __restrict__ Sm, float* __restrict__ P,
+    int64_t E) {
+  // 32 quadruplets per tile: 27 KB of LDS per workgroup keeps 5 workgroups (20 waves) per CU — the gathered x rows are
+  // two dependent L2 round trips per K-step, and with 64-quadruplet tiles (2 workgroups per CU) nothing hid them
+  constexpr int TQ = 32, LD = C + 4;
+  constexpr int YSZ = (TQ * LDY > 52 * LD) ? TQ * LDY : 52 * LD;
+  __shared__ __attribute__((aligned(16))) float ysm[4][YSZ];   // Y rows of one tile; later Sm[52][LD] of the edge
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  float* __restrict__ ys = ysm[wave];
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  v4f_a acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+  for (int tb = t0; tb < t1; tb += TQ) {
+    const int nq = min(TQ, t1 - tb);
+    int gq = 0;                          // expand row of quadruplet tb + lane: one coalesced load per tile,
+    if (lane < nq) {                     // handed to the lanes that need it by a wave shuffle (no dependent index load)
+      gq = expand_idx[tb + lane];
+      const float4 a4 = ang[tb + lane];
+      ylm7_row_T<float>(a4.x, a4.y, a4.z, a4.w, ys + lane * LDY);
+    }
+    wave_lds_sync();
+    // K-steps of 4 quadruplets: lane (l15, lg) supplies Y[q = k + lg][16 mt + l15] and x[g(q)][16 nt + l15]
+    auto loadx = [&](int k, float (&b)[2]) {
+      const int q = k + lg;
+      const bool ok = q < nq;
+      const float* __restrict__ xr = x + (int64_t)__shfl(gq, min(q, nq - 1), 64) * C + l15;
+      const float x0 = xr[0], x1 = xr[16];
+      b[0] = ok ? x0 : 0.f;
+      b[1] = ok ? x1 : 0.f;
+    };
+    float b0[2], b1[2];
+    loadx(0, b0);
+    for (int k = 0; k < nq; k += 8) {
+      loadx(k + 4, b1);                 // next K-step's gathered rows in flight under this one's MFMAs
+      {
+        const int q = k + lg;
+        const bool ok = q < nq;
+        const float* __restrict__ yr = ys + min(q, nq - 1) * LDY;
+        const float a0 = ok ? yr[l15] : 0.f, a1 = ok ? yr[16 + l15] : 0.f, a2 = ok ? yr[32 + l15] : 0.f, a3 = ok ? yr[48] : 0.f;
+        const float a[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0[nt], acc[mt][nt], 0, 0, 0);
+      }
+      loadx(k + 8, b0);
+      {
+        const int q = k + 4 + lg;
+        const bool ok = q < nq;
+        const float* __restrict__ yr = ys + min(q, nq - 1) * LDY;
+        const float a0 = ok ? yr[l15] : 0.f, a1 = ok ? yr[16 + l15] : 0.f, a2 = ok ? yr[32 + l15] : 0.f, a3 = ok ? yr[48] : 0.f;
+        const float a[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    wave_lds_sync();   // every fragment read of this tile has returned before the next tile overwrites it
+  }
+  // D layout: col = l15 (c within tile), row = 4 lg + r (s within tile); tile mt = 3 carries only s = 48
+  float* __restrict__ so = Sm + e * (int64_t)S * C;
+  float (*sml)[LD] = reinterpret_cast<float (*)[LD]>(ys);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int srow = 16 * mt + 4 * lg + r;
+        const float v = acc[mt][nt][r];
+        if (srow < S) so[srow * C + 16 * nt + l15] = v;
+        if (srow < 52) sml[srow][16 * nt + l15] = srow < S ? v : 0.f;
+      }
+  wave_lds_sync();
+  // K2: P[i,c] = sum_s B[e,s,i] Sm[s,c]
+  v4f_a pacc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) pacc[mt][nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ be = B + e * (int64_t)S * I;
+#pragma unroll
+  for (int kk = 0; kk < 13; ++kk) {
+    const int sk = 4 * kk + lg;
+    const bool ok = sk < S;
+    const float a_0 = ok ? be[sk * I + l15] : 0.f;
+    const float a_1 = ok ? be[sk * I + 16 + l15] : 0.f;
+    const float b_0 = sml[sk][l15];
+    const float b_1 = sml[sk][16 + l15];
+    pacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_0, pacc[0][0], 0, 0, 0);
+    pacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_1, pacc[0][1], 0, 0, 0);
+    pacc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_0, pacc[1][0], 0, 0, 0);
+    pacc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_1, pacc[1][1], 0, 0, 0);
+  }
+  float* __restrict__ po = P + e * (int64_t)I * C;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) po[(16 * mt + 4 * lg + r) * C + 16 * nt + l15] = pacc[mt][nt][r];
+}
+
+// ---- x-adjoint, grouped by reduce edge: dxt[seg(e)] (K4 x C) = Yseg (K4 x S) @ dSm[e] (S x C) -------------------------
+__global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __restrict__ ang, const float* __restrict__ dSm,
+                                                             const int32_t* __restrict__ seg_off, float* __restrict__ dxt,
+                                                             int64_t E) {
+  constexpr int TQ = 32;   // 27 KB of LDS per workgroup: 5 workgroups per CU
+  __shared__ float ysm[4][TQ * LDY];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  float* __restrict__ ys = ysm[wave];
+  const float* __restrict__ De = dSm + e * (int64_t)S * C;
+  float bd[13][2];   // dSm[4 kk + lg][16 nt + l15]
+#pragma unroll
+  for (int kk = 0; kk < 13; ++kk) {
+    const int sr = 4 * kk + lg;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float v = De[min(sr, S - 1) * C + 16 * nt + l15];
+      bd[kk][nt] = sr < S ? v : 0.f;
+    }
+  }
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  for (int tb = t0; tb < t1; tb += TQ) {
+    const int nq = min(TQ, t1 - tb);
+    if (lane < nq) {
+      const float4 a4 = ang[tb + lane];
+      ylm7_row_T<float>(a4.x, a4.y, a4.z, a4.w, ys + lane * LDY);
+    }
+    wave_lds_sync();
+    for (int sub = 0; sub < nq; sub += 16) {   // row tiles of 16 quadruplets: lane (l15, lg) <- Y[sub + l15][4 kk + lg]
+      const float* __restrict__ yb = ys + min(sub + l15, nq - 1) * LDY + lg;
+      v4f_a c0 = (v4f_a){0.f, 0.f, 0.f, 0.f}, c1 = (v4f_a){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 13; ++kk) {
+        const float yv = yb[4 * kk];
+        const float a = (kk < 12 || lg == 0) ? yv : 0.f;
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bd[kk][0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bd[kk][1], c1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = sub + 4 * lg + r;
+        if (q < nq) {
+          float* __restrict__ o = dxt + (int64_t)(tb + q) * C + l15;
+          o[0] = c0[r];
+          o[16] = c1[r];
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+// ---- angle gradient of all blocks that share the basis, one pass ------------------------------------------------------
+struct gn_dy_ang_args {
+  const float* dS[4];
+  const float* x[4];
+  int nb;
+};
+
+// One WORKGROUP per reduce edge: the dSm_b[e] blocks of all nb blocks (nb x 6.3 KB) are staged in LDS once and shared by
+// the four waves, which split the edge's quadruplets in tiles of 16.  (One wave per edge with the 4 x 32 B fragments in
+// registers — the layout of bil_dy_multi_mfma49 — needs 256 VGPRs once the angle contraction is added: one wave per
+// SIMD, and the gathered x rows were fully exposed: 3.1 ms instead of 1.6 ms at 9 M quadruplets.)
+__global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_args a, const float4* __restrict__ ang,
+                                                               const int32_t* __restrict__ expand_idx,
+                                                               const int32_t* __restrict__ seg_off, float4* __restrict__ g_ang,
+                                                               int64_t E) {
+  constexpr int LDD = C + 4;                          // row pitch of a staged dSm block: 16-byte aligned, conflict-free
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // [nb][S][LDD] then [4 waves][16][LDY]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = blockIdx.x;
+  const int nb = a.nb;
+  float* __restrict__ dy = dsm + nb * S * LDD + wave * 16 * LDY;
+  for (int b = 0; b < nb; ++b) {                      // stage dSm_b[e] (49 x 32): 392 float4 per block
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.dS[b] + e * (int64_t)S * C);
+    for (int i = threadIdx.x; i < S * C / 4; i += 256) {
+      const int r = i >> 3, c4i = i & 7;
+      *reinterpret_cast<float4*>(dsm + (b * S + r) * LDD + 4 * c4i) = src[i];
+    }
+  }
+  __syncthreads();
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  for (int tb = t0 + 16 * wave; tb < t1; tb += 64) {
+    const int tq = tb + l15;
+    const bool ok = tq < t1;
+    const int64_t g = ok ? expand_idx[tq] : 0;
+    v4f_a c4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c4[nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nb; ++b) {
+      float4 ax0 = z4, ax1 = z4;
+      if (ok) {
+        const float* __restrict__ xr = a.x[b] + g * C + 4 * lg;
+        ax0 = *reinterpret_cast<const float4*>(xr);
+        ax1 = *reinterpret_cast<const float4*>(xr + 16);
+      }
+      const float* __restrict__ db = dsm + b * S * LDD;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        // B fragments: dSm_b[e][s = 16 nt + l15][16 j + 4 lg ..]; rows >= 49 (tile nt = 3, l15 > 0) contribute nothing
+        const int sr = 16 * nt + l15;
+        const float* __restrict__ row = db + min(sr, S - 1) * LDD + 4 * lg;
+        float4 b0 = *reinterpret_cast<const float4*>(row), b1 = *reinterpret_cast<const float4*>(row + 16);
+        if (sr >= S) { b0 = z4; b1 = z4; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          c4[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ax0, q), comp(b0, q), c4[nt], 0, 0, 0);
+          c4[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ax1, q), comp(b1, q), c4[nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      // D layout: row = quadruplet 4 lg + r, col = s = 16 nt + l15 (tile nt = 3: only s = 48)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nt < 3 || l15 == 0) dy[(4 * lg + r) * LDY + 16 * nt + l15] = c4[nt][r];
+    }
+    wave_lds_sync();
+    if (lane < 16 && tb + lane < t1) {   // one lane per quadruplet: contract its dY row with dY/d(polar, azimuth)
+      const float4 a4 = ang[tb + lane];
+      float g_first, g_second;
+      ylm7_dot_grad_T<float>(a4.x, a4.y, a4.z, a4.w, dy + lane * LDY, g_first, g_second);
+      g_ang[tb + lane] = make_float4(g_first, g_second, 0.f, 0.f);
+    }
+    wave_lds_sync();
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx,
+                                             const int32_t* seg_off, const float* B, float* Sm, float* P, int64_t E, int S_,
+                                             int C_, int I_, void* stream) {
+  if (E <= 0) return 0;
+  if (S_ != S || C_ != C || I_ != I || !aligned16(ang)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bil_reduce_project_ang_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(ang), x, expand_idx, seg_off, B, Sm, P, E);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S_,
+                                     int C_, void* stream) {
+  if (E <= 0) return 0;
+  if (S_ != S || C_ != C || !aligned16(ang)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bil_expand_ang_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float* const* x_list, int nb, const float* ang,
+                                       const int32_t* expand_idx, const int32_t* seg_off, float* g_ang, int64_t E, int S_,
+                                       int C_, void* stream) {
+  if (E <= 0 || nb <= 0) return 0;
+  if (nb > 4 || S_ != S || C_ != C || !aligned16(ang) || !aligned16(g_ang)) return (int)hipErrorInvalidValue;
+  gn_dy_ang_args a;
+  a.nb = nb;
+  for (int b = 0; b < 4; ++b) {
+    a.dS[b] = b < nb ? dSm_list[b] : nullptr;
+    a.x[b] = b < nb ? x_list[b] : nullptr;
+    if (b < nb && (!aligned16(a.dS[b]) || !aligned16(a.x[b]))) return (int)hipErrorInvalidValue;
+  }
+  const size_t smem = ((size_t)nb * S * (C + 4) + 4 * 16 * LDY) * sizeof(float);   // 42 KB at nb = 4
+  hipLaunchKernelGGL(bil_dy_multi_ang_kernel, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream), a,
+                     reinterpret_cast<const float4*>(ang), expand_idx, seg_off, reinterpret_cast<float4*>(g_ang), E);
+  GN_LAUNCH_CHECK();
+  return 0;
+}

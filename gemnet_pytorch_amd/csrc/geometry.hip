@@ -260,6 +260,52 @@ __global__ __launch_bounds__(256) void quad_basis_bwd_kernel(const float* __rest
   }
 }
 
+// Angle form of the tensor basis: instead of the (Q, 49) harmonics (196 B per quadruplet, re-read by every interaction
+// block: 1.8 GB per pass at 9 M quadruplets) only (sin, cos) of the polar angle Phi_cab and of the azimuth Theta_cabd
+// leave this kernel — 16 B per quadruplet; the bilinear kernels rebuild Y_lm from them in registers / LDS
+// (csrc/bilinear.hip, *_ang kernels; basis_layers.py:239-295 evaluates sympy expressions of the same two angles).
+__global__ __launch_bounds__(256) void quad_angles_fwd_kernel(const float* __restrict__ R, const int32_t* __restrict__ qc,
+                                                              const int32_t* __restrict__ qa, const int32_t* __restrict__ qb,
+                                                              const int32_t* __restrict__ qd, float4* __restrict__ ang,
+                                                              int64_t Q) {
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < Q; q += (int64_t)gridDim.x * 256) {
+    const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
+    const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
+    const V3 uba = (-1.0f) * uab;
+    double sn, cs, s1, c1;
+    angle_uv_sc(uab, uac, sn, cs);
+    angle_uv_sc(reject(uac, uab), reject(ubd, uba), s1, c1);
+    ang[q] = make_float4((float)sn, (float)cs, (float)s1, (float)c1);
+  }
+}
+
+// Adjoint of the angle form: g_ang[q] = (dE/dPhi_cab, dE/dTheta_cabd, -, -) -> per-quadruplet force contributions.
+__global__ __launch_bounds__(256) void quad_angles_bwd_kernel(const float4* __restrict__ g_ang, const float* __restrict__ R,
+                                                              const int32_t* __restrict__ qc, const int32_t* __restrict__ qa,
+                                                              const int32_t* __restrict__ qb, const int32_t* __restrict__ qd,
+                                                              float* __restrict__ Gc, float* __restrict__ Gb,
+                                                              float* __restrict__ Gd, int64_t Q, int ldc, int ldb, int ldd) {
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < Q; q += (int64_t)gridDim.x * 256) {
+    const V3 Ra = v3(R + 3 * (int64_t)qa[q]), Rb = v3(R + 3 * (int64_t)qb[q]);
+    const V3 uac = v3(R + 3 * (int64_t)qc[q]) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * (int64_t)qd[q]) - Rb;
+    const V3 uba = (-1.0f) * uab;
+    const V3 p1 = reject(uac, uab), p2 = reject(ubd, uba);
+    const float4 g = g_ang[q];
+    const float g_phi = g.x, g_th = g.y;
+    V3 g_ab, g_ac, gp1, gp2, t1, t2, g_bd, g_ba;
+    angle_uv_bwd(uab, uac, g_phi, g_ab, g_ac);
+    angle_uv_bwd(p1, p2, g_th, gp1, gp2);
+    reject_bwd(uac, uab, gp1, t1, t2);
+    g_ac = g_ac + t1; g_ab = g_ab + t2;
+    reject_bwd(ubd, uba, gp2, g_bd, g_ba);
+    g_ab = g_ab - g_ba;
+    const V3 gc = g_ac, gd = g_bd, gb = g_ab - g_bd;
+    Gc[ldc * q] = gc.x; Gc[ldc * q + 1] = gc.y; Gc[ldc * q + 2] = gc.z;
+    Gb[ldb * q] = gb.x; Gb[ldb * q + 1] = gb.y; Gb[ldb * q + 2] = gb.z;
+    Gd[ldd * q] = gd.x; Gd[ldd * q + 1] = gd.y; Gd[ldd * q + 2] = gd.z;
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -335,6 +381,26 @@ extern "C" int gn_quad_basis_bwd_ld_f32(const float* gY, const float* R, const i
   if (S > 7 || ldc < 3 || ldb < 3 || ldd < 3) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(quad_basis_bwd_kernel, dim3(grid_for(Q)), dim3(256), (size_t)256 * S * S * sizeof(float),
                      static_cast<hipStream_t>(stream), gY, R, qc, qa, qb, qd, Gc, Gb, Gd, Q, S, ldc, ldb, ldd);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_quad_angles_fwd_f32(const float* R, const int32_t* qc, const int32_t* qa, const int32_t* qb,
+                                      const int32_t* qd, float* ang, int64_t Q, void* stream) {
+  if (Q <= 0) return 0;
+  hipLaunchKernelGGL(quad_angles_fwd_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream), R, qc, qa,
+                     qb, qd, reinterpret_cast<float4*>(ang), Q);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_quad_angles_bwd_ld_f32(const float* g_ang, const float* R, const int32_t* qc, const int32_t* qa,
+                                         const int32_t* qb, const int32_t* qd, float* Gc, int ldc, float* Gb, int ldb,
+                                         float* Gd, int ldd, int64_t Q, void* stream) {
+  if (Q <= 0) return 0;
+  if (ldc < 3 || ldb < 3 || ldd < 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(quad_angles_bwd_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(g_ang), R, qc, qa, qb, qd, Gc, Gb, Gd, Q, ldc, ldb, ldd);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -235,8 +235,13 @@ def bil_reduce_t(Y, D, sp):
     """dx[j,c] = sum_{t: g(t)=j} sum_s Y[t,s] D[r(t),s,c]."""
     require_device(Y, D)
     Y, D = _f32c(Y), _f32c(D)
-    S, C = Y.shape[1], D.shape[2]
+    S, C = D.shape[1], D.shape[2]
     permT, segT = sp.expand.csr
+    if is_angle_form(Y, S):
+        dxt = torch.empty((sp.size, C), device=Y.device, dtype=torch.float32)
+        check(_lib.load().gn_bil_expand_ang_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(dxt), sp.n_reduce, S, C, stream()),
+              "gn_bil_expand_ang_f32")
+        return segsum(dxt, permT, segT, sp.n_expand)
     if S > 8:
         # tensor basis: per-quadruplet rows grouped by reduce edge (dSm[e] read once per edge), then one CSR sum
         dxt = torch.empty((sp.size, C), device=Y.device, dtype=torch.float32)
@@ -617,9 +622,14 @@ def bil_reduce_project(Y, x, B, sp):
     """Fused K1+K2 -> (Sm (E,S,C), P (E,I,C)); B = rbf_W1 (E,S,I)."""
     require_device(Y, x, B)
     Y, x, B = _f32c(Y), _f32c(x), _f32c(B)
-    S, C, I = Y.shape[1], x.shape[1], B.shape[2]
+    S, C, I = B.shape[1], x.shape[1], B.shape[2]
     Sm = torch.empty((sp.n_reduce, S, C), device=x.device, dtype=torch.float32)
     P = torch.empty((sp.n_reduce, I, C), device=x.device, dtype=torch.float32)
+    if is_angle_form(Y, S):   # Y_lm rebuilt in-kernel from (sin, cos) of the two angles
+        check(_lib.load().gn_bil_reduce_project_ang_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
+                                                        ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
+              "gn_bil_reduce_project_ang_f32")
+        return Sm, P
     check(_lib.load().gn_bil_reduce_project_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
                                                 ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
           "gn_bil_reduce_project_f32")
@@ -644,13 +654,57 @@ def bil_fused_fwd_supported(S, C, I, O):
     return (S, C, I, O) == (7, 64, 16, 64)
 
 
-def bil_dy_multi(dSm_list, x_list, sp):
-    """dY (T,S) = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c] for the blocks b that share one tensor basis (one pass)."""
+def is_angle_form(Y, S):
+    """The tensor basis given as (Q,4) = (sin, cos) of Phi_cab and Theta_cabd instead of the (Q,49) harmonics."""
+    return S == 49 and Y.dim() == 2 and Y.shape[1] == 4
+
+
+def quad_angles_fwd(R, qc, qa, qb, qd):
+    """-> ang (Q,4): (sin, cos) of the polar angle Phi_cab and of the azimuth Theta_cabd (gemnet.py:334-418)."""
+    require_device(R, qc, qa, qb, qd)
+    R = _f32c(R)
+    Q = qc.shape[0]
+    ang = torch.empty((Q, 4), device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_quad_angles_fwd_f32(ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(ang), Q, stream()),
+          "gn_quad_angles_fwd_f32")
+    return ang
+
+
+def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
+    """g_ang (Q,4) = (dE/dPhi_cab, dE/dTheta_cabd, -, -) -> (Gc, Gb, Gd) (Q,3) each, or packed: Gc and
+    Gbd (Q,8) = [Gb xyz, 0, Gd xyz, 0]."""
+    require_device(g_ang, R)
+    g_ang, R = _f32c(g_ang), _f32c(R)
+    Q = qc.shape[0]
+    Gc = torch.empty((Q, 3), device=R.device, dtype=torch.float32)
+    if packed:
+        Gbd = torch.zeros((Q, 8), device=R.device, dtype=torch.float32)
+        base = Gbd.data_ptr()
+        check(_lib.load().gn_quad_angles_bwd_ld_f32(ptr(g_ang), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), 3,
+                                                    base, 8, base + 16, 8, Q, stream()), "gn_quad_angles_bwd_ld_f32")
+        return Gc, Gbd
+    Gb, Gd = torch.empty_like(Gc), torch.empty_like(Gc)
+    check(_lib.load().gn_quad_angles_bwd_ld_f32(ptr(g_ang), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), 3,
+                                                ptr(Gb), 3, ptr(Gd), 3, Q, stream()), "gn_quad_angles_bwd_ld_f32")
+    return Gc, Gb, Gd
+
+
+def bil_dy_multi(dSm_list, x_list, sp, ang=None):
+    """dY (T,S) = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c] for the blocks b that share one tensor basis (one pass).
+    With `ang` (the basis in angle form): the gradient w.r.t. the two angles, (T,4), instead."""
     require_device(*dSm_list, *x_list)
     dSm_list = [_f32c(t) for t in dSm_list]
     x_list = [_f32c(t) for t in x_list]
     nb = len(dSm_list)
     E, S, C = dSm_list[0].shape
+    if ang is not None:
+        ang = _f32c(ang)
+        g_ang = torch.empty((sp.size, 4), device=ang.device, dtype=torch.float32)
+        arr = ctypes.c_void_p * nb
+        check(_lib.load().gn_bil_dy_multi_ang_f32(arr(*[t.data_ptr() for t in dSm_list]), arr(*[t.data_ptr() for t in x_list]),
+                                                  nb, ptr(ang), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(g_ang), E, S, C,
+                                                  stream()), "gn_bil_dy_multi_ang_f32")
+        return g_ang
     dY = torch.empty((sp.size, S), device=x_list[0].device, dtype=torch.float32)
     arr = ctypes.c_void_p * nb
     check(_lib.load().gn_bil_dy_multi_f32(arr(*[t.data_ptr() for t in dSm_list]), arr(*[t.data_ptr() for t in x_list]),

@@ -200,7 +200,10 @@ class GemNet(torch.nn.Module):
             y_abd = ops.trip_basis(R, qg["a_of_exp"], qg["b_of_exp"], qg["d_of_exp"], self.num_spherical)
             S, NR = self.num_spherical, b4.num_radial
             cbf4 = (ops.gather_rows(rad4, plan.intm_ab) * y_abd[:, :, None]).reshape(-1, S * NR)
-            sbf4 = (rad3, ops.share_gradient(ops.quad_basis(R, plan.q_c, plan.q_a, plan.q_b, plan.q_d, S, plan=plan)))
+            # (angle form for the published quadruplet widths: the bilinear kernels rebuild Y_lm from 16 B per quadruplet)
+            ang = self.int_blocks[0].quad_interaction.mlp_sbf.weight.shape[:2] == (32, 32)
+            sbf4 = (rad3, ops.share_gradient(ops.quad_basis(R, plan.q_c, plan.q_a, plan.q_b, plan.q_d, S, plan=plan,
+                                                            angle_form=ang)))
         elif not T:
             D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
             Phi_cab, Phi_abd, Theta_cabd = self.calculate_angles(R, plan)

@@ -618,7 +618,10 @@ class _FusedBilinear(torch.autograd.Function):
             ctx.sink.consumers += 1
         C, I, O = W.shape
         keep_p = W.requires_grad and _PARAM_GRADS
-        if not keep_p and K.bil_fused_fwd_supported(sph.shape[1], C, I, O):
+        ctx.ang = K.is_angle_form(sph, rbf_W1.shape[1])
+        if ctx.ang and (C, I) != (32, 32):
+            raise ValueError("the angle-form tensor basis needs emb_size_quad = emb_size_sbf = 32")
+        if not keep_p and not ctx.ang and K.bil_fused_fwd_supported(sph.shape[1], C, I, O):
             Sm, out = K.bil_fused_fwd(sph, x, rbf_W1, bilinear_weight(W, True), sp, alpha)   # K1 + K2 + K3, P stays in LDS
             P = None
         else:
@@ -638,14 +641,21 @@ class _FusedBilinear(torch.autograd.Function):
         g = g.contiguous()
         dP = K.gemm(g, bilinear_weight(W, False), alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is (N=I*C, K=O)
         sink = ctx.sink
-        if sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64)) and sink.consumers <= 4:
+        if need[1] and ctx.ang and (sink is None or sink.consumers > 4):
+            # angle form without a shared sink: this block's angle gradient alone
+            gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False)
+            gsph = K.bil_dy_multi([dSm], [x], sp, ang=sph)
+            if sink is not None:
+                sink.arrive()
+        elif sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64)) and sink.consumers <= 4:
             # gB and dSm now, the Y gradient of all consumers of this basis in ONE pass when the last one arrives
             gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False)
             last = sink.arrive()
             sink.pending.append((dSm, x))
             gsph = None
             if last:
-                gsph = K.bil_dy_multi([d for d, _ in sink.pending], [xx for _, xx in sink.pending], sp)
+                gsph = K.bil_dy_multi([d for d, _ in sink.pending], [xx for _, xx in sink.pending], sp,
+                                      ang=sph if ctx.ang else None)
                 sink.pending = []
         elif sink is not None and need[1]:
             # the Y gradient is summed across the consumers of `sph` inside the kernel (see GradSink)
@@ -1043,10 +1053,14 @@ class _QuadBasis(torch.autograd.Function):
     """(R) -> real Y_lm(Phi_cab, Theta_cabd) of every quadruplet in one launch (first-order adjoint)."""
 
     @staticmethod
-    def forward(ctx, R, ri_c, ri_a, ri_b, ri_d, S, plan=None):
-        Y = K.quad_basis_fwd(R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
+    def forward(ctx, R, ri_c, ri_a, ri_b, ri_d, S, plan=None, angle_form=False):
+        if angle_form:   # (Q,4) = (sin, cos) of the two angles: the bilinear kernels rebuild Y_lm (csrc/bilinear_ang.hip)
+            Y = K.quad_angles_fwd(R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32)
+        else:
+            Y = K.quad_basis_fwd(R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
         ctx.save_for_backward(R)
         ctx.cfg = (ri_c, ri_a, ri_b, ri_d, S, plan)
+        ctx.angle_form = angle_form
         return Y
 
     @staticmethod
@@ -1055,9 +1069,13 @@ class _QuadBasis(torch.autograd.Function):
         (R,) = ctx.saved_tensors
         ri_c, ri_a, ri_b, ri_d, S, plan = ctx.cfg
         if not ctx.needs_input_grad[0]:
-            return (None,) * 7
+            return (None,) * 8
+        idx = (ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32)
         if plan is None:
-            Gc, Gb, Gd = K.quad_basis_bwd(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
+            if ctx.angle_form:
+                Gc, Gb, Gd = K.quad_angles_bwd(gY, R, *idx)
+            else:
+                Gc, Gb, Gd = K.quad_basis_bwd(gY, R, *idx, S)
             gR = (K.segsum(Gc, *ri_c.csr, ri_c.n_rows) + K.segsum(Gb, *ri_b.csr, ri_b.n_rows)
                   + K.segsum(Gd, *ri_d.csr, ri_d.n_rows) - K.segsum(Gc + Gb + Gd, *ri_a.csr, ri_a.n_rows))
         else:
@@ -1066,7 +1084,10 @@ class _QuadBasis(torch.autograd.Function):
             # permutation by atom ran at 180 GB/s), then the 18 k edge rows go to the atoms
             # b and d are shared by the quadruplets of one intermediate triplet (a, b, d): [Gb | Gd] rows of 32 B
             # are summed per intermediate triplet in one float4 pass, then the 0.6 M rows go to the atoms
-            Gc, Gbd = K.quad_basis_bwd_packed(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32, S)
+            if ctx.angle_form:
+                Gc, Gbd = K.quad_angles_bwd(gY, R, *idx, packed=True)
+            else:
+                Gc, Gbd = K.quad_basis_bwd_packed(gY, R, *idx, S)
             seg, E = plan.quad.seg_off, plan.n_edges
             Ec = K.segsum(Gc, None, seg, E)
             Ebd = K.segsum(Gbd, None, seg, E)
@@ -1076,9 +1097,15 @@ class _QuadBasis(torch.autograd.Function):
             gR = (K.segsum(Ec, *plan.id_c.csr, plan.id_c.n_rows) - K.segsum(Ea, *plan.id_a.csr, plan.id_a.n_rows)
                   + K.segsum(Ibd[:, 0:3].contiguous(), *rb.csr, rb.n_rows)
                   + K.segsum(Ibd[:, 4:7].contiguous(), *rd.csr, rd.n_rows))
-        return (gR,) + (None,) * 6
+        return (gR,) + (None,) * 7
 
 
-def quad_basis(R, ri_c, ri_a, ri_b, ri_d, S, plan=None):
-    """plan: the GraphPlan the four atom indices came from (enables the two-level force reduction)."""
-    return _QuadBasis.apply(R, ri_c, ri_a, ri_b, ri_d, int(S), plan)
+# The tensor basis of GemNet-Q in angle form (16 B per quadruplet instead of the 196-B harmonics row, rebuilt inside the
+# bilinear kernels).  Only for the published shapes (num_spherical 7, emb_size_quad = emb_size_sbf = 32).
+USE_QUAD_ANGLES = os.environ.get("GEMNET_QUAD_ANGLES", "1") == "1"
+
+
+def quad_basis(R, ri_c, ri_a, ri_b, ri_d, S, plan=None, angle_form=False):
+    """plan: the GraphPlan the four atom indices came from (enables the two-level force reduction).
+    angle_form: return (Q,4) (sin, cos) pairs of (Phi_cab, Theta_cabd) for the *_ang bilinear kernels."""
+    return _QuadBasis.apply(R, ri_c, ri_a, ri_b, ri_d, int(S), plan, bool(angle_form and USE_QUAD_ANGLES and S == 7))

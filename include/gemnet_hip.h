@@ -180,6 +180,27 @@ int gn_rbf_aggregate_fwd_f32(const float* m, const float* rbf, const float* W, c
 int gn_rbf_aggregate_bwd_f32(const float* g_out, const float* m, const float* rbf, const float* W, const int32_t* id_a,
                              float* g_m, float* g_rbf, int64_t E, int C, int R, float scale, void* stream);
 
+/* ---- tensor basis in ANGLE form (csrc/geometry.hip, csrc/bilinear_ang.hip) ------------------------------------------
+ * Instead of the (Q, S^2 = 49) harmonics of TensorBasisLayer (basis_layers.py:239-295) — 196 B per quadruplet, re-read
+ * by every interaction block — the geometry kernel emits ang (Q,4) = (sin, cos) of Phi_cab and of Theta_cabd (16 B) and
+ * the bilinear kernels rebuild Y_lm on the fly.  g_ang (Q,4) = (dE/dPhi_cab, dE/dTheta_cabd, 0, 0).
+ * Shapes: S = 49, C = I = 32 (the published GemNet-Q configuration); anything else: hipErrorInvalidValue. */
+int gn_quad_angles_fwd_f32(const float* R, const int32_t* qc, const int32_t* qa, const int32_t* qb, const int32_t* qd,
+                           float* ang, int64_t Q, void* stream);
+int gn_quad_angles_bwd_ld_f32(const float* g_ang, const float* R, const int32_t* qc, const int32_t* qa, const int32_t* qb,
+                              const int32_t* qd, float* Gc, int ldc, float* Gb, int ldb, float* Gd, int ldd, int64_t Q,
+                              void* stream);
+/* K1 + K2 of the bilinear layer as gn_bil_reduce_project_f32, Y given as angles */
+int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
+                                  const float* B, float* Sm, float* P, int64_t E, int S, int C, int I, void* stream);
+/* per-quadruplet x-adjoint rows as gn_bil_expand_f32, Y given as angles */
+int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,
+                          void* stream);
+/* gradient w.r.t. the two angles of all nb <= 4 blocks sharing the basis (gn_bil_dy_multi_f32 contracted with dY/d angle) */
+int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float* const* x_list, int nb, const float* ang,
+                            const int32_t* expand_idx, const int32_t* seg_off, float* g_ang, int64_t E, int S, int C,
+                            void* stream);
+
 /* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
  * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */
 int gn_bmm_f32(const float* A, const float* B, float* C, int batch, int m, int n, int k,

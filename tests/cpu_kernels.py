@@ -94,6 +94,8 @@ def bil_reduce(Y, x, sp):
 
 
 def bil_reduce_t(Y, D, sp):
+    if is_angle_form(Y, D.shape[1]):
+        Y = _ang_to_Y(Y)
     contrib = torch.einsum("ts,tsc->tc", Y, D[sp.reduce.idx32.long()])
     out = torch.zeros((sp.n_expand, D.shape[2]), dtype=D.dtype)
     return out.index_add(0, sp.expand.idx32.long(), contrib)
@@ -311,13 +313,53 @@ def chain(prog):
                 slots[o["y2"]] = new
 
 
+def is_angle_form(Y, S):
+    return S == 49 and Y.dim() == 2 and Y.shape[1] == 4
+
+
+def _ang_to_Y(ang):
+    """(Q,4) (sin, cos) pairs -> the (Q,49) harmonics (what the *_ang kernels rebuild in LDS)."""
+    return B.real_sph_harm_full(7, torch.atan2(ang[:, 0], ang[:, 1]), torch.atan2(ang[:, 2], ang[:, 3]))
+
+
 def bil_reduce_project(Y, x, Bm, sp):
+    if is_angle_form(Y, Bm.shape[1]):
+        Y = _ang_to_Y(Y)
     Sm = bil_reduce(Y, x, sp)
     return Sm, torch.bmm(Bm.transpose(1, 2), Sm)
 
 
-def bil_dy_multi(dSm_list, x_list, sp):
-    return sum(bil_dot(d, x, sp) for d, x in zip(dSm_list, x_list))
+def bil_dy_multi(dSm_list, x_list, sp, ang=None):
+    dY = sum(bil_dot(d, x, sp) for d, x in zip(dSm_list, x_list))
+    if ang is None:
+        return dY
+    with torch.enable_grad():   # chain rule to the two angles
+        th = torch.atan2(ang[:, 0], ang[:, 1]).detach().requires_grad_(True)
+        ph = torch.atan2(ang[:, 2], ang[:, 3]).detach().requires_grad_(True)
+        gt, gp = torch.autograd.grad((dY * B.real_sph_harm_full(7, th, ph)).sum(), (th, ph))
+    out = torch.zeros_like(ang)
+    out[:, 0], out[:, 1] = gt, gp
+    return out
+
+
+def quad_angles_fwd(R, qc, qa, qb, qd):
+    phi, th = _quad_angles(R[qc.long()], R[qa.long()], R[qb.long()], R[qd.long()])
+    return torch.stack([torch.sin(phi), torch.cos(phi), torch.sin(th), torch.cos(th)], dim=1)
+
+
+def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
+    with torch.enable_grad():
+        Rc = R[qc.long()].detach().clone().requires_grad_(True)
+        Rb = R[qb.long()].detach().clone().requires_grad_(True)
+        Rd = R[qd.long()].detach().clone().requires_grad_(True)
+        Ra = R[qa.long()].detach()
+        phi, th = _quad_angles(Rc, Ra, Rb, Rd)
+        Gc, Gb, Gd = torch.autograd.grad((g_ang[:, 0] * phi + g_ang[:, 1] * th).sum(), (Rc, Rb, Rd))
+    if not packed:
+        return Gc, Gb, Gd
+    Gbd = torch.zeros((Gb.shape[0], 8), dtype=Gb.dtype)
+    Gbd[:, 0:3], Gbd[:, 4:7] = Gb, Gd
+    return Gc, Gbd
 
 
 def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True):
@@ -381,7 +423,7 @@ def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=Tru
     return (g * (rbf @ W.t()) if want_m else None), ((g * m) @ W if want_rbf else None)
 
 
-_NAMES = ["rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -17,4 +17,24 @@ void shim_ylm0(const double* th, float* out, int n, int S, int k) { for (int i =
 void shim_ylm(const double* th, const double* ph, float* out, int n, int S, int kt, int kp) {
   for (int i = 0; i < n; ++i) ylm_row(th[i], ph[i], S, kt, kp, out + i * S * S);
 }
+void shim_ylm7_row_f32(const double* th, const double* ph, float* out, int n) {
+  for (int i = 0; i < n; ++i)
+    ylm7_row_T<float>((float)sin(th[i]), (float)cos(th[i]), (float)sin(ph[i]), (float)cos(ph[i]), out + i * 49);
+}
+void shim_ylm_row_f64(const double* th, const double* ph, float* out, int n) {
+  for (int i = 0; i < n; ++i) ylm_row_sc(sin(th[i]), cos(th[i]), sin(ph[i]), cos(ph[i]), 7, out + i * 49);
+}
+void shim_ylm7_dot_grad(const double* th, const double* ph, const float* g, double* out, int n, int use_f32) {
+  for (int i = 0; i < n; ++i) {
+    if (use_f32) {
+      float a, b;
+      ylm7_dot_grad_T<float>((float)sin(th[i]), (float)cos(th[i]), (float)sin(ph[i]), (float)cos(ph[i]), g + i * 49, a, b);
+      out[2 * i] = a; out[2 * i + 1] = b;
+    } else {
+      double a, b;
+      ylm_dot_grad_sc(sin(th[i]), cos(th[i]), sin(ph[i]), cos(ph[i]), 7, g + i * 49, a, b);
+      out[2 * i] = a; out[2 * i + 1] = b;
+    }
+  }
+}
 }

@@ -630,3 +630,57 @@ def test_rbf_aggregate_fused_vs_reference_ops(n_atoms, deg):
     close(gr, (gsel * m) @ W, rtol=1e-5, atol=2e-5 * max(1.0, float(((gsel * m) @ W).abs().max())))
     gm2, gr2 = K.rbf_aggregate_bwd(f32(go), f32(m), f32(rbf), f32(W), id_a.to(torch.int32).to(DEV), 0.37, want_m=False)
     assert gm2 is None and torch.equal(gr2, gr)
+
+
+@pytest.mark.parametrize("E,J,mk", [(60, 300, 80), (9, 40, 700), (33, 120, 3)])
+def test_tensor_basis_angle_form_kernels(E, J, mk):
+    """The *_ang kernels (Y_lm rebuilt in LDS from (sin, cos) of the two angles, 16 B per quadruplet) against the
+    float64 restatements working on the explicit (Q,49) harmonics: K1 + K2 forward, the x-adjoint, and the gradient
+    w.r.t. the two angles of several blocks at once; segments of 0 .. 700 quadruplets (tiles of 64 and 16)."""
+    g = torch.Generator().manual_seed(E * mk)
+    S, C, I = 49, 32, 32
+    cpu, dev = _segplan(g, E, J, mk)
+    Q = cpu.size
+    th, ph = torch.rand(Q, generator=g, dtype=torch.float64) * 3.1, torch.rand(Q, generator=g, dtype=torch.float64) * 3.1
+    ang = torch.stack([torch.sin(th), torch.cos(th), torch.sin(ph), torch.cos(ph)], 1)
+    x, B_, D = rnd(g, J, C), rnd(g, E, S, I), rnd(g, E, S, C)
+    Sm, P = K.bil_reduce_project(f32(ang), f32(x), f32(B_), dev)
+    Sm_ref, P_ref = CK.bil_reduce_project(ang, x, B_, cpu)
+    close(Sm, Sm_ref, atol=2e-5 * max(1.0, float(Sm_ref.abs().max())))
+    close(P, P_ref, atol=2e-5 * max(1.0, float(P_ref.abs().max())))
+    dx_ref = CK.bil_reduce_t(ang, D, cpu)
+    close(K.bil_reduce_t(f32(ang), f32(D), dev), dx_ref, atol=2e-5 * max(1.0, float(dx_ref.abs().max())))
+    Ds, xs = [rnd(g, E, S, C) for _ in range(3)], [rnd(g, J, C) for _ in range(3)]
+    for nb in (1, 3):
+        g_ref = CK.bil_dy_multi(Ds[:nb], xs[:nb], cpu, ang=ang)
+        got = K.bil_dy_multi([f32(d) for d in Ds[:nb]], [f32(v) for v in xs[:nb]], dev, ang=f32(ang))
+        close(got, g_ref, atol=3e-5 * max(1.0, float(g_ref.abs().max())))
+
+
+def test_quad_angles_geometry_fwd_bwd():
+    """gn_quad_angles_fwd / bwd: (sin, cos) of Phi_cab, Theta_cabd per quadruplet and the force contributions of a
+    gradient given w.r.t. the two angles, against autograd on the float64 geometry (gemnet.py:334-418)."""
+    g = torch.Generator().manual_seed(3)
+    A, Q = 40, 3000
+    R = rnd(g, A, 3) * 2.0
+    idx = [torch.randint(0, A, (Q,), generator=g) for _ in range(4)]
+    keep = (idx[0] != idx[1]) & (idx[1] != idx[2]) & (idx[2] != idx[3]) & (idx[0] != idx[2]) & (idx[1] != idx[3])
+    qc, qa, qb, qd = (i[keep].to(torch.int32) for i in idx)
+    ang_ref = CK.quad_angles_fwd(R, qc, qa, qb, qd)
+    dev_idx = [t.to(DEV) for t in (qc, qa, qb, qd)]
+    ang = K.quad_angles_fwd(f32(R), *dev_idx)
+    close(ang, ang_ref, atol=2e-5)
+    g_ang = torch.zeros(qc.shape[0], 4, dtype=torch.float64)
+    g_ang[:, :2] = rnd(g, qc.shape[0], 2)
+    ref = CK.quad_angles_bwd(g_ang, R, qc, qa, qb, qd)
+    got = K.quad_angles_bwd(f32(g_ang), f32(R), *dev_idx)
+    # exclude the nearly collinear configurations (sin of either angle < 0.05: the angle gradient ~ 1 / sin is
+    # ill-conditioned in fp32 there; the clamp case itself is covered by test_trip_basis / the linear-molecule goldens)
+    okq = (ang_ref[:, 0].abs() > 0.05) & (ang_ref[:, 2].abs() > 0.05)
+    assert int(okq.sum()) > 0.8 * okq.shape[0]
+    for a, b in zip(got, ref):
+        err = (a.double().cpu() - b).abs()[okq]
+        scale = b.abs()[okq].clamp(min=1.0)
+        assert float((err / scale).median()) <= 1e-5 and float((err / scale).max()) <= 5e-3
+    Gc, Gbd = K.quad_angles_bwd(f32(g_ang), f32(R), *dev_idx, packed=True)
+    assert torch.equal(Gc, got[0]) and torch.equal(Gbd[:, 0:3], got[1]) and torch.equal(Gbd[:, 4:7], got[2])

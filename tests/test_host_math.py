@@ -133,3 +133,24 @@ def test_ylm(shim, golden_basis, kt, kp):
         np.testing.assert_allclose(out, golden_basis["y_lm_dtheta"], rtol=5e-6, atol=5e-6)
     if (kt, kp) == (0, 1):
         np.testing.assert_allclose(out, golden_basis["y_lm_dphi"], rtol=5e-6, atol=5e-6)
+
+
+def test_fixed_size_f32_rows_match_the_f64_visitors(shim):
+    """ylm7_row_T<float> / ylm7_dot_grad_T<float> (what csrc/bilinear_ang.hip evaluates per quadruplet and pass) against
+    the f64 visitors used by the geometry kernels: <= 2e-6 of the largest harmonic, 2e-5 relative on the two gradients."""
+    rs = np.random.RandomState(0)
+    n = 4000
+    th = np.concatenate([rs.uniform(0, np.pi, n - 6), [1e-4, np.pi - 1e-4, 0.5 * np.pi, 1e-7, 1.0, 3.0]])
+    ph = np.concatenate([rs.uniform(0, np.pi, n - 6), [0.3, 2.0, 1e-5, 3.1, np.pi - 1e-6, 0.0]])
+    a, b = np.zeros((n, 49), np.float32), np.zeros((n, 49), np.float32)
+    shim.shim_ylm7_row_f32(_p(th), _p(ph), _p(a), n)
+    shim.shim_ylm_row_f64(_p(th), _p(ph), _p(b), n)
+    ref = B.real_sph_harm_full(7, torch.tensor(th), torch.tensor(ph)).numpy()
+    assert np.abs(b - ref).max() <= 2e-6                       # the f64 visitor is the oracle's formula
+    assert np.abs(a.astype(np.float64) - ref).max() <= 2e-6 * np.abs(ref).max()
+    g = rs.standard_normal((n, 49)).astype(np.float32)
+    o32, o64 = np.zeros((n, 2)), np.zeros((n, 2))
+    shim.shim_ylm7_dot_grad(_p(th), _p(ph), _p(g), _p(o32), n, 1)
+    shim.shim_ylm7_dot_grad(_p(th), _p(ph), _p(g), _p(o64), n, 0)
+    scale = np.abs(o64).max()
+    assert np.abs(o32 - o64).max() <= 2e-5 * scale, (np.abs(o32 - o64).max(), scale)
