@@ -143,7 +143,7 @@ class LaunchTimer:
         outs = out if isinstance(out, tuple) else (out,)
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
-    FAMILIES = ["gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
+    FAMILIES = ["rbf_aggregate_fwd", "rbf_aggregate_bwd", "gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
                 "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_fused_fwd", "bil_project_bwd", "bil_dy_multi", "bessel_rbf", "sph_radial", "ylm0",
                 "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
                 "quad_basis_bwd"]
@@ -215,9 +215,10 @@ class LaunchTimer:
 
 def pmc_traffic(name):
     """HBM-side bytes per launch of a launcher family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes (profiles/r1_traffic.json, produced by tools/gpu_artifacts.sh; gfx950 FETCH_SIZE correction applied)."""
+    passes (profiles/r2_traffic.json, produced by tools/gpu_artifacts.sh + tools/pmc_summary.py; gfx950 FETCH_SIZE
+    correction applied).  null when that family was not profiled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
             return int(json.load(f)[name]["bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None

@@ -8,8 +8,8 @@
 // pass: m is read once, W (8 KB) lives in registers, the per-edge products never reach memory.
 //   forward : one 256-thread workgroup per atom; wave w walks the atom's incoming edges w, w+4, .. (CSR by target
 //             atom), lane l owns columns 2l, 2l+1; four partial rows are summed through LDS in fixed order (no atomics)
-//   adjoint : one wave per edge; g_m[e] = scale * g_out[a(e)] (.) (W rbf_e),  g_rbf[e] = scale * W^T (g_out[a(e)] (.) m_e)
-//             (a 64-lane butterfly over the 16 radial components)
+//   adjoint : waves stride over the edges; g_m[e] = scale * g_out[a(e)] (.) (W rbf_e),  g_rbf[e] = scale * W^T (g_out[a(e)] (.) m_e)
+//             (a 128 x 16 mat-vec through 512 B of wave-private LDS)
 // Constraints: C (columns) == 128, R (radial features) == 16 — the shapes of every published GemNet configuration
 // (emb_size_edge 128, emb_size_rbf 16); other shapes take the GEMM + segmented-sum path.
 #include "common.h"
@@ -58,14 +58,20 @@ __global__ __launch_bounds__(256) void rbf_aggregate_fwd_kernel(const float* __r
   }
 }
 
+// Adjoint: a wave walks edges e = wave id, + #waves, ...  Per edge
+//   g_m[e][c]   = scale * g_out[a(e)][c] * (W rbf[e])[c]            lane l owns columns 2l, 2l+1 (as in the forward)
+//   g_rbf[e][k] = scale * sum_c g_out[a(e)][c] m[e][c] W[c][k]      a 128 x 16 mat-vec: the products t_c pass through
+//                 this wave's 512 B of LDS; lane (k = l % 16, part = l / 16) sums its 32 columns against W[c][k] held
+//                 in registers, two xor-shuffles fold the four parts (a 64-lane butterfly over 16 values took 96
+//                 ds_bpermute per edge: 27 us per launch instead of 11)
 __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ m,
                                                                 const float* __restrict__ rbf, const float* __restrict__ W,
                                                                 const int32_t* __restrict__ id_a, float* __restrict__ g_m,
                                                                 float* __restrict__ g_rbf, int64_t E, float scale) {
-  const int lane = threadIdx.x & 63;
-  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (e >= E) return;
-  float w0[R], w1[R];
+  __shared__ __attribute__((aligned(16))) float tsm[4][C];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kq = lane & 15, part = lane >> 4;
+  float w0[R], w1[R];          // W rows 2l, 2l+1 (for g_m)
 #pragma unroll
   for (int q = 0; q < R / 4; ++q) {
     const float4 u = *reinterpret_cast<const float4*>(W + (size_t)(2 * lane) * R + 4 * q);
@@ -73,35 +79,42 @@ __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __r
     w0[4 * q] = u.x; w0[4 * q + 1] = u.y; w0[4 * q + 2] = u.z; w0[4 * q + 3] = u.w;
     w1[4 * q] = v.x; w1[4 * q + 1] = v.y; w1[4 * q + 2] = v.z; w1[4 * q + 3] = v.w;
   }
-  const int a = id_a[e];
-  const float2 g = *reinterpret_cast<const float2*>(g_out + (size_t)a * C + 2 * lane);
-  const float gx = g.x * scale, gy = g.y * scale;
-  if (g_m) {
-    float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-    for (int q = 0; q < R / 4; ++q) {
-      const float4 b = *reinterpret_cast<const float4*>(rbf + (size_t)e * R + 4 * q);
-      r0 += w0[4 * q] * b.x + w0[4 * q + 1] * b.y + w0[4 * q + 2] * b.z + w0[4 * q + 3] * b.w;
-      r1 += w1[4 * q] * b.x + w1[4 * q + 1] * b.y + w1[4 * q + 2] * b.z + w1[4 * q + 3] * b.w;
-    }
-    *reinterpret_cast<float2*>(g_m + (size_t)e * C + 2 * lane) = make_float2(gx * r0, gy * r1);
-  }
+  float wt[32];                // W[32 part + j][kq] (for g_rbf)
   if (g_rbf) {
-    const float2 me = *reinterpret_cast<const float2*>(m + (size_t)e * C + 2 * lane);
-    const float t0 = gx * me.x, t1 = gy * me.y;
-    float s[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) s[k] = t0 * w0[k] + t1 * w1[k];
-    // butterfly over the 64 lanes, fixed order -> deterministic
+    for (int j = 0; j < 32; ++j) wt[j] = W[(size_t)(32 * part + j) * R + kq];
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t e = (int64_t)blockIdx.x * 4 + wave; e < E; e += stride) {
+    const int a = id_a[e];
+    const float2 g = *reinterpret_cast<const float2*>(g_out + (size_t)a * C + 2 * lane);
+    const float gx = g.x * scale, gy = g.y * scale;
+    if (g_m) {
+      float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
+      for (int q = 0; q < R / 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(rbf + (size_t)e * R + 4 * q);
+        r0 += w0[4 * q] * b.x + w0[4 * q + 1] * b.y + w0[4 * q + 2] * b.z + w0[4 * q + 3] * b.w;
+        r1 += w1[4 * q] * b.x + w1[4 * q + 1] * b.y + w1[4 * q + 2] * b.z + w1[4 * q + 3] * b.w;
+      }
+      *reinterpret_cast<float2*>(g_m + (size_t)e * C + 2 * lane) = make_float2(gx * r0, gy * r1);
+    }
+    if (g_rbf) {
+      const float2 me = *reinterpret_cast<const float2*>(m + (size_t)e * C + 2 * lane);
+      *reinterpret_cast<float2*>(&tsm[wave][2 * lane]) = make_float2(gx * me.x, gy * me.y);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < R; ++k) s[k] += __shfl_xor(s[k], off, 64);
-    if (lane < R) {
-      float v = 0.f;
-#pragma unroll
-      for (int k = 0; k < R; ++k) v = (lane == k) ? s[k] : v;
-      g_rbf[(size_t)e * R + lane] = v;
+      for (int j4 = 0; j4 < 8; ++j4) {
+        const float4 t = *reinterpret_cast<const float4*>(&tsm[wave][32 * part + 4 * j4]);
+        s += t.x * wt[4 * j4] + t.y * wt[4 * j4 + 1] + t.z * wt[4 * j4 + 2] + t.w * wt[4 * j4 + 3];
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < R) g_rbf[(size_t)e * R + lane] = s;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();   // all lanes have read tsm before the next edge overwrites it
     }
   }
 }
@@ -124,8 +137,9 @@ extern "C" int gn_rbf_aggregate_bwd_f32(const float* g_out, const float* m, cons
                                         void* stream) {
   if (C_ != C || R_ != R) return (int)hipErrorInvalidValue;
   if (E <= 0) return 0;
-  hipLaunchKernelGGL(rbf_aggregate_bwd_kernel, dim3((unsigned)gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale);
+  const int64_t blocks = gn_cdiv(E, 4);
+  hipLaunchKernelGGL(rbf_aggregate_bwd_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale);
   GN_LAUNCH_CHECK();
   return 0;
 }

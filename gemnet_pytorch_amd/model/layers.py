@@ -128,7 +128,9 @@ class AtomUpdateBlock(torch.nn.Module):
         # one-pass Dense(rbf) (.) m -> atom sum (csrc/aggregate.hip).  On for the AtomUpdateBlocks of the interaction
         # blocks; OutputBlocks keep the GEMM + segmented-sum form while they run on the side stream: with the fused
         # kernel there, hipGraph replays of the overlapped step stopped being bit-reproducible on MI355X (eager runs
-        # and the non-overlapped graph are; bisected in DESIGN.md section 9), so it is not used where streams overlap.
+        # and the non-overlapped graph are; bisected in DESIGN.md section 9), and aggregating on the main stream
+        # instead (OutputBlock.aggregate) puts 5 x ~30 us on the critical path that the side stream used to hide
+        # (3.14 -> 3.25 ms per step, measured).
         self.fuse_aggregate = True
 
     def get_mlp(self, units, nHidden, activation):
@@ -193,7 +195,7 @@ class OutputBlock(AtomUpdateBlock):
         self.output_init = output_init
         self.direct_forces = direct_forces
         self.dense_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
-        self.fuse_aggregate = False
+        self.fuse_aggregate = False    # see AtomUpdateBlock.__init__
         self.seq_energy = self.layers  # alias (reference atom_update_block.py:130)
         self.out_energy = Dense(emb_size_atom, num_targets, bias=False, activation=None)
         if self.direct_forces:
@@ -214,8 +216,13 @@ class OutputBlock(AtomUpdateBlock):
         else:
             raise UserWarning(f"Unknown output_init: {self.output_init}")
 
-    def forward(self, h, m, rbf, id_a):
-        x_E, x = self._aggregate(m, rbf, id_a, want_x=self.direct_forces)
+    def aggregate(self, m, rbf, id_a):
+        """The edge -> atom part of forward() (atom_update_block.py:160-166), callable ahead of the rest."""
+        return self._aggregate(m, rbf, id_a, want_x=self.direct_forces)
+
+    def forward(self, h, m, rbf, id_a, agg=None):
+        """`agg`: the result of `aggregate(m, rbf, id_a)` when the caller computed it already (on another stream)."""
+        x_E, x = agg if agg is not None else self._aggregate(m, rbf, id_a, want_x=self.direct_forces)
         if self._stackable(self.seq_energy):
             x_E = self._mlp_stack(x_E, self.seq_energy)
         else:

@@ -1,6 +1,6 @@
 """Per-kernel HBM-side traffic from the two rocprofv3 PMC passes of tools/gpu_artifacts.sh (runs anywhere: pandas only).
 
-    python tools/pmc_summary.py gpurun_out/<tag>  ->  profiles/r1_final_pmc_traffic.txt, profiles/r1_traffic.json
+    python tools/pmc_summary.py gpurun_out/<tag> [r2]  ->  profiles/<round>_pmc_traffic.txt, profiles/<round>_traffic.json
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-reports wide coalesced reads by 2x, so
 bytes_per_launch = (2 * fetch_kb + write_kb) * 1024; WRITE_SIZE is taken at face value."""
@@ -8,6 +8,7 @@ import glob, json, os, re, sys
 import pandas as pd
 
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -37,10 +38,16 @@ head = """# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `
 # bytes_per_launch = (2 * fetch_kb + write_kb) * 1024.  WRITE_SIZE is uncalibrated for 4-byte strided stores (taken at face value).
 # The working set of this batch is Infinity-Cache resident: these are L2 memory-side requests, not DRAM bytes.
 """
-with open(os.path.join(root, "profiles", "r1_final_pmc_traffic.txt"), "w") as f:
+with open(os.path.join(root, "profiles", rnd + "_pmc_traffic.txt"), "w") as f:
     f.write(head + t.head(40).round(1).to_string() + "\n")
-fam = {"chain": [k for k in t.index if k.startswith("chain_kernel")],
-       "gemm": [k for k in t.index if k.startswith("gemm_")]}
+fam = {"chain": [k for k in t.index if k.startswith("chain_kernel") or k.startswith("chain_split_kernel")],
+       "gemm": [k for k in t.index if k.startswith("gemm_")],
+       "bil_fused_fwd": [k for k in t.index if k.startswith("bil_fused_fwd")],
+       "bil_project_bwd": [k for k in t.index if k.startswith("bil_project_bwd")],
+       "bil_dy_multi": [k for k in t.index if k.startswith("bil_dy_multi")],
+       "bil_reduce_t": [k for k in t.index if k.startswith("bil_reduce_t") or k.startswith("bil_expand")],
+       "bil_reduce_project": [k for k in t.index if k.startswith("bil_reduce_project")]}
+fam = {k: v for k, v in fam.items() if v}
 out = {}
 for name, ks in fam.items():
     sub = t.loc[ks]
@@ -49,8 +56,8 @@ for name, ks in fam.items():
                  "fetch_kb_raw": round(float((sub["fetch_kb"] * sub["n"]).sum() / n), 1),
                  "write_kb_raw": round(float((sub["write_kb"] * sub["n"]).sum() / n), 1),
                  "bytes_per_launch": int((sub["bytes_per_launch"] * sub["n"]).sum() / n),
-                 "source": "profiles/r1_final_pmc_traffic.txt"}
-with open(os.path.join(root, "profiles", "r1_traffic.json"), "w") as f:
+                 "source": "profiles/%s_pmc_traffic.txt" % rnd}
+with open(os.path.join(root, "profiles", rnd + "_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(t.head(16).round(1).to_string())
 print(json.dumps({k: v["bytes_per_launch"] for k, v in out.items()}))
