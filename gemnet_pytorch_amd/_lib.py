@@ -85,7 +85,7 @@ SIGNATURES = {
     "gn_bil_dy_multi_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gn_rbf_aggregate_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp],
-    "gn_rbf_aggregate_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp],
+    "gn_rbf_aggregate_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "gn_quad_angles_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_quad_angles_bwd_ld_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp],
     "gn_bil_reduce_project_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void rbf_aggregate_fwd_kernel(const float* __r
 //                 ds_bpermute per edge: 27 us per launch instead of 11)
 __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ m,
                                                                 const float* __restrict__ rbf, const float* __restrict__ W,
-                                                                const int32_t* __restrict__ id_a, float* __restrict__ g_m,
-                                                                float* __restrict__ g_rbf, int64_t E, float scale) {
+                                                                const int32_t* __restrict__ id_a, float* g_m, float* g_rbf,
+                                                                int64_t E, float scale, int accum) {
   __shared__ __attribute__((aligned(16))) float tsm[4][C];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int kq = lane & 15, part = lane >> 4;
@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __r
         r0 += w0[4 * q] * b.x + w0[4 * q + 1] * b.y + w0[4 * q + 2] * b.z + w0[4 * q + 3] * b.w;
         r1 += w1[4 * q] * b.x + w1[4 * q + 1] * b.y + w1[4 * q + 2] * b.z + w1[4 * q + 3] * b.w;
       }
-      *reinterpret_cast<float2*>(g_m + (size_t)e * C + 2 * lane) = make_float2(gx * r0, gy * r1);
+      float2 o = make_float2(gx * r0, gy * r1);
+      if (accum & 1) {   // running gradient of m (ops.accumulate_gradient): the same lane reads and rewrites its element
+        const float2 p = *reinterpret_cast<const float2*>(g_m + (size_t)e * C + 2 * lane);
+        o.x += p.x; o.y += p.y;
+      }
+      *reinterpret_cast<float2*>(g_m + (size_t)e * C + 2 * lane) = o;
     }
     if (g_rbf) {
       const float2 me = *reinterpret_cast<const float2*>(m + (size_t)e * C + 2 * lane);
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __r
       }
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (lane < R) g_rbf[(size_t)e * R + lane] = s;
+      if (lane < R) g_rbf[(size_t)e * R + lane] = (accum & 2) ? g_rbf[(size_t)e * R + lane] + s : s;
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();   // all lanes have read tsm before the next edge overwrites it
     }
@@ -134,12 +139,12 @@ extern "C" int gn_rbf_aggregate_fwd_f32(const float* m, const float* rbf, const 
 
 extern "C" int gn_rbf_aggregate_bwd_f32(const float* g_out, const float* m, const float* rbf, const float* W,
                                         const int32_t* id_a, float* g_m, float* g_rbf, int64_t E, int C_, int R_, float scale,
-                                        void* stream) {
+                                        int accum, void* stream) {
   if (C_ != C || R_ != R) return (int)hipErrorInvalidValue;
   if (E <= 0) return 0;
   const int64_t blocks = gn_cdiv(E, 4);
   hipLaunchKernelGGL(rbf_aggregate_bwd_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale);
+                     static_cast<hipStream_t>(stream), g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale, accum);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -34,8 +34,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifdef GN_CHAIN_TRACE
 // diagnosis build only (tools/chain2_trace.py): shader-clock stamps of wave 0 of two workgroups
 __device__ unsigned long long gn_chain2_trace_buf[2][GN_CHAIN_MAX_OPS][8];
-#define GN2_STAMP(i) do { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) \
-    gn_chain2_trace_buf[blockIdx.x == 100][oi][i] = clock64(); } while (0)
+#define GN2_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == GN_TRACE_WAVE) && blockIdx.x == 100) \
+    gn_chain2_trace_buf[wave != 0][oi][i] = clock64(); } while (0)
+#ifndef GN_TRACE_WAVE
+#define GN_TRACE_WAVE 7
+#endif
 #else
 #define GN2_STAMP(i) do { } while (0)
 #endif
@@ -288,6 +291,22 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       if (active) {
         const unsigned char* xb = smem + a_slot * SLOT + l15 * ROWB;   // row 16 t + l15: swizzle key = l15
         const int kc = (K + 31) >> 5;
+        // X fragments are double-buffered by hand: the reads of step (c, t) + 1 are issued before the MFMAs of step
+        // (c, t) — the compiler's own schedule waited on lgkmcnt(0) in front of every group of six MFMAs.
+        // The widest instance (adjoint programs at RT = 5) has no registers left for the third plane's second buffer:
+        // there the lo plane — used by one MFMA, issued last — is read at the top of its own step.
+        constexpr bool LATE_LO = ADJ && RT == 5 && NPL >= 3;
+        uint4 xf[2][3];
+        auto xload = [&](uint4 (&f)[3], int c, int t) {
+          const unsigned char* xp = xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4);
+          f[0] = *reinterpret_cast<const uint4*>(xp);
+          if (NPL >= 2) f[1] = *reinterpret_cast<const uint4*>(xp + PLANE);
+          if (NPL >= 3 && !LATE_LO) f[2] = *reinterpret_cast<const uint4*>(xp + 2 * PLANE);
+        };
+        xload(xf[0], 0, 0);
+#if defined(GN_EXP) && GN_EXP == 1
+        xload(xf[1], 0, 0);
+#endif
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           if (c < kc) {
@@ -297,17 +316,30 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
             if (NPL >= 3) wl = __builtin_bit_cast(bf16x8, bcur[c][NPL >= 3 ? 2 : 0]);
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-              const unsigned char* xp = xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4);
-              const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp));
+              const int cur = (c * RT + t) & 1;
+#if !defined(GN_EXP) || GN_EXP != 1
+              if (t + 1 < RT) xload(xf[cur ^ 1], c, t + 1);
+              else if (c + 1 < 4 && c + 1 < kc) xload(xf[cur ^ 1], c + 1, 0);
+#endif
+#if defined(GN_EXP) && GN_EXP == 2
+              { uint4 q = xf[cur][0]; for (int pl = 1; pl < NPL; ++pl) { q.x ^= xf[cur][pl].x; q.y ^= xf[cur][pl].y; q.z ^= xf[cur][pl].z; q.w ^= xf[cur][pl].w; }
+                a0[t][0] += __uint_as_float(q.x); a0[t][1] += __uint_as_float(q.y); a0[t][2] += __uint_as_float(q.z); a0[t][3] += __uint_as_float(q.w); }
+              continue;
+#endif
+              const bf16x8 xh = __builtin_bit_cast(bf16x8, xf[cur][0]);
               bf16x8 xm, xl;
-              if (NPL >= 2) xm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp + PLANE));
-              if (NPL >= 3) xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp + 2 * PLANE));
-              if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, a1[t], 0, 0, 0);
+              if (NPL >= 2) xm = __builtin_bit_cast(bf16x8, xf[cur][1]);
+              if (NPL >= 3 && !LATE_LO) xl = __builtin_bit_cast(bf16x8, xf[cur][2]);
+              if (LATE_LO)
+                xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                    xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4) + 2 * PLANE));
+              if (NPL >= 3 && !LATE_LO) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, a1[t], 0, 0, 0);
               a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, a0[t], 0, 0, 0);
               if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, a1[t], 0, 0, 0);
               if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, a1[t], 0, 0, 0);
               if (NPL >= 2) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, a1[t], 0, 0, 0);
               if (NPL >= 2) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, a1[t], 0, 0, 0);
+              if (LATE_LO) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, a1[t], 0, 0, 0);
             }
           }
         }

@@ -39,9 +39,11 @@ def _rowsize(t):
 
 def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_out=False,
          mul=None, alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
-         ridx=None, res2=None, beta2=1.0, cfg=-1):
+         ridx=None, res2=None, beta2=1.0, cfg=-1, out=None):
     """C = epilogue(opA(A) @ opB(B)); see gn_gemm_f32 in include/gemnet_hip.h.
-    trans_b=False means B is a torch Linear weight (N, K).  Returns C or (C, pre)."""
+    trans_b=False means B is a torch Linear weight (N, K).  Returns C or (C, pre).
+    `out`: write C there instead of into a new tensor; `out is res2` accumulates in place (every element is read and
+    rewritten by the same thread)."""
     require_device(A, B)
     if (trans_a and trans_b and cfg < 0 and a_dact_pre is None and not act and not pre_out and mul is None
             and res is None and res2 is None and gadd1 is None and gadd2 is None):
@@ -55,7 +57,9 @@ def gemm(A, B, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_
     N, Kb = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
     if K != Kb:
         raise ValueError(f"gemm shape mismatch: {tuple(A.shape)} ta={trans_a} x {tuple(B.shape)} tb={trans_b}")
-    C = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    if out is not None:
+        assert tuple(out.shape) == (M, N) and out.dtype == torch.float32 and out.is_contiguous()
+    C = out if out is not None else torch.empty((M, N), device=A.device, dtype=torch.float32)
     pre = torch.empty_like(C) if pre_out else None
     a = GemmArgs()
     a.A, a.B, a.C = ptr(A), ptr(B), ptr(C)
@@ -162,14 +166,18 @@ def rbf_aggregate_fwd(m, rbf, W, perm, seg_off, n_atoms, scale):
     return out
 
 
-def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=True):
-    """-> (g_m (E,C) or None, g_rbf (E,R) or None) (gn_rbf_aggregate_bwd_f32)."""
+def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=True, acc_m=None, acc_rbf=None):
+    """-> (g_m (E,C) or None, g_rbf (E,R) or None) (gn_rbf_aggregate_bwd_f32).  acc_m / acc_rbf: running gradients
+    the contribution is ADDED to in the same pass (and which are returned) instead of new tensors."""
     require_device(g_out, m, rbf, W)
     g_out, m, rbf, W = _f32c(g_out), _f32c(m), _f32c(rbf), _f32c(W)
-    g_m = torch.empty_like(m) if want_m else None
-    g_rbf = torch.empty_like(rbf) if want_rbf else None
+    for t, like in ((acc_m, m), (acc_rbf, rbf)):
+        assert t is None or (t.shape == like.shape and t.dtype == torch.float32 and t.is_contiguous())
+    g_m = acc_m if acc_m is not None else (torch.empty_like(m) if want_m else None)
+    g_rbf = acc_rbf if acc_rbf is not None else (torch.empty_like(rbf) if want_rbf else None)
+    accum = (1 if acc_m is not None else 0) | (2 if acc_rbf is not None else 0)
     check(_lib.load().gn_rbf_aggregate_bwd_f32(ptr(g_out), ptr(m), ptr(rbf), ptr(W), ptr(id_a32), ptr(g_m), ptr(g_rbf),
-                                               m.shape[0], m.shape[1], rbf.shape[1], float(scale), stream()),
+                                               m.shape[0], m.shape[1], rbf.shape[1], float(scale), accum, stream()),
           "gn_rbf_aggregate_bwd_f32")
     return g_m, g_rbf
 

@@ -212,17 +212,19 @@ class GemNet(torch.nn.Module):
             sbf4 = (rad3, ops.ylm(Phi_cab, Theta_cabd, self.num_spherical))  # ((E,S,R), (Q,S^2))
 
         h = self.atom_emb(plan.z_rows)
+        rbf = ops.accumulate_gradient(rbf)
         m = self.edge_emb(h, rbf, plan.id_c, plan.id_a)
 
         if not T:
-            rbf4 = self.mlp_rbf4(rbf)
+            rbf4 = ops.accumulate_gradient(self.mlp_rbf4(rbf))
             cbf4 = self.mlp_cbf4(cbf4)
             sbf4 = (self.mlp_sbf4(sbf4[0]), sbf4[1])
         else:
             rbf4 = cbf4 = sbf4 = None
-        rbf3 = self.mlp_rbf3(rbf)
+        # radial projections shared by all blocks: their gradients are summed inside the consumers' backward kernels
+        rbf3 = ops.accumulate_gradient(self.mlp_rbf3(rbf))
         cbf3 = (self.mlp_cbf3(rad3), sph3)
-        rbf_h = self.mlp_rbf_h(rbf)
+        rbf_h = ops.accumulate_gradient(self.mlp_rbf_h(rbf))
         rbf_out = self.mlp_rbf_out(rbf)
 
         # OutputBlock i only feeds the final energy sum: it runs on a side stream, concurrently with
@@ -232,22 +234,36 @@ class GemNet(torch.nn.Module):
         side = self._side_stream(R.device) if self.overlap_output_blocks and R.is_cuda else None
         outs = []
 
-        def out_block(i, h, m):
+        def ready():
+            """Event on the main stream: (h, m) of this point exist.  None without a side stream."""
+            if side is None:
+                return None
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            return ev
+
+        def out_block(i, h, m, ev):
             if side is None:
                 outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a))
                 return
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
+            side.wait_event(ev)
             with torch.cuda.stream(side):
                 for t in (h, m, rbf_out):
                     t.record_stream(side)
                 outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a))
 
-        out_block(0, h, m)
+        # OutputBlock i is ISSUED after InteractionBlock i (it only waits for the event recorded before it): in a
+        # captured hipGraph the first-captured successor of a fork keeps the queue, and with the output block issued
+        # first the main chain changed queues at every block (10-17 us idle per hop, tools/timeline.py); the later
+        # issue also gives the output block the higher autograd sequence number, so its backward is enqueued (on the
+        # side stream) before the backward of the interaction block that needs its contribution to dE/dm.
         for i in range(self.num_blocks):
+            ev = ready()
+            h_i, m_i = h, m
             h, m = self.int_blocks[i](h=h, m=m, rbf4=rbf4, cbf4=cbf4, sbf4=sbf4, rbf3=rbf3, cbf3=cbf3,
                                       rbf_h=rbf_h, plan=plan)
-            out_block(i + 1, h, m)
+            out_block(i, h_i, m_i, ev)
+        out_block(self.num_blocks, h, m, ready())
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         E_a, F_ca = outs[0]

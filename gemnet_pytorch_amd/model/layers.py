@@ -16,6 +16,7 @@ Reference counterparts (file:line under /root/reference/gemnet/model/layers):
   TripletInteraction/QuadrupletInteraction/InteractionBlock(TripletsOnly)  interaction_block.py:11-696
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -125,12 +126,8 @@ class AtomUpdateBlock(torch.nn.Module):
         self.dense_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
         self.scale_sum = ScalingFactor(scale_file=scale_file, name=name + "_sum")
         self.layers = self.get_mlp(emb_size_atom, nHidden, activation)
-        # one-pass Dense(rbf) (.) m -> atom sum (csrc/aggregate.hip).  On for the AtomUpdateBlocks of the interaction
-        # blocks; OutputBlocks keep the GEMM + segmented-sum form while they run on the side stream: with the fused
-        # kernel there, hipGraph replays of the overlapped step stopped being bit-reproducible on MI355X (eager runs
-        # and the non-overlapped graph are; bisected in DESIGN.md section 9), and aggregating on the main stream
-        # instead (OutputBlock.aggregate) puts 5 x ~30 us on the critical path that the side stream used to hide
-        # (3.14 -> 3.25 ms per step, measured).
+        # one-pass Dense(rbf) (.) m -> atom sum (csrc/aggregate.hip); GEMNET_OUT_FUSE=0 keeps the GEMM + segmented-sum
+        # form in the OutputBlocks (the A/B switch of DESIGN.md section 9)
         self.fuse_aggregate = True
 
     def get_mlp(self, units, nHidden, activation):
@@ -195,7 +192,7 @@ class OutputBlock(AtomUpdateBlock):
         self.output_init = output_init
         self.direct_forces = direct_forces
         self.dense_rbf = Dense(emb_size_rbf, emb_size_edge, activation=None, bias=False)
-        self.fuse_aggregate = False    # see AtomUpdateBlock.__init__
+        self.fuse_aggregate = os.environ.get("GEMNET_OUT_FUSE", "1") == "1"    # see AtomUpdateBlock.__init__
         self.seq_energy = self.layers  # alias (reference atom_update_block.py:130)
         self.out_energy = Dense(emb_size_atom, num_targets, bias=False, activation=None)
         if self.direct_forces:
@@ -268,11 +265,14 @@ class EfficientInteractionDownProjection(torch.nn.Module):
         else:
             assert L * L == S, "tensor basis expects num_spherical**2 weight slots"
             sizes = [2 * l + 1 for l in range(L)]
-        blocks, start = [], 0
-        for n in sizes:  # rows (r) x cols (slot-in-l, i)
-            blocks.append(self.weight[start:start + n].permute(1, 0, 2).reshape(R, n * I))
-            start += n
-        Wbd = torch.block_diag(*blocks)                               # (L*R, S*I)
+        def make(W=self.weight):
+            blocks, start = [], 0
+            for n in sizes:  # rows (r) x cols (slot-in-l, i)
+                blocks.append(W[start:start + n].permute(1, 0, 2).reshape(R, n * I))
+                start += n
+            return torch.block_diag(*blocks)                          # (L*R, S*I)
+        # frozen weight (inference): the block-diagonal form is built once, not with 2 S + 1 small launches per step
+        Wbd = make() if self.weight.requires_grad else ops.cached_form("bd", self.weight, lambda: make(self.weight.detach()))
         out = ops.mm(rad.reshape(-1, L * R), Wbd, False, True)        # (E, S*I)
         return out.reshape(-1, S, I)
 
@@ -403,14 +403,32 @@ class TripletInteraction(torch.nn.Module):
                 and all(d.bias is None and d.weight.shape[0] <= 128 and d.weight.shape[1] <= 128
                         and d.weight.shape[1] % 16 == 0 for d in ws) and not self.mlp_rbf.act)
 
-    def forward(self, m, rbf3, cbf3, plan):
+    def _pair_ok(self):
+        ups = (self.up_projection_ca, self.up_projection_ac)
+        return all(d.bias is None and d.weight.shape[0] % 16 == 0 and d.weight.shape[0] <= 128
+                   and d.weight.shape[1] % 4 == 0 and d.weight.shape[1] <= 128 for d in ups) \
+            and self.up_projection_ca.act == self.up_projection_ac.act
+
+    def forward(self, m, rbf3, cbf3, plan, pair=False):
+        """`pair`: return the two up projections as ops.SwappedPair (y_ca, y_ac, id_swap) instead of
+        x3 = (y_ca + y_ac[id_swap]) / sqrt2 — the caller's stack adds them in its first epilogue."""
         rbf_W1, sph = cbf3
         if self._head_ok():  # dense_ba, radial Hadamard, down projection: one LDS-resident launch
             x_ba = ops.dense_hadamard_down(m, rbf3, self.dense_ba.weight, self.mlp_rbf.weight,
                                            self.down_projection.weight, self.dense_ba.act,
                                            self.down_projection.act, self.scale_rbf.value())
             x = self.mlp_cbf(rbf_W1, sph, x_ba, plan.trip, alpha=self.scale_cbf_sum.value())
-            return self.up_projection_ca(x, res=self.up_projection_ac(x), res_rows=plan.id_swap, beta=INV_SQRT_2)
+            if pair and self._pair_ok() and plan.id_swap.inverse is not None:
+                # both up projections in one launch (and one adjoint launch); the swap gather and the sum move into
+                # the epilogue of the stack that consumes them
+                y_ac, y_ca = ops.up_project_pair(x, self.up_projection_ac.weight, self.up_projection_ca.weight,
+                                                 plan.id_swap, self.up_projection_ca.act, INV_SQRT_2)
+                return ops.SwappedPair(y_ca, y_ac, plan.id_swap)
+            x = ops.accumulate_gradient(x)
+            # (up_ca(x) + up_ac(x)[id_swap]) / sqrt2 with the factor on both activations (alpha): the adjoint of the
+            # swapped term is then a pure row gather of the incoming gradient, no scaling pass
+            return self.up_projection_ca(x, alpha=INV_SQRT_2, res=self.up_projection_ac(x, alpha=INV_SQRT_2),
+                                         res_rows=plan.id_swap)
         x_ba = self.dense_ba(m)
         if ops.is_fused() or not AutomaticFit.fitting_mode:
             x_ba = self.mlp_rbf(rbf3, mul=x_ba, alpha=self.scale_rbf.value())
@@ -456,8 +474,9 @@ class QuadrupletInteraction(torch.nn.Module):
                                            self.down_projection.act, self.scale_rbf.value())
             x_db = ops.gather_rows(x_db, plan.intm_db)
             x_db = self.mlp_cbf(cbf, mul=x_db, alpha=self.scale_cbf.value())
-            x = self.mlp_sbf(rbf_W1, sph, x_db, plan.quad, alpha=self.scale_sbf_sum.value())
-            return self.up_projection_ca(x, res=self.up_projection_ac(x), res_rows=plan.id_swap, beta=INV_SQRT_2)
+            x = ops.accumulate_gradient(self.mlp_sbf(rbf_W1, sph, x_db, plan.quad, alpha=self.scale_sbf_sum.value()))
+            return self.up_projection_ca(x, alpha=INV_SQRT_2, res=self.up_projection_ac(x, alpha=INV_SQRT_2),
+                                         res_rows=plan.id_swap)
         x_db = self.dense_db(m)
         if ops.is_fused() or not AutomaticFit.fitting_mode:
             x_db = self.mlp_rbf(rbf, mul=x_db, alpha=self.scale_rbf.value())
@@ -511,14 +530,17 @@ class _InteractionBase(torch.nn.Module):
         {dense_ca(+x3[,x4]) -> residuals before skip (+m) -> residuals after skip} and
         {concat-Dense (atom terms gathered in its epilogue) -> residual_m (+m)}."""
         first = dict(W=self.dense_ca.weight, act=self.dense_ca.act)
-        if x4 is None:
+        if isinstance(x3, ops.SwappedPair):   # (dense_ca(m) + y_ca + y_ac[id_swap]) / sqrt2, one gradient for the pair
+            first.update(res=x3.y_ac, res_rows=x3.swap, beta=1.0, res2=x3.y_ca, beta2=INV_SQRT_2, tied=True)
+        elif x4 is None:
             first.update(res=x3, beta=INV_SQRT_2)
         else:
             first.update(res=x3, beta=1.0, res2=x4, beta2=INV_SQRT_3)
         layers = [l.as_stack_layer() for l in self.layers_before_skip]
         layers[-1].update(skip=m, skip_beta=INV_SQRT_2)
         layers += [l.as_stack_layer() for l in self.layers_after_skip]
-        m = ops.stack(m, first=first, layers=layers, s=INV_SQRT_2)
+        # consumed by the atom update's aggregation and by the second stack: one running gradient (ops.accumulate_gradient)
+        m = ops.accumulate_gradient(ops.stack(m, first=first, layers=layers, s=INV_SQRT_2))
         A = self.concat_layer.atom_features
         W = self.concat_layer.dense.weight
         if self.atom_update._stackable(self.atom_update.layers):
@@ -560,7 +582,8 @@ class InteractionBlockTripletsOnly(_InteractionBase):
                            num_concat, num_atom, activation, scale_file, block_nr)
 
     def forward(self, h, m, rbf3, cbf3, rbf_h, plan, **kwargs):
-        x3 = self.trip_interaction(m, rbf3, cbf3, plan)
+        m = ops.accumulate_gradient(m)   # dense_ca stack + the interaction heads (+ the output block, through autograd)
+        x3 = self.trip_interaction(m, rbf3, cbf3, plan, pair=self._stack_ok())
         if self._stack_ok():
             return self._update_stacked(h, m, x3, None, rbf_h, plan)
         x = self.dense_ca(m, res=x3, beta=INV_SQRT_2)
@@ -587,6 +610,7 @@ class InteractionBlock(_InteractionBase):
                            num_concat, num_atom, activation, scale_file, block_nr)
 
     def forward(self, h, m, rbf4, cbf4, sbf4, rbf3, cbf3, rbf_h, plan, **kwargs):
+        m = ops.accumulate_gradient(m)
         x4 = self.quad_interaction(m, rbf4, cbf4, sbf4, plan)
         x3 = self.trip_interaction(m, rbf3, cbf3, plan)
         if self._stack_ok():

@@ -445,6 +445,11 @@ def _cached(key, version, make):
     return val
 
 
+def cached_form(tag, W, make):
+    """A derived form of the frozen weight W, cached on its address and version inside `weight_cache`."""
+    return _cached((tag, W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version, make)
+
+
 def transposed(W):
     """W^T contiguous, so backward GEMMs also run the k-contiguous ("NT") pipelined kernel.  Cached
     for frozen weights (inference); recomputed per call for trainable ones."""
@@ -460,6 +465,7 @@ class _FusedDense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, mul, res, res2, g1, g2, cfg):
         act, alpha, beta, beta2, res_rows, i1, i2 = cfg
+        ctx.acc = _acc_join(x)
         need_z = act or mul is not None
         if not W.requires_grad and (W.stride(0) % 4 or W.data_ptr() % 16) and W.shape[1] % 4 == 0:
             W = contiguous_weight(W)   # column slice of a wider frozen matrix (edge embedding): copied once, not per call
@@ -492,7 +498,7 @@ class _FusedDense(torch.autograd.Function):
         if has_res:
             c *= beta
             if need[3]:
-                t = g * c
+                t = g * c if c != 1.0 else g
                 if res_rows is None:
                     gres = t
                 elif res_rows.inverse is not None:
@@ -503,10 +509,18 @@ class _FusedDense(torch.autograd.Function):
         want_w = need[1] and _PARAM_GRADS and x is not None
         want_gmul = has_mul and need[2]
         explicit = has_mul or want_w or (has_g1 and need[5]) or (has_g2 and need[6])
+        acc = ctx.acc
+        out = prev = None
+        last = True
+        if acc is not None:
+            if need[0]:
+                out, prev, last = acc.target((g.shape[0], W.shape[1]), g)
+            else:
+                gx = acc.skip()
         if explicit:
             dz, gmul = K.dact_mul(g, z, act, mul, c, want_gmul=want_gmul)
             if need[0]:
-                gx = K.gemm(dz, transposed(W))
+                gx = K.gemm(dz, transposed(W), res2=prev, out=out)
             if has_g1 and need[5]:
                 gg1 = K.segsum(dz, *i1.csr, i1.n_rows)
             if has_g2 and need[6]:
@@ -514,7 +528,9 @@ class _FusedDense(torch.autograd.Function):
             if want_w:
                 gW = K.gemm(dz, x, True, True)          # dz^T @ x  (N, K)
         elif need[0]:
-            gx = K.gemm(g, transposed(W), a_dact_pre=z if act else None, alpha=c)
+            gx = K.gemm(g, transposed(W), a_dact_pre=z if act else None, alpha=c, res2=prev, out=out)
+        if not last:
+            gx = None
         return gx, gW, gmul, gres, gres2, gg1, gg2, None
 
 
@@ -555,6 +571,7 @@ class _RbfAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, rbf, W, ri, scale):
         perm, seg = ri.csr
+        ctx.acc_m, ctx.acc_rbf = _acc_join(m), _acc_join(rbf)
         ctx.save_for_backward(m, rbf, W)
         ctx.ri, ctx.scale = ri, scale
         return K.rbf_aggregate_fwd(m, rbf, W, perm, seg, ri.n_rows, scale)
@@ -564,8 +581,17 @@ class _RbfAggregate(torch.autograd.Function):
     def backward(ctx, g):
         m, rbf, W = ctx.saved_tensors
         need = ctx.needs_input_grad
-        g_m, g_rbf = K.rbf_aggregate_bwd(g.contiguous(), m, rbf, W, ctx.ri.idx32, ctx.scale, want_m=need[0], want_rbf=need[1])
-        return g_m, g_rbf, None, None, None
+        acc_m, acc_r = ctx.acc_m, ctx.acc_rbf
+        prev_m, last_m = acc_m.enter() if acc_m is not None else (None, True)
+        prev_r, last_r = acc_r.enter() if acc_r is not None else (None, True)
+        g_m, g_rbf = K.rbf_aggregate_bwd(g.contiguous(), m, rbf, W, ctx.ri.idx32, ctx.scale,
+                                         want_m=need[0] or acc_m is not None, want_rbf=need[1] or acc_r is not None,
+                                         acc_m=prev_m, acc_rbf=prev_r)
+        if acc_m is not None:
+            acc_m.leave(g_m, last_m)
+        if acc_r is not None:
+            acc_r.leave(g_rbf, last_r)
+        return g_m if last_m else None, g_rbf if last_r else None, None, None, None
 
 
 def rbf_aggregate(m, rbf, W, ri, scale):
@@ -590,6 +616,7 @@ class GradSink:
         self.left = 0       # consumers whose backward has not run yet in the CURRENT backward pass
         self.buf = None
         self.pending = []   # (dSm_b, x_b) of the consumers whose Y gradient is deferred to one combined pass
+        self.stream = None  # accumulate_gradient: HIP stream of the participating consumers
 
     def arrive(self):
         """Called once per consumer backward; returns True for the last consumer of this pass."""
@@ -597,8 +624,41 @@ class GradSink:
             self.left = self.consumers
             self.buf = None
             self.pending = []
+            # the sum only reaches autograd through the LAST consumer: a pass that prunes one of them (a gradient
+            # of something that does not depend on every consumer) must fail loudly, not return a partial sum
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
         self.left -= 1
         return self.left == 0
+
+    def _end_of_pass(self):
+        if self.left != 0:
+            missing, self.left, self.buf, self.pending = self.left, 0, None, []
+            raise RuntimeError(
+                f"shared-gradient accumulation: {missing} of {self.consumers} fused consumers did not run in this "
+                "backward pass, the gradient would be incomplete; set GEMNET_GRAD_ACC=0 for such graphs")
+
+    def target(self, shape, like):
+        """-> (out, prev, last): the tensor this consumer's kernel writes, the running sum it must add in the same
+        kernel (None for the first consumer of the pass; `out is prev` otherwise: in place, element by element) and
+        whether this consumer hands the sum to autograd."""
+        prev, last = self.enter()
+        out = prev if prev is not None else torch.empty(shape, device=like.device, dtype=like.dtype)
+        self.leave(out, last)
+        return out, prev, last
+
+    def enter(self):
+        """-> (running sum so far or None, is this the last consumer of the pass); pair with `leave`."""
+        last = self.arrive()
+        return self.buf, last
+
+    def leave(self, out, last):
+        self.buf = None if last else out
+
+    def skip(self):
+        """A consumer that has no contribution in this pass (undefined incoming gradient)."""
+        last = self.arrive()
+        out, self.buf = self.buf, (None if last else self.buf)
+        return out if last else None
 
 
 def share_gradient(t):
@@ -606,6 +666,33 @@ def share_gradient(t):
     if t.requires_grad and _FUSED:
         t._gn_sink = GradSink()
     return t
+
+
+USE_GRAD_ACC = os.environ.get("GEMNET_GRAD_ACC", "1") == "1"
+
+
+def accumulate_gradient(t):
+    """Mark the activation `t` as consumed by several fused ops: each of them adds its gradient contribution to the
+    running sum inside its own backward kernel (residual input of the last GEMM / an accumulate flag) and the last one
+    returns the sum, so the autograd engine never launches its own elementwise adds (32 per forward+force step of the
+    4-block model, 4-6 us each: tools/exp/grad_fanin.py, tools/exp/aten_ops.py).  Consumers on another HIP stream than
+    the first one (the output blocks) do not take part: their gradient reaches `t` through autograd as before."""
+    if _FUSED and USE_GRAD_ACC and t.requires_grad and not hasattr(t, "_gn_acc"):
+        t._gn_acc = GradSink()
+        t._gn_acc.stream = torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+    return t
+
+
+def _acc_join(t):
+    """Forward side of `accumulate_gradient`: register the calling fused op as a consumer of `t`."""
+    acc = getattr(t, "_gn_acc", None)
+    if acc is None:
+        return None
+    st = torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+    if acc.stream != st:
+        return None
+    acc.consumers += 1
+    return acc
 
 
 class _FusedBilinear(torch.autograd.Function):
@@ -826,6 +913,7 @@ class _Stack(torch.autograd.Function):
         first, layers, s = spec["first"], spec["layers"], spec["s"]
         M = x.shape[0]
         dev, dt = x.device, x.dtype
+        ctx.acc = _acc_join(x)
         prog = K.ChainProgram(M)
         x = x.contiguous()
         prog.load(0, x)
@@ -837,11 +925,12 @@ class _Stack(torch.autograd.Function):
         if first is not None:
             W0 = contiguous_weight(first["W"])
             z0 = torch.empty((M, W0.shape[0]), device=dev, dtype=dt) if first["act"] else None
+            rr = first.get("res_rows")
             _gemm(prog, first["W"], a_slot=0, y_slot=1, act=first["act"],
                       gadd1=g1, gidx1=None if g1 is None else first["i1"].idx32,
                       gadd2=g2, gidx2=None if g2 is None else first["i2"].idx32,
-                      pre_out=z0, res=res, beta=first["beta"], res2=res2, beta2=first["beta2"],
-                      out=None if layers else y)
+                      pre_out=z0, res=res, res_rows=None if rr is None else rr.idx32, beta=first["beta"],
+                      res2=res2, beta2=first["beta2"], out=None if layers else y)
             zs.append(z0)
             cur, oth = 1, 0
             width = W0.shape[0]
@@ -886,8 +975,9 @@ class _Stack(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         zs = [saved.pop(0) if m else None for m in ctx.z_mask]
         live = [t for t in (g, *g_tails) if t is not None]
+        acc = ctx.acc
         if not live:
-            return (None,) * (6 + len(layers))
+            return (None, acc.skip() if acc is not None else None) + (None,) * (4 + len(layers))
         M, width = ctx.out_shape
         dev, dt = live[0].device, live[0].dtype
         if g is None:
@@ -934,7 +1024,8 @@ class _Stack(torch.autograd.Function):
                     c *= first["beta2"]
             if has_res:
                 c *= first["beta"]
-                if need[2]:
+                # tied residuals (up_project_pair): res2 + res[rows] with ONE gradient, handed over as dL/d res2
+                if need[2] and not first.get("tied"):
                     g_res = torch.empty((M, width), device=dev, dtype=dt)
                     prog.scale(cur, cur, c, out=g_res, width=width)
                     c = 1.0
@@ -945,11 +1036,21 @@ class _Stack(torch.autograd.Function):
                 # into the other slot: the producing GEMM then emits it as its second output (K.fuse_program)
                 prog.scale(oth, cur, c, Z=z0, out=dz0, width=width)
                 src = oth
+            last = True
             if need[1]:
-                gx = torch.empty((M, ctx.in_width), device=dev, dtype=dt)
+                prev = None
+                if acc is not None:   # running gradient of x: added in this GEMM's epilogue, in place
+                    gx, prev, last = acc.target((M, ctx.in_width), g)
+                else:
+                    gx = torch.empty((M, ctx.in_width), device=dev, dtype=dt)
                 parked = park >= 0 and has_skips[park] and need[6 + park]
-                _gemm(prog, first["W"], trans=True, a_slot=src, y_slot=-1, out=gx, res=2 if parked else None, beta=1.0)
+                _gemm(prog, first["W"], trans=True, a_slot=src, y_slot=-1, out=gx, res=2 if parked else None, beta=1.0,
+                      res2=prev, beta2=1.0)
+            elif acc is not None:
+                gx = acc.skip()
             K.chain(K.fuse_program(prog))
+            if not last:
+                gx = None
             if has_g1 and need[4]:
                 gg1 = K.segsum(dz0, *first["i1"].csr, first["i1"].n_rows)
             if has_g2 and need[5]:
@@ -958,6 +1059,13 @@ class _Stack(torch.autograd.Function):
             gx = torch.empty((M, width), device=dev, dtype=dt)
             prog.store(cur, gx)
             K.chain(K.fuse_program(prog))
+            if acc is not None:
+                prev, last = acc.enter()
+                if prev is not None:
+                    gx = prev.add_(gx)
+                acc.leave(gx, last)
+                if not last:
+                    gx = None
         return (None, gx, g_res, g_res2, gg1, gg2) + tuple(g_skips)
 
 
@@ -971,7 +1079,11 @@ def stack(x, first=None, layers=(), s=0.7071067811865475, tails=()):
     res = res2 = g1 = g2 = None
     if first is not None:
         spec["first"] = dict(W=first["W"], act=bool(first.get("act", False)), beta=float(first.get("beta", 1.0)),
-                             beta2=float(first.get("beta2", 1.0)), i1=first.get("i1"), i2=first.get("i2"))
+                             beta2=float(first.get("beta2", 1.0)), i1=first.get("i1"), i2=first.get("i2"),
+                             res_rows=first.get("res_rows"), tied=bool(first.get("tied", False)))
+        if spec["first"]["res_rows"] is not None:
+            # the row-gathered residual exists for the pair form only: its gradient is the one of res2 (see _UpPair)
+            assert spec["first"]["tied"] and spec["first"]["beta"] == 1.0 and first.get("res2") is not None
         res, res2, g1, g2 = first.get("res"), first.get("res2"), first.get("g1"), first.get("g2")
     skips = [L.get("skip") for L in layers]
     spec["skip_is_x"] = next((k for k, sk in enumerate(skips) if sk is x), -1)
@@ -988,6 +1100,7 @@ class _DenseHadamardDown(torch.autograd.Function):
         act_a, act_d, alpha = cfg
         M = x.shape[0]
         dev, dt = x.device, x.dtype
+        ctx.acc_x, ctx.acc_rbf = _acc_join(x), _acc_join(rbf)
         x, rbf = x.contiguous(), rbf.contiguous()
         Wa_c, Wr_c, Wd_c = contiguous_weight(Wa), contiguous_weight(Wr), contiguous_weight(Wd)
         z1 = torch.empty((M, Wa_c.shape[0]), device=dev, dtype=dt)
@@ -1014,8 +1127,17 @@ class _DenseHadamardDown(torch.autograd.Function):
         M, dev, dt = g.shape[0], g.device, g.dtype
         g = g.contiguous()
         nd, nh = Wd.shape[0], Wa.shape[0]
-        gx = torch.empty((M, Wa.shape[1]), device=dev, dtype=dt) if need[0] else None
-        grbf = torch.empty((M, Wr.shape[1]), device=dev, dtype=dt) if need[1] else None
+        # running gradients of x / rbf (ops.accumulate_gradient): joined in the epilogue of the GEMM that produces ours
+        px = pr = None
+        last_x = last_r = True
+        if ctx.acc_x is not None and need[0]:
+            gx, px, last_x = ctx.acc_x.target((M, Wa.shape[1]), g)
+        else:
+            gx = torch.empty((M, Wa.shape[1]), device=dev, dtype=dt) if need[0] else None
+        if ctx.acc_rbf is not None and need[1]:
+            grbf, pr, last_r = ctx.acc_rbf.target((M, Wr.shape[1]), g)
+        else:
+            grbf = torch.empty((M, Wr.shape[1]), device=dev, dtype=dt) if need[1] else None
         prog = K.ChainProgram(M)
         prog.load(0, g)
         if act_d:
@@ -1025,23 +1147,93 @@ class _DenseHadamardDown(torch.autograd.Function):
             # d r = dh * x_a * alpha with x_a = act(z1) recomputed (second output, taken before the `mul` stage, slot 0)
             _gemm(prog, Wd, trans=True, a_slot=0, y_slot=1, mul=r, mul_mode=1, alpha=alpha,
                   y2=0, y2_src=1, alpha2=alpha, Z2=z1, mode2=2 if act_a else 1)
-            _gemm(prog, Wr, trans=True, a_slot=0, y_slot=-1, out=grbf)           # d rbf = d r @ Wr
+            _gemm(prog, Wr, trans=True, a_slot=0, y_slot=-1, out=grbf, res=pr, beta=1.0)   # d rbf = d r @ Wr
             if act_a:
                 prog.scale(1, 1, 1.0, Z=z1, width=nh, mode=0)                    # dz1
-            _gemm(prog, Wa, trans=True, a_slot=1, y_slot=-1, out=gx)
+            _gemm(prog, Wa, trans=True, a_slot=1, y_slot=-1, out=gx, res=px, beta=1.0)
         else:
             _gemm(prog, Wd, trans=True, a_slot=0, y_slot=1)                      # d(hadamard) in slot 1
             if need[1]:
                 # d r = dh * x_a * alpha, x_a = act(z1) recomputed;  d rbf = d r @ Wr
                 prog.scale(0, 1, alpha, Z=z1, width=nh, mode=2 if act_a else 1)
-                _gemm(prog, Wr, trans=True, a_slot=0, y_slot=-1, out=grbf)
+                _gemm(prog, Wr, trans=True, a_slot=0, y_slot=-1, out=grbf, res=pr, beta=1.0)
             if need[0]:
                 prog.scale(1, 1, alpha, Z=r, width=nh, mode=1)                   # d x_a = dh * r * alpha
                 if act_a:
                     prog.scale(1, 1, 1.0, Z=z1, width=nh, mode=0)                # dz1
-                _gemm(prog, Wa, trans=True, a_slot=1, y_slot=-1, out=gx)
+                _gemm(prog, Wa, trans=True, a_slot=1, y_slot=-1, out=gx, res=px, beta=1.0)
         K.chain(K.fuse_program(prog))
-        return gx, grbf, None, None, None, None
+        return gx if last_x else None, grbf if last_r else None, None, None, None, None
+
+
+class _UpPair(torch.autograd.Function):
+    """(y_ac, y_ca) = (act(x W_ac^T), act(x W_ca^T)) * alpha, both up projections of the interaction tail
+    (interaction_block.py:696-705) in ONE launch.  The reference then forms x3 = (y_ca + y_ac[id_swap]) / sqrt2; here the
+    pair is consumed by the next stack as two residuals (`tied`: the swapped one gathered in its epilogue), and that
+    stack returns the ONE gradient G of their sum as dL/dy_ca.  The adjoint is one launch as well:
+        dL/dx = (G[swap^-1] (.) act'(z_ac)) W_ac + (G (.) act'(z_ca)) W_ca
+    with the inverse-permutation gather folded into the tile load.  Constant weights (force pass)."""
+
+    @staticmethod
+    def forward(ctx, x, W_ac, W_ca, swap, act, alpha):
+        M = x.shape[0]
+        dev, dt = x.device, x.dtype
+        ctx.acc = _acc_join(x)
+        x = x.contiguous()
+        N = W_ac.shape[0]
+        z_ac = torch.empty((M, N), device=dev, dtype=dt) if act else None
+        z_ca = torch.empty((M, N), device=dev, dtype=dt) if act else None
+        y_ac = torch.empty((M, N), device=dev, dtype=dt)
+        y_ca = torch.empty((M, N), device=dev, dtype=dt)
+        prog = K.ChainProgram(M)
+        prog.load(0, x)
+        _gemm(prog, W_ac, a_slot=0, y_slot=-1, act=act, alpha=alpha, pre_out=z_ac, out=y_ac)
+        _gemm(prog, W_ca, a_slot=0, y_slot=-1, act=act, alpha=alpha, pre_out=z_ca, out=y_ca)
+        K.chain(prog)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z_ac, z_ca, W_ac, W_ca)
+        ctx.swap, ctx.act, ctx.alpha, ctx.width = swap, act, alpha, x.shape[1]
+        return y_ac, y_ca
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_ac, g_ca):
+        if g_ac is not None:
+            raise RuntimeError("up_project_pair: y_ac may only be consumed together with y_ca as a tied residual pair")
+        acc = ctx.acc
+        if g_ca is None or not ctx.needs_input_grad[0]:
+            return (acc.skip() if acc is not None else None), None, None, None, None, None
+        z_ac, z_ca, W_ac, W_ca = ctx.saved_tensors
+        G = g_ca.contiguous()
+        M = G.shape[0]
+        if acc is not None:
+            gx, prev, last = acc.target((M, ctx.width), G)
+        else:
+            gx, prev, last = torch.empty((M, ctx.width), device=G.device, dtype=G.dtype), None, True
+        inv = ctx.swap.inverse if ctx.swap.inverse is not None else None
+        assert inv is not None, "id_swap is a permutation"
+        prog = K.ChainProgram(M)
+        mode = 0 if ctx.act else 1
+        # slot 1 <- raw rows, slot 0 <- rows * alpha * act'(z): the second tensor of the load
+        prog.load(1, G, rows=inv.idx32, y2=0, alpha2=ctx.alpha, Z2=z_ac, mode2=mode)
+        _gemm(prog, W_ac, trans=True, a_slot=0, y_slot=2)                        # parked in registers
+        prog.load(1, G, y2=0, alpha2=ctx.alpha, Z2=z_ca, mode2=mode)
+        _gemm(prog, W_ca, trans=True, a_slot=0, y_slot=-1, res=2, beta=1.0, res2=prev, beta2=1.0, out=gx)
+        K.chain(prog)
+        return (gx if last else None), None, None, None, None, None
+
+
+class SwappedPair:
+    """y_ca + y_ac[swap] kept as its two terms (ops.up_project_pair -> ops.stack(first=dict(..., tied=True)))."""
+    __slots__ = ("y_ca", "y_ac", "swap")
+
+    def __init__(self, y_ca, y_ac, swap):
+        self.y_ca, self.y_ac, self.swap = y_ca, y_ac, swap
+
+
+def up_project_pair(x, W_ac, W_ca, swap, act, alpha):
+    assert constant_weights(), "the fused up-projection pair is the constant-weight inference path"
+    return _UpPair.apply(x, W_ac, W_ca, swap, bool(act), float(alpha))
 
 
 def dense_hadamard_down(x, rbf, Wa, Wr, Wd, act_a, act_d, alpha):

@@ -174,11 +174,12 @@ int gn_gemm_tn_grouped_f32(const gn_tn_problem* probs, int n_prob, int total_wg,
  *   m (E,C) rbf (E,R) W (C,R) row-major; perm/seg_off = CSR of the edges by target atom (perm NULL: edges sorted);
  *   out (n_atoms, C).  C == 128 and R == 16 (every published configuration); other shapes: hipErrorInvalidValue.
  * Adjoint w.r.t. m and rbf (W constant: the force pass), one pass, deterministic:
- *   g_m[e] = scale * g_out[id_a[e]] (.) (W rbf[e]);  g_rbf[e] = scale * W^T (g_out[id_a[e]] (.) m[e]);  either may be NULL. */
+ *   g_m[e] = scale * g_out[id_a[e]] (.) (W rbf[e]);  g_rbf[e] = scale * W^T (g_out[id_a[e]] (.) m[e]);  either may be NULL.
+ *   accum bit 0: g_m += instead of =; bit 1: g_rbf += (running gradient of a tensor with several fused consumers). */
 int gn_rbf_aggregate_fwd_f32(const float* m, const float* rbf, const float* W, const int32_t* perm, const int32_t* seg_off,
                              float* out, int64_t n_atoms, int C, int R, float scale, void* stream);
 int gn_rbf_aggregate_bwd_f32(const float* g_out, const float* m, const float* rbf, const float* W, const int32_t* id_a,
-                             float* g_m, float* g_rbf, int64_t E, int C, int R, float scale, void* stream);
+                             float* g_m, float* g_rbf, int64_t E, int C, int R, float scale, int accum, void* stream);
 
 /* ---- tensor basis in ANGLE form (csrc/geometry.hip, csrc/bilinear_ang.hip) ------------------------------------------
  * Instead of the (Q, S^2 = 49) harmonics of TensorBasisLayer (basis_layers.py:239-295) — 196 B per quadruplet, re-read

@@ -28,7 +28,7 @@ def _act(z, k):
 
 def gemm(A, B_, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre_out=False, mul=None,
          alpha=1.0, res=None, beta=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
-         ridx=None, res2=None, beta2=1.0, cfg=-1):
+         ridx=None, res2=None, beta2=1.0, cfg=-1, out=None):
     a = A
     if a_dact_pre is not None:
         a = a * _act(a_dact_pre, 1)
@@ -47,6 +47,8 @@ def gemm(A, B_, trans_a=False, trans_b=False, *, a_dact_pre=None, act=False, pre
         y = (y + (res if ridx is None else res[ridx.long()])) * beta
     if res2 is not None:
         y = (y + res2) * beta2
+    if out is not None:
+        y = out.copy_(y)
     return (y, z) if pre_out else y
 
 
@@ -418,9 +420,15 @@ def rbf_aggregate_fwd(m, rbf, W, perm, seg_off, n_atoms, scale):
     return segsum(m * (rbf @ W.t()), perm, seg_off, n_atoms) * scale
 
 
-def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=True):
+def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=True, acc_m=None, acc_rbf=None):
     g = g_out[id_a32.long()] * scale
-    return (g * (rbf @ W.t()) if want_m else None), ((g * m) @ W if want_rbf else None)
+    g_m = g * (rbf @ W.t()) if (want_m or acc_m is not None) else None
+    g_rbf = (g * m) @ W if (want_rbf or acc_rbf is not None) else None
+    if acc_m is not None:
+        g_m = acc_m.add_(g_m)
+    if acc_rbf is not None:
+        g_rbf = acc_rbf.add_(g_rbf)
+    return g_m, g_rbf
 
 
 _NAMES = ["is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",

@@ -433,6 +433,29 @@ def test_split_six_products_is_fp32_equivalent():
     assert torch.equal(rt, x)
 
 
+@pytest.mark.parametrize("mode", ["f32", "split6"])
+@pytest.mark.parametrize("M", [300, 18122])
+def test_chain_gemm_accumulates_into_its_residual(mode, M):
+    """A chain GEMM whose global residual IS its output (res / res2 = out): the running-gradient form used by
+    ops.accumulate_gradient; every element is read and rewritten by one thread — same bits as the two-tensor form."""
+    g = torch.Generator().manual_seed(M)
+    x, W, W16 = f32(rnd(g, M, 128)), f32(rnd(g, 128, 128) / 11), f32(rnd(g, 16, 128) / 11)
+    base, base16 = f32(rnd(g, M, 128)), f32(rnd(g, M, 16))
+    outs = []
+    for inplace in (False, True):
+        run, run16 = base.clone(), base16.clone()
+        y = run if inplace else torch.empty_like(run)
+        y16 = run16 if inplace else torch.empty_like(run16)
+        p = K.ChainProgram(M)
+        p.load(0, x)
+        p.gemm(W16, a_slot=0, y_slot=-1, out=y16, res=run16, beta=1.0)
+        p.gemm(W, a_slot=0, y_slot=1, out=y, res2=run, beta2=1.0)
+        K.chain(p, mode=mode)
+        outs.append((y.clone(), y16.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    close(outs[1][0], base.double().cpu() + x.double().cpu() @ W.double().cpu().t(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("M,N,Kd,ta,tb", [(128, 128, 18122, True, True), (64, 128, 5000, True, True),
                                           (16, 6, 20000, True, True), (128, 1024, 18122, True, True)])
 def test_gemm_splitk_weight_gradient_shapes(M, N, Kd, ta, tb):
@@ -630,6 +653,23 @@ def test_rbf_aggregate_fused_vs_reference_ops(n_atoms, deg):
     close(gr, (gsel * m) @ W, rtol=1e-5, atol=2e-5 * max(1.0, float(((gsel * m) @ W).abs().max())))
     gm2, gr2 = K.rbf_aggregate_bwd(f32(go), f32(m), f32(rbf), f32(W), id_a.to(torch.int32).to(DEV), 0.37, want_m=False)
     assert gm2 is None and torch.equal(gr2, gr)
+    # accumulate form (ops.accumulate_gradient): the contribution joins a running gradient in the same pass, in place
+    base_m, base_r = rnd(g, E, 128), rnd(g, E, 16)
+    run_m, run_r = f32(base_m), f32(base_r)
+    gm3, gr3 = K.rbf_aggregate_bwd(f32(go), f32(m), f32(rbf), f32(W), id_a.to(torch.int32).to(DEV), 0.37, acc_m=run_m, acc_rbf=run_r)
+    assert gm3 is run_m and gr3 is run_r
+    assert torch.equal(gm3, f32(base_m) + gm) and torch.equal(gr3, f32(base_r) + gr)
+
+
+def test_gemm_accumulates_in_place():
+    """K.gemm(out = res2): C += A @ W^T element by element in one launch (the running gradient of a tensor with several
+    fused consumers); same bits as the separate add."""
+    g = torch.Generator().manual_seed(5)
+    A, W, base = f32(rnd(g, 777, 64)), f32(rnd(g, 128, 64)), f32(rnd(g, 777, 128))
+    ref = K.gemm(A, W, res2=base)
+    run = base.clone()
+    out = K.gemm(A, W, res2=run, out=run)
+    assert out is run and torch.equal(run, ref)
 
 
 @pytest.mark.parametrize("E,J,mk", [(60, 300, 80), (9, 40, 700), (33, 120, 3)])

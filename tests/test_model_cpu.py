@@ -71,10 +71,11 @@ def test_eval_mode_fused_first_order_path(golden_model, tag, stacks, monkeypatch
         model = build(cfg, params).eval()
         inputs["R"] = inputs["R"].double()
         E, F = model(inputs)
-    # every block: 2 edge stacks + atom stack + interaction head(s) (1 for T, 2 for Q), every output block: 1 stack;
-    # each once forward, once backward
+    # every block: 2 edge stacks + atom stack + interaction head(s) (1 for T, 2 for Q) + (T) the up-projection pair,
+    # every output block: 1 stack; each once forward, once backward
     heads = 1 if cfg["triplets_only"] else 2
-    assert calls["chain"] == (2 * ((3 + heads) * cfg["num_blocks"] + cfg["num_blocks"] + 1) if stacks else 0), calls
+    pairs = 1 if cfg["triplets_only"] else 0
+    assert calls["chain"] == (2 * ((3 + heads + pairs) * cfg["num_blocks"] + cfg["num_blocks"] + 1) if stacks else 0), calls
     assert not F.requires_grad and inputs["R"].requires_grad is False
     Fref, Eref = g[f"{tag}.F"], g[f"{tag}.E"]
     assert np.abs(F.numpy() - Fref).mean() <= 1e-9 * max(1.0, float(np.abs(Fref).mean()))

@@ -195,3 +195,42 @@ def test_fuse_program_preserves_semantics():
     cpu_kernels.chain(f)
     for a, b in zip(o0, o1):
         assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(a.abs().max()))
+
+
+def _shared_consumer_graph(mark):
+    """x -> three fused consumers (Dense, Dense with an activation, the radial aggregation) -> scalar."""
+    torch.manual_seed(3)
+    E_, A = 40, 7
+    x0 = torch.randn(E_, 128, dtype=torch.float64, requires_grad=True)
+    rbf = torch.randn(E_, 16, dtype=torch.float64)
+    W1, W2 = torch.randn(32, 128, dtype=torch.float64) / 11, torch.randn(64, 128, dtype=torch.float64) / 11
+    Wr = torch.randn(128, 16, dtype=torch.float64) / 4
+    ri = RowIndex(torch.randint(0, A, (E_,)), A)
+    x = x0 * 1.0          # a non-leaf, like every activation of the model
+    if mark:
+        ops.accumulate_gradient(x)
+    ys = [ops.dense(x, W1), ops.dense(x, W2, True), ops.rbf_aggregate(x, rbf, Wr, ri, 0.5)]
+    return x0, ys
+
+
+def test_accumulate_gradient_matches_autograd_sum():
+    """ops.accumulate_gradient: the consumers' in-kernel running sum equals autograd's own accumulation; a backward
+    pass that prunes a registered consumer fails loudly instead of returning a partial gradient."""
+    with cpu_kernels.emulate(), ops.fused_first_order(True), ops.param_grads(False):
+        grads = {}
+        for mark in (False, True):
+            x0, ys = _shared_consumer_graph(mark)
+            assert all(y is not None for y in ys)
+            loss = sum((y * y).sum() for y in ys)
+            grads[mark], = torch.autograd.grad(loss, x0)
+        torch.testing.assert_close(grads[True], grads[False], rtol=1e-12, atol=1e-12)
+        # two passes over one graph (several energy targets): the running state is per pass
+        x0, ys = _shared_consumer_graph(True)
+        loss = sum((y * y).sum() for y in ys)
+        g1, = torch.autograd.grad(loss, x0, retain_graph=True)
+        g2, = torch.autograd.grad(loss, x0)
+        torch.testing.assert_close(g1, grads[False], rtol=1e-12, atol=1e-12)
+        torch.testing.assert_close(g2, grads[False], rtol=1e-12, atol=1e-12)
+        x0, ys = _shared_consumer_graph(True)
+        with pytest.raises(RuntimeError, match="fused consumers did not run"):
+            torch.autograd.grad((ys[0] * ys[0]).sum(), x0)

@@ -3,10 +3,12 @@ import ctypes, os, sys, subprocess, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "gemnet_pytorch_amd", "csrc")
-TRACE_LIB = os.path.join(CSRC, "libgemnet_hip_trace.so")
+DEFS = os.environ.get("GN_TRACE_DEFS", "").split()     # extra -D flags (experiments), e.g. GN_TRACE_DEFS="-DGN_EXP=1"
+TRACE_LIB = os.path.join(CSRC, "libgemnet_hip_trace%s.so" % "".join(d.replace("-D", "_").replace("=", "") for d in DEFS))
+QUICK = "--quick" in sys.argv
 if not os.path.exists(TRACE_LIB) or "--build" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                           "-DGN_CHAIN_TRACE", "-I", os.path.join(ROOT, "include")] + sorted(glob.glob(CSRC + "/*.hip"))
+                           "-DGN_CHAIN_TRACE", "-I", os.path.join(ROOT, "include")] + DEFS + sorted(glob.glob(CSRC + "/*.hip"))
                           + ["-o", TRACE_LIB])
     if "--build" in sys.argv:
         sys.exit(0)
@@ -16,9 +18,9 @@ _lib.LIB_PATH = TRACE_LIB
 from gemnet_pytorch_amd import kernels as K
 lib = _lib.load()
 lib.gn_chain2_trace_read.argtypes = [ctypes.c_void_p]
-for mode in ("split6", "bf16"):
-  for M in (1024, 18122):
-    for pre in (0, 1):
+for mode in (("split6",) if QUICK else ("split6", "bf16")):
+  for M in ((18122,) if QUICK else (1024, 18122)):
+    for pre in ((0,) if QUICK else (0, 1)):
         n = 5
         x = torch.randn(M, 128, device="cuda")
         Ws = [torch.randn(128, 128, device="cuda") / 11 for _ in range(n)]
@@ -36,11 +38,14 @@ for mode in ("split6", "bf16"):
         torch.cuda.synchronize()
         buf = np.zeros((2, 20, 8), dtype=np.uint64)
         lib.gn_chain2_trace_read(buf.ctypes.data_as(ctypes.c_void_p))
-        print(f"[{mode}] M={M} pre/act={pre}: cycles per phase [wait-W, mfma, epilogue, barrier | op total] (block 0 / block 100)")
+        print(f"[{mode}] M={M} pre/act={pre}: cycles per phase [wait-W, mfma, epilogue, barrier | op total] (wave 0 / wave 7 of block 100)")
         for b in range(2):
             t = buf[b].astype(np.int64)
-            print(f"   blk{b*100:3d} LOAD: work {int(t[0,3]-t[0,0])} barrier {int(t[0,4]-t[0,3])}")
+            print(f"   wave{b*7} LOAD: work {int(t[0,3]-t[0,0])} barrier {int(t[0,4]-t[0,3])}")
             for oi in range(1, n + 1):
                 d = [int(t[oi, i + 1] - t[oi, i]) for i in range(4)]
                 gap = int(t[oi, 0] - t[oi - 1, 4])
-                print(f"   blk{b*100:3d} op{oi}: gap {gap:6d}  {d}  total {int(t[oi,4]-t[oi,0])}")
+                if b == 1:
+                    t0 = buf[0].astype(np.int64)
+                    d.append(("vs wave0 at stamps", [int(t[oi, i] - t0[oi, i]) for i in range(5)]))
+                print(f"   wave{b*7} op{oi}: gap {gap:6d}  {d}  total {int(t[oi,4]-t[oi,0])}")
