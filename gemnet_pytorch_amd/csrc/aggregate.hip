@@ -9,7 +9,8 @@
 //   forward : one 256-thread workgroup per atom; wave w walks the atom's incoming edges w, w+4, .. (CSR by target
 //             atom), lane l owns columns 2l, 2l+1; four partial rows are summed through LDS in fixed order (no atomics)
 //   adjoint : waves stride over the edges; g_m[e] = scale * g_out[a(e)] (.) (W rbf_e),  g_rbf[e] = scale * W^T (g_out[a(e)] (.) m_e)
-//             (a 128 x 16 mat-vec through 512 B of wave-private LDS)
+//             (a 128 x 16 mat-vec through 512 B of wave-private LDS; a reduce-scatter over the lanes with 17 shuffles
+//             instead measured 45 us against 27)
 // Constraints: C (columns) == 128, R (radial features) == 16 — the shapes of every published GemNet configuration
 // (emb_size_edge 128, emb_size_rbf 16); other shapes take the GEMM + segmented-sum path.
 #include "common.h"
@@ -34,18 +35,35 @@ __global__ __launch_bounds__(256) void rbf_aggregate_fwd_kernel(const float* __r
   }
   const int beg = seg_off[a], end = seg_off[a + 1];
   float2 acc = make_float2(0.f, 0.f);
-  for (int i = beg + wave; i < end; i += 4) {
-    const int e = perm ? perm[i] : i;
-    const float2 me = *reinterpret_cast<const float2*>(m + (size_t)e * C + 2 * lane);
-    float r0 = 0.f, r1 = 0.f;
+  // Two edges per trip, every load of the pair issued before the first use: the trip is a chain of dependent loads
+  // (perm -> row address -> 512 B row from HBM), and an atom has only ~4 edges per wave to hide it behind.
+  // The per-edge products are added in the same order as in the one-edge form (edge i, then edge i + 4).
+  for (int i = beg + wave; i < end; i += 8) {
+    const bool two = i + 4 < end;
+    const int e0 = perm ? perm[i] : i;
+    const int e1 = two ? (perm ? perm[i + 4] : i + 4) : e0;
+    const float2 m0 = *reinterpret_cast<const float2*>(m + (size_t)e0 * C + 2 * lane);
+    const float2 m1 = *reinterpret_cast<const float2*>(m + (size_t)e1 * C + 2 * lane);
+    float4 b0[R / 4], b1[R / 4];
 #pragma unroll
     for (int q = 0; q < R / 4; ++q) {
-      const float4 b = *reinterpret_cast<const float4*>(rbf + (size_t)e * R + 4 * q);   // same address in every lane
-      r0 += w0[4 * q] * b.x + w0[4 * q + 1] * b.y + w0[4 * q + 2] * b.z + w0[4 * q + 3] * b.w;
-      r1 += w1[4 * q] * b.x + w1[4 * q + 1] * b.y + w1[4 * q + 2] * b.z + w1[4 * q + 3] * b.w;
+      b0[q] = *reinterpret_cast<const float4*>(rbf + (size_t)e0 * R + 4 * q);   // same address in every lane
+      b1[q] = *reinterpret_cast<const float4*>(rbf + (size_t)e1 * R + 4 * q);
     }
-    acc.x += me.x * r0;
-    acc.y += me.y * r1;
+    float r0 = 0.f, r1 = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < R / 4; ++q) {
+      r0 += w0[4 * q] * b0[q].x + w0[4 * q + 1] * b0[q].y + w0[4 * q + 2] * b0[q].z + w0[4 * q + 3] * b0[q].w;
+      r1 += w1[4 * q] * b0[q].x + w1[4 * q + 1] * b0[q].y + w1[4 * q + 2] * b0[q].z + w1[4 * q + 3] * b0[q].w;
+      s0 += w0[4 * q] * b1[q].x + w0[4 * q + 1] * b1[q].y + w0[4 * q + 2] * b1[q].z + w0[4 * q + 3] * b1[q].w;
+      s1 += w1[4 * q] * b1[q].x + w1[4 * q + 1] * b1[q].y + w1[4 * q + 2] * b1[q].z + w1[4 * q + 3] * b1[q].w;
+    }
+    acc.x += m0.x * r0;
+    acc.y += m0.y * r1;
+    if (two) {
+      acc.x += m1.x * s0;
+      acc.y += m1.y * s1;
+    }
   }
   part[wave][lane] = acc;
   __syncthreads();

@@ -662,7 +662,8 @@ __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
       const float4 v = *reinterpret_cast<const float4*>(b + c);
       acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
     }
-    gB[e * (int64_t)S * I + o] = acc;
+    float* go = gB + e * (int64_t)S * I + o;
+    *go = (accumulate & 2) ? *go + acc : acc;     // bit 1: running gradient of the radial basis shared by the blocks
   }
   // dSm[s,c] = sum_i B[s,i] dP[i,c]
   for (int o = tid; o < S * C; o += nt) {
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void bil_project_bwd_kernel(
       const float4 b = *reinterpret_cast<const float4*>(xr + c);
       acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
     }
-    if (accumulate) dY[(int64_t)t * S + s] += acc;
+    if (accumulate & 1) dY[(int64_t)t * S + s] += acc;
     else dY[(int64_t)t * S + s] = acc;
   }
 }
@@ -703,7 +704,7 @@ template <bool ACC>
 __global__ __launch_bounds__(256) void bil_project_bwd_mfma7_kernel(
     const float* __restrict__ dP, const float* __restrict__ Sm, const float* __restrict__ B,
     const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
-    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int64_t E) {
+    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int64_t E, int gb_acc) {
   constexpr int S = 7, C = 64, I = 16, LD = C + 4;
   __shared__ __attribute__((aligned(16))) float dsl[4][8][LD];   // dSm of this wave's edge (row 7: MFMA padding)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma7_kernel(
   float* __restrict__ gbo = gB + e * (int64_t)S * I;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    if (4 * lg + r < S) gbo[(4 * lg + r) * I + l15] = g[r];
+    if (4 * lg + r < S) gbo[(4 * lg + r) * I + l15] = gb_acc ? gbo[(4 * lg + r) * I + l15] + g[r] : g[r];
   // ---- (2) dSm = B dP
   v4f_b d[4];
 #pragma unroll
@@ -807,7 +808,7 @@ template <bool ACC>
 __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
     const float* __restrict__ dP, const float* __restrict__ Sm, const float* __restrict__ B,
     const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
-    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int64_t E) {
+    float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int64_t E, int gb_acc) {
   constexpr int S = 49, C = 32, I = 32, LD = C + 4;
   __shared__ __attribute__((aligned(16))) float dsl[4][64][LD];   // dSm of this wave's edge (rows >= 49 zero)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma49_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int srow = 16 * mt + 4 * lg + r;
-        if (srow < S) gBe[srow * I + 16 * nt + l15] = acc[mt][nt][r];
+        if (srow < S) gBe[srow * I + 16 * nt + l15] = gb_acc ? gBe[srow * I + 16 * nt + l15] + acc[mt][nt][r] : acc[mt][nt][r];
       }
   // (2) dSm[s,c] = sum_i B[s,i] dP[i,c]: A rows of B (k = i contiguous), Bop[k = i][n = c] = dP[i][c] (scalar loads)
   float dpcol[2][2][4];   // dP[16 j + 4 lg + q][16 nt + l15]
@@ -1320,24 +1321,25 @@ extern "C" int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, cons
   if (E <= 0) return 0;
   if (S <= 0 || C <= 0 || (C % 4) != 0 || I <= 0) return (int)hipErrorInvalidValue;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int gb_acc = (accumulate >> 1) & 1;
   if (S == 49 && C == 32 && I == 32 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)) {
-    if (accumulate)
+    if (accumulate & 1)
       hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, dP, Sm, B, x,
-                         expand_idx, seg_off, gB, dSm, dY, E);
+                         expand_idx, seg_off, gB, dSm, dY, E, gb_acc);
     else
       hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel<false>, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, dP, Sm, B, x,
-                         expand_idx, seg_off, gB, dSm, dY, E);
+                         expand_idx, seg_off, gB, dSm, dY, E, gb_acc);
     GN_LAUNCH_CHECK();
     return 0;
   }
   if (S == 7 && C == 64 && I == 16 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)) {
     const dim3 grid(gn_cdiv(E, 4));
-    if (accumulate)
+    if (accumulate & 1)
       hipLaunchKernelGGL(bil_project_bwd_mfma7_kernel<true>, grid, dim3(256), 0, st, dP, Sm, B, x, expand_idx, seg_off, gB,
-                         dSm, dY, E);
+                         dSm, dY, E, gb_acc);
     else
       hipLaunchKernelGGL(bil_project_bwd_mfma7_kernel<false>, grid, dim3(256), 0, st, dP, Sm, B, x, expand_idx, seg_off, gB,
-                         dSm, dY, E);
+                         dSm, dY, E, gb_acc);
     GN_LAUNCH_CHECK();
     return 0;
   }

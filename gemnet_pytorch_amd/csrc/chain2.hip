@@ -43,6 +43,10 @@ __device__ unsigned long long gn_chain2_trace_buf[2][GN_CHAIN_MAX_OPS][8];
 #define GN2_STAMP(i) do { } while (0)
 #endif
 
+#ifndef GN_X_PREFETCH
+#define GN_X_PREFETCH 1
+#endif
+
 namespace {
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every op would wait for its
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         // The widest instance (adjoint programs at RT = 5) has no registers left for the third plane's second buffer:
         // there the lo plane — used by one MFMA, issued last — is read at the top of its own step.
         constexpr bool LATE_LO = ADJ && RT == 5 && NPL >= 3;
-        uint4 xf[2][3];
+        constexpr int PD = (GN_X_PREFETCH >= 2 && !ADJ) ? 2 : 1;   // steps of look-ahead (PD + 1 register buffers)
+        uint4 xf[PD + 1][3];
         auto xload = [&](uint4 (&f)[3], int c, int t) {
           const unsigned char* xp = xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4);
           f[0] = *reinterpret_cast<const uint4*>(xp);
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
           if (NPL >= 3 && !LATE_LO) f[2] = *reinterpret_cast<const uint4*>(xp + 2 * PLANE);
         };
         xload(xf[0], 0, 0);
+        if (PD == 2) { if (RT > 1) xload(xf[1], 0, 1); else if (kc > 1) xload(xf[1], 1, 0); }
 #if defined(GN_EXP) && GN_EXP == 1
         xload(xf[1], 0, 0);
 #endif
@@ -316,10 +322,12 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
             if (NPL >= 3) wl = __builtin_bit_cast(bf16x8, bcur[c][NPL >= 3 ? 2 : 0]);
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-              const int cur = (c * RT + t) & 1;
+              const int cur = (c * RT + t) % (PD + 1);
 #if !defined(GN_EXP) || GN_EXP != 1
-              if (t + 1 < RT) xload(xf[cur ^ 1], c, t + 1);
-              else if (c + 1 < 4 && c + 1 < kc) xload(xf[cur ^ 1], c + 1, 0);
+              {
+                const int s2 = c * RT + t + PD, c2 = s2 / RT, t2 = s2 - c2 * RT;   // the step PD ahead
+                if (c2 < 4 && c2 < kc) xload(xf[s2 % (PD + 1)], c2, t2);
+              }
 #endif
 #if defined(GN_EXP) && GN_EXP == 2
               { uint4 q = xf[cur][0]; for (int pl = 1; pl < NPL; ++pl) { q.x ^= xf[cur][pl].x; q.y ^= xf[cur][pl].y; q.z ^= xf[cur][pl].z; q.w ^= xf[cur][pl].w; }

@@ -584,9 +584,11 @@ __global__ __launch_bounds__(256) void gemm_smallk(const gn_gemm_args p) {
   }
 }
 
-// N = 1 (the energy / scalar heads): C[m] = alpha * <A[m,:], b>, one wave per row, no epilogue stages.
+// N = 1 (the energy / scalar heads): C[m] = (alpha * <A[m,:], b> + res[m]) * beta, one wave per row; the optional
+// ungathered residual is the only epilogue stage (the running sum of the output blocks' energies).
 __global__ __launch_bounds__(256) void gemm_n1(const float* __restrict__ A, int lda, const float* __restrict__ b,
-                                               float* __restrict__ C, int ldc, int M, int K, float alpha, int vec) {
+                                               float* __restrict__ C, int ldc, int M, int K, float alpha, int vec,
+                                               const float* __restrict__ res, int ldres, float beta) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= M) return;
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(256) void gemm_n1(const float* __restrict__ A, int 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (lane == 0) C[(size_t)r * ldc] = acc * alpha;
+  if (lane == 0) C[(size_t)r * ldc] = res ? (acc * alpha + res[(size_t)r * ldres]) * beta : acc * alpha;
 }
 
 }  // namespace
@@ -616,9 +618,11 @@ extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) 
   const int vecB = (p.ldb % 4 == 0) && aligned16(p.B);
   const bool fast = !p.trans_a && !p.trans_b && vecA && vecB && (p.K % 4 == 0) && p.splitk <= 1;
   const bool plain = !p.a_dact_pre && !p.act && !p.pre_out && !p.mul && !p.res && !p.res2 && !p.gadd1 && !p.gadd2;
-  if (cfg < 0 && !p.trans_a && p.splitk <= 1 && p.N == 1 && plain && (p.trans_b ? p.ldb == 1 : true)) {
+  const bool plain_res = !p.a_dact_pre && !p.act && !p.pre_out && !p.mul && !p.res2 && !p.gadd1 && !p.gadd2 && !p.ridx;
+  if (cfg < 0 && !p.trans_a && p.splitk <= 1 && p.N == 1 && plain_res && (p.trans_b ? p.ldb == 1 : true)) {
     const int vec = vecA && aligned16(p.B) && (p.K % 4 == 0);
-    hipLaunchKernelGGL(gemm_n1, dim3(gn_cdiv(p.M, 4)), dim3(256), 0, st, p.A, p.lda, p.B, p.C, p.ldc, p.M, p.K, p.alpha, vec);
+    hipLaunchKernelGGL(gemm_n1, dim3(gn_cdiv(p.M, 4)), dim3(256), 0, st, p.A, p.lda, p.B, p.C, p.ldc, p.M, p.K, p.alpha, vec,
+                       p.res, p.ldres, p.beta);
     GN_LAUNCH_CHECK();
     return 0;
   }

@@ -721,14 +721,16 @@ def bil_dy_multi(dSm_list, x_list, sp, ang=None):
     return dY
 
 
-def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True):
+def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True, gB_accum=None):
     """Fused adjoint of K2 and of K1 w.r.t. Y -> (gB (E,S,I), dSm (E,S,C), dY (T,S)); with `dY_accum` the Y
-    gradient is ADDED into that (T,S) buffer (and returned) instead of written to a fresh one."""
+    gradient is ADDED into that (T,S) buffer (and returned) instead of written to a fresh one; `gB_accum` likewise."""
     require_device(dP, Sm, B, x)
     dP, Sm, B, x = _f32c(dP), _f32c(Sm), _f32c(B), _f32c(x)
     E, S, C = Sm.shape
     I = B.shape[2]
-    gB = torch.empty((E, S, I), device=x.device, dtype=torch.float32)
+    if gB_accum is not None:
+        assert gB_accum.shape == (E, S, I) and gB_accum.is_contiguous() and gB_accum.dtype == torch.float32
+    gB = gB_accum if gB_accum is not None else torch.empty((E, S, I), device=x.device, dtype=torch.float32)
     dSm = torch.empty((E, S, C), device=x.device, dtype=torch.float32)
     if dY_accum is not None:
         assert dY_accum.shape == (sp.size, S) and dY_accum.is_contiguous() and dY_accum.dtype == torch.float32
@@ -738,7 +740,8 @@ def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True):
         dY = dY_accum if dY_accum is not None else torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
     check(_lib.load().gn_bil_project_bwd_acc_f32(ptr(dP), ptr(Sm), ptr(B), ptr(x), ptr(sp.expand.idx32),
                                                  ptr(sp.seg_off), ptr(gB), ptr(dSm), ptr(dY), E, S, C, I,
-                                                 int(dY_accum is not None), stream()), "gn_bil_project_bwd_acc_f32")
+                                                 int(dY_accum is not None) | (2 if gB_accum is not None else 0), stream()),
+          "gn_bil_project_bwd_acc_f32")
     return gB, dSm, dY
 
 

@@ -80,6 +80,7 @@ class GemNet(torch.nn.Module):
         self.matmul_precision = None
         self.overlap_output_blocks = True
         self._side = None
+        self._cot = None      # cached force cotangents (see _cotangent)
         self._wcache = {}  # derived (transposed / contiguous) copies of frozen weights, see ops.weight_cache
 
         AutomaticFit.reset()
@@ -218,12 +219,12 @@ class GemNet(torch.nn.Module):
         if not T:
             rbf4 = ops.accumulate_gradient(self.mlp_rbf4(rbf))
             cbf4 = self.mlp_cbf4(cbf4)
-            sbf4 = (self.mlp_sbf4(sbf4[0]), sbf4[1])
+            sbf4 = (ops.accumulate_gradient(self.mlp_sbf4(sbf4[0])), sbf4[1])
         else:
             rbf4 = cbf4 = sbf4 = None
         # radial projections shared by all blocks: their gradients are summed inside the consumers' backward kernels
         rbf3 = ops.accumulate_gradient(self.mlp_rbf3(rbf))
-        cbf3 = (self.mlp_cbf3(rad3), sph3)
+        cbf3 = (ops.accumulate_gradient(self.mlp_cbf3(rad3)), sph3)
         rbf_h = ops.accumulate_gradient(self.mlp_rbf_h(rbf))
         rbf_out = self.mlp_rbf_out(rbf)
 
@@ -243,14 +244,17 @@ class GemNet(torch.nn.Module):
             return ev
 
         def out_block(i, h, m, ev):
+            # the energies are summed along the chain of output blocks (epilogue of each energy head); the direct
+            # force terms, when present, are summed below
+            E_sum = outs[-1][0] if outs else None
             if side is None:
-                outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a))
+                outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a, E_sum=E_sum))
                 return
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 for t in (h, m, rbf_out):
                     t.record_stream(side)
-                outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a))
+                outs.append(self.out_blocks[i](h, m, rbf_out, plan.id_a, E_sum=E_sum))
 
         # OutputBlock i is ISSUED after InteractionBlock i (it only waits for the event recorded before it): in a
         # captured hipGraph the first-captured successor of a fork keeps the queue, and with the output block issued
@@ -266,10 +270,9 @@ class GemNet(torch.nn.Module):
         out_block(self.num_blocks, h, m, ready())
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-        E_a, F_ca = outs[0]
-        for E, F in outs[1:]:
+        E_a, F_ca = outs[-1][0], outs[0][1]
+        for _, F in outs[1:]:
             F_ca = F_ca + F
-            E_a = E_a + E
 
         E_mol = ops.segsum_rows(E_a, plan.batch_seg)                      # (nMolecules, num_targets)
         if not self.extensive:
@@ -310,13 +313,30 @@ class GemNet(torch.nn.Module):
                 F_j = ops.segsum_rows(F_ji, plan.id_a)                         # (nAtoms, num_targets, 3)
             else:
                 with ops.param_grads(False):  # only dE/dR is needed here
+                    # F = -d(sum_mol E)/dR: the cotangent -1 (one column per target) goes in directly — no reduction,
+                    # no ones_like fill and no negation launch
                     if self.num_targets > 1:
                         F_j = torch.stack(
-                            [-torch.autograd.grad(E_mol[:, i].sum(), R, create_graph=graph, retain_graph=True)[0]
-                             for i in range(self.num_targets)], dim=1)
+                            [torch.autograd.grad(E_mol, R, grad_outputs=self._cotangent(E_mol, i), create_graph=graph,
+                                                 retain_graph=True)[0] for i in range(self.num_targets)], dim=1)
                     else:
-                        F_j = -torch.autograd.grad(E_mol.sum(), R, create_graph=graph)[0]
+                        F_j = torch.autograd.grad(E_mol, R, grad_outputs=self._cotangent(E_mol, 0),
+                                                  create_graph=graph)[0]
         return E_mol, F_j
+
+    def _cotangent(self, E_mol, target):
+        """Constant -1 in column `target` (zeros elsewhere) shaped like E_mol, cached per (shape, device)."""
+        key = (tuple(E_mol.shape), E_mol.device, E_mol.dtype, target)
+        c = self._cot.get(key) if self._cot is not None else None
+        if c is None:
+            c = torch.zeros(E_mol.shape, device=E_mol.device, dtype=E_mol.dtype)
+            c[:, target] = -1.0
+            if E_mol.is_cuda and torch.cuda.is_current_stream_capturing():
+                return c      # memory of a capture's private pool must not outlive it in a cache
+            if self._cot is None or len(self._cot) > 64:
+                self._cot = {}
+            self._cot[key] = c
+        return c
 
     def _side_stream(self, device):
         """One side stream per calling stream (several molecule shards may run this module concurrently)."""

@@ -217,15 +217,22 @@ class OutputBlock(AtomUpdateBlock):
         """The edge -> atom part of forward() (atom_update_block.py:160-166), callable ahead of the rest."""
         return self._aggregate(m, rbf, id_a, want_x=self.direct_forces)
 
-    def forward(self, h, m, rbf, id_a, agg=None):
-        """`agg`: the result of `aggregate(m, rbf, id_a)` when the caller computed it already (on another stream)."""
+    def forward(self, h, m, rbf, id_a, agg=None, E_sum=None):
+        """`agg`: the result of `aggregate(m, rbf, id_a)` when the caller computed it already (on another stream).
+        `E_sum`: running sum of the energies of the earlier output blocks; returned energy = E_sum + this block's
+        (added in the epilogue of the energy head instead of by one elementwise launch per block)."""
         x_E, x = agg if agg is not None else self._aggregate(m, rbf, id_a, want_x=self.direct_forces)
         if self._stackable(self.seq_energy):
             x_E = self._mlp_stack(x_E, self.seq_energy)
         else:
             for layer in self.seq_energy:
                 x_E = layer(x_E)
-        x_E = self.out_energy(x_E)
+        if E_sum is not None and ops.is_fused() and self.out_energy.bias is None:
+            x_E = self.out_energy(x_E, res=E_sum)
+        else:
+            x_E = self.out_energy(x_E)
+            if E_sum is not None:
+                x_E = E_sum + x_E
         if self.direct_forces:
             if ops.is_fused() or not AutomaticFit.fitting_mode:  # x already carries scale_sum: rescale to scale_rbf
                 x_F = x * (self.scale_rbf.value() / self.scale_sum.value())

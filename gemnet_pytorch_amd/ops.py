@@ -703,6 +703,7 @@ class _FusedBilinear(torch.autograd.Function):
         ctx.sink = getattr(sph, "_gn_sink", None)
         if ctx.sink is not None:
             ctx.sink.consumers += 1
+        ctx.acc_B = _acc_join(rbf_W1)
         C, I, O = W.shape
         keep_p = W.requires_grad and _PARAM_GRADS
         ctx.ang = K.is_angle_form(sph, rbf_W1.shape[1])
@@ -728,15 +729,17 @@ class _FusedBilinear(torch.autograd.Function):
         g = g.contiguous()
         dP = K.gemm(g, bilinear_weight(W, False), alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is (N=I*C, K=O)
         sink = ctx.sink
+        accB = ctx.acc_B   # running gradient of the radial part of the basis (shared by the blocks)
+        prevB, lastB = accB.enter() if accB is not None else (None, True)
         if need[1] and ctx.ang and (sink is None or sink.consumers > 4):
             # angle form without a shared sink: this block's angle gradient alone
-            gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False)
+            gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False, gB_accum=prevB)
             gsph = K.bil_dy_multi([dSm], [x], sp, ang=sph)
             if sink is not None:
                 sink.arrive()
         elif sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64)) and sink.consumers <= 4:
             # gB and dSm now, the Y gradient of all consumers of this basis in ONE pass when the last one arrives
-            gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False)
+            gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False, gB_accum=prevB)
             last = sink.arrive()
             sink.pending.append((dSm, x))
             gsph = None
@@ -747,12 +750,16 @@ class _FusedBilinear(torch.autograd.Function):
         elif sink is not None and need[1]:
             # the Y gradient is summed across the consumers of `sph` inside the kernel (see GradSink)
             last = sink.arrive()
-            gB, dSm, sink.buf = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, dY_accum=sink.buf)
+            gB, dSm, sink.buf = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, dY_accum=sink.buf, gB_accum=prevB)
             gsph = sink.buf if last else None
             if last:
                 sink.buf = None
         else:
-            gB, dSm, gsph = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp)      # 2 bmm + bil_dot in one launch
+            gB, dSm, gsph = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, gB_accum=prevB)      # 2 bmm + bil_dot in one launch
+        if accB is not None:
+            accB.leave(gB, lastB)
+            if not lastB:
+                gB = None
         gx = gW = None
         if not need[0]:
             gB = None

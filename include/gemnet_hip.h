@@ -288,8 +288,9 @@ int gn_bil_fused_fwd_f32(const float* Y, const float* x, const int32_t* expand_i
 int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,
                            const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
                            int64_t E, int S, int C, int I, void* stream);
-/* Same with `accumulate != 0`: dY += (the Y gradient summed over the interaction blocks that share one basis tensor
- * — saves a (T,S)-sized add per block: 1.8 GB for the quadruplet basis at B = 32). */
+/* Same with `accumulate` bit 0: dY += (the Y gradient summed over the interaction blocks that share one basis tensor
+ * — saves a (T,S)-sized add per block: 1.8 GB for the quadruplet basis at B = 32); bit 1: gB += (the radial part of the
+ * basis is shared by the blocks in the same way). */
 int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, const float* B, const float* x,
                                const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
                                int64_t E, int S, int C, int I, int accumulate, void* stream);

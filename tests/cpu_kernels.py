@@ -364,8 +364,10 @@ def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
     return Gc, Gbd
 
 
-def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True):
+def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True, gB_accum=None):
     gB = torch.bmm(Sm, dP.transpose(1, 2))
+    if gB_accum is not None:
+        gB = gB_accum.add_(gB)
     dSm = torch.bmm(Bm, dP)
     if not want_dY:
         return gB, dSm, None

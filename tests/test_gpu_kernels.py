@@ -483,6 +483,10 @@ def test_bilinear_fused_project_kernels(S, C, I, E, J, mk):
     close(dY, rdY, atol=2e-4 * float(rdY.abs().max()))
     gB2, dSm2, none = K.bil_project_bwd(f32(dP), f32(rSm), f32(Bm), f32(x), dev, want_dY=False)
     assert none is None and torch.equal(gB2, gB) and torch.equal(dSm2, dSm)
+    base = f32(rnd(g, E, S, I))        # running gradient of the shared radial basis: gB joins it in the same launch
+    run = base.clone()
+    gB3, _, _ = K.bil_project_bwd(f32(dP), f32(rSm), f32(Bm), f32(x), dev, want_dY=False, gB_accum=run)
+    assert gB3 is run and torch.equal(run, base + gB)
 
 
 def test_quad_basis_fused_fwd_bwd():
