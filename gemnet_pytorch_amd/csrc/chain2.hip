@@ -34,17 +34,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifdef GN_CHAIN_TRACE
 // diagnosis build only (tools/chain2_trace.py): shader-clock stamps of wave 0 of two workgroups
 __device__ unsigned long long gn_chain2_trace_buf[2][GN_CHAIN_MAX_OPS][8];
-#define GN2_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == GN_TRACE_WAVE) && blockIdx.x == 100) \
+#define GN2_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == GN_TRACE_WAVE) && blockIdx.x == (gridDim.x > 100 ? 100u : 0u)) \
     gn_chain2_trace_buf[wave != 0][oi][i] = clock64(); } while (0)
 #ifndef GN_TRACE_WAVE
 #define GN_TRACE_WAVE 7
 #endif
 #else
 #define GN2_STAMP(i) do { } while (0)
-#endif
-
-#ifndef GN_X_PREFETCH
-#define GN_X_PREFETCH 1
 #endif
 
 namespace {
@@ -134,6 +130,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
   // profiles/r2_wfetch.txt); a second set held across the MFMA phase pushed the RT = 5 kernel into scratch.
   wload_op(bcur, 0);
   int gord = 0;
+  // Row tiles of one or two blocks (M <= 8 k rows: the atom-side stacks, 64 workgroups) are latency-bound (4.8 k cycles
+  // per op for 0.8 k of MFMA pipe time, tools/chain2_trace.py --small).  Tried for them and dropped, none moved the op
+  // time: a second weight-fragment set requested one op ahead, one accumulator set per product (six independent MFMA
+  // chains), X fragments read three steps ahead (all reads of the op in flight before the first MFMA).
 
   float4 park[ADJ ? RT : 1];   // register slot 2 (accumulator layout)
 #pragma unroll
@@ -286,12 +286,14 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
 #endif
       GN2_STAMP(1);
 
-      v4f a0[RT], a1[RT];   // hh | the cross terms hm + mh + hl + lh + mm (summed among themselves first)
+      // hh | the cross terms hm + mh + hl + lh + mm (summed among themselves first)
+      constexpr int NACC = 2;
+      v4f acc[NACC][RT];
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        a0[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-        a1[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-      }
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#define GN2_ACC(k) acc[(k) != 0][t]     /* product k: 0 hh, 1 hm, 2 mh, 3 hl, 4 lh, 5 mm */
       if (active) {
         const unsigned char* xb = smem + a_slot * SLOT + l15 * ROWB;   // row 16 t + l15: swizzle key = l15
         const int kc = (K + 31) >> 5;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         // The widest instance (adjoint programs at RT = 5) has no registers left for the third plane's second buffer:
         // there the lo plane — used by one MFMA, issued last — is read at the top of its own step.
         constexpr bool LATE_LO = ADJ && RT == 5 && NPL >= 3;
-        constexpr int PD = (GN_X_PREFETCH >= 2 && !ADJ) ? 2 : 1;   // steps of look-ahead (PD + 1 register buffers)
+        constexpr int PD = 1;   // steps of look-ahead (PD + 1 register buffers); 2 and 3 measured: no change
         uint4 xf[PD + 1][3];
         auto xload = [&](uint4 (&f)[3], int c, int t) {
           const unsigned char* xp = xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4);
@@ -309,7 +311,11 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
           if (NPL >= 3 && !LATE_LO) f[2] = *reinterpret_cast<const uint4*>(xp + 2 * PLANE);
         };
         xload(xf[0], 0, 0);
-        if (PD == 2) { if (RT > 1) xload(xf[1], 0, 1); else if (kc > 1) xload(xf[1], 1, 0); }
+#pragma unroll
+        for (int s0 = 1; s0 < PD; ++s0) {     // steps 1 .. PD - 1 of the look-ahead window
+          const int c0 = s0 / RT, t0 = s0 - c0 * RT;
+          if (c0 < kc) xload(xf[s0], c0, t0);
+        }
 #if defined(GN_EXP) && GN_EXP == 1
         xload(xf[1], 0, 0);
 #endif
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
 #endif
 #if defined(GN_EXP) && GN_EXP == 2
               { uint4 q = xf[cur][0]; for (int pl = 1; pl < NPL; ++pl) { q.x ^= xf[cur][pl].x; q.y ^= xf[cur][pl].y; q.z ^= xf[cur][pl].z; q.w ^= xf[cur][pl].w; }
-                a0[t][0] += __uint_as_float(q.x); a0[t][1] += __uint_as_float(q.y); a0[t][2] += __uint_as_float(q.z); a0[t][3] += __uint_as_float(q.w); }
+                GN2_ACC(0)[0] += __uint_as_float(q.x); GN2_ACC(0)[1] += __uint_as_float(q.y); GN2_ACC(0)[2] += __uint_as_float(q.z); GN2_ACC(0)[3] += __uint_as_float(q.w); }
               continue;
 #endif
               const bf16x8 xh = __builtin_bit_cast(bf16x8, xf[cur][0]);
@@ -341,13 +347,13 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
               if (LATE_LO)
                 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
                     xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4) + 2 * PLANE));
-              if (NPL >= 3 && !LATE_LO) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, a1[t], 0, 0, 0);
-              a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, a0[t], 0, 0, 0);
-              if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, a1[t], 0, 0, 0);
-              if (NPL >= 3) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, a1[t], 0, 0, 0);
-              if (NPL >= 2) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, a1[t], 0, 0, 0);
-              if (NPL >= 2) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, a1[t], 0, 0, 0);
-              if (LATE_LO) a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, a1[t], 0, 0, 0);
+              if (NPL >= 3 && !LATE_LO) GN2_ACC(3) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, GN2_ACC(3), 0, 0, 0);
+              GN2_ACC(0) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, GN2_ACC(0), 0, 0, 0);
+              if (NPL >= 3) GN2_ACC(4) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, GN2_ACC(4), 0, 0, 0);
+              if (NPL >= 3) GN2_ACC(5) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, GN2_ACC(5), 0, 0, 0);
+              if (NPL >= 2) GN2_ACC(1) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, GN2_ACC(1), 0, 0, 0);
+              if (NPL >= 2) GN2_ACC(2) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, GN2_ACC(2), 0, 0, 0);
+              if (LATE_LO) GN2_ACC(3) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, GN2_ACC(3), 0, 0, 0);
             }
           }
         }
@@ -355,9 +361,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       float4 v[RT];            // the three partial sums collapse here: their registers are free for the prefetch below
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        const v4f s = NPL >= 2 ? a0[t] + a1[t] : a0[t];
+        const v4f s = NPL >= 2 ? acc[0][t] + acc[1][t] : acc[0][t];
         v[t] = make_float4(s[0], s[1], s[2], s[3]);
       }
+#undef GN2_ACC
       wload_op(bcur, gord);   // next GEMM's fragments (no-op after the last one): in flight under the epilogue
 #ifdef GN_CHAIN_TRACE
       if (active) { float sink = 0.f; for (int t = 0; t < RT; ++t) sink += v[t].x; if (sink == 1.2345e30f) smem[0] = 1; }

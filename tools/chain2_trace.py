@@ -19,7 +19,7 @@ from gemnet_pytorch_amd import kernels as K
 lib = _lib.load()
 lib.gn_chain2_trace_read.argtypes = [ctypes.c_void_p]
 for mode in (("split6",) if QUICK else ("split6", "bf16")):
-  for M in ((18122,) if QUICK else (1024, 18122)):
+  for M in (((1024,) if "--small" in sys.argv else (18122,)) if QUICK else (1024, 18122)):
     for pre in ((0,) if QUICK else (0, 1)):
         n = 5
         x = torch.randn(M, 128, device="cuda")
