@@ -113,6 +113,45 @@ __global__ __launch_bounds__(256) void segsum_block(const VT* __restrict__ y, co
   }
 }
 
+// x[r, c] = sum_k sign_k * sum_{i in seg_k(r)} y_k[perm_k[i], c]: up to four CSR lists over the same rows in ONE launch.
+// The position gradient is such a sum: dE/dR[a] collects per-triplet terms through the triplet's three atoms and
+// per-edge terms through the edge's two atoms (gemnet.py:420-451, :334-350 differentiated); as separate segmented sums
+// plus their combining adds that was 10 launches of ~5 us on the tail of the force pass.
+// One workgroup per row, C <= 4 narrow rows: thread t takes entries t, t + 256, .. of every list (fixed assignment),
+// partial sums fold through LDS in a fixed order — deterministic, no atomics.
+struct SegTerms {
+  const float* y[4];
+  const int32_t* perm[4];
+  const int32_t* seg[4];
+  float sign[4];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void segsum_multi_kernel(const SegTerms T, float* __restrict__ x, int C) {
+  __shared__ float part[256][4];
+  const int64_t r = blockIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < T.n; ++k) {
+    const int k0 = T.seg[k][r], k1 = T.seg[k][r + 1];
+    const float* __restrict__ y = T.y[k];
+    const int32_t* __restrict__ perm = T.perm[k];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = k0 + threadIdx.x; i < k1; i += 256) {
+      const int64_t s = perm ? perm[i] : i;
+      for (int c = 0; c < C; ++c) a[c] += y[s * C + c];
+    }
+    for (int c = 0; c < C; ++c) acc[c] += T.sign[k] * a[c];
+  }
+  for (int c = 0; c < 4; ++c) part[threadIdx.x][c] = acc[c];
+  __syncthreads();
+  for (int h = 128; h >= 1; h >>= 1) {
+    if ((int)threadIdx.x < h)
+      for (int c = 0; c < 4; ++c) part[threadIdx.x][c] += part[threadIdx.x + h][c];
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < C) x[r * C + threadIdx.x] = part[0][threadIdx.x];
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
@@ -153,6 +192,24 @@ extern "C" int gn_segsum_rows_f32(const float* y, const int32_t* perm, const int
   } else {
     hipLaunchKernelGGL(segsum_wave<float>, grid, block, 0, st, y, perm, seg_off, x, N, C);
   }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_segsum_multi_f32(int n_terms, const float* const* y, const int32_t* const* perm,
+                                   const int32_t* const* seg_off, const float* sign, float* x, int64_t N, int C,
+                                   void* stream) {
+  if (N <= 0) return 0;
+  if (n_terms < 1 || n_terms > 4 || C < 1 || C > 4) return (int)hipErrorInvalidValue;
+  SegTerms T;
+  T.n = n_terms;
+  for (int k = 0; k < 4; ++k) {
+    T.y[k] = k < n_terms ? y[k] : nullptr;
+    T.perm[k] = k < n_terms ? perm[k] : nullptr;
+    T.seg[k] = k < n_terms ? seg_off[k] : nullptr;
+    T.sign[k] = k < n_terms ? sign[k] : 0.f;
+  }
+  hipLaunchKernelGGL(segsum_multi_kernel, dim3((unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream), T, x, C);
   GN_LAUNCH_CHECK();
   return 0;
 }

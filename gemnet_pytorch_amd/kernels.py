@@ -152,6 +152,24 @@ def segsum(y, perm, seg_off, n_rows):
     return x
 
 
+def segsum_multi(terms, n_rows):
+    """x[n] = sum_k sign_k * segsum(y_k, perm_k, seg_k)[n] for up to 4 terms (y, perm, seg_off, sign) sharing the row
+    space, rows of <= 4 floats, in one launch (gn_segsum_multi_f32)."""
+    ys = [_f32c(t[0]) for t in terms]
+    require_device(*ys)
+    C = _rowsize(ys[0])
+    assert 1 <= len(terms) <= 4 and C <= 4 and all(_rowsize(y) == C for y in ys)
+    n = len(terms)
+    x = torch.empty((n_rows,) + tuple(ys[0].shape[1:]), device=ys[0].device, dtype=torch.float32)
+    P = ctypes.c_void_p * n
+    yp = P(*[ptr(y) for y in ys])
+    pp = P(*[ptr(t[1]) for t in terms])
+    sp = P(*[ptr(t[2]) for t in terms])
+    sg = (ctypes.c_float * n)(*[float(t[3]) for t in terms])
+    check(_lib.load().gn_segsum_multi_f32(n, yp, pp, sp, sg, ptr(x), n_rows, C, stream()), "gn_segsum_multi_f32")
+    return x
+
+
 def rbf_aggregate_supported(m, rbf, W):
     return m.shape[1] == 128 and rbf.shape[1] == 16 and tuple(W.shape) == (128, 16)
 

@@ -261,6 +261,9 @@ class GemNet(torch.nn.Module):
         # first the main chain changed queues at every block (10-17 us idle per hop, tools/timeline.py); the later
         # issue also gives the output block the higher autograd sequence number, so its backward is enqueued (on the
         # side stream) before the backward of the interaction block that needs its contribution to dE/dm.
+        # (Issuing the output block of the LAST interaction block early — so that its backward is not enqueued between
+        # the backward of output block nb, which the main chain waits for, and the main chain itself — measured 4 %
+        # slower on the same box.)
         for i in range(self.num_blocks):
             ev = ready()
             h_i, m_i = h, m

@@ -824,7 +824,7 @@ class _EdgeBasis(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             W = K.edge_basis_bwd(gD, g_rbf, g_rad, R, ri_c.idx32, ri_a.idx32, freq if want_rbf else None,
                                  z, nrm, cutoff, p)
-            gR = K.segsum(W, *ri_a.csr, ri_a.n_rows) - K.segsum(W, *ri_c.csr, ri_c.n_rows)
+            gR = K.segsum_multi([(W, *ri_a.csr, 1.0), (W, *ri_c.csr, -1.0)], ri_a.n_rows)
         if want_rbf and ctx.needs_input_grad[1] and _PARAM_GRADS and g_rbf is not None:
             gf = (g_rbf * K.bessel_rbf(D, freq, cutoff, p, 0, 1)).sum(dim=0)
         return gR, gf, None, None, None, None, None, None, None, None
@@ -853,8 +853,8 @@ class _TripBasis(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None
         Gc, Gb = K.trip_basis_bwd(gY, R, ri_c.idx32, ri_a.idx32, ri_b.idx32)
-        gR = (K.segsum(Gc, *ri_c.csr, ri_c.n_rows) + K.segsum(Gb, *ri_b.csr, ri_b.n_rows)
-              - K.segsum(Gc + Gb, *ri_a.csr, ri_a.n_rows))
+        gR = K.segsum_multi([(Gc, *ri_c.csr, 1.0), (Gb, *ri_b.csr, 1.0), (Gc, *ri_a.csr, -1.0), (Gb, *ri_a.csr, -1.0)],
+                            ri_c.n_rows)
         return gR, None, None, None, None
 
 

@@ -240,6 +240,12 @@ int gn_gather_rows_f32(const float* x, const int32_t* idx, float* y, int64_t T, 
 /* x[n,:] = sum_{k in [seg_off[n], seg_off[n+1])} y[perm ? perm[k] : k, :]   (deterministic, no atomics) */
 int gn_segsum_rows_f32(const float* y, const int32_t* perm, const int32_t* seg_off, float* x,
                        int64_t N, int C, void* stream);
+/* x[n,:] = sum_{k < n_terms} sign[k] * sum_{i in [seg_off[k][n], seg_off[k][n+1])} y[k][perm[k] ? perm[k][i] : i, :]
+ * — up to 4 CSR lists over the same N rows in one launch (y / perm / seg_off / sign: HOST arrays of n_terms device
+ * pointers / floats); rows of C <= 4 floats.  The assembly of dE/dR from the per-triplet and per-edge terms of the
+ * geometry adjoint (gemnet.py:420-451 differentiated; the reference: autograd through index_select).  Deterministic. */
+int gn_segsum_multi_f32(int n_terms, const float* const* y, const int32_t* const* perm, const int32_t* const* seg_off,
+                        const float* sign, float* x, int64_t N, int C, void* stream);
 
 /* ---- bilinear aggregation, CSR-segmented (P4: efficient.py:159-189 without the zero-padded
  *      (E,Kmax,C) tensors; SURVEY.md Appendix D kernels K1 and its two adjoints) -----------

@@ -665,6 +665,37 @@ def test_rbf_aggregate_fused_vs_reference_ops(n_atoms, deg):
     assert torch.equal(gm3, f32(base_m) + gm) and torch.equal(gr3, f32(base_r) + gr)
 
 
+@pytest.mark.parametrize("N,T,C", [(1024, 300000, 3), (37, 500, 3), (5, 0, 1), (200, 9000, 4)])
+def test_segsum_multi_matches_separate_sums(N, T, C):
+    """gn_segsum_multi_f32 (the dE/dR assembly: up to four signed CSR sums over the same atoms in one launch) against the
+    float64 composition, with unsorted and sorted (perm = None) index lists and empty rows; deterministic."""
+    g = torch.Generator().manual_seed(N + T)
+    terms_cpu, terms_dev = [], []
+    for k, sign in enumerate((1.0, 1.0, -1.0, -0.5)):
+        idx = torch.randint(0, N, (T,), generator=g)
+        if k == 1:
+            idx = torch.sort(idx).values
+        if N > 5 and T:
+            idx[idx == 2] = 3                      # row 2 empty
+        y = rnd(g, T, C)
+        if k == 1:
+            perm = None
+            seg = torch.searchsorted(idx.contiguous(), torch.arange(N + 1)).to(torch.int32)
+        else:
+            perm = torch.argsort(idx, stable=True)
+            seg = torch.searchsorted(idx[perm].contiguous(), torch.arange(N + 1)).to(torch.int32)
+            perm = perm.to(torch.int32)
+        terms_cpu.append((y, idx, sign))
+        terms_dev.append((f32(y), None if perm is None else perm.to(DEV), seg.to(DEV), sign))
+    ref = sum(sg * torch.zeros(N, C, dtype=torch.float64).index_add(0, idx, y) for y, idx, sg in terms_cpu)
+    out = K.segsum_multi(terms_dev, N)
+    close(out, ref, rtol=1e-5, atol=1e-5 * max(1.0, float(ref.abs().max())))
+    assert torch.equal(out, K.segsum_multi(terms_dev, N))
+    out2 = K.segsum_multi(terms_dev[:2], N)
+    close(out2, sum(sg * torch.zeros(N, C, dtype=torch.float64).index_add(0, idx, y) for y, idx, sg in terms_cpu[:2]),
+          rtol=1e-5, atol=1e-5 * max(1.0, float(ref.abs().max())))
+
+
 def test_gemm_accumulates_in_place():
     """K.gemm(out = res2): C += A @ W^T element by element in one launch (the running gradient of a tensor with several
     fused consumers); same bits as the separate add."""
