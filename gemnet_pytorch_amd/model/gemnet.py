@@ -264,6 +264,8 @@ class GemNet(torch.nn.Module):
         # (Issuing the output block of the LAST interaction block early — so that its backward is not enqueued between
         # the backward of output block nb, which the main chain waits for, and the main chain itself — measured 4 %
         # slower on the same box.)
+        # Same-box A/B of the issue lag (output block i after interaction block i + lag - 1): lag 0 (before) 11.20 k,
+        # 1 (here) 11.36-11.45 k, 2 11.16 k, 3 11.00 k, all at the end 10.84 k molecules/s.
         for i in range(self.num_blocks):
             ev = ready()
             h_i, m_i = h, m
