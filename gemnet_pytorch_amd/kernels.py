@@ -763,6 +763,27 @@ def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True, gB_accum=None
     return gB, dSm, dY
 
 
+def bil_fused_bwd_supported(S, C, I, O):
+    return (S, C, I, O) == (7, 64, 16, 64)
+
+
+def bil_fused_bwd(g, W2, Sm, B, alpha=1.0, gB_accum=None):
+    """Adjoint of the bilinear tail in one launch -> (gB (E,S,I), dSm (E,S,C)); W2 (I*C, O) = the bilinear weight
+    (gn_bil_fused_bwd_f32: dP = alpha g W2^T stays in LDS).  `gB_accum`: running gradient gB is added to (and returned)."""
+    require_device(g, W2, Sm, B)
+    g, W2, Sm, B = _f32c(g), _f32c(W2), _f32c(Sm), _f32c(B)
+    E, S, C = Sm.shape
+    I, O = B.shape[2], g.shape[1]
+    assert tuple(W2.shape) == (I * C, O) and B.shape[:2] == (E, S) and g.shape[0] == E
+    if gB_accum is not None:
+        assert gB_accum.shape == (E, S, I) and gB_accum.is_contiguous() and gB_accum.dtype == torch.float32
+    gB = gB_accum if gB_accum is not None else torch.empty((E, S, I), device=g.device, dtype=torch.float32)
+    dSm = torch.empty((E, S, C), device=g.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_fused_bwd_f32(ptr(g), ptr(W2), ptr(Sm), ptr(B), ptr(gB), ptr(dSm), E, S, C, I, O, float(alpha),
+                                           2 if gB_accum is not None else 0, stream()), "gn_bil_fused_bwd_f32")
+    return gB, dSm
+
+
 def quad_basis_fwd(R, qc, qa, qb, qd, S):
     """-> Y (Q, S^2) = Y_lm(Phi_cab, Theta_cabd) from the 4 atoms of every quadruplet (gemnet.py:334-418)."""
     require_device(R, qc, qa, qb, qd)

@@ -727,8 +727,13 @@ class _FusedBilinear(torch.autograd.Function):
         sp, alpha = ctx.sp, ctx.alpha
         need = ctx.needs_input_grad
         g = g.contiguous()
-        dP = K.gemm(g, bilinear_weight(W, False), alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is (N=I*C, K=O)
         sink = ctx.sink
+        # K3^T + the gB / dSm part in ONE launch when the Y gradient is deferred anyway (dP stays in LDS)
+        fused_tail = (need[1] and not ctx.ang and sink is not None and sink.consumers <= 4
+                      and tuple(Sm.shape[1:]) == (7, 64) and K.bil_fused_bwd_supported(Sm.shape[1], C, I, O)
+                      and not (need[3] and _PARAM_GRADS and P is not None))
+        dP = None if fused_tail else \
+            K.gemm(g, bilinear_weight(W, False), alpha=alpha).reshape(-1, I, C)   # g @ W2^T: W2 is (N=I*C, K=O)
         accB = ctx.acc_B   # running gradient of the radial part of the basis (shared by the blocks)
         prevB, lastB = accB.enter() if accB is not None else (None, True)
         if need[1] and ctx.ang and (sink is None or sink.consumers > 4):
@@ -739,7 +744,10 @@ class _FusedBilinear(torch.autograd.Function):
                 sink.arrive()
         elif sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64)) and sink.consumers <= 4:
             # gB and dSm now, the Y gradient of all consumers of this basis in ONE pass when the last one arrives
-            gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False, gB_accum=prevB)
+            if fused_tail:
+                gB, dSm = K.bil_fused_bwd(g, bilinear_weight(W, False), Sm, rbf_W1, alpha, gB_accum=prevB)
+            else:
+                gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False, gB_accum=prevB)
             last = sink.arrive()
             sink.pending.append((dSm, x))
             gsph = None

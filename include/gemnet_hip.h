@@ -300,6 +300,13 @@ int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, con
 int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, const float* B, const float* x,
                                const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
                                int64_t E, int S, int C, int I, int accumulate, void* stream);
+/* The adjoint of the whole bilinear tail in one launch (K3^T then the gB / dSm part of the fused adjoint above; dP never
+ * leaves LDS):  dP[e,(i,c)] = alpha * sum_o g[e,o] W2[(i,c),o];  gB[e] = Sm[e] dP[e]^T;  dSm[e] = B[e] dP[e].
+ * W2 = the bilinear weight as (I*C, O) row-major (efficient.py:159-189 differentiated).  (S, C, I, O) = (7, 64, 16, 64)
+ * only (else hipErrorInvalidValue); `accumulate` bit 1: gB += (as gn_bil_project_bwd_acc_f32).  Bit-identical to
+ * gn_gemm_f32 + gn_bil_project_bwd_f32(dY = NULL). */
+int gn_bil_fused_bwd_f32(const float* g, const float* W2, const float* Sm, const float* B, float* gB, float* dSm,
+                         int64_t E, int S, int C, int I, int O, float alpha, int accumulate, void* stream);
 /* gn_bil_project_bwd*_f32 accept dY == NULL (gB and dSm only).  The deferred Y gradient of up to 4 blocks that
  * share one basis tensor (S = 49, C = 32 or S = 7, C = 64; else hipErrorInvalidValue) is then produced in one pass:
  *   dY[t,s] = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c]        (dSm_list / x_list: host arrays of nb device pointers) */

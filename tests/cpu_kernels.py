@@ -382,6 +382,20 @@ def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True, gB_accum=Non
     return gB, dSm, dY
 
 
+def bil_fused_bwd_supported(S, C, I, O):
+    return (S, C, I, O) == (7, 64, 16, 64)
+
+
+def bil_fused_bwd(g, W2, Sm, Bm, alpha=1.0, gB_accum=None):
+    E, S, C = Sm.shape
+    I = Bm.shape[2]
+    dP = (alpha * (g @ W2.t())).reshape(E, I, C)
+    gB = torch.bmm(Sm, dP.transpose(1, 2))
+    if gB_accum is not None:
+        gB = gB_accum.add_(gB)
+    return gB, torch.bmm(Bm, dP)
+
+
 def _quad_angles(Rc, Ra, Rb, Rd):
     def ang(u, v):
         x = (u * v).sum(1)
@@ -437,7 +451,7 @@ def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=Tru
     return g_m, g_rbf
 
 
-_NAMES = ["segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

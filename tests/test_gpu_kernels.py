@@ -489,6 +489,27 @@ def test_bilinear_fused_project_kernels(S, C, I, E, J, mk):
     assert gB3 is run and torch.equal(run, base + gB)
 
 
+@pytest.mark.parametrize("E", [500, 18122, 7])
+def test_bilinear_tail_adjoint_one_launch(E):
+    """gn_bil_fused_bwd_f32 (dP = alpha g W2^T kept in LDS, then gB and dSm) is bit-identical to the K = 64 / N = 1024 GEMM
+    followed by gn_bil_project_bwd_f32 without the Y gradient; also in the accumulate-into-gB form."""
+    g = torch.Generator().manual_seed(E)
+    S, C, I, O = 7, 64, 16, 64
+    gr, W2, Sm, Bm = f32(rnd(g, E, O)), f32(rnd(g, I * C, O) / 8), f32(rnd(g, E, S, C)), f32(rnd(g, E, S, I))
+    cpu, dev = _segplan(g, E, max(E, 8), 4)
+    x = f32(rnd(g, max(E, 8), C))
+    dP = K.gemm(gr, W2, alpha=0.7).reshape(E, I, C)
+    gB0, dSm0, _ = K.bil_project_bwd(dP, Sm, Bm, x, dev, want_dY=False)
+    gB1, dSm1 = K.bil_fused_bwd(gr, W2, Sm, Bm, 0.7)
+    assert torch.equal(gB1, gB0) and torch.equal(dSm1, dSm0)
+    ref = CK.bil_fused_bwd(gr.double().cpu(), W2.double().cpu(), Sm.double().cpu(), Bm.double().cpu(), 0.7)
+    close(gB1, ref[0], atol=2e-4 * float(ref[0].abs().max())); close(dSm1, ref[1], atol=2e-4 * float(ref[1].abs().max()))
+    base = f32(rnd(g, E, S, I))
+    run = base.clone()
+    gB2, _ = K.bil_fused_bwd(gr, W2, Sm, Bm, 0.7, gB_accum=run)
+    assert gB2 is run and torch.equal(run, base + gB0)
+
+
 def test_quad_basis_fused_fwd_bwd():
     g = torch.Generator().manual_seed(31)
     n_atoms, Q = 30, 1500
