@@ -159,10 +159,13 @@ class GraphPlan:
         return out
 
     def warm(self):
-        """Materialise every lazily-built CSR (call before hipGraph capture)."""
-        for ri in self.row_indices():
-            ri.csr
-        self.trip.groups
+        """Materialise every lazily-built CSR: before a hipGraph capture, and before a forward that forks onto a side
+        stream — a structure first built (sorted) on one stream and read by a kernel of the other is a race."""
+        if not getattr(self, "_warmed", False):
+            for ri in self.row_indices():
+                ri.csr
+            self.trip.groups
+            self._warmed = True
         return self
 
     def to(self, *args, **kwargs):

@@ -288,6 +288,11 @@ class GemNet(torch.nn.Module):
         R = inputs["R"]
         self._check_inputs(R)
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
+        if R.is_cuda and self.overlap_output_blocks:
+            # the output blocks run on a side stream: every lazily-built index structure they share with the main
+            # stream (CSR sorts, triplet groups) must exist before the fork, not be built by whichever stream gets
+            # there first (an un-warmed GemNet-Q batch aborted with a memory fault in one of three runs)
+            plan.warm()
         if not self.direct_forces:
             # The reference flips `inputs["R"].requires_grad` on the caller's tensor (gemnet.py:494,:613).  Here the
             # force is differentiated w.r.t. a FRESH leaf that shares R's storage: autograd keeps a leaf's gradient
