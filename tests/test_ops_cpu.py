@@ -234,3 +234,20 @@ def test_accumulate_gradient_matches_autograd_sum():
         x0, ys = _shared_consumer_graph(True)
         with pytest.raises(RuntimeError, match="fused consumers did not run"):
             torch.autograd.grad((ys[0] * ys[0]).sum(), x0)
+
+
+def test_accumulate_gradient_is_per_forward():
+    """A long-lived tensor marked again by every forward (a leaf fed to one block repeatedly): each forward gets its own
+    running sum, consumers of an earlier forward are not counted (bench.py extra.interaction_block_fwd_bwd)."""
+    with cpu_kernels.emulate(), ops.fused_first_order(True), ops.param_grads(False):
+        torch.manual_seed(5)
+        x = (torch.randn(30, 128, dtype=torch.float64)).requires_grad_(True) * 1.0
+        x.retain_grad()
+        W1, W2 = torch.randn(32, 128, dtype=torch.float64) / 11, torch.randn(64, 128, dtype=torch.float64) / 11
+        ref = None
+        for _ in range(3):
+            ops.accumulate_gradient(x)
+            loss = (ops.dense(x, W1) ** 2).sum() + (ops.dense(x, W2, True) ** 2).sum()
+            g, = torch.autograd.grad(loss, x)
+            ref = g if ref is None else ref
+            torch.testing.assert_close(g, ref, rtol=1e-12, atol=1e-12)

@@ -12,6 +12,8 @@ echo "== bench f32-MFMA chain (A/B of the Dense-stack arithmetic)"; timeout 900 
 echo "== rocprof kernel stats (same command as the bench line, hipGraph replay)"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-extras > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1 )
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" | cut -c1-200
+echo "== timeline of one hipGraph replay (queues, gaps, exclusive time per kernel)"
+python tools/timeline.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) --list > $OUT/timeline.txt 2>&1; head -5 $OUT/timeline.txt
 echo "== rocprof kernel stats, training step"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_train -o trace -- python $GRAFT_REPO_ROOT/bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/$OUT/rocprof_train.log 2>&1 )
 echo "== rocprof kernel stats, GemNet-Q"
@@ -26,6 +28,8 @@ echo "== chain micro-benchmarks"
 timeout 300 python tools/chain_bench.py > $OUT/chain_bench.txt 2>&1
 timeout 300 python tools/chain_programs.py > $OUT/chain_programs.txt 2>&1; tail -13 $OUT/chain_programs.txt
 timeout 300 python tools/chain2_trace.py > $OUT/chain2_trace.txt 2>&1
+timeout 100 python tools/exp/agg_bench.py 2>&1 | grep " us" > $OUT/agg_bench.txt
+./tools/exp/bin/lds_read_bench > $OUT/lds_read_bench.txt 2>&1
 ./tools/exp/bin/wfetch_bench > $OUT/wfetch.txt 2>&1
 echo "== BASELINE configs[4] shard (64 molecules x 64 atoms, GemNet-Q, bf16 operands vs default)"
 timeout 900 python tools/config4_shard.py 64 64 > $OUT/config4_shard.txt 2>&1; tail -2 $OUT/config4_shard.txt | cut -c1-900
