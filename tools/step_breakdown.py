@@ -7,7 +7,7 @@ chain_kernel<5> per GemNet-T forward+force step)."""
 import csv, re, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-per_step = {"chain_split_kernel<5, 3, true>": 12, "chain_kernel<5>": 24}
+per_step = {"chain_split_kernel<5, 3, true>": 16, "chain_kernel<5>": 24}
 steps = None
 for r in rows:
     for k, n in per_step.items():
