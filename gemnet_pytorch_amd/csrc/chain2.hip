@@ -31,6 +31,9 @@ typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Diagnosis switches of the trace build (never defined in the product library; GN_TRACE_DEFS of tools/chain2_trace.py):
+//   GN_EXP == 1  the MFMA phase without its LDS fragment reads (pipe time alone)
+//   GN_EXP == 2  the fragment reads without the MFMAs (LDS time alone)          -> DESIGN.md section 5
 #ifdef GN_CHAIN_TRACE
 // diagnosis build only (tools/chain2_trace.py): shader-clock stamps of wave 0 of two workgroups
 __device__ unsigned long long gn_chain2_trace_buf[2][GN_CHAIN_MAX_OPS][8];

@@ -182,12 +182,48 @@ class GemNet(torch.nn.Module):
     def _energy(self, R, plan):
         T = self.triplets_only
         b3 = self.cbf_basis3
+        side = self._side_stream(R.device) if self.overlap_output_blocks and R.is_cuda else None
+        # The head of the forward is a string of small launches (110 us at B = 32); only distances -> edge embedding ->
+        # rbf3 are needed by the first kernel of block 0.  With a side stream the rest forks off: the triplet angles,
+        # the atom embedding and its two concat-Dense terms need positions / atomic numbers only and run beside the edge
+        # geometry kernel; the circular-basis and the atom-update / output radial projections run beside the edge
+        # embedding.  Autograd replays a node on its forward stream, so the tail of the backward overlaps the same way.
+        # Triplets-only models only: with the quadruplet geometry on the main stream in between, one GemNet-Q test
+        # (8 x 64 atoms, after other models had run in the process) lost the bit-equality of graph replay and eager
+        # run; not reproduced in isolation, not understood — the quadruplet models keep the sequential head.
+        fork = side is not None and ops.is_fused() and T
+        main = torch.cuda.current_stream(R.device) if fork else None
+        h = terms = rbf_W1_3 = rbf_h = rbf_out = None
         if ops.is_fused():
+            if fork:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    sph3 = ops.share_gradient(ops.trip_basis(R, plan.t_c, plan.t_a, plan.t_b, self.num_spherical))
+                    h = self.atom_emb(plan.z_rows)
+                    terms = self.edge_emb.atom_terms(h)
+                    ev_a = torch.cuda.Event()
+                    ev_a.record(side)
             # one launch: distances + Bessel rbf + spherical-Bessel radial basis; one launch: angles + Y_l0
             D_ca, V_ca, rbf, rad3 = ops.edge_basis(R, self.rbf_basis.frequencies, plan.id_c, plan.id_a,
                                                    b3.z_ln, b3.n_ln, b3.cutoff, b3.p,
                                                    want_V=self.direct_forces)
-            sph3 = ops.share_gradient(ops.trip_basis(R, plan.t_c, plan.t_a, plan.t_b, self.num_spherical))
+            if fork:
+                ev_1 = torch.cuda.Event()
+                ev_1.record(main)
+                side.wait_event(ev_1)
+                with torch.cuda.stream(side):
+                    rbf.record_stream(side)
+                    rad3.record_stream(side)
+                    rbf_W1_3 = self.mlp_cbf3(rad3)
+                    rbf_h = self.mlp_rbf_h(rbf)
+                    rbf_out = self.mlp_rbf_out(rbf)
+                    ev_b = torch.cuda.Event()
+                    ev_b.record(side)
+                main.wait_event(ev_a)
+                for t in (sph3, h) + tuple(terms):
+                    t.record_stream(main)
+            else:
+                sph3 = ops.share_gradient(ops.trip_basis(R, plan.t_c, plan.t_a, plan.t_b, self.num_spherical))
         else:
             D_ca, V_ca = self.calculate_interatomic_vectors(R, plan.id_c, plan.id_a)
             rbf = self.rbf_basis(D_ca)
@@ -212,9 +248,10 @@ class GemNet(torch.nn.Module):
             # the tensor basis shares cutoff and radial tables with cbf_basis3: reuse rad3
             sbf4 = (rad3, ops.ylm(Phi_cab, Theta_cabd, self.num_spherical))  # ((E,S,R), (Q,S^2))
 
-        h = self.atom_emb(plan.z_rows)
+        if h is None:
+            h = self.atom_emb(plan.z_rows)
         rbf = ops.accumulate_gradient(rbf)
-        m = self.edge_emb(h, rbf, plan.id_c, plan.id_a)
+        m = self.edge_emb(h, rbf, plan.id_c, plan.id_a, terms=terms)
 
         if not T:
             rbf4 = ops.accumulate_gradient(self.mlp_rbf4(rbf))
@@ -224,15 +261,21 @@ class GemNet(torch.nn.Module):
             rbf4 = cbf4 = sbf4 = None
         # radial projections shared by all blocks: their gradients are summed inside the consumers' backward kernels
         rbf3 = ops.accumulate_gradient(self.mlp_rbf3(rbf))
-        cbf3 = (ops.accumulate_gradient(self.mlp_cbf3(rad3)), sph3)
-        rbf_h = ops.accumulate_gradient(self.mlp_rbf_h(rbf))
-        rbf_out = self.mlp_rbf_out(rbf)
+        if fork:
+            main.wait_event(ev_b)
+            for t in (rbf_W1_3, rbf_h):    # produced on the side stream, consumed (and summed: `stream=`) on the main one
+                t.record_stream(main)
+            cbf3 = (ops.accumulate_gradient(rbf_W1_3, stream=main), sph3)
+            rbf_h = ops.accumulate_gradient(rbf_h, stream=main)
+        else:
+            cbf3 = (ops.accumulate_gradient(self.mlp_cbf3(rad3)), sph3)
+            rbf_h = ops.accumulate_gradient(self.mlp_rbf_h(rbf))
+            rbf_out = self.mlp_rbf_out(rbf)
 
         # OutputBlock i only feeds the final energy sum: it runs on a side stream, concurrently with
         # InteractionBlock i+1 (and, since autograd replays a node on its forward stream, so does its
         # backward).  Its kernels are atom-side (A = 1024 rows: 32 workgroups) and latency-bound, so
         # overlapping them is free.  Captured hipGraphs keep the fork/join as graph edges.
-        side = self._side_stream(R.device) if self.overlap_output_blocks and R.is_cuda else None
         outs = []
 
         def ready():

@@ -110,11 +110,17 @@ class EdgeEmbedding(torch.nn.Module):
         self.atom_features = atom_features
         self.dense = Dense(2 * atom_features + edge_features, out_features, activation=activation, bias=False)
 
-    def forward(self, h, m_rbf, id_c, id_a):
+    def atom_terms(self, h):
+        """(h W_c^T, h W_a^T): the two atom-row GEMMs of forward(), callable ahead of the edge term (other stream)."""
         A = self.atom_features
         W = self.dense.weight
-        return ops.dense(m_rbf, W[:, 2 * A:], self.dense.act,
-                         g1=ops.dense(h, W[:, :A]), i1=id_c, g2=ops.dense(h, W[:, A:2 * A]), i2=id_a)
+        return ops.dense(h, W[:, :A]), ops.dense(h, W[:, A:2 * A])
+
+    def forward(self, h, m_rbf, id_c, id_a, terms=None):
+        A = self.atom_features
+        W = self.dense.weight
+        g1, g2 = terms if terms is not None else self.atom_terms(h)
+        return ops.dense(m_rbf, W[:, 2 * A:], self.dense.act, g1=g1, i1=id_c, g2=g2, i2=id_a)
 
 
 class AtomUpdateBlock(torch.nn.Module):

@@ -671,7 +671,7 @@ def share_gradient(t):
 USE_GRAD_ACC = os.environ.get("GEMNET_GRAD_ACC", "1") == "1"
 
 
-def accumulate_gradient(t):
+def accumulate_gradient(t, stream=None):
     """Mark the activation `t` as consumed by several fused ops: each of them adds its gradient contribution to the
     running sum inside its own backward kernel (residual input of the last GEMM / an accumulate flag) and the last one
     returns the sum, so the autograd engine never launches its own elementwise adds (32 per forward+force step of the
@@ -681,7 +681,11 @@ def accumulate_gradient(t):
         # a NEW running sum per call: a long-lived tensor (a leaf fed to a block again and again) must not count the
         # consumers of an earlier forward; the ops of that forward keep their reference to the sink they joined
         t._gn_acc = GradSink()
-        t._gn_acc.stream = torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+        # the stream of the participating CONSUMERS (default: the current one); the producer may live elsewhere
+        if stream is not None:
+            t._gn_acc.stream = stream.cuda_stream
+        else:
+            t._gn_acc.stream = torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
     return t
 
 

@@ -114,5 +114,8 @@ def test_hipgraph_replay_equals_eager_bitwise(setup):
     graph.replay()
     torch.cuda.synchronize()
     E, F = model(inputs)
+    print(f"{setup['kind']} {setup['n_mol']}x{setup['n_atoms']}: graph vs eager max|dF| = {float((F - Fg).abs().max()):.3e} "
+          f"({int((F != Fg).sum())} elements), eager vs first eager {float((F - setup['F']).abs().max()):.3e}, "
+          f"graph vs first eager {float((Fg - setup['F']).abs().max()):.3e}")
     assert torch.equal(E, Eg) and torch.equal(F, Fg)
     assert torch.equal(F, setup["F"])     # and run-to-run reproducible (no atomics)

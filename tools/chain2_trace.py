@@ -1,4 +1,7 @@
-"""Phase timing inside gn_chain_split_f32 (diagnosis build with -DGN_CHAIN_TRACE): shader-clock stamps per op."""
+"""Phase timing inside gn_chain_split_f32 (diagnosis build with -DGN_CHAIN_TRACE): shader-clock stamps per op.
+
+    python tools/chain2_trace.py [--quick [--small]]            all modes / only split6 at M = 18122 (M = 1024)
+    GN_TRACE_DEFS="-DGN_EXP=1" python tools/chain2_trace.py --quick   MFMA phase without its LDS reads (2: reads only)"""
 import ctypes, os, sys, subprocess, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
