@@ -130,6 +130,16 @@ class LaunchTimer:
             fl = 2.0 * sp.size * S * C + 2.0 * E * S * I * C + 2.0 * E * I * C * O
             by = sp.size * (S * f32 + 8) + (sp.n_expand * C + E * (S * C + S * I + O) + W2T.numel()) * f32
             return fl, by
+        if name == "bil_fused_bwd":
+            g, W2, Sm, B = args[:4]
+            E, S, C = Sm.shape
+            I, O = B.shape[2], g.shape[1]
+            fl = 2.0 * E * I * C * O + 4.0 * E * S * I * C
+            by = (g.numel() + W2.numel() + 2 * Sm.numel() + 2 * B.numel()) * f32
+            return fl, by
+        if name == "segsum_multi":
+            terms = args[0]
+            return 0.0, (sum(t[0].numel() for t in terms) + out.numel()) * f32 + sum(t[0].shape[0] for t in terms) * 4
         if name in ("bil_reduce", "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd"):
             sp = next(a for a in reversed(args) if hasattr(a, "n_reduce"))
             if name == "bil_project_bwd":
@@ -144,7 +154,8 @@ class LaunchTimer:
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
     FAMILIES = ["rbf_aggregate_fwd", "rbf_aggregate_bwd", "gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
-                "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_fused_fwd", "bil_project_bwd", "bil_dy_multi", "bessel_rbf", "sph_radial", "ylm0",
+                "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_fused_fwd", "bil_fused_bwd", "bil_project_bwd", "bil_dy_multi", "segsum_multi",
+                "bessel_rbf", "sph_radial", "ylm0",
                 "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
                 "quad_basis_bwd"]
 
