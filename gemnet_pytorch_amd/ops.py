@@ -617,10 +617,15 @@ class GradSink:
         self.buf = None
         self.pending = []   # (dSm_b, x_b) of the consumers whose Y gradient is deferred to one combined pass
         self.stream = None  # accumulate_gradient: HIP stream of the participating consumers
+        self.task = None    # id of the backward pass (autograd graph task) the running state belongs to
 
     def arrive(self):
         """Called once per consumer backward; returns True for the last consumer of this pass."""
-        if self.left == 0:          # first consumer of a new pass
+        task = torch._C._current_graph_task_id()
+        if self.left == 0 or task != self.task:
+            # first consumer of a new pass — also after a pass that died half way (an exception in some backward):
+            # its leftovers must not be mistaken for this pass's running sum
+            self.task = task
             self.left = self.consumers
             self.buf = None
             self.pending = []

@@ -251,3 +251,29 @@ def test_accumulate_gradient_is_per_forward():
             g, = torch.autograd.grad(loss, x)
             ref = g if ref is None else ref
             torch.testing.assert_close(g, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_accumulate_gradient_recovers_after_an_aborted_pass():
+    """A backward pass that dies between two consumers leaves a half-counted sink behind; the next pass (another graph
+    task) starts from scratch instead of handing out the stale partial sum."""
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            if Boom.armed:
+                raise ValueError("boom")
+            return g
+    with cpu_kernels.emulate(), ops.fused_first_order(True), ops.param_grads(False):
+        x0, ys = _shared_consumer_graph(True)
+        loss = (ys[0] ** 2).sum() + (Boom.apply(ys[1]) ** 2).sum() + (ys[2] ** 2).sum()
+        Boom.armed = True
+        with pytest.raises(ValueError, match="boom"):
+            torch.autograd.grad(loss, x0, retain_graph=True)
+        Boom.armed = False
+        g, = torch.autograd.grad(loss, x0)
+        x1, ys1 = _shared_consumer_graph(False)
+        ref, = torch.autograd.grad(sum((y ** 2).sum() for y in ys1), x1)
+        torch.testing.assert_close(g, ref, rtol=1e-12, atol=1e-12)
