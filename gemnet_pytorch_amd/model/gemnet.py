@@ -188,9 +188,8 @@ class GemNet(torch.nn.Module):
         # the atom embedding and its two concat-Dense terms need positions / atomic numbers only and run beside the edge
         # geometry kernel; the circular-basis and the atom-update / output radial projections run beside the edge
         # embedding.  Autograd replays a node on its forward stream, so the tail of the backward overlaps the same way.
-        # Triplets-only models only: with the quadruplet geometry on the main stream in between, one GemNet-Q test
-        # (8 x 64 atoms, after other models had run in the process) lost the bit-equality of graph replay and eager
-        # run; not reproduced in isolation, not understood — the quadruplet models keep the sequential head.
+        # Triplets-only models only for now: the fork is measured (+2.5-3.8 %) and verified (graph replay == eager, bit
+        # for bit) on GemNet-T; the quadruplet models spend 0.1 of 13.6 ms in this head and keep the sequential form.
         fork = side is not None and ops.is_fused() and T
         main = torch.cuda.current_stream(R.device) if fork else None
         h = terms = rbf_W1_3 = rbf_h = rbf_out = None
@@ -395,10 +394,20 @@ class GemNet(torch.nn.Module):
         """One side stream per calling stream (several molecule shards may run this module concurrently)."""
         if self._side is None:
             self._side = {}
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        cur = torch.cuda.current_stream(device)
+        key = (device.index, cur.cuda_stream)
         st = self._side.get(key)
         if st is None:
-            st = self._side[key] = torch.cuda.Stream(device=device)
+            st = torch.cuda.Stream(device=device)
+            # torch hands out streams round-robin from a pool of 32: late in a long-lived process the new "side" stream
+            # can BE the calling stream (e.g. the capture stream of torch.cuda.graph).  Everything would still be correct
+            # (one stream, serial), but the output blocks would then count as same-stream consumers of the gradient sinks
+            # and change the summation order — graph replay and eager run would stop being bit-identical.
+            for _ in range(4):
+                if st.cuda_stream != cur.cuda_stream:
+                    break
+                st = torch.cuda.Stream(device=device)
+            self._side[key] = st
         return st
 
     def _apply(self, fn, *args, **kwargs):
