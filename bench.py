@@ -51,10 +51,24 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_batch(cfg, n_mol, n_atoms, first, device):
+def shard_ids(world, rank, batch, n_atoms, cutoff=5.0):
+    """Molecule numbers of this rank's shard: the global batch of world x batch synthetic molecules partitioned by
+    `partition_molecules` (longest-processing-time on the per-molecule triplet count), as the data-parallel trainer
+    does it.  One rank: the first `batch` molecules."""
+    if world == 1:
+        return list(range(batch))
+    from gemnet_pytorch_amd.synthetic import make_molecule, triplet_count
+    from gemnet_pytorch_amd.training.ddp import partition_molecules
+    costs = [triplet_count(make_molecule(n_atoms, 1000 * 2 + i)["R"], cutoff) for i in range(world * batch)]
+    return partition_molecules(costs, world)[rank]
+
+
+def make_batch(cfg, n_mol, n_atoms, first, device, ids=None):
     from gemnet_pytorch_amd.synthetic import make_dataset
     from gemnet_pytorch_amd.training.data_container import DataContainer
-    ds = make_dataset(n_mol, n_atoms, config=2, first=first)
+    if ids is not None:
+        n_mol = len(ids)
+    ds = make_dataset(n_mol, n_atoms, config=2, first=first, ids=ids)
     dc = DataContainer.from_arrays(ds, cfg["cutoff"], cfg["int_cutoff"], triplets_only=cfg["triplets_only"])
     batch = dc[list(range(n_mol))]
     targets = {k: batch.pop(k).to(device) for k in ("E", "F")}
@@ -122,7 +136,10 @@ class LaunchTimer:
         if name == "bil_dy_multi":
             sp, nb = args[2], len(args[0])
             S, C = args[0][0].shape[1], args[0][0].shape[2]
-            return 2.0 * nb * sp.size * S * C, nb * (sp.n_reduce * S * C + sp.n_expand * C) * f32 + sp.size * (S * f32 + 4)
+            ang = kwargs.get("ang") is not None
+            fl = 2.0 * nb * sp.size * S * C + (2.0 * 600 * sp.size if ang else 0.0)   # + Y_lm and both angle derivatives
+            by = nb * (sp.n_reduce * S * C + sp.n_expand * C) * f32 + sp.size * ((32 if ang else S * f32) + 4)
+            return fl, by
         if name == "bil_fused_fwd":
             Y, x, B, W2T, sp = args[:5]
             S, C, I, O = Y.shape[1], x.shape[1], B.shape[2], W2T.shape[0]
@@ -142,13 +159,32 @@ class LaunchTimer:
             return 0.0, (sum(t[0].numel() for t in terms) + out.numel()) * f32 + sum(t[0].shape[0] for t in terms) * 4
         if name in ("bil_reduce", "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_project_bwd"):
             sp = next(a for a in reversed(args) if hasattr(a, "n_reduce"))
+            E = sp.n_reduce
             if name == "bil_project_bwd":
                 S, C = args[1].shape[1], args[1].shape[2]
-            else:
-                S = args[0].shape[1]
-                C = args[1].shape[-1]
-            by = sp.size * (S * f32 + 8) + sp.n_expand * C * f32 + sp.n_reduce * S * C * f32
-            return 2.0 * sp.size * S * C, by
+                I = args[2].shape[2]
+                want_dY = kwargs.get("want_dY", True)
+                # gB = Sm dP^T and dSm = B dP per edge; the per-triplet Y gradient only when it is not deferred to
+                # bil_dy_multi (then nothing of size T or Q is touched by this launch)
+                fl = 4.0 * E * S * I * C + (2.0 * sp.size * S * C if want_dY else 0.0)
+                by = E * (I * C + 2 * S * C + 2 * S * I) * f32
+                if want_dY:
+                    by += sp.size * (S * f32 + 8) + sp.n_expand * C * f32
+                return fl, by
+            Y = args[0]
+            ang = Y.dim() == 2 and Y.shape[1] == 4 and name != "bil_dot"
+            S = 49 if ang else Y.shape[1]
+            C = args[1].shape[-1]
+            ybytes = 16 if ang else S * f32           # angle form: (sin, cos) of two angles per quadruplet
+            by = sp.size * (ybytes + 8) + sp.n_expand * C * f32 + E * S * C * f32
+            fl = 2.0 * sp.size * S * C
+            if ang:
+                fl += 2.0 * 200 * sp.size             # Y_lm rebuilt per quadruplet: ~200 f32 FMA (csrc/bilinear_ang.hip)
+            if name == "bil_reduce_project":
+                I = args[2].shape[2]
+                fl += 2.0 * E * S * I * C
+                by += E * (S * I + I * C) * f32
+            return fl, by
         numel = sum(a.numel() for a in args if torch.is_tensor(a))
         outs = out if isinstance(out, tuple) else (out,)
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
@@ -191,7 +227,10 @@ class LaunchTimer:
         torch.cuda.synchronize()
         fam = {}
         for name, fn, args, kwargs, fl, by in self.records:
-            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, calls=[]))
+            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, calls=[], ang=False))
+            if name.startswith("bil_"):
+                Y0 = kwargs.get("ang") if name == "bil_dy_multi" else (args[0] if args and torch.is_tensor(args[0]) else None)
+                d["ang"] = d["ang"] or (Y0 is not None and Y0.dim() == 2 and Y0.shape[1] == 4)
             d["flops"] += fl
             d["bytes"] += by
             d["launches"] += 1
@@ -224,33 +263,84 @@ class LaunchTimer:
         return fam
 
 
-def pmc_traffic(name):
-    """HBM-side bytes per launch of a launcher family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes (profiles/r2_traffic.json, produced by tools/gpu_artifacts.sh + tools/pmc_summary.py; gfx950 FETCH_SIZE
-    correction applied).  null when that family was not profiled."""
+PEAK_SPLIT6_TFLOPS = 2500.0 / 6   # fp32-equivalent ceiling of six bf16 products on the 2.5 PF dense bf16 pipe
+PEAK_BF16_TFLOPS = 2500.0
+PROFILE_ROUND = "r3"
+
+
+def _profile_json(name):
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
-            return int(json.load(f)[name]["bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
 
 
-def roofline_from(fam):
+def pmc_traffic(name, mode):
+    """(HBM-side bytes per launch, source) of a launcher family from the COMMITTED rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of the same workload `mode` ("T" forward+force, "Q", "train"): profiles/r3_traffic_<mode>.json,
+    written by tools/gpu_artifacts.sh + tools/pmc_summary.py on the builder's GPU box (gfx950 FETCH_SIZE correction
+    applied).  Not measured in this run: the counters need rocprofv3 around the process.  (None, None) when that
+    family / mode was not profiled."""
+    fn = f"{PROFILE_ROUND}_traffic_{mode}.json"
+    tab = _profile_json(fn)
+    try:
+        return int(tab[name]["bytes_per_launch"]), f"profiles/{fn} (builder rocprofv3 --pmc pass, not this run)"
+    except (TypeError, KeyError, ValueError):
+        return None, None
+
+
+def mfma_busy(name, mode):
+    """MFMA-busy percentage of the family's kernels (SQ_VALU_MFMA_BUSY_CYCLES / (duration x clock x SIMDs)) from the
+    committed SQ counter pass (profiles/r3_mfma_busy.json); None when not profiled."""
+    tab = _profile_json(f"{PROFILE_ROUND}_mfma_busy.json")
+    try:
+        return float(tab[mode][name]["mfma_busy_pct"])
+    except (TypeError, KeyError, ValueError):
+        return None
+
+
+MFMA_FAMILIES = ("gemm", "gemm_tn", "bmm", "chain", "bil_fused_fwd", "bil_fused_bwd")
+
+
+def family_bound(name, calls_ang):
+    """Which roof bounds a launcher family: the matrix pipe, the f32 vector ALU (the angle-form tensor-basis kernels
+    rebuild Y_lm per quadruplet: DESIGN.md section 8.4), or HBM."""
+    if name in MFMA_FAMILIES:
+        return "mfma"
+    if calls_ang and name in ("bil_reduce_project", "bil_reduce_t", "bil_dy_multi"):
+        return "valu"
+    return "hbm"
+
+
+def roofline_from(fam, mode="T"):
+    from gemnet_pytorch_amd import kernels as K
     name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     sec = d["ms"] * 1e-3
-    if name in ("gemm", "gemm_tn", "bmm", "chain"):
+    bound = family_bound(name, d.get("ang", False))
+    traffic, src = pmc_traffic(name, mode)
+    common = dict(traffic=traffic, traffic_source=src,
+                  algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
+                  avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2), launches=d["launches"],
+                  share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
+    if bound in ("mfma", "valu"):
         ach = d["flops"] / sec / 1e12
-        return dict(kernel=name, bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(name),
-                    algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
-                    avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2), launches=d["launches"],
-                    share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
+        out = dict(kernel=name, bound=bound, achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                   frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common)
+        if bound == "mfma":
+            out["mfma_busy_pct"] = mfma_busy(name, mode)
+        if name == "chain" and K.CHAIN_MODE != "f32":
+            # the Dense stacks execute on the bf16 pipe: fraction of THAT pipe's ceiling for this arithmetic
+            nprod = K.CHAIN_MODES[K.CHAIN_MODE]
+            out["executing_pipe"] = f"bf16 MFMA, {nprod} product(s) per fp32 product"
+            out["frac_of_executing_pipe"] = round(ach * nprod / PEAK_BF16_TFLOPS, 4)
+            out["peak_executing_pipe_fp32_equiv"] = round(PEAK_BF16_TFLOPS / nprod, 1)
+        if bound == "valu":
+            out["note"] = "f32 vector-ALU bound (256 FLOP/clk/CU = the f32 MFMA rate); flops include the in-kernel Y_lm rebuild"
+        return out
     ach = d["bytes"] / sec / 1e9
     return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                frac=round(ach / PEAK_HBM_GBS, 4), traffic=pmc_traffic(name),
-                algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
-                avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2), launches=d["launches"],
-                share_of_kernel_time=round(d["ms"] / sum(v["ms"] for v in fam.values()), 3))
+                frac=round(ach / PEAK_HBM_GBS, 4), **common)
 
 
 def cpu_baseline(cfg, n_atoms, budget_s=14.0, n_mol=8):
@@ -282,6 +372,32 @@ def cpu_baseline(cfg, n_atoms, budget_s=14.0, n_mol=8):
                 sample=f"{steps} steps of forward+force on {n_mol} molecules x {n_atoms} atoms "
                        f"(same generator/config as the GPU workload), torch CPU fp32, {cores} threads",
                 ms_per_step=round(dt / steps * 1e3, 1))
+
+
+def cpu_baseline_train(cfg, n_atoms, n_mol=8, budget_s=10.0, threads=32):
+    """The full training step of the oracle on the host cores (forward + force + loss + the second-order
+    loss.backward(), trainer.py:325-360; no optimizer — negligible beside the double backward), bounded sample."""
+    from oracle import gemnet_oracle as GO
+    inputs, targets = make_batch(cfg, n_mol, n_atoms, first=0, device="cpu")
+    params = GO.make_params(cfg, 0, GO.load_scale_factors(SCALE_FILE), dtype=torch.float32)
+    leaves = [p.requires_grad_(True) for p in params.values() if p.dim() > 0]
+    torch.set_num_threads(threads)
+
+    def step():
+        E, F = GO.forward(cfg, params, inputs, create_graph=True)
+        loss = GO.training_loss(E[:, :1], F, targets["E"].reshape(-1, 1), targets["F"])
+        torch.autograd.grad(loss, leaves, allow_unused=True)
+    step()
+    t0, steps = time.time(), 0
+    while True:
+        step()
+        steps += 1
+        if time.time() - t0 > budget_s or steps >= 10:
+            break
+    dt = time.time() - t0
+    return dict(value=round(n_mol * steps / dt, 3), unit="molecules/s", cores=threads, kind="port",
+                sample=f"{steps} training steps (forward + force + loss.backward through the force) on {n_mol} molecules x "
+                       f"{n_atoms} atoms, torch CPU fp32, {threads} threads", ms_per_step=round(dt / steps * 1e3, 1))
 
 
 # ------------------------------------------------------------------------------------------------ timing helpers
@@ -327,12 +443,13 @@ def time_steps(run, steps, warmup, world=1):
     return elapsed
 
 
-def family_roofline(step):
-    """Instrument one eager pass of `step` and return (roofline of the dominant family, per-family table)."""
+def family_roofline(step, mode="T"):
+    """Instrument one eager pass of `step` and return (roofline of the dominant family, per-family table).
+    `mode` names the workload ("T", "Q", "train") for the committed-counter lookups."""
     with LaunchTimer() as lt:
         step()
     fam = lt.summary()
-    return roofline_from(fam), fam
+    return roofline_from(fam, mode), fam
 
 
 def log_families(title, fam):
@@ -367,9 +484,21 @@ def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, w
                            % (ts.buf.flat.numel() * 4 / 1e6)) if world > 1 else "none (single process)",
                optimizer="fused rescale + clip + AdamW(amsgrad) + EMA, 2 launches (csrc/optim.hip)",
                loss=float(ts.last_loss))
+    if world > 1:
+        # the collective alone: the flat gradient buffer through RCCL, back to back between two syncs (max over ranks)
+        import torch.distributed as dist
+        reps = 20
+        for _ in range(3):
+            dist.all_reduce(ts.buf.flat)
+        el = time_steps(lambda: dist.all_reduce(ts.buf.flat), reps, 0, world)
+        nbytes = ts.buf.flat.numel() * 4
+        out["allreduce_alone_us"] = round(el / reps * 1e6, 1)
+        out["allreduce_bytes"] = nbytes
+        # ring all-reduce moves 2 (N-1)/N of the buffer through every link
+        out["allreduce_bus_gbs"] = round(2 * (world - 1) / world * nbytes / (el / reps) / 1e9, 2)
     if want_roofline:
         held, ts._graph = getattr(ts, "_graph", None), None
-        roof, fam = family_roofline(lambda: ts(inputs, targets, step_optimizer=False))
+        roof, fam = family_roofline(lambda: ts(inputs, targets, step_optimizer=False), mode="train")
         ts._graph = held
         log_families("training step", fam)
         out["roofline"] = roof
@@ -437,7 +566,7 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3):
         step()
     graph, _ = capture(step)
     elapsed = time_steps(graph.replay, steps, warmup)
-    roof, fam = family_roofline(step)
+    roof, fam = family_roofline(step, mode="Q")
     log_families("GemNet-Q forward+force", fam)
     return dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / elapsed, 1),
                 steps=steps, warmup=warmup, per_gpu=sizes, hipgraph=True, roofline=roof)
@@ -479,6 +608,29 @@ def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12,
                      "positions / Z / N resident in HBM")
 
 
+def dry_run(args, rank, world):
+    """The N-rank plumbing without a GPU: process group (gloo), the shard of the global batch, one all-reduce; rank 0
+    prints the JSON skeleton.  Everything the real run does before touching the device."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = shard_ids(world, rank, args.batch, args.atoms)
+    t = torch.zeros(world * args.batch, dtype=torch.float64)
+    t[ids] = 1.0 + rank
+    if world > 1:
+        dist.all_reduce(t)
+    owners = (t - 1.0).long().tolist()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": None, "n_gpus": world, "steps": 0, "warmup": 0,
+                          "dry_run": True, "shard_sizes": [owners.count(r) for r in range(world)],
+                          "every_molecule_owned_once": bool(((t >= 1.0) & (t <= world)).all()) and len(owners) == world * args.batch,
+                          "collective": "gloo all_reduce" if world > 1 else "none"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     import faulthandler
     faulthandler.enable(file=sys.stderr)
@@ -498,15 +650,38 @@ def main():
                     help="skip the `extra` object (training step, isolated InteractionBlock, GemNet-Q, dynamic shapes)")
     ap.add_argument("--chain-mode", choices=["f32", "split6", "split3", "bf16"], default=None,
                     help="arithmetic of the Dense stacks (default: kernels.CHAIN_MODE = split6, fp32-equivalent)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: launch the ranks, shard the global batch, run one gloo all-reduce and print the JSON "
+                         "skeleton (proves the N-rank launch path on a machine without GPUs; tests/test_bench_cpu.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+        # 127.0.0.1) and hand their exit code back; rank 0's JSON line passes through on stdout.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        log(f"[bench] --gpus {args.gpus} without a launcher: re-executing under torch.distributed.run (port {port})")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    if torch.cuda.device_count() < max(world, local + 1):
+        raise SystemExit(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
@@ -532,12 +707,14 @@ def main():
         cfg["triplets_only"] = False
     torch.manual_seed(1234)
     model = GemNet(**cfg, scale_file=SCALE_FILE).to(device)
-    inputs, targets = make_batch(cfg, args.batch, args.atoms, first=rank * args.batch, device=device)
+    ids = shard_ids(world, rank, args.batch, args.atoms, cfg["cutoff"])
+    inputs, targets = make_batch(cfg, args.batch, args.atoms, first=0, device=device, ids=ids)
+    n_local = len(ids)
     plan = GraphPlan.from_inputs(inputs, cfg["triplets_only"]).warm()
     sizes = dict(atoms=plan.n_atoms, edges=plan.n_edges, triplets=plan.trip.size)
     if args.model == "Q":
         sizes.update(interaction_edges=plan.n_int, intermediate_triplets=plan.n_intm, quadruplets=plan.quad.size)
-    log(f"[bench] rank {rank}/{world}: {args.batch} molecules, {sizes}, Dense-stack arithmetic {K.CHAIN_MODE}")
+    log(f"[bench] rank {rank}/{world}: {n_local} molecules, {sizes}, Dense-stack arithmetic {K.CHAIN_MODE}")
 
     extra = {}
     if args.mode == "train":   # explicit request: the training step IS the timed region
@@ -599,9 +776,13 @@ def main():
             cpu["full_batch"] = cpu_baseline(cfg, args.atoms, budget_s=8.0, n_mol=args.batch)
         except Exception as ex:  # noqa: BLE001
             cpu["full_batch"] = {"error": f"{type(ex).__name__}: {ex}"}
+        try:
+            cpu["train_step"] = cpu_baseline_train(cfg, args.atoms, n_mol=4, budget_s=8.0, threads=cpu["cores"])
+        except Exception as ex:  # noqa: BLE001
+            cpu["train_step"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
-        mol_per_s = world * args.batch * args.steps / elapsed
+        mol_per_s = world * args.batch * args.steps / elapsed     # the shards of all ranks hold world x batch molecules
         line = {
             "metric": f"molecules/sec (forward+force) GemNet-{args.model} on COLL-shaped batches"
                       + ("" if args.mode == "force" else " [training step: fwd+force+backward+allreduce+AdamW]"),

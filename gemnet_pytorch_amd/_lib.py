@@ -57,6 +57,7 @@ class ChainOp(ctypes.Structure):
         ("res2_slot", _i), ("res2_g", _vp), ("beta2", _f),
         ("out", _vp),
         ("mul_mode", _i), ("y2_slot", _i), ("y2_src", _i), ("mode2", _i), ("alpha2", _f), ("Z2", _vp), ("out2", _vp),
+        ("src_stage", _i), ("src_mode", _i), ("src_alpha", _f), ("srcP", _vp), ("srcQ", _vp),
     ]
 
 

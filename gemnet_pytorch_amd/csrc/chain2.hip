@@ -80,6 +80,13 @@ __device__ __forceinline__ float4 join4(const uint2 H, const uint2 M, const uint
                      (bf_lo(H.y) + bf_lo(M.y)) + bf_lo(L.y), (bf_hi(H.y) + bf_hi(M.y)) + bf_hi(L.y));
 }
 
+// s = src_alpha * phis(z) * p * q  (second-order source term, include/gemnet_hip.h); z is only read when mode == 1
+__device__ __forceinline__ float4 src_term(const float4 z, const float4 p, const float4 q, const int mode, const float a) {
+  float4 s = make_float4(a * p.x * q.x, a * p.y * q.y, a * p.z * q.z, a * p.w * q.w);
+  if (mode == 1) { s.x *= gn_d2ssilu(z.x); s.y *= gn_d2ssilu(z.y); s.z *= gn_d2ssilu(z.z); s.w *= gn_d2ssilu(z.w); }
+  return s;
+}
+
 // NPL = planes that enter the MFMAs: 1 -> 1 product (bf16 operands), 2 -> 3 products, 3 -> 6 products
 // ADJ: the program uses the register parking slot or second outputs (the adjoint programs); plain forward stacks run the
 // leaner variant (park / y2 registers would push the RT = 5 kernel into scratch, and a kernel with a scratch segment pays
@@ -181,6 +188,11 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       const float* __restrict__ const src = op.src;
       const float* __restrict__ const Z2 = op.Z2;
       const int32_t* __restrict__ const rows = op.rows;
+      const bool lsrc = ADJ && op.src_stage == 2 && y2_slot >= 0 && op.srcP;
+      const float* __restrict__ const srcP = op.srcP;
+      const float* __restrict__ const srcQ = op.srcQ;
+      const int src_mode = op.src_mode;
+      const float src_alpha = op.src_alpha;
       // all global loads of the tile are issued before the first one is consumed (a tile is at most RT passes of the
       // 512 threads): the serial load -> split -> write form took 6.7 k cycles for 40 KB (tools/chain2_trace.py)
       float4 v[RT], zz[RT];
@@ -214,6 +226,13 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
               else if (mode2 == 1) { u.x *= z.x; u.y *= z.y; u.z *= z.z; u.w *= z.w; }
               else { u.x *= gn_ssilu(z.x); u.y *= gn_ssilu(z.y); u.z *= gn_ssilu(z.z); u.w *= gn_ssilu(z.w); }
             }
+            if (lsrc && in[i]) {
+              const int64_t gr = row0 + r;
+              const float4 p = *reinterpret_cast<const float4*>(srcP + gr * width + c);
+              const float4 q = srcQ ? *reinterpret_cast<const float4*>(srcQ + gr * width + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+              const float4 sv = src_term(zz[i], p, q, src_mode, src_alpha);
+              u.x += sv.x; u.y += sv.y; u.z += sv.z; u.w += sv.w;
+            }
             slot_write(y2_slot, r, c, u);
           }
         }
@@ -244,11 +263,18 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
           const int64_t gr = row0 + r;
           float4 v = slot_read(a_slot, r, c);
           v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+          float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
           if (src && gr < M) {
-            const float4 z = *reinterpret_cast<const float4*>(src + gr * ld + c);
+            z = *reinterpret_cast<const float4*>(src + gr * ld + c);
             if (mode == 0) { v.x *= gn_dssilu(z.x); v.y *= gn_dssilu(z.y); v.z *= gn_dssilu(z.z); v.w *= gn_dssilu(z.w); }
             else if (mode == 1) { v.x *= z.x; v.y *= z.y; v.z *= z.z; v.w *= z.w; }
             else { v.x *= gn_ssilu(z.x); v.y *= gn_ssilu(z.y); v.z *= gn_ssilu(z.z); v.w *= gn_ssilu(z.w); }
+          }
+          if (ADJ && op.src_stage == 1 && op.srcP && gr < M) {
+            const float4 p = *reinterpret_cast<const float4*>(op.srcP + gr * ld + c);
+            const float4 q = op.srcQ ? *reinterpret_cast<const float4*>(op.srcQ + gr * ld + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sv = src_term(z, p, q, op.src_mode, op.src_alpha);
+            v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
           }
           slot_write(slot, r, c, v);
           if (out && gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = v;
@@ -282,6 +308,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       const float alpha2 = op.alpha2;
       const float* __restrict__ const Z2 = op.Z2;
       float* __restrict__ const out2 = op.out2;
+      const int src_stage = ADJ ? op.src_stage : 0, src_mode = op.src_mode;
+      const float src_alpha = op.src_alpha;
+      const float* __restrict__ const srcP = op.srcP;
+      const float* __restrict__ const srcQ = op.srcQ;
       const bool active = wave * 16 < N;
       ++gord;
 #ifdef GN_CHAIN_TRACE
@@ -418,6 +448,15 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
           } else {
             GN2_EACH(q[t] = make_float4(v[t].x * alpha2, v[t].y * alpha2, v[t].z * alpha2, v[t].w * alpha2);)
           }
+          if (src_stage == 2 && srcP) {   // one row block at a time: no register room for RT more float4 triples here
+            GN2_EACH(if (ok[t]) {
+              const float4 zs = Z2 ? *reinterpret_cast<const float4*>(Z2 + off[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+              const float4 pp = *reinterpret_cast<const float4*>(srcP + off[t]);
+              const float4 qq = srcQ ? *reinterpret_cast<const float4*>(srcQ + off[t]) : make_float4(1.f, 1.f, 1.f, 1.f);
+              const float4 sv = src_term(zs, pp, qq, src_mode, src_alpha);
+              q[t].x += sv.x; q[t].y += sv.y; q[t].z += sv.z; q[t].w += sv.w;
+            })
+          }
           if (out2) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(out2 + off[t]) = q[t];)
           if (y2_slot >= 0) GN2_EACH(slot_write(y2_slot, 16 * t + l15, n0, ok[t] ? q[t] : make_float4(0.f, 0.f, 0.f, 0.f));)
         };
@@ -432,6 +471,15 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
           GN2_EACH(GN2_MUL(q[t]))
         }
         if (alpha != 1.0f) GN2_EACH(v[t].x *= alpha; v[t].y *= alpha; v[t].z *= alpha; v[t].w *= alpha;)
+        if (src_stage == 1 && srcP) {     // y += src_alpha * phis(mul_g) * P * Q, one row block at a time (see y2)
+          GN2_EACH(if (ok[t]) {
+            const float4 zs = (mul_g && src_mode == 1) ? *reinterpret_cast<const float4*>(mul_g + off[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 pp = *reinterpret_cast<const float4*>(srcP + off[t]);
+            const float4 qq = srcQ ? *reinterpret_cast<const float4*>(srcQ + off[t]) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sv = src_term(zs, pp, qq, src_mode, src_alpha);
+            v[t].x += sv.x; v[t].y += sv.y; v[t].z += sv.z; v[t].w += sv.w;
+          })
+        }
         if (ADJ && res_slot == 2) GN2_EACH(GN2_RES(park[ADJ ? t : 0], beta))
         else if (res_slot >= 0) GN2_EACH(const float4 q = slot_read_acc(res_slot, t); GN2_RES(q, beta))
         else if (res_g) {
@@ -564,21 +612,28 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
       if (o.mul_slot > 2 || o.res_slot > 2 || o.res2_slot > 2 || o.y2_slot > 1) return (int)hipErrorInvalidValue;
       if (o.y2_slot >= 0 && (o.y2_slot == o.slot || o.y2_slot == o.mul_slot || o.y2_slot == o.res_slot ||
                              o.y2_slot == o.res2_slot)) return (int)hipErrorInvalidValue;
+      if (o.src_stage < 0 || o.src_stage > 2 || (o.src_stage && !o.srcP)) return (int)hipErrorInvalidValue;
+      if (o.src_stage == 1 && o.src_mode == 1 && !o.mul_g) return (int)hipErrorInvalidValue;
+      if (o.src_stage == 2 && ((o.y2_slot < 0 && !o.out2) || (o.src_mode == 1 && !o.Z2))) return (int)hipErrorInvalidValue;
     } else {
       if (o.width <= 0 || o.width > SW || (o.width % 4) != 0 || (o.ld % 4) != 0) return (int)hipErrorInvalidValue;
       if (o.slot < 0 || o.slot > 2) return (int)hipErrorInvalidValue;
       if (o.slot == 2 && (o.kind != GN_OP_SCALE || o.src || o.out)) return (int)hipErrorInvalidValue;
       if (o.kind == GN_OP_LOAD && (o.y2_slot > 1 || o.y2_slot == o.slot)) return (int)hipErrorInvalidValue;
       if (o.kind == GN_OP_SCALE && (o.a_slot < 0 || o.a_slot > 1)) return (int)hipErrorInvalidValue;
+      if (o.src_stage && (!o.srcP || o.kind == GN_OP_STORE || (o.kind == GN_OP_SCALE && (o.src_stage != 1 || o.slot == 2)) ||
+                          (o.kind == GN_OP_LOAD && (o.src_stage != 2 || o.y2_slot < 0)))) return (int)hipErrorInvalidValue;
+      if (o.src_stage && o.src_mode == 1 && !(o.kind == GN_OP_SCALE ? o.src : o.Z2)) return (int)hipErrorInvalidValue;
     }
   }
   bool adj = false;   // does the program touch the parking slot or a second output?
   for (int i = 0; i < args->n_ops; ++i) {
     const gn_chain_op& o = args->ops[i];
     if (o.kind == GN_OP_GEMM)
-      adj = adj || o.slot == 2 || o.mul_slot == 2 || o.res_slot == 2 || o.res2_slot == 2 || o.y2_slot >= 0 || o.out2;
+      adj = adj || o.slot == 2 || o.mul_slot == 2 || o.res_slot == 2 || o.res2_slot == 2 || o.y2_slot >= 0 || o.out2 ||
+            o.src_stage != 0;
     else
-      adj = adj || o.slot == 2 || (o.kind == GN_OP_LOAD && o.y2_slot >= 0);
+      adj = adj || o.slot == 2 || (o.kind == GN_OP_LOAD && o.y2_slot >= 0) || o.src_stage != 0;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nprod == 6) return dispatch_adj<3>(args, adj, st);

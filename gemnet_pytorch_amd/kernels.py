@@ -409,25 +409,37 @@ class ChainProgram:
         self.M = int(M)
         self.ops = []
 
-    def load(self, slot, src, rows=None, alpha=1.0, y2=-1, alpha2=1.0, Z2=None, mode2=0):
-        """slot <- src[rows] * alpha; optional second tensor y2 (slot) <- that * alpha2 * phi2(Z2) (as for gemm)."""
+    def load(self, slot, src, rows=None, alpha=1.0, y2=-1, alpha2=1.0, Z2=None, mode2=0, add2=None):
+        """slot <- src[rows] * alpha; optional second tensor y2 (slot) <- that * alpha2 * phi2(Z2) (as for gemm)
+        [+ add2: a source term, see `source`]."""
         self.ops.append(dict(kind="load", slot=slot, src=src, rows=rows, alpha=float(alpha), y2=int(y2),
-                             alpha2=float(alpha2), Z2=Z2, mode2=int(mode2)))
+                             alpha2=float(alpha2), Z2=Z2, mode2=int(mode2), add2=add2))
 
-    def scale(self, dst, a, alpha=1.0, Z=None, out=None, width=None, mode=0):
-        """dst <- a * alpha * phi(Z): mode 0 phi = ssilu', 1 identity (Hadamard with Z), 2 ssilu."""
+    def scale(self, dst, a, alpha=1.0, Z=None, out=None, width=None, mode=0, add=None):
+        """dst <- a * alpha * phi(Z) [+ add]: mode 0 phi = ssilu', 1 identity (Hadamard with Z), 2 ssilu;
+        `add`: a source term (see `source`; its phis(Z) uses this op's Z)."""
         self.ops.append(dict(kind="scale", slot=dst, a_slot=a, alpha=float(alpha), Z=Z, out=out, width=width,
-                             mode=int(mode)))
+                             mode=int(mode), add=add))
+
+    @staticmethod
+    def source(P, Q=None, d2=False, alpha=1.0):
+        """The extra summand  alpha * (ssilu''(Z) if d2 else 1) * P * Q  of the second-order sweeps (gn_chain_op.src_*);
+        Z is the factor tensor of the op (stage) it is attached to.  P, Q: global (M,N) tensors (Q optional)."""
+        return dict(P=P, Q=Q, mode=1 if d2 else 0, alpha=float(alpha))
 
     def gemm(self, W, a_slot, y_slot=-1, act=False, alpha=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
              pre_out=None, mul=None, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0, out=None, packed=None,
-             mul_mode=1, y2=-1, y2_src=0, alpha2=1.0, Z2=None, mode2=0, out2=None):
+             mul_mode=1, y2=-1, y2_src=0, alpha2=1.0, Z2=None, mode2=0, out2=None, add=None, add2=None):
         """W: the (N,K) fp32 weight; `packed`: its split-bf16 fragment form (pack_weight_split(W)) if the caller
         caches it — the split-operand kernel packs on the fly otherwise.
         mul_mode (global `mul` only): 1 identity, 2 ssilu'(mul), 3 ssilu(mul).
         Second output: y2 (slot) / out2 (global) <- (y2_src ? activation output : final y) * alpha2 * phi2(Z2),
-        phi2 by mode2: 0 ssilu', 1 identity, 2 ssilu (Z2 None: plain scale)."""
+        phi2 by mode2: 0 ssilu', 1 identity, 2 ssilu (Z2 None: plain scale).
+        add / add2: a source term (`source`) added to y after the mul and alpha stages (its ssilu'' factor reads the
+        GLOBAL mul operand) / to the second output (ssilu'' of Z2); at most one of them per op."""
+        assert add is None or add2 is None, "one source term per op"
         self.ops.append(dict(kind="gemm", W=W, packed=packed, a_slot=a_slot, slot=y_slot, act=bool(act), alpha=float(alpha),
+                             add=add, add2=add2,
                              mul_mode=int(mul_mode), y2=int(y2), y2_src=int(y2_src), alpha2=float(alpha2), Z2=Z2,
                              mode2=int(mode2), out2=out2,
                              gadd1=gadd1, gidx1=gidx1, gadd2=gadd2, gidx2=gidx2, pre_out=pre_out, mul=mul,
@@ -462,7 +474,7 @@ def fuse_program(prog):
                 i += 1
             while (i < len(ops) and ops[i]["kind"] == "scale" and ops[i]["slot"] == y and ops[i]["a_slot"] == y
                    and (ops[i]["width"] or N) == N and ops[i]["Z"] is None and ops[i]["out"] is None
-                   and ops[i]["alpha"] != 0.0 and g["y2"] < 0):
+                   and ops[i].get("add") is None and ops[i]["alpha"] != 0.0 and g["y2"] < 0):
                 g["alpha"] *= ops[i]["alpha"]
                 for pk in parks:
                     pk["alpha"] /= ops[i]["alpha"]
@@ -471,7 +483,7 @@ def fuse_program(prog):
                 sc = ops[i]
                 if (sc["kind"] == "scale" and sc["slot"] in (0, 1) and sc["slot"] != y and sc["a_slot"] == y
                         and (sc["width"] or N) == N and sc["out"] is None):
-                    g.update(y2=sc["slot"], alpha2=sc["alpha"], Z2=sc["Z"], mode2=sc.get("mode", 0))
+                    g.update(y2=sc["slot"], alpha2=sc["alpha"], Z2=sc["Z"], mode2=sc.get("mode", 0), add2=sc.get("add"))
                     i += 1
             out.extend(parks)
             continue
@@ -491,12 +503,14 @@ def fuse_program(prog):
                 g["alpha"] *= c
 
         # A: activation-derivative / Hadamard factor of a plain GEMM
-        if (i < len(ops) and is_scale(ops[i], y, y) and ops[i]["Z"] is not None and ops[i]["out"] is None
+        if (i < len(ops) and is_scale(ops[i], y, y) and ops[i]["Z"] is not None
                 and g["mul"] is None and g["res"] is None and g["res2"] is None and g["out"] is None and g["y2"] < 0
-                and g.get("out2") is None):
+                and g.get("out2") is None and g.get("add") is None and g.get("add2") is None):
             sc = ops[i]
             g["mul"], g["mul_mode"] = sc["Z"], {0: 2, 1: 1, 2: 3}[sc.get("mode", 0)]
             g["alpha"] *= sc["alpha"]
+            g["out"] = sc["out"]          # the value after the mul / alpha (/ source) stages
+            g["add"] = sc.get("add")      # y = a phi(Z) alpha + source: the GEMM's stage-1 source term
             i += 1
         parks = []
         while i < len(ops) and ops[i]["kind"] == "scale" and ops[i]["slot"] == 2 and ops[i]["a_slot"] == y:
@@ -504,7 +518,7 @@ def fuse_program(prog):
             i += 1
         # B: in-place plain scales of y
         while (i < len(ops) and is_scale(ops[i], y, y) and ops[i]["Z"] is None and ops[i]["alpha"] != 0.0
-               and g["y2"] < 0 and g.get("out2") is None):
+               and ops[i].get("add") is None and g.get("add") is None and g["y2"] < 0 and g.get("out2") is None):
             sc = ops[i]
             if sc["out"] is not None:
                 if g["out"] is not None:
@@ -521,8 +535,10 @@ def fuse_program(prog):
             sc = ops[i]
             o = sc.get("slot")
             used = {y} | {x for x in (g["mul"], g["res"], g["res2"]) if isinstance(x, int)}
-            if sc["kind"] == "scale" and o in (0, 1) and o not in used and sc["a_slot"] == y and (sc["width"] or N) == N:
-                g.update(y2=o, y2_src=0, alpha2=sc["alpha"], Z2=sc["Z"], mode2=sc.get("mode", 0), out2=sc["out"])
+            if (sc["kind"] == "scale" and o in (0, 1) and o not in used and sc["a_slot"] == y and (sc["width"] or N) == N
+                    and not (sc.get("add") is not None and g.get("add") is not None)):
+                g.update(y2=o, y2_src=0, alpha2=sc["alpha"], Z2=sc["Z"], mode2=sc.get("mode", 0), out2=sc["out"],
+                         add2=sc.get("add"))
                 i += 1
         out.extend(parks)
     fused = ChainProgram(prog.M)
@@ -592,9 +608,19 @@ def chain(prog, mode=None):
             assert t.shape[1] == cols, (t.shape, cols)
         return t
 
+    def source(c, src, stage, cols):
+        if src is None:
+            return
+        c.src_stage, c.src_mode, c.src_alpha = stage, int(src["mode"]), float(src["alpha"])
+        c.srcP = ptr(mat(src["P"], cols))
+        c.srcQ = ptr(mat(src["Q"], cols)) if src["Q"] is not None else None
+        has_src[0] = True
+
+    has_src = [False]
     for i, o in enumerate(prog.ops):
         c = a.ops[i]
         c.slot, c.a_slot, c.mul_slot, c.res_slot, c.res2_slot, c.y2_slot = -1, -1, -1, -1, -1, -1
+        c.src_stage = 0
         if o["kind"] == "load":
             src = mat(o["src"])
             assert o["rows"] is not None or src.shape[0] == M
@@ -602,6 +628,7 @@ def chain(prog, mode=None):
             c.src, c.rows = ptr(src), ptr(o["rows"])
             c.alpha, c.y2_slot, c.alpha2, c.mode2 = o.get("alpha", 1.0), o.get("y2", -1), o.get("alpha2", 1.0), o.get("mode2", 0)
             c.Z2 = ptr(mat(o["Z2"], src.shape[1])) if o.get("Z2") is not None else None
+            source(c, o.get("add2"), 2, src.shape[1])
         elif o["kind"] == "scale":
             Z, out = o["Z"], o["out"]
             w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
@@ -609,18 +636,21 @@ def chain(prog, mode=None):
             c.act = o.get("mode", 0)
             c.src = ptr(mat(Z, w)) if Z is not None else None
             c.out = ptr(mat(out, w)) if out is not None else None
+            source(c, o.get("add"), 1, w)
         elif o["kind"] == "store":
             out = mat(o["out"])
             c.kind, c.slot, c.width, c.ld, c.out = GN_OP_STORE, o["slot"], out.shape[1], out.stride(0), ptr(out)
         else:
-            W = mat(o["W"])
+            W = o["W"]
             N, Kd = W.shape
             if nprod:
-                Wp = o.get("packed")
+                Wp = o.get("packed")     # with the packed planes given, `W` only carries the shape (any strides)
                 if Wp is None:
-                    Wp = pack_weight_split(W)
+                    Wp = pack_weight_split(mat(W))
                 keep.append(Wp)
                 W = Wp
+            else:
+                W = mat(W)
             c.kind, c.W, c.N, c.K, c.a_slot, c.slot = GN_OP_GEMM, ptr(W), N, Kd, o["a_slot"], o["slot"]
             c.act, c.alpha, c.beta, c.beta2 = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
             for name in ("gadd1", "gadd2"):
@@ -638,6 +668,11 @@ def chain(prog, mode=None):
             c.out2 = ptr(mat(o["out2"], N)) if o["out2"] is not None else None
             if o["mul_mode"] > 1:
                 assert c.mul_slot < 0 and c.mul_g is not None, "mul_mode applies to a global mul operand"
+            source(c, o.get("add"), 1, N)
+            source(c, o.get("add2"), 2, N)
+    if has_src[0] and not nprod:
+        raise RuntimeError("chain programs with second-order source terms run on the split-operand kernel only "
+                           "(CHAIN_MODE f32 / an unsupported shape): use the composite training path")
     if nprod:
         check(_lib.load().gn_chain_split_f32(ctypes.byref(a), nprod, stream()), "gn_chain_split_f32")
     else:

@@ -31,6 +31,11 @@ from .scaling import AutomaticFit
 _nullcontext = contextlib.nullcontext
 
 
+def K_chain_mode():
+    from .. import kernels
+    return kernels.CHAIN_MODE
+
+
 class GemNet(torch.nn.Module):
     def __init__(
         self,
@@ -341,7 +346,12 @@ class GemNet(torch.nn.Module):
             # accumulator — tied to the stream of its first backward — on the tensor object, and positions that once
             # went through a forward on the default stream made later hipGraph captures of the same batch fail
             # (the engine synchronised the capturing stream with the default stream).
-            R = R.detach().requires_grad_(True)
+            # A caller whose R already takes part in an autograd graph (a non-leaf, or a leaf that requires grad:
+            # Hessians, position-dependent losses) keeps its tensor, as in the reference.
+            if R.requires_grad:
+                pass
+            else:
+                R = R.detach().requires_grad_(True)
         # second-order graph only when it can be used (see module docstring)
         graph = self.force_graph
         if graph is None:
@@ -353,7 +363,12 @@ class GemNet(torch.nn.Module):
         # force-by-autograd without a second-order graph: the graph of E is consumed right here, so
         # parameter gradients can never be requested -> weights are constants (enables ops.stack)
         const_w = fused and not self.direct_forces
+        # force training: the Dense stacks as twice-differentiable single-launch Functions (ops_train.py), the rest on
+        # the composite closure; the split-operand chain kernel only (its f32 sibling has no second-order source terms)
+        mode = self.matmul_precision or K_chain_mode()
+        t2 = bool(graph) and ops.USE_TRAIN2 and not AutomaticFit.fitting_mode and mode != "f32"
         with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w), \
+                ops.train2(t2), \
                 ops.chain_mode(self.matmul_precision), torch.enable_grad() if not self.direct_forces else _nullcontext():
             E_mol, F_ca, V_ca = self._energy(R, plan)
 
@@ -385,7 +400,9 @@ class GemNet(torch.nn.Module):
             c[:, target] = -1.0
             if E_mol.is_cuda and torch.cuda.is_current_stream_capturing():
                 return c      # memory of a capture's private pool must not outlive it in a cache
-            if self._cot is None or len(self._cot) > 64:
+            # never evicted: a hipGraph captured after this call bakes the address in and reads it at every replay
+            # (one (n_molecules, n_targets) tensor per distinct batch size: bytes)
+            if self._cot is None:
                 self._cot = {}
             self._cot[key] = c
         return c
@@ -409,6 +426,11 @@ class GemNet(torch.nn.Module):
                 st = torch.cuda.Stream(device=device)
             self._side[key] = st
         return st
+
+    def train(self, mode=True):
+        if bool(mode) != self.training:
+            self._wcache = {}   # weights change while training: derived forms cached for inference are stale afterwards
+        return super().train(mode)
 
     def _apply(self, fn, *args, **kwargs):
         self._wcache = {}  # .to()/.float()/.cuda() replace the parameters' storage

@@ -285,7 +285,7 @@ class EfficientInteractionDownProjection(torch.nn.Module):
                 start += n
             return torch.block_diag(*blocks)                          # (L*R, S*I)
         # frozen weight (inference): the block-diagonal form is built once, not with 2 S + 1 small launches per step
-        Wbd = make() if self.weight.requires_grad else ops.cached_form("bd", self.weight, lambda: make(self.weight.detach()))
+        Wbd = ops.cached_form("bd", self.weight, lambda: make(self.weight.detach())) if ops._frozen(self.weight) else make()
         out = ops.mm(rad.reshape(-1, L * R), Wbd, False, True)        # (E, S*I)
         return out.reshape(-1, S, I)
 
@@ -396,6 +396,13 @@ class TensorBasisLayer(_RadialTables):
 
 
 # ------------------------------------------------------------------------ interaction blocks
+def _up_pair_train(inter, x, plan):
+    """(up_ca(x) + up_ac(x)[id_swap]) / sqrt2 (interaction_block.py:696-705) in the training form: each up projection one
+    twice-differentiable launch (ops.dense -> ops_train.stack), the swap a row gather, the sum in the second epilogue."""
+    y_sw = ops.gather_rows(inter.up_projection_ac(x), plan.id_swap)
+    return inter.up_projection_ca(x, res=y_sw, beta=INV_SQRT_2)
+
+
 class TripletInteraction(torch.nn.Module):
     def __init__(self, emb_size_edge, emb_size_trip, emb_size_bilinear, emb_size_rbf, emb_size_cbf,
                  activation=None, scale_file=None, name="TripletInteraction", **kwargs):
@@ -412,14 +419,14 @@ class TripletInteraction(torch.nn.Module):
 
     def _head_ok(self):
         ws = (self.dense_ba, self.mlp_rbf, self.down_projection)
-        return (ops.is_fused() and ops.stacks_enabled() and not AutomaticFit.fitting_mode
+        return (ops.stacks_enabled() and not AutomaticFit.fitting_mode
                 and all(d.bias is None and d.weight.shape[0] <= 128 and d.weight.shape[1] <= 128
                         and d.weight.shape[1] % 16 == 0 for d in ws) and not self.mlp_rbf.act)
 
     def _pair_ok(self):
         ups = (self.up_projection_ca, self.up_projection_ac)
         return all(d.bias is None and d.weight.shape[0] % 16 == 0 and d.weight.shape[0] <= 128
-                   and d.weight.shape[1] % 4 == 0 and d.weight.shape[1] <= 128 for d in ups) \
+                   and d.weight.shape[1] % 16 == 0 and d.weight.shape[1] <= 128 for d in ups) \
             and self.up_projection_ca.act == self.up_projection_ac.act
 
     def forward(self, m, rbf3, cbf3, plan, pair=False):
@@ -431,12 +438,14 @@ class TripletInteraction(torch.nn.Module):
                                            self.down_projection.weight, self.dense_ba.act,
                                            self.down_projection.act, self.scale_rbf.value())
             x = self.mlp_cbf(rbf_W1, sph, x_ba, plan.trip, alpha=self.scale_cbf_sum.value())
-            if pair and self._pair_ok() and plan.id_swap.inverse is not None:
+            if pair and ops.constant_weights() and self._pair_ok() and plan.id_swap.inverse is not None:
                 # both up projections in one launch (and one adjoint launch); the swap gather and the sum move into
                 # the epilogue of the stack that consumes them
                 y_ac, y_ca = ops.up_project_pair(x, self.up_projection_ac.weight, self.up_projection_ca.weight,
                                                  plan.id_swap, self.up_projection_ca.act, INV_SQRT_2)
                 return ops.SwappedPair(y_ca, y_ac, plan.id_swap)
+            if ops.train2_enabled():
+                return _up_pair_train(self, x, plan)
             x = ops.accumulate_gradient(x)
             # (up_ca(x) + up_ac(x)[id_swap]) / sqrt2 with the factor on both activations (alpha): the adjoint of the
             # swapped term is then a pure row gather of the incoming gradient, no scaling pass
@@ -479,7 +488,7 @@ class QuadrupletInteraction(torch.nn.Module):
     def forward(self, m, rbf, cbf, sbf, plan):
         rbf_W1, sph = sbf
         ws = (self.dense_db, self.mlp_rbf, self.down_projection)
-        if (ops.is_fused() and ops.stacks_enabled() and not AutomaticFit.fitting_mode and not self.mlp_rbf.act
+        if (ops.stacks_enabled() and not AutomaticFit.fitting_mode and not self.mlp_rbf.act
                 and all(d.bias is None and d.weight.shape[0] <= 128 and d.weight.shape[1] <= 128
                         and d.weight.shape[1] % 16 == 0 for d in ws)):
             x_db = ops.dense_hadamard_down(m, rbf, self.dense_db.weight, self.mlp_rbf.weight,
@@ -488,6 +497,8 @@ class QuadrupletInteraction(torch.nn.Module):
             x_db = ops.gather_rows(x_db, plan.intm_db)
             x_db = self.mlp_cbf(cbf, mul=x_db, alpha=self.scale_cbf.value())
             x = ops.accumulate_gradient(self.mlp_sbf(rbf_W1, sph, x_db, plan.quad, alpha=self.scale_sbf_sum.value()))
+            if ops.train2_enabled():
+                return _up_pair_train(self, x, plan)
             return self.up_projection_ca(x, alpha=INV_SQRT_2, res=self.up_projection_ac(x, alpha=INV_SQRT_2),
                                          res_rows=plan.id_swap)
         x_db = self.dense_db(m)

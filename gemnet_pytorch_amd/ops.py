@@ -445,6 +445,14 @@ def _cached(key, version, make):
     return val
 
 
+def _frozen(W):
+    """May derived forms of W be cached?  Yes when it does not require grad, and also while the weights are treated as
+    constants (force-by-autograd inference on a model whose nn.Parameters still require grad — the default after
+    `.eval()`): the cache is keyed on `W._version`, and GemNet drops it on every train()/eval() switch, on
+    load_state_dict and after a fused optimizer step (whose kernel updates the flat buffer without touching versions)."""
+    return (not W.requires_grad) or constant_weights()
+
+
 def cached_form(tag, W, make):
     """A derived form of the frozen weight W, cached on its address and version inside `weight_cache`."""
     return _cached((tag, W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version, make)
@@ -453,7 +461,7 @@ def cached_form(tag, W, make):
 def transposed(W):
     """W^T contiguous, so backward GEMMs also run the k-contiguous ("NT") pipelined kernel.  Cached
     for frozen weights (inference); recomputed per call for trainable ones."""
-    if W.requires_grad:
+    if not _frozen(W):
         return W.detach().t().contiguous()
     return _cached(("t", W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version,
                    lambda: W.detach().t().contiguous())
@@ -467,7 +475,7 @@ class _FusedDense(torch.autograd.Function):
         act, alpha, beta, beta2, res_rows, i1, i2 = cfg
         ctx.acc = _acc_join(x)
         need_z = act or mul is not None
-        if not W.requires_grad and (W.stride(0) % 4 or W.data_ptr() % 16) and W.shape[1] % 4 == 0:
+        if _frozen(W) and (W.stride(0) % 4 or W.data_ptr() % 16) and W.shape[1] % 4 == 0:
             W = contiguous_weight(W)   # column slice of a wider frozen matrix (edge embedding): copied once, not per call
         out = K.gemm(x, W, act=act, pre_out=need_z, mul=mul, alpha=alpha,
                      res=res, ridx=None if res_rows is None else res_rows.idx32, beta=beta,
@@ -541,6 +549,13 @@ def dense(x, W, act=False, *, mul=None, alpha=1.0, res=None, res_rows=None, beta
     if _FUSED:
         return _FusedDense.apply(x, W, mul, res, res2, g1, g2, (bool(act), float(alpha), float(beta), float(beta2),
                                                                 res_rows, i1, i2))
+    if (_TRAIN2 and USE_STACKS and mul is None and alpha == 1.0 and res_rows is None and W.dim() == 2
+            and W.shape[0] % 16 == 0 and W.shape[0] <= 128 and W.shape[1] % 4 == 0 and W.shape[1] <= 128
+            and x.dim() == 2 and x.dtype == W.dtype and (x.is_cuda or K.CHAIN_MODE != "f32")):
+        # a single Dense as a one-GEMM stack: twice differentiable, one launch per sweep (ops_train.py)
+        from . import ops_train
+        return ops_train.stack(x, first=dict(W=W, act=act, res=res, beta=beta, res2=res2, beta2=beta2,
+                                             g1=g1, i1=i1, g2=g2, i2=i2))
     z = linear(x, W)
     if g1 is not None:
         z = z + gather_rows(g1, i1)
@@ -800,7 +815,7 @@ def bilinear_weight(W, transposed_form):
     def make():
         W2 = W.detach().permute(1, 0, 2).reshape(I * C, O)
         return W2.t().contiguous() if transposed_form else W2
-    if W.requires_grad:
+    if not _frozen(W):
         return make()
     return _cached(("bilT" if transposed_form else "bil", W.data_ptr(), tuple(W.shape)), W._version, make)
 
@@ -897,7 +912,54 @@ USE_STACKS = os.environ.get("GEMNET_STACKS", "1") == "1"
 
 
 def stacks_enabled():
-    return USE_STACKS and constant_weights()
+    return USE_STACKS and (constant_weights() or _TRAIN2)
+
+
+# Fused force TRAINING (ops_train.py): the Dense stacks as twice-differentiable single-launch Functions, everything else
+# on the composite ops above.  Set by GemNet.forward while it builds the force with create_graph=True.
+_TRAIN2 = False
+USE_TRAIN2 = os.environ.get("GEMNET_TRAIN2", "1") == "1"
+_STEP_PACKED = None     # per-forward cache of split-bf16 weight planes (the weights change every step)
+
+
+@contextlib.contextmanager
+def train2(enabled: bool):
+    global _TRAIN2, _STEP_PACKED
+    old, old_cache = _TRAIN2, _STEP_PACKED
+    _TRAIN2 = bool(enabled)
+    if enabled:
+        _STEP_PACKED = {}
+    try:
+        yield
+    finally:
+        _TRAIN2, _STEP_PACKED = old, old_cache
+
+
+def train2_enabled():
+    return _TRAIN2
+
+
+def step_cache():
+    """The per-step dict of packed weights (None outside `train2`): a stack keeps a reference for its later sweeps."""
+    return _STEP_PACKED
+
+
+def step_packed(W, trans, cache=None):
+    """Split-bf16 fragment form of a TRAINABLE weight (or of its transpose), packed once per training step and shared
+    by the four sweeps of that step (ops_train.py); None on the f32 chain kernel / the host emulation.
+    `cache`: the dict a stack captured in its forward — the S3 / S4 sweeps run inside loss.backward(), after the
+    `train2` context of the forward has closed."""
+    if K.CHAIN_MODE == "f32" or not W.is_cuda:
+        return None
+    if cache is None:
+        cache = _STEP_PACKED
+    key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()), bool(trans))
+    if cache is None:
+        return K.pack_weight_split(W.detach(), trans=trans)
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = K.pack_weight_split(W.detach(), trans=trans)
+    return hit
 
 
 def contiguous_weight(W):
@@ -915,7 +977,7 @@ def packed_weight(W, trans):
     runs on the f32 MFMA or on the host emulation."""
     if K.CHAIN_MODE == "f32" or not W.is_cuda:
         return None
-    if W.requires_grad:
+    if not _frozen(W):
         return K.pack_weight_split(W.detach(), trans=trans)
     return _cached(("pkt" if trans else "pk", W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version,
                    lambda: K.pack_weight_split(W.detach(), trans=trans))
@@ -1098,7 +1160,11 @@ class _Stack(torch.autograd.Function):
 def stack(x, first=None, layers=(), s=0.7071067811865475, tails=()):
     """first: dict(W, act, res=None, beta=1, res2=None, beta2=1, g1=None, i1=None, g2=None, i2=None) or None;
     layers: sequence of dict(W1, W2, skip=None, skip_beta=1); tails: weights Wt -> extra outputs y @ Wt^T.
-    Returns y, or (y, *tail outputs).  Requires constant_weights()."""
+    Returns y, or (y, *tail outputs).  Constant weights (force pass), or the twice-differentiable training form
+    (ops_train.stack) inside `train2`."""
+    if _TRAIN2:
+        from . import ops_train
+        return ops_train.stack(x, first=first, layers=layers, s=s, tails=tails)
     assert constant_weights(), "ops.stack is the constant-weight inference path"
     spec = dict(first=None, layers=[dict(W1=L["W1"], W2=L["W2"], skip_beta=float(L.get("skip_beta", 1.0)))
                                     for L in layers], s=float(s), tails=tuple(tails))
@@ -1263,6 +1329,9 @@ def up_project_pair(x, W_ac, W_ca, swap, act, alpha):
 
 
 def dense_hadamard_down(x, rbf, Wa, Wr, Wd, act_a, act_d, alpha):
+    if _TRAIN2:
+        from . import ops_train
+        return ops_train.dense_hadamard_down(x, rbf, Wa, Wr, Wd, act_a, act_d, alpha)
     assert constant_weights(), "the fused interaction head is the constant-weight inference path"
     return _DenseHadamardDown.apply(x, rbf, Wa, Wr, Wd, (bool(act_a), bool(act_d), float(alpha)))
 

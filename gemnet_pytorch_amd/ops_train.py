@@ -1,0 +1,551 @@
+"""Twice-differentiable LDS-resident layer stacks: the fused force-TRAINING path.
+
+The reference's training step is `loss.backward()` through `autograd.grad(E, R, create_graph=True)`
+(gemnet/model/gemnet.py:603-611, gemnet/training/trainer.py:338-346).  With F = -dE/dR and u = dL/dF the parameter
+gradient of the force term is the gradient of the directional derivative of E along u, so the whole step is FOUR
+sweeps over the layer graph, each of them one chain program (csrc/chain2.hip) per stack:
+
+    S1  forward                     x -> z_k, a_k                                  (values)
+    S2  adjoint  (builds F)         mu_y -> mu_h_k, mu_z_k = mu_h_k f'(z_k)        (create_graph=True pass)
+    S3  tangent  (along u)          dx -> dz_k, da_k = f'(z_k) dz_k                (double backward of S2)
+    S4  second adjoint              ybar -> zbar_k = hbar_k f'(z_k) + mu_h_k f''(z_k) dz_k        (backward of S1)
+        weight gradients            dW_k = zbar_k^T a_{k-1} + mu_z_k^T da_{k-1}    (queued: one grouped launch per step)
+
+Inside PyTorch's autograd each stack is a pair of Functions: `X` (forward = S1; its backward is S4 — or, while the force
+graph is being built, a call of `XB`) and `XB` (forward = S2, backward = S3).  X and XB share a record (`_Rec`) through
+which S4 finds what S2 and S3 left behind (mu_h, dz); a zero-size token output of X that XB takes as an input makes the
+engine run XB's backward (S3) before X's (S4).  The source term mu_h f''(z) dz is added inside the S4 program
+(`ChainProgram.source`, gn_chain_op.src_*), so no per-layer pointwise launch exists on this path.
+
+Everything that is not a Dense stack (bases, bilinear layer, aggregation, geometry) stays on the composite ops of
+`ops.py`, which are closed under differentiation; both kinds of nodes live in one autograd graph.
+"""
+import torch
+
+from . import kernels as K
+from . import ops
+
+
+class _Rec:
+    """What the four sweeps of one stack instance share (tensors are fp32 (M, N) unless noted)."""
+
+    def __init__(self):
+        self.s1 = None    # dict: z[site], a_in[gemm]
+        self.s2 = None    # dict: mu_h[site], mu_z[gemm], g, g_tails
+        self.s3 = None    # dict: zdot[site], adot[gemm]
+        self.cache = ops.step_cache()   # packed weights of this training step (shared by all four sweeps)
+
+
+def _new(M, N, like):
+    return torch.empty((M, N), device=like.device, dtype=like.dtype)
+
+
+def _wgrad(W, zb, a):
+    """W.grad += zb^T a, queued into the grouped launch when W is a queueable leaf; returns the tensor gradient
+    otherwise (weight slices, CPU emulation)."""
+    if zb is None or a is None:
+        return None
+    if ops._queueable(W):
+        ops._WGRAD_QUEUE.add(W, zb, a)
+        return None
+    return K.gemm(zb, a, True, True)
+
+
+def _add(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return a + b
+
+
+def _gemm(prog, W, trans=False, cache=None, **kw):
+    """Append x @ W^T (trans: x @ W) with W a TRAINABLE weight: packed once per step (ops.step_packed)."""
+    packed = ops.step_packed(W, trans, cache)
+    if packed is not None:
+        # the split-operand kernel reads the packed planes; the fp32 matrix only carries the shape
+        prog.gemm(W.detach().t() if trans else W.detach(), packed=packed, **kw)
+    else:
+        prog.gemm(W.detach().t().contiguous() if trans else ops.contiguous_weight(W), packed=None, **kw)
+
+
+# ============================================================================================ Dense + ResidualLayer*
+class _Stack2(torch.autograd.Function):
+    """ops._Stack with trainable weights, twice differentiable.  Inputs: x, res, res2, g1, g2, *skips, *weights
+    (weights in the order W0?, (W1, W2) per layer, tails)."""
+
+    @staticmethod
+    def forward(ctx, spec, x, res, res2, g1, g2, *rest):
+        first, layers, s = spec["first"], spec["layers"], spec["s"]
+        nL, nT = len(layers), len(spec["tails"])
+        skips, Ws = rest[:nL], rest[nL:]
+        M = x.shape[0]
+        x = x.contiguous()
+        rec = _Rec()
+        z, a_in = {}, {}
+        prog = K.ChainProgram(M)
+        prog.load(0, x)
+        cur, oth = 0, 1
+        wi = 0
+        y_prev = x
+        if first is not None:
+            W0 = Ws[wi]; wi += 1
+            N0 = W0.shape[0]
+            z0 = _new(M, N0, x) if first["act"] else None
+            y0 = _new(M, N0, x)
+            _gemm(prog, cache=rec.cache, W=W0, a_slot=0, y_slot=1, act=first["act"],
+                  gadd1=g1, gidx1=None if g1 is None else first["i1"].idx32,
+                  gadd2=g2, gidx2=None if g2 is None else first["i2"].idx32,
+                  pre_out=z0, res=res, beta=first["beta"], res2=res2, beta2=first["beta2"], out=y0)
+            z["0"] = z0
+            a_in["0"] = x
+            cur, oth = 1, 0
+            y_prev = y0
+        for k, L in enumerate(layers):
+            W1, W2 = Ws[wi], Ws[wi + 1]; wi += 2
+            width = W1.shape[0]
+            z1, h1, z2, yk = (_new(M, width, x) for _ in range(4))
+            _gemm(prog, cache=rec.cache, W=W1, a_slot=cur, y_slot=oth, act=True, pre_out=z1, out=h1)
+            _gemm(prog, cache=rec.cache, W=W2, a_slot=oth, y_slot=cur, act=True, pre_out=z2, res=cur, beta=s,
+                  res2=skips[k], beta2=L["skip_beta"], out=yk)
+            z[(k, 1)], z[(k, 2)] = z1, z2
+            a_in[(k, 1)], a_in[(k, 2)] = y_prev, h1
+            y_prev = yk
+        tails = []
+        for j in range(nT):
+            Wt = Ws[wi]; wi += 1
+            t = _new(M, Wt.shape[0], x)
+            _gemm(prog, cache=rec.cache, W=Wt, a_slot=cur, y_slot=-1, out=t)
+            a_in[("t", j)] = y_prev
+            tails.append(t)
+        K.chain(prog)
+        rec.s1 = dict(z=z, a_in=a_in)
+        tok = x.new_empty(0)
+        ctx.rec, ctx.spec, ctx.n = rec, spec, (nL, nT)
+        ctx.has = (res is not None, res2 is not None, g1 is not None, g2 is not None, tuple(sk is not None for sk in skips))
+        ctx.in_width, ctx.out_shape = x.shape[1], tuple(y_prev.shape)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(tok, *Ws)
+        return (y_prev, *tails, tok)
+
+    @staticmethod
+    def backward(ctx, g, *rest):
+        nL, nT = ctx.n
+        g_tails = rest[:nT]
+        tok, *Ws = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (spec, x, res, res2, g1, g2, *skips, *Ws)
+        n_in = 6 + nL + len(Ws)
+        if g is None and all(t is None for t in g_tails):
+            return (None,) * n_in
+        want = dict(x=need[1], res=need[2], res2=need[3], g1=need[4], g2=need[5], skips=tuple(need[6:6 + nL]))
+        if torch.is_grad_enabled():
+            # the force graph is being built: S2 as a differentiable node
+            outs = _Stack2B.apply(ctx.rec, ctx.spec, ctx.has, want, (ctx.in_width, ctx.out_shape), g, *g_tails, tok, *Ws)
+            return (None, *outs, *([None] * len(Ws)))
+        # final pass: S4 (first-order adjoint when no tangent sweep ran through this stack)
+        s3 = ctx.rec.s3
+        ctx.rec.s3 = None
+        out, zbar = _stack_adjoint(ctx.rec, ctx.spec, ctx.has, want, (ctx.in_width, ctx.out_shape), g, g_tails, Ws,
+                                   second=s3, store="zbar")
+        gWs = [None] * len(Ws)
+        if ops._PARAM_GRADS:
+            a_in = ctx.rec.s1["a_in"]
+            for i, key in enumerate(_gemm_keys(ctx.spec)):
+                if need[6 + nL + i]:
+                    gWs[i] = _wgrad(Ws[i], zbar.get(key), a_in.get(key))
+        return (None, *out, *gWs)
+
+
+def _gemm_keys(spec):
+    """Keys of the GEMMs of a stack in weight order."""
+    keys = []
+    if spec["first"] is not None:
+        keys.append("0")
+    for k in range(len(spec["layers"])):
+        keys += [(k, 1), (k, 2)]
+    keys += [("t", j) for j in range(len(spec["tails"]))]
+    return keys
+
+
+def _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second, store):
+    """The reverse sweep of a stack as one chain program.  S2 (second is None, store = "mu": mu_h per activation and
+    mu_z per GEMM are written out for the later sweeps) and S4 (store = "zbar"; `second` = the record of the tangent
+    sweep, whose dz enter as source terms mu_h f''(z) dz).  Returns ((gx, g_res, g_res2, gg1, gg2, *g_skips), stored)."""
+    first, layers, s = spec["first"], spec["layers"], spec["s"]
+    has_res, has_res2, has_g1, has_g2, has_skips = has
+    in_width, (M, width) = shapes
+    z = rec.s1["z"]
+    live = [t for t in (g, *g_tails) if t is not None]
+    like = live[0]
+    if g is None:
+        g = torch.zeros((M, width), device=like.device, dtype=like.dtype)
+    g = g.contiguous()
+    keys = _gemm_keys(spec)
+    Wof = dict(zip(keys, Ws))
+    mu_h, stored = {}, {}
+
+    def src(site):
+        if second is None or rec.s2 is None or second["zdot"].get(site) is None or rec.s2["mu_h"].get(site) is None:
+            return None
+        return K.ChainProgram.source(rec.s2["mu_h"][site], second["zdot"][site], d2=True)
+
+    prog = K.ChainProgram(M)
+    prog.load(0, g)
+    cur, oth = 0, 1
+    for j, gt in enumerate(g_tails):
+        if gt is not None:
+            gt = gt.contiguous()
+            stored[("t", j)] = gt                      # dL/d(tail j) is the pre-activation adjoint of that GEMM
+            prog.load(oth, gt)
+            _gemm(prog, cache=rec.cache, W=Wof[("t", j)], trans=True, a_slot=oth, y_slot=cur, res=cur, beta=1.0)
+    g_skips = [None] * len(layers)
+    for k in range(len(layers) - 1, -1, -1):
+        L = layers[k]
+        c = s
+        if has_skips[k]:
+            if want["skips"][k]:
+                g_skips[k] = _new(M, width, like)
+                prog.scale(cur, cur, L["skip_beta"], out=g_skips[k], width=width)
+            else:
+                c = s * L["skip_beta"]
+        mh2 = _new(M, width, like) if store == "mu" else None
+        prog.scale(cur, cur, c, out=mh2, width=width)                       # Gs = adjoint of ssilu(z2)
+        stored[(k, 2)] = _new(M, width, like)
+        prog.scale(oth, cur, 1.0, Z=z[(k, 2)], add=src((k, 2)), out=stored[(k, 2)], width=width)   # adjoint of z2
+        mh1 = _new(M, width, like) if store == "mu" else None
+        _gemm(prog, cache=rec.cache, W=Wof[(k, 2)], trans=True, a_slot=oth, y_slot=oth, pre_out=mh1)                    # adjoint of h1
+        stored[(k, 1)] = _new(M, width, like)
+        prog.scale(oth, oth, 1.0, Z=z[(k, 1)], add=src((k, 1)), out=stored[(k, 1)], width=width)   # adjoint of z1
+        _gemm(prog, cache=rec.cache, W=Wof[(k, 1)], trans=True, a_slot=oth, y_slot=cur, res=cur, beta=1.0)              # adjoint of y_{k-1}
+        mu_h[(k, 2)], mu_h[(k, 1)] = mh2, mh1
+    gx = g_res = g_res2 = gg1 = gg2 = None
+    if first is not None:
+        z0 = z["0"]
+        c = 1.0
+        if has_res2:
+            if want["res2"]:
+                g_res2 = _new(M, width, like)
+                prog.scale(cur, cur, first["beta2"], out=g_res2, width=width)
+            else:
+                c *= first["beta2"]
+        if has_res:
+            c *= first["beta"]
+            if want["res"]:
+                g_res = _new(M, width, like)
+                prog.scale(cur, cur, c, out=g_res, width=width)
+                c = 1.0
+        dz0 = _new(M, width, like)
+        stored["0"] = dz0
+        if z0 is not None:
+            mh0 = _new(M, width, like) if store == "mu" else None
+            if mh0 is not None or c != 1.0:
+                prog.scale(cur, cur, c, out=mh0, width=width)
+            mu_h["0"] = mh0
+            prog.scale(oth, cur, 1.0, Z=z0, add=src("0"), out=dz0, width=width)
+        else:
+            prog.scale(oth, cur, c, out=dz0, width=width)
+        if want["x"]:
+            gx = _new(M, in_width, like)
+            _gemm(prog, cache=rec.cache, W=Wof["0"], trans=True, a_slot=oth, y_slot=-1, out=gx)
+        K.chain(K.fuse_program(prog))
+        if has_g1 and want["g1"]:
+            gg1 = K.segsum(dz0, *first["i1"].csr, first["i1"].n_rows)
+        if has_g2 and want["g2"]:
+            gg2 = K.segsum(dz0, *first["i2"].csr, first["i2"].n_rows)
+    else:
+        gx = _new(M, width, like)
+        prog.store(cur, gx)
+        K.chain(K.fuse_program(prog))
+    if store == "mu":
+        stored = dict(mu_h=mu_h, mu_z=stored)
+    return (gx, g_res, g_res2, gg1, gg2, *g_skips), stored
+
+
+class _Stack2B(torch.autograd.Function):
+    """S2 of a stack as a differentiable node: forward = the adjoint program (+ mu stores), backward = S3."""
+
+    @staticmethod
+    def forward(ctx, rec, spec, has, want, shapes, g, *rest):
+        nT = len(spec["tails"])
+        g_tails, Ws = rest[:nT], rest[nT + 1:]
+        out, st = _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second=None, store="mu")
+        rec.s2 = st
+        rec.s3 = None
+        ctx.rec, ctx.spec, ctx.has, ctx.shapes, ctx.nT = rec, spec, has, shapes, nT
+        ctx.g_none = (g is None, tuple(t is None for t in g_tails))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*Ws)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, t_x, t_res, t_res2, t_g1, t_g2, *t_skips):
+        rec, spec, nT = ctx.rec, ctx.spec, ctx.nT
+        Ws = ctx.saved_tensors
+        first, layers, s = spec["first"], spec["layers"], spec["s"]
+        has_res, has_res2, has_g1, has_g2, has_skips = ctx.has
+        in_width, (M, width) = ctx.shapes
+        need = ctx.needs_input_grad    # (rec, spec, has, want, shapes, g, *g_tails, tok, *Ws)
+        n_lead = 5
+        ts = [t for t in (t_x, t_res, t_res2, t_g1, t_g2, *t_skips) if t is not None]
+        if not ts:
+            return (None,) * (n_lead + 1 + nT + 1 + len(Ws))
+        like = ts[0]
+        z = rec.s1["z"]
+        keys = _gemm_keys(spec)
+        Wof = dict(zip(keys, Ws))
+        zdot, adot = {}, {}
+        prog = K.ChainProgram(M)
+        cur, oth = 0, 1
+        if first is not None:
+            if t_x is None:
+                t_x = torch.zeros((M, in_width), device=like.device, dtype=like.dtype)
+            t_x = t_x.contiguous()
+            prog.load(0, t_x)
+            adot["0"] = t_x
+            z0 = z["0"]
+            zd0 = _new(M, width, like) if z0 is not None else None
+            y0 = _new(M, width, like)
+            # y0 = ((f(z0) + res) beta + res2) beta2  ->  dy0 = ((f'(z0) dz0 + dres) beta + dres2) beta2; a residual whose
+            # tangent is absent still leaves its factor on the stages before it
+            alpha, beta, beta2 = 1.0, first["beta"], first["beta2"]
+            tr = t_res.contiguous() if (has_res and t_res is not None) else None
+            tr2 = t_res2.contiguous() if (has_res2 and t_res2 is not None) else None
+            if has_res and tr is None:
+                alpha *= beta
+            if has_res2 and tr2 is None:
+                if tr is not None:
+                    beta *= beta2
+                else:
+                    alpha *= beta2
+            _gemm(prog, cache=rec.cache, W=Wof["0"], a_slot=0, y_slot=1,
+                  gadd1=None if t_g1 is None else t_g1.contiguous(), gidx1=None if t_g1 is None else first["i1"].idx32,
+                  gadd2=None if t_g2 is None else t_g2.contiguous(), gidx2=None if t_g2 is None else first["i2"].idx32,
+                  pre_out=zd0, mul=z0, mul_mode=2 if z0 is not None else 1, alpha=alpha,
+                  res=tr, beta=beta if tr is not None else 1.0, res2=tr2, beta2=beta2 if tr2 is not None else 1.0, out=y0)
+            zdot["0"] = zd0
+            cur, oth = 1, 0
+            y_prev = y0
+        else:
+            if t_x is None:
+                t_x = torch.zeros((M, width), device=like.device, dtype=like.dtype)
+            t_x = t_x.contiguous()
+            prog.load(0, t_x)
+            y_prev = t_x
+        for k, L in enumerate(layers):
+            zd1, hd1, zd2, yk = (_new(M, width, like) for _ in range(4))
+            tsk = t_skips[k] if has_skips[k] else None
+            _gemm(prog, cache=rec.cache, W=Wof[(k, 1)], a_slot=cur, y_slot=oth, pre_out=zd1, mul=z[(k, 1)], mul_mode=2, out=hd1)
+            _gemm(prog, cache=rec.cache, W=Wof[(k, 2)], a_slot=oth, y_slot=cur, pre_out=zd2, mul=z[(k, 2)], mul_mode=2, res=cur, beta=s,
+                  res2=None if tsk is None else tsk.contiguous(), beta2=L["skip_beta"] if tsk is not None else 1.0, out=yk)
+            if has_skips[k] and tsk is None and L["skip_beta"] != 1.0:
+                _scale_last_gemm(prog, L["skip_beta"])
+            zdot[(k, 1)], zdot[(k, 2)] = zd1, zd2
+            adot[(k, 1)], adot[(k, 2)] = y_prev, hd1
+            y_prev = yk
+        t_tails = []
+        for j in range(nT):
+            Wt = Wof[("t", j)]
+            if need[n_lead + 1 + j]:
+                tt = _new(M, Wt.shape[0], like)
+                _gemm(prog, cache=rec.cache, W=Wt, a_slot=cur, y_slot=-1, out=tt)
+            else:
+                tt = None
+            adot[("t", j)] = y_prev
+            t_tails.append(tt)
+        K.chain(prog)
+        rec.s3 = dict(zdot=zdot, adot=adot)
+        gWs = [None] * len(Ws)
+        if ops._PARAM_GRADS:
+            mu_z = rec.s2["mu_z"]
+            for i, key in enumerate(keys):
+                if need[n_lead + 1 + nT + 1 + i]:
+                    gWs[i] = _wgrad(Ws[i], mu_z.get(key), adot.get(key))
+        g_y = y_prev if need[n_lead] else None
+        return (None,) * n_lead + (g_y, *t_tails, None, *gWs)
+
+
+def _scale_last_gemm(prog, c):
+    """Fold a constant factor into the LAST stage of the most recent GEMM op of `prog`."""
+    o = prog.ops[-1]
+    if o["res2"] is not None:
+        o["beta2"] *= c
+    elif o["res"] is not None:
+        o["beta"] *= c
+    else:
+        o["alpha"] *= c
+
+
+def stack(x, first=None, layers=(), s=0.7071067811865475, tails=()):
+    """ops.stack for trainable weights (same arguments), twice differentiable."""
+    spec = dict(first=None, layers=[dict(skip_beta=float(L.get("skip_beta", 1.0))) for L in layers], s=float(s),
+                tails=tuple(range(len(tails))))
+    res = res2 = g1 = g2 = None
+    Ws = []
+    if first is not None:
+        assert first.get("res_rows") is None and not first.get("tied"), \
+            "the tied / row-gathered residual pair (ops.up_project_pair) is a constant-weight form"
+        spec["first"] = dict(act=bool(first.get("act", False)), beta=float(first.get("beta", 1.0)),
+                             beta2=float(first.get("beta2", 1.0)), i1=first.get("i1"), i2=first.get("i2"))
+        res, res2, g1, g2 = first.get("res"), first.get("res2"), first.get("g1"), first.get("g2")
+        Ws.append(first["W"])
+    for L in layers:
+        Ws += [L["W1"], L["W2"]]
+    Ws += list(tails)
+    skips = [L.get("skip") for L in layers]
+    out = _Stack2.apply(spec, x, res, res2, g1, g2, *skips, *Ws)
+    out = out[:-1]              # drop the ordering token
+    return out if tails else out[0]
+
+
+# ======================================================================== Dense -> radial Hadamard -> down projection
+class _Head2(torch.autograd.Function):
+    """ops._DenseHadamardDown (interaction_block.py:667-675, :531-541) with trainable weights, twice differentiable:
+    z1 = x Wa^T, xa = f(z1);  r = rbf Wr^T;  h = r (.) xa alpha;  z3 = h Wd^T, y = f(z3)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, rbf, Wa, Wr, Wd):
+        act_a, act_d, alpha = cfg
+        M = x.shape[0]
+        x, rbf = x.contiguous(), rbf.contiguous()
+        rec = _Rec()
+        nh, nd = Wa.shape[0], Wd.shape[0]
+        z1 = _new(M, nh, x) if act_a else None
+        xa, r, h = _new(M, nh, x), _new(M, nh, x), _new(M, nh, x)
+        z3 = _new(M, nd, x) if act_d else None
+        y = _new(M, nd, x)
+        prog = K.ChainProgram(M)
+        prog.load(0, x)
+        _gemm(prog, Wa, cache=rec.cache, a_slot=0, y_slot=1, act=act_a, pre_out=z1, out=xa)
+        prog.load(0, rbf)
+        _gemm(prog, Wr, cache=rec.cache, a_slot=0, y_slot=0, pre_out=r, mul=1, alpha=alpha, out=h)
+        _gemm(prog, Wd, cache=rec.cache, a_slot=0, y_slot=1, act=act_d, pre_out=z3, out=y)
+        K.chain(prog)
+        rec.s1 = dict(x=x, rbf=rbf, z1=z1, xa=xa, r=r, h=h, z3=z3)
+        tok = x.new_empty(0)
+        ctx.rec, ctx.cfg = rec, cfg
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(tok, Wa, Wr, Wd)
+        return y, tok
+
+    @staticmethod
+    def backward(ctx, g, g_tok):
+        tok, Wa, Wr, Wd = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (cfg, x, rbf, Wa, Wr, Wd)
+        if g is None:
+            return (None,) * 6
+        if torch.is_grad_enabled():
+            gx, grbf = _Head2B.apply(ctx.rec, ctx.cfg, g, tok, Wa, Wr, Wd)
+            return None, gx, grbf, None, None, None
+        s3 = ctx.rec.s3
+        ctx.rec.s3 = None
+        (gx, grbf), st = _head_adjoint(ctx.rec, ctx.cfg, g, (Wa, Wr, Wd), second=s3, store="zbar")
+        s1 = ctx.rec.s1
+        gWa = gWr = gWd = None
+        if ops._PARAM_GRADS:
+            if need[3]:
+                gWa = _wgrad(Wa, st["z1"], s1["x"])
+            if need[4]:
+                gWr = _wgrad(Wr, st["r"], s1["rbf"])
+            if need[5]:
+                gWd = _wgrad(Wd, st["z3"], s1["h"])
+        return None, gx, grbf, gWa, gWr, gWd
+
+
+def _head_adjoint(rec, cfg, g, Ws, second, store):
+    """Reverse sweep of the head: S2 (store = "mu") or S4 (store = "zbar", `second` = the tangent record).
+    -> ((gx, grbf), dict of the adjoints at z3, dh, r, xa, z1)."""
+    act_a, act_d, alpha = cfg
+    Wa, Wr, Wd = Ws
+    s1 = rec.s1
+    M = g.shape[0]
+    g = g.contiguous()
+    nh, nd = Wa.shape[0], Wd.shape[0]
+    S = K.ChainProgram.source
+    sec = second if (second is not None and rec.s2 is not None) else None
+    s2 = rec.s2
+    st = {}
+    prog = K.ChainProgram(M)
+    prog.load(0, g)
+    if act_d:
+        st["z3"] = _new(M, nd, g)
+        prog.scale(0, 0, 1.0, Z=s1["z3"], width=nd, out=st["z3"],
+                   add=S(s2["g"], sec["zd3"], d2=True) if sec is not None else None)
+    else:
+        st["z3"] = g
+    st["dh"] = _new(M, nh, g) if store == "mu" else None
+    _gemm(prog, Wd, trans=True, cache=rec.cache, a_slot=0, y_slot=1, out=st["dh"])           # adjoint of h
+    st["r"] = _new(M, nh, g)
+    prog.scale(0, 1, alpha, Z=s1["xa"], mode=1, width=nh, out=st["r"],
+               add=S(s2["dh"], sec["xad"], alpha=alpha) if sec is not None else None)          # adjoint of r
+    grbf = _new(M, Wr.shape[1], g)
+    _gemm(prog, Wr, trans=True, cache=rec.cache, a_slot=0, y_slot=-1, out=grbf)
+    st["xa"] = _new(M, nh, g) if (store == "mu" or not act_a) else None
+    prog.scale(1, 1, alpha, Z=s1["r"], mode=1, width=nh, out=st["xa"],
+               add=S(s2["dh"], sec["rd"], alpha=alpha) if sec is not None else None)           # adjoint of xa
+    if act_a:
+        st["z1"] = _new(M, nh, g)
+        prog.scale(1, 1, 1.0, Z=s1["z1"], mode=0, width=nh, out=st["z1"],
+                   add=S(s2["xa"], sec["zd1"], d2=True) if sec is not None else None)          # adjoint of z1
+    else:
+        st["z1"] = st["xa"]
+    gx = _new(M, Wa.shape[1], g)
+    _gemm(prog, Wa, trans=True, cache=rec.cache, a_slot=1, y_slot=-1, out=gx)
+    K.chain(K.fuse_program(prog))
+    return (gx, grbf), st
+
+
+class _Head2B(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rec, cfg, g, tok, Wa, Wr, Wd):
+        out, st = _head_adjoint(rec, cfg, g, (Wa, Wr, Wd), second=None, store="mu")
+        st["g"] = g.contiguous()
+        rec.s2, rec.s3 = st, None
+        ctx.rec, ctx.cfg = rec, cfg
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(Wa, Wr, Wd)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, t_x, t_rbf):
+        rec, (act_a, act_d, alpha) = ctx.rec, ctx.cfg
+        Wa, Wr, Wd = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (rec, cfg, g, tok, Wa, Wr, Wd)
+        if t_x is None and t_rbf is None:
+            return (None,) * 7
+        s1, s2 = rec.s1, rec.s2
+        like = t_x if t_x is not None else t_rbf
+        M = like.shape[0]
+        nh, nd = Wa.shape[0], Wd.shape[0]
+        t_x = torch.zeros_like(s1["x"]) if t_x is None else t_x.contiguous()
+        t_rbf = torch.zeros_like(s1["rbf"]) if t_rbf is None else t_rbf.contiguous()
+        zd1 = _new(M, nh, like) if act_a else None
+        xad, rd, hd = _new(M, nh, like), _new(M, nh, like), _new(M, nh, like)
+        zd3 = _new(M, nd, like) if act_d else None
+        yd = _new(M, nd, like)
+        prog = K.ChainProgram(M)
+        prog.load(0, t_x)
+        # d xa = f'(z1) dz1 -> memory; d xa (.) r -> slot 1 (the second output of the same op)
+        _gemm(prog, Wa, cache=rec.cache, a_slot=0, y_slot=-1, pre_out=zd1, mul=s1["z1"], mul_mode=2 if act_a else 1, out=xad,
+              y2=1, y2_src=0, alpha2=1.0, Z2=s1["r"], mode2=1)
+        prog.load(0, t_rbf)
+        # dh = (dr (.) xa + d xa (.) r) alpha
+        _gemm(prog, Wr, cache=rec.cache, a_slot=0, y_slot=0, pre_out=rd, mul=s1["xa"], mul_mode=1, res=1, beta=alpha, out=hd)
+        _gemm(prog, Wd, cache=rec.cache, a_slot=0, y_slot=-1, pre_out=zd3, mul=s1["z3"], mul_mode=2 if act_d else 1, out=yd)
+        K.chain(prog)
+        rec.s3 = dict(zd1=zd1, xad=xad, rd=rd, hd=hd, zd3=zd3)
+        gWa = gWr = gWd = None
+        if ops._PARAM_GRADS:
+            if need[4]:
+                gWa = _wgrad(Wa, s2["z1"], t_x)
+            if need[5]:
+                gWr = _wgrad(Wr, s2["r"], t_rbf)
+            if need[6]:
+                gWd = _wgrad(Wd, s2["z3"], hd)
+        return None, None, (yd if need[2] else None), None, gWa, gWr, gWd
+
+
+def dense_hadamard_down(x, rbf, Wa, Wr, Wd, act_a, act_d, alpha):
+    y, _ = _Head2.apply((bool(act_a), bool(act_d), float(alpha)), x, rbf, Wa, Wr, Wd)
+    return y

@@ -26,9 +26,12 @@ def make_molecule(n_atoms: int, seed: int, box: float = None, min_dist: float = 
                 E=np.float32(E), F=F.astype(np.float32))
 
 
-def make_dataset(n_mol: int, n_atoms: int, config: int = 2, first: int = 0):
-    """-> dict with the COLL npz keys: N (M,), Z (sumN,), R (sumN,3), E (M,), F (sumN,3)."""
-    mols = [make_molecule(n_atoms, 1000 * config + first + i) for i in range(n_mol)]
+def make_dataset(n_mol: int, n_atoms: int, config: int = 2, first: int = 0, ids=None):
+    """-> dict with the COLL npz keys: N (M,), Z (sumN,), R (sumN,3), E (M,), F (sumN,3).
+    `ids`: explicit molecule numbers (a rank's shard of a global batch) instead of first .. first + n_mol - 1."""
+    if ids is None:
+        ids = range(first, first + n_mol)
+    mols = [make_molecule(n_atoms, 1000 * config + int(i)) for i in ids]
     return dict(
         N=np.array([m["N"] for m in mols], dtype=np.int32),
         Z=np.concatenate([m["Z"] for m in mols]),
@@ -36,3 +39,11 @@ def make_dataset(n_mol: int, n_atoms: int, config: int = 2, first: int = 0):
         E=np.array([m["E"] for m in mols], dtype=np.float32),
         F=np.concatenate([m["F"] for m in mols]),
     )
+
+
+def triplet_count(R, cutoff=5.0):
+    """Number of triplets (c->a, b->a, b != c) of one molecule: the per-molecule cost GemNet-T's kernels scale with
+    (used to balance molecule shards across ranks, training/ddp.py::partition_molecules)."""
+    d = np.linalg.norm(R[:, None, :].astype(np.float64) - R[None, :, :].astype(np.float64), axis=-1)
+    deg = ((d < cutoff) & (d > 0)).sum(axis=1)
+    return int((deg * (deg - 1)).sum())

@@ -49,8 +49,9 @@ class FlatGradBuffer:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    def all_reduce(self, always=False):
+        """Sum over the ranks; `always`: issue the collective even in a one-rank group (exercises RCCL on one GPU)."""
+        if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size() > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
 
@@ -102,7 +103,9 @@ class TrainStep:
             self.opt = optimizer if optimizer is not None else make_optimizer(model)
         self.global_counts = global_counts  # (B_global, A_global) if known statically
         self.last_loss = None
+        self.always_reduce = False   # issue the gradient all-reduce even when the process group has one rank
         self._pinned_counts = None   # ((B_local, A_local), (B_global, A_global)) of the captured static batch
+        self._use_pinned = False     # True only inside capture(): the graph replays with the counts it was captured with
         self.wgrad = None
         if self.buf.params[0].is_cuda:
             from .wgrad_queue import WeightGradQueue
@@ -110,11 +113,15 @@ class TrainStep:
 
     def _counts(self, n_mol, n_atoms, device):
         """(B_global, A_global).  Batches of a real loader vary in atom count and the last one is partial
-        (drop_last=False), so the counts are exchanged EVERY step unless the caller fixed them (`global_counts=`)
-        or the step was captured for one static batch (`capture()` pins them for that batch only)."""
+        (drop_last=False), so the counts are exchanged EVERY step unless the caller fixed them (`global_counts=`).
+        The counts pinned by `capture()` are used ONLY while that batch is being captured (the graph must not hold a
+        collective): whether a rank skips the exchange has to be the same decision on every rank, and "my local shape
+        equals the captured one" is not — one rank could match while another holds a partial last batch, and its
+        2-element all-reduce would then pair with the first rank's gradient all-reduce."""
         if self.global_counts is not None:
             return self.global_counts
-        if self._pinned_counts is not None and self._pinned_counts[0] == (n_mol, n_atoms):
+        if self._use_pinned and self._pinned_counts is not None:
+            assert self._pinned_counts[0] == (n_mol, n_atoms), "captured step replayed on a different batch"
             return self._pinned_counts[1]
         if self.world_size > 1:
             t = torch.tensor([n_mol, n_atoms], dtype=torch.float64, device=device)
@@ -151,17 +158,22 @@ class TrainStep:
         self.model.train()
         local = (int(inputs["N"].shape[0]), int(inputs["Z"].shape[0]))
         self._pinned_counts = None
+        self._use_pinned = False
         self._pinned_counts = (local, self._counts(*local, inputs["Z"].device))   # no collective inside the graph
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._forward_backward(inputs, targets)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._graph_loss = self._forward_backward(inputs, targets)
+        self._use_pinned = True
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._forward_backward(inputs, targets)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_loss = self._forward_backward(inputs, targets)
+        finally:
+            self._use_pinned = False
         self._graph_key = id(inputs)
         return self
 
@@ -189,7 +201,7 @@ class TrainStep:
             loss = self._graph_loss
         else:
             loss = self._eager(inputs, targets)
-        self.buf.all_reduce()
+        self.buf.all_reduce(always=self.always_reduce)
         if self.fused is not None:
             if step_optimizer:
                 self.fused.step()

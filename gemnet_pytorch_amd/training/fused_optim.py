@@ -49,12 +49,16 @@ class FusedAdamWEMA:
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.lr, self.betas, self.eps, self.ema_decay, self.clip = lr, betas, eps, ema_decay, grad_clip_max
         self.steps = 0
+        self._model = model
 
     def zero_grad(self):
         self.flat_g.zero_()
 
     def step(self, lr=None):
         self.steps += 1
+        cache = getattr(self._model, "_wcache", None)
+        if cache:
+            cache.clear()   # the kernel below rewrites the flat parameter buffer without touching tensor versions
         check(self.lib.gn_adamw_ema_step_f32(
             ptr(self.flat_p), ptr(self.flat_g), ptr(self.gscale), ptr(self.wd), ptr(self.m), ptr(self.v),
             ptr(self.vmax), ptr(self.ema), self.n, ptr(self.partial), float(self.clip),

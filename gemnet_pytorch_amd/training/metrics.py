@@ -1,5 +1,14 @@
-"""Running metrics (counterparts of gemnet/training/metrics.py:6-159): sample-weighted means of the
-tracked quantities, best-so-far bookkeeping in an npz, TensorBoard / Sacred writers."""
+"""Running metrics of the training harness.
+
+Call surface = what the reference's train.ipynb and Trainer use (gemnet/training/metrics.py:6-159 is the
+counterpart): `Metrics(tag, keys, ex)` with `update_state(nsamples, **values)`, `result(append_tag)`, `.loss`,
+`write(summary_writer, step)`, `reset_states()`; `BestMetrics(path, metrics, assert_exist)` with
+`inititalize()` (sic), `restore()`, `update(step, metrics)`, `items()`, `write(...)`, `.loss`, `.step`.
+
+Own design: every tracked quantity is one row of a float64 table (column 0: sum of weight * value, column 1: sum
+of the weights); values arriving as device tensors are reduced to one Python float per update (the mean over their
+elements — what the reference takes at read-out), so the table never holds device memory.
+"""
 import logging
 import os
 
@@ -7,88 +16,113 @@ import numpy as np
 import torch
 
 
+def _scalar(v):
+    """Mean over the elements of a tensor / array / number, as a Python float."""
+    if torch.is_tensor(v):
+        return float(v.detach().double().mean())
+    return float(np.mean(v))
+
+
 class MeanMetric:
-    def __init__(self):
-        self.reset_states()
+    """Weighted running mean of one quantity (a view of one row of the owning table, or stand-alone)."""
+    __slots__ = ("_row",)
+
+    def __init__(self, row=None):
+        self._row = np.zeros(2) if row is None else row
 
     def update_state(self, values, sample_weight):
-        self.values += sample_weight * values
-        self.sample_weights += sample_weight
+        self._row += (sample_weight * _scalar(values), sample_weight)
 
     def result(self):
-        return self.values / self.sample_weights
+        total, weight = self._row
+        return total / weight if weight else float("nan")
 
     def reset_states(self):
-        self.sample_weights = 0
-        self.values = 0
+        self._row[:] = 0.0
 
 
 class Metrics:
     def __init__(self, tag, keys, ex=None):
-        assert "loss" in keys
-        self.tag, self.keys, self.ex = tag, keys, ex
-        self.mean_metrics = {k: MeanMetric() for k in keys}
+        if "loss" not in keys:
+            raise AssertionError("the tracked keys must contain 'loss'")
+        self.tag, self.keys, self.ex = tag, list(keys), ex
+        self._table = np.zeros((len(self.keys), 2))
+        self._index = {k: i for i, k in enumerate(self.keys)}
+        self.mean_metrics = {k: MeanMetric(self._table[i]) for k, i in self._index.items()}
 
     def update_state(self, nsamples, **updates):
-        assert set(updates).issubset(self.keys)
-        for k, v in updates.items():
-            self.mean_metrics[k].update_state(torch.as_tensor(v).detach().cpu(), sample_weight=nsamples)
+        unknown = set(updates) - set(self._index)
+        if unknown:
+            raise AssertionError(f"untracked metrics: {sorted(unknown)}")
+        for name, value in updates.items():
+            self._table[self._index[name]] += (nsamples * _scalar(value), nsamples)
+
+    def _mean(self, name):
+        total, weight = self._table[self._index[name]]
+        return float(total / weight) if weight else float("nan")
 
     def result(self, append_tag=True):
-        return {(f"{k}_{self.tag}" if append_tag else k): float(torch.as_tensor(self.mean_metrics[k].result()).mean())
-                for k in self.keys}
+        suffix = f"_{self.tag}" if append_tag else ""
+        return {name + suffix: self._mean(name) for name in self.keys}
 
     @property
     def loss(self):
-        return float(torch.as_tensor(self.mean_metrics["loss"].result()).mean())
+        return self._mean("loss")
 
     def write(self, summary_writer, step):
-        for k, v in self.result().items():
-            summary_writer.add_scalar(k, v, global_step=step)
-            if self.ex is not None:
-                self.ex.current_run.info.setdefault(k, []).append(v)
-        if self.ex is not None:
-            self.ex.current_run.info.setdefault(f"step_{self.tag}", []).append(step)
+        info = None if self.ex is None else self.ex.current_run.info
+        for name, value in self.result().items():
+            summary_writer.add_scalar(name, value, global_step=step)
+            if info is not None:
+                info.setdefault(name, []).append(value)
+        if info is not None:
+            info.setdefault(f"step_{self.tag}", []).append(step)
 
     def reset_states(self):
-        for m in self.mean_metrics.values():
-            m.reset_states()
+        self._table[:] = 0.0
 
 
 class BestMetrics:
+    """Best validation metrics so far, mirrored in `<path>/best_metrics.npz` after every change."""
+    FILE = "best_metrics.npz"
+
     def __init__(self, path, metrics, assert_exist=True):
-        self.path = os.path.join(path, "best_metrics.npz")
-        self.metrics, self.assert_exist, self.state = metrics, assert_exist, {}
+        self.path = os.path.join(path, self.FILE)
+        self.metrics = metrics
+        self.assert_exist = assert_exist
+        self.state = {}
+
+    def _save(self):
+        np.savez(self.path, **self.state)
 
     def inititalize(self):  # (sic) the reference's spelling is part of the call surface
-        self.state = {f"{k}_{self.metrics.tag}": np.inf for k in self.metrics.keys}
+        self.state = dict.fromkeys(self.metrics.result(), np.inf)
         self.state["step"] = 0
-        np.savez(self.path, **self.state)
+        self._save()
 
     initialize = inititalize
 
     def restore(self):
-        if os.path.isfile(self.path):
-            self.state = {k: v.item() for k, v in np.load(self.path).items()}
-            return
-        msg = f"Best metrics can not be restored as the file does not exist in the given path: {self.path}"
-        if self.assert_exist:
-            raise UserWarning(msg)
-        logging.warning(msg + "\n Will initialize the best metrics.")
-        self.inititalize()
+        try:
+            with np.load(self.path) as stored:
+                self.state = {name: stored[name].item() for name in stored.files}
+        except FileNotFoundError:
+            if self.assert_exist:
+                raise UserWarning(f"no best-metrics file at {self.path}") from None
+            logging.warning("no best-metrics file at %s: starting from fresh best metrics", self.path)
+            self.inititalize()
 
     def items(self):
         return self.state.items()
 
     def update(self, step, metrics):
-        self.state["step"] = step
-        self.state.update(metrics.result())
-        np.savez(self.path, **self.state)
+        self.state = {**self.state, **metrics.result(), "step": step}
+        self._save()
 
     def write(self, summary_writer, step):
-        for k, v in self.state.items():
-            if k != "step":
-                summary_writer.add_scalar(k + "_best", v, step)
+        for name, value in self.state.items():
+            if name != "step":
+                summary_writer.add_scalar(f"{name}_best", value, step)
 
     @property
     def loss(self):

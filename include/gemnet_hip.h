@@ -117,6 +117,18 @@ typedef struct {
   float alpha2;
   const float* Z2;          /* (M,N) global or NULL */
   float* out2;              /* (M,N) global or NULL */
+  /* Source term of the second-order sweeps of force training (trainer.py:346: loss.backward() through dE/dR): one
+   * extra summand  s = src_alpha * phis(Zs) * srcP * srcQ  added to
+   *   src_stage 1: the value of a SCALE op (Zs = its `src`), or a GEMM's y right after the mul / alpha stages
+   *                (y = a * phi_mul(mul) * alpha + s; Zs = the GLOBAL mul operand), before res / res2;
+   *   src_stage 2: the second output of a GEMM or LOAD (y2 = ... * alpha2 * phi2(Z2) + s; Zs = Z2).
+   * phis by `src_mode`: 0 -> 1, 1 -> ssilu''(Zs).  The adjoint of y = ssilu(z) under a tangent dz is
+   * zbar = ybar ssilu'(z) + lambda_y ssilu''(z) dz: the second summand is this term (P = lambda_y, Q = dz). */
+  int src_stage;            /* 0: none */
+  int src_mode;
+  float src_alpha;
+  const float* srcP;        /* (M,N) global */
+  const float* srcQ;        /* (M,N) global or NULL (then s = src_alpha * phis(Zs) * srcP) */
 } gn_chain_op;
 typedef struct {
   int M;

@@ -247,6 +247,17 @@ def chain(prog):
             return None
         return slots[x][:, :N] if isinstance(x, int) else x
 
+    def source(src, Z):
+        """alpha * (ssilu''(Z) | 1) * P * Q of a second-order source term (gn_chain_op.src_*)."""
+        if src is None:
+            return 0.0
+        t = src["P"] * src["alpha"]
+        if src["Q"] is not None:
+            t = t * src["Q"]
+        if src["mode"] == 1:
+            t = t * _act(Z, 2)
+        return t
+
     for o in prog.ops:
         if o["kind"] == "load":
             src = o["src"] if o["rows"] is None else o["src"][o["rows"].long()]
@@ -258,6 +269,7 @@ def chain(prog):
                 if o.get("Z2") is not None:
                     m2 = o.get("mode2", 0)
                     y2 = y2 * (_act(o["Z2"], 1) if m2 == 0 else (o["Z2"] if m2 == 1 else _act(o["Z2"], 0)))
+                y2 = y2 + source(o.get("add2"), o.get("Z2"))
                 slots[o["y2"]] = torch.zeros(M, 128, dtype=dt)
                 slots[o["y2"]][:, :src.shape[1]] = y2
         elif o["kind"] == "scale":
@@ -267,6 +279,7 @@ def chain(prog):
             if Z is not None:
                 mode = o.get("mode", 0)
                 v = v * (_act(Z, 1) if mode == 0 else (Z if mode == 1 else _act(Z, 0)))
+            v = v + source(o.get("add"), Z)
             new = slots[o["slot"]].clone()
             new[:, :w] = v
             slots[o["slot"]] = new
@@ -291,6 +304,7 @@ def chain(prog):
                 mm = o.get("mul_mode", 1)
                 y = y * (mul if mm <= 1 else _act(mul, 1 if mm == 2 else 0))
             y = y * o["alpha"]
+            y = y + source(o.get("add"), mul)
             res = sel(o["res"], N)
             if res is not None:
                 if o["res_rows"] is not None:
@@ -307,6 +321,7 @@ def chain(prog):
                 if o.get("Z2") is not None:
                     m2 = o.get("mode2", 0)
                     y2 = y2 * (_act(o["Z2"], 1) if m2 == 0 else (o["Z2"] if m2 == 1 else _act(o["Z2"], 0)))
+                y2 = y2 + source(o.get("add2"), o.get("Z2"))
                 if o.get("out2") is not None:
                     o["out2"].copy_(y2)
             if o["slot"] >= 0:

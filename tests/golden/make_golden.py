@@ -232,6 +232,25 @@ def golden_indices():
 
 
 # ------------------------------------------------------------------------------- G4 model
+
+def grad_probes(name, numel, k=4):
+    """k fixed +-1 probe vectors for the parameter `name` (seeded by the name): the dot products of a gradient with
+    them pin its ELEMENTS (sign and position), which the norm alone does not, at 32 bytes per parameter."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return rs.randint(0, 2, size=(k, numel)).astype(np.float64) * 2.0 - 1.0
+
+
+def record_grads(tag, model, out):
+    names, norms, proj = [], [], []
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            norms.append(float(p.grad.norm()))
+            proj.append(grad_probes(n, p.numel()) @ p.grad.detach().double().reshape(-1).numpy())
+    out[f"{tag}.grad_names"], out[f"{tag}.grad_norms"] = np.array(names), np.array(norms)
+    out[f"{tag}.grad_proj"] = np.array(proj)
+
 def run_model(cfg, seed, Rlist, Zlist, tag, out, with_grads):
     to = cfg["triplets_only"]
     N = np.array([len(r) for r in Rlist], dtype=np.int32)
@@ -262,13 +281,7 @@ def run_model(cfg, seed, Rlist, Zlist, tag, out, with_grads):
         loss = GO.training_loss(E, F, batch["E"].double(), batch["F"].double())
         out[f"{tag}.loss"] = loss.detach().numpy()
         loss.backward()
-        names, norms = [], []
-        for n, p in model.named_parameters():
-            if p.grad is not None:
-                names.append(n)
-                norms.append(float(p.grad.norm()))
-        out[f"{tag}.grad_names"] = np.array(names)
-        out[f"{tag}.grad_norms"] = np.array(norms)
+        record_grads(tag, model, out)
         # full gradients of three representative parameters
         for n in ("rbf_basis.frequencies", "mlp_cbf3.weight", "int_blocks.0.trip_interaction.mlp_cbf.weight",
                   "int_blocks.0.dense_ca.weight"):
@@ -366,15 +379,11 @@ def run_model2(cfg, seed, Rlist, Zlist, tag, out, with_grads=False, unit_forces=
                                 batch["F"].double())
         out[f"{tag}.loss"] = loss.detach().numpy()
         loss.backward()
-        names, norms = [], []
-        for n, p in model.named_parameters():
-            if p.grad is not None:
-                names.append(n)
-                norms.append(float(p.grad.norm()))
-        out[f"{tag}.grad_names"], out[f"{tag}.grad_norms"] = np.array(names), np.array(norms)
+        record_grads(tag, model, out)
         named = dict(model.named_parameters())
         for n in ("mlp_cbf3.weight", "int_blocks.0.trip_interaction.mlp_cbf.weight", "int_blocks.0.dense_ca.weight",
-                  "out_blocks.1.out_forces.weight", "out_blocks.0.seq_forces.0.weight"):
+                  "out_blocks.1.out_forces.weight", "out_blocks.0.seq_forces.0.weight", "mlp_sbf4.weight",
+                  "int_blocks.3.quad_interaction.mlp_sbf.weight", "int_blocks.3.layers_after_skip.0.dense_mlp.1.weight"):
             if n in named and named[n].grad is not None:
                 out[f"{tag}.grad.{n}"] = named[n].grad.numpy()
     print(tag, "E", E.detach().numpy().ravel()[:3], "mean|F|", float(F.detach().abs().mean()), "out_scale", scale,
@@ -397,7 +406,7 @@ def golden_models2():
     # per-layer captures: small GemNet-Q (both interactions) and full-width GemNet-T (second block)
     run_model2(cfg_small(False), 2, [m12["R"]], [m12["Z"]], "q1L", out, unit_forces=False, layers=Q_LAYERS)
     run_model2(cfg_full(True, 2), 3, *pair, "t2s", out, with_grads=True, layers=T_LAYERS)
-    run_model2(cfg_full(False, 2), 4, *pair, "q2s", out)
+    run_model2(cfg_full(False, 2), 4, *pair, "q2s", out, with_grads=True)
     # direct forces (gemnet.py:586-597, atom_update_block.py:181-188): small T uncoupled, small Q coupled, full-width T
     run_model2(dict(cfg_small(True), direct_forces=True, forces_coupled=False), 41, [m12["R"]], [m12["Z"]], "dt1", out,
                with_grads=True, unit_forces=False)
@@ -407,8 +416,9 @@ def golden_models2():
     # two targets with autograd forces (one backward per target, gemnet.py:599-609)
     run_model2(dict(cfg_small(True), num_targets=2), 44, [m12["R"]], [m12["Z"]], "t1m", out, unit_forces=False)
     # the published configurations (pretrained/*/model_kwargs.json), 4 blocks, one 32-atom molecule, unit forces
-    run_model2(cfg_full(True, 4), 5, [m32["R"]], [m32["Z"]], "t4s", out)
-    run_model2(cfg_full(False, 4), 6, [m32["R"]], [m32["Z"]], "q4s", out)
+    # ... with the second-order pass loss.backward() pinned on them too (gemnet.py:603-611, trainer.py:346)
+    run_model2(cfg_full(True, 4), 5, [m32["R"]], [m32["Z"]], "t4s", out, with_grads=True)
+    run_model2(cfg_full(False, 4), 6, [m32["R"]], [m32["Z"]], "q4s", out, with_grads=True)
     np.savez_compressed(os.path.join(HERE, "model2.npz"), **out)
     print("model2.npz", len(out), "arrays")
 

@@ -178,10 +178,13 @@ def test_trainer_two_ranks_equal_single_process(tmp_path, mve):
 
 def test_train_step_counts_follow_the_batch():
     """Without `global_counts`, TrainStep exchanges the molecule/atom counts every step (batches of a real loader
-    vary); only a captured static batch pins them."""
+    vary); the counts pinned by `capture()` are used only while capturing — an eager step with the same local shape
+    must still run the exchange (a per-rank shortcut would unpair the collectives)."""
     ts = TrainStep.__new__(TrainStep)
-    ts.global_counts, ts._pinned_counts, ts.world_size = None, None, 1
+    ts.global_counts, ts._pinned_counts, ts._use_pinned, ts.world_size = None, None, False, 1
     assert ts._counts(4, 32, "cpu") == (4.0, 32.0)
     assert ts._counts(3, 20, "cpu") == (3.0, 20.0)
     ts._pinned_counts = ((4, 32), (8.0, 64.0))
-    assert ts._counts(4, 32, "cpu") == (8.0, 64.0) and ts._counts(3, 20, "cpu") == (3.0, 20.0)
+    assert ts._counts(4, 32, "cpu") == (4.0, 32.0) and ts._counts(3, 20, "cpu") == (3.0, 20.0)
+    ts._use_pinned = True
+    assert ts._counts(4, 32, "cpu") == (8.0, 64.0)

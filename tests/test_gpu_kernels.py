@@ -511,25 +511,39 @@ def test_bilinear_tail_adjoint_one_launch(E):
 
 
 def test_quad_basis_fused_fwd_bwd():
+    """Explicit (Q,49) harmonics + adjoint (the path of non-published tensor-basis widths; the published ones use the
+    angle form).  Quadruplets are drawn WELL-CONDITIONED — bond lengths >= 0.8 A, sin of the polar angle c-a-b and of
+    a-b-d >= 0.25 (the chain rule through atan2 / the projections divides by them) — so the bar is elementwise, for
+    every quadruplet, not a quantile."""
     g = torch.Generator().manual_seed(31)
-    n_atoms, Q = 30, 1500
+    n_atoms, Q = 30, 6000
     R = torch.rand(n_atoms, 3, generator=g, dtype=torch.float64) * 5.0
     idx = torch.stack([torch.randperm(n_atoms, generator=g)[:4] for _ in range(Q)])  # 4 distinct atoms each
-    qc, qa, qb, qd = (idx[:, i].contiguous().int() for i in range(4))
     R32 = R.float().double()
+    c, a, b, d = (R32[idx[:, i]] for i in range(4))
+
+    def sin_between(u, v):
+        return torch.linalg.cross(u, v).norm(dim=1) / (u.norm(dim=1) * v.norm(dim=1))
+    ok = ((c - a).norm(dim=1) >= 0.8) & ((b - a).norm(dim=1) >= 0.8) & ((d - b).norm(dim=1) >= 0.8) \
+        & (sin_between(c - a, b - a) >= 0.25) & (sin_between(a - b, d - b) >= 0.25)
+    idx = idx[ok][:1500]
+    Q = idx.shape[0]
+    assert Q >= 1000
+    qc, qa, qb, qd = (idx[:, i].contiguous().int() for i in range(4))
     Y = K.quad_basis_fwd(f32(R), qc.to(DEV), qa.to(DEV), qb.to(DEV), qd.to(DEV), 7)
     rY = CK.quad_basis_fwd(R32, qc, qa, qb, qd, 7)
-    close(Y, rY, rtol=1e-3, atol=2e-4)
+    close(Y, rY, rtol=1e-4, atol=2e-5)
     gY = rnd(g, Q, 49)
     G = K.quad_basis_bwd(f32(gY), f32(R), qc.to(DEV), qa.to(DEV), qb.to(DEV), qd.to(DEV), 7)
     rG = CK.quad_basis_bwd(gY, R32, qc, qa, qb, qd, 7)
-    for out, ref in zip(G, rG):
-        # near-degenerate dihedrals amplify f32 rounding: bulk check by quantile + all finite
+    for name, out, ref in zip("cbd", G, rG):
         err = (out.cpu().double() - ref).abs()
-        scale = ref.abs().median()
+        scale = float(ref.abs().median())
+        print(f"quad_basis_bwd G{name}: median err {float(err.median()) / scale:.2e}, p99 {float(torch.quantile(err, 0.99)) / scale:.2e}, "
+              f"max {float(err.max()) / scale:.2e} (x median |ref| = {scale:.3e})")
         assert torch.isfinite(out).all()
-        assert float(err.median()) <= 1e-4 * float(scale)
-        assert float(torch.quantile(err, 0.99)) <= 3e-2 * float(scale)
+        assert float(err.median()) <= 2e-5 * scale
+        assert float(err.max()) <= 2e-3 * scale
 
 
 @pytest.mark.parametrize("Kd,M,N", [(1024, 128, 128), (17800, 128, 128), (17801, 128, 16), (5003, 64, 128),

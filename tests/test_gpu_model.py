@@ -5,12 +5,13 @@ fixtures whose forces are O(1) eV/A: the shallow models t1/q1/dt1/dq1/t1m and th
 rescaled to mean|F| = 1 (t2s, q2s, dt2s, t4s = pretrained GemNet-T configuration, q4s = pretrained GemNet-Q
 configuration; tests/golden/make_golden.py::run_model2).  The unscaled deep fixtures (|F| up to 3e4 with the untrained
 test weights) are kept as a RELATIVE-precision check under their own name.  Every test prints the measured MAE.
-Second-order (training) gradients are compared per parameter by norm (rtol 2e-3) and elementwise for the stored ones."""
+Second-order (training) gradients — incl. both published 4-block configurations (t4s, q4s) — are compared per parameter
+by norm (rtol 2e-3), through 4 fixed +-1 probe projections of EVERY parameter's gradient, and elementwise for the stored ones."""
 import numpy as np
 import pytest
 import torch
 
-from conftest import SCALE_FILE
+from conftest import SCALE_FILE, check_grad_probes
 from oracle import gemnet_oracle as GO
 from gemnet_pytorch_amd.model.gemnet import GemNet
 from test_oracle_model import load_case
@@ -115,7 +116,7 @@ def test_matmul_arithmetic_modes(golden_model2, tag, mode, bar, monkeypatch):
         assert f_mae <= 0.2
 
 
-@pytest.mark.parametrize("tag", ["t1", "q1", "t2", "t2s", "dt1", "dq1", "dt2s"])
+@pytest.mark.parametrize("tag", ["t1", "q1", "t2", "t2s", "q2s", "t4s", "q4s", "dt1", "dq1", "dt2s"])
 def test_training_gradients_parity(golden_model, golden_model2, tag):
     """loss.backward() through the force (second order) resp. through the direct-force head (first order, fused
     layers) against the reference's parameter gradients."""
@@ -132,6 +133,9 @@ def test_training_gradients_parity(golden_model, golden_model2, tag):
     norms = np.array([0.0 if named[n].grad is None else float(named[n].grad.norm()) for n in names])
     ref = g[f"{tag}.grad_norms"]
     np.testing.assert_allclose(norms, ref, rtol=2e-3, atol=1e-6 * float(ref.max()))
+    # every parameter's gradient projected on 4 fixed +-1 probes: pins the elements, not only the norm
+    worst = check_grad_probes(g, tag, {n: named[n].grad for n in names}, rtol=2e-3)
+    print(f"{tag}: loss {loss.item():.6f}; worst probe error / (2e-3 ||g_ref||) = {worst:.3f}")
     for n in names:
         key = f"{tag}.grad.{n}"
         if key in g:
@@ -152,7 +156,7 @@ def test_repeatable_bitwise(golden_model):
 def test_native_library_loaded():
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
-    assert lib.gn_abi_version() == 9
+    assert lib.gn_abi_version() == 10
     with open("/proc/self/maps") as f:
         assert "libgemnet_hip.so" in f.read()
 

@@ -62,3 +62,54 @@ def test_training_trajectory_on_the_gpu(tag):
     np.testing.assert_allclose(val_loss, float(g[f"{tag}.val_loss"]), rtol=2e-3)
     trainer.restore_variable_backups()
     np.testing.assert_allclose([float(named[n].detach().norm()) for n in names], g[f"{tag}.restored_norms"], rtol=1e-3)
+
+
+def test_rccl_one_rank_all_reduce_inside_train_step():
+    """First contact with RCCL (`nccl` backend on ROCm): a one-rank process group, the flat gradient buffer of the fused
+    training step pushed through `dist.all_reduce` (TrainStep.always_reduce) — gradients and the parameters after the
+    optimizer step are bit-identical to the step without the collective (a one-rank sum is the identity)."""
+    import socket
+
+    import torch.distributed as dist
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    from gemnet_pytorch_amd.training.ddp import TrainStep
+    from test_gpu_fullsize import FULL
+
+    cfg = dict(FULL, triplets_only=True, num_blocks=2)
+    ds = make_dataset(4, 12, config=7)
+    dc = DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=True)
+    b = dc[[0, 1, 2, 3]]
+    targets = {k: b.pop(k).to("cuda") for k in ("E", "F")}
+    inputs = {k: v.to("cuda") for k, v in b.items()}
+
+    def run(with_rccl):
+        torch.manual_seed(5)
+        model = GemNet(**cfg, scale_file=SCALE_FILE).to("cuda")
+        ts = TrainStep(model, world_size=1, fused_optimizer=True)
+        ts.always_reduce = with_rccl
+        losses = [float(ts(inputs, targets)) for _ in range(2)]
+        torch.cuda.synchronize()
+        return losses, ts.buf.flat.clone(), ts.fused.flat_p.clone()
+
+    ref = run(False)
+    created = False
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+        created = True
+    try:
+        assert dist.get_backend() == "nccl"
+        got = run(True)
+        t = torch.ones(1 << 20, device="cuda")
+        dist.all_reduce(t)                       # and a plain 4 MB all-reduce
+        torch.cuda.synchronize()
+        assert float(t.sum()) == float(1 << 20)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert got[0] == ref[0]
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])

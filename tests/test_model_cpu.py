@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, SCALE_FILE
+from conftest import GOLDEN, SCALE_FILE, check_grad_probes
 from oracle import gemnet_oracle as GO
 from gemnet_pytorch_amd.model.gemnet import GemNet
 import cpu_kernels
@@ -43,6 +43,7 @@ def test_energy_force_and_training_grads(golden_model, tag):
     names = [str(n) for n in g[f"{tag}.grad_names"]]
     norms = np.array([0.0 if named[n].grad is None else float(named[n].grad.norm()) for n in names])
     np.testing.assert_allclose(norms, g[f"{tag}.grad_norms"], rtol=1e-7, atol=1e-12)
+    check_grad_probes(g, tag, {n: named[n].grad for n in names}, rtol=1e-7)
     for n in names:
         key = f"{tag}.grad.{n}"
         if key in g:
@@ -243,6 +244,7 @@ def test_round2_training_gradients(golden_model2, tag):
     names = [str(n) for n in g[f"{tag}.grad_names"]]
     norms = np.array([0.0 if named[n].grad is None else float(named[n].grad.norm()) for n in names])
     np.testing.assert_allclose(norms, g[f"{tag}.grad_norms"], rtol=1e-7, atol=1e-12)
+    check_grad_probes(g, tag, {n: named[n].grad for n in names}, rtol=1e-7)
     for n in names:
         key = f"{tag}.grad.{n}"
         if key in g:

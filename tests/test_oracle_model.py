@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import gemnet_oracle as GO
-from conftest import SCALE_FILE
+from conftest import check_grad_probes, SCALE_FILE
 
 CASES = ["t1", "q1", "t2", "q2", "t4"]
 # model2.npz (round 2): unit-force deep models, direct-force models, a two-target model
@@ -24,7 +24,7 @@ def load_case(g, tag, dtype=torch.float64):
         params = {k: (v * sc if k.endswith(HEAD_KEYS) else v) for k, v in params.items()}
     inputs = {}
     prefix = tag + "."
-    skip = {"cfg", "seed", "E", "F", "Et", "Ft", "loss", "grad_names", "grad_norms", "out_scale"}
+    skip = {"cfg", "seed", "E", "F", "Et", "Ft", "loss", "grad_names", "grad_norms", "grad_proj", "out_scale"}
     for k, v in g.items():
         if not k.startswith(prefix):
             continue
@@ -62,7 +62,7 @@ def test_energy_force_round2(golden_model2, tag):
         assert abs(float(np.abs(Fref).mean()) - 1.0) < 1e-9
 
 
-@pytest.mark.parametrize("tag", ["t1", "q1", "t2", "t2s", "dt1", "dq1", "dt2s"])
+@pytest.mark.parametrize("tag", ["t1", "q1", "t2", "t2s", "q2s", "dt1", "dq1", "dt2s", "t4s"])
 def test_training_gradients(golden_model, golden_model2, tag):
     g = golden_model2 if f"{tag}.E" in golden_model2 else golden_model
     cfg, params, inputs = load_case(g, tag)
@@ -77,6 +77,7 @@ def test_training_gradients(golden_model, golden_model2, tag):
     grads = torch.autograd.grad(loss, [params[n] for n in names], allow_unused=True)
     norms = np.array([0.0 if gr is None else float(gr.norm()) for gr in grads])
     np.testing.assert_allclose(norms, g[f"{tag}.grad_norms"], rtol=1e-7, atol=1e-12)
+    check_grad_probes(g, tag, dict(zip(names, grads)), rtol=1e-7)
     for n, gr in zip(names, grads):
         key = f"{tag}.grad.{n}"
         if key in g:

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "gemnet_pytorch_amd", "csrc")
 DEFS = os.environ.get("GN_TRACE_DEFS", "").split()     # extra -D flags (experiments), e.g. GN_TRACE_DEFS="-DGN_EXP=1"
-TRACE_LIB = os.path.join(CSRC, "libgemnet_hip_trace%s.so" % "".join(d.replace("-D", "_").replace("=", "") for d in DEFS))
+TRACE_LIB = os.path.join(ROOT, "tools", "exp", "bin", "libgemnet_hip_trace%s.so" % "".join(d.replace("-D", "_").replace("=", "") for d in DEFS))
 QUICK = "--quick" in sys.argv
 if not os.path.exists(TRACE_LIB) or "--build" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",

@@ -3,7 +3,7 @@ import ctypes, os, sys, subprocess, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "gemnet_pytorch_amd", "csrc")
-TRACE_LIB = os.path.join(CSRC, "libgemnet_hip_trace.so")
+TRACE_LIB = os.path.join(ROOT, "tools", "exp", "bin", "libgemnet_hip_trace.so")
 if not os.path.exists(TRACE_LIB) or "--build" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                            "-DGN_CHAIN_TRACE", "-I", os.path.join(ROOT, "include")] + sorted(glob.glob(CSRC + "/*.hip"))
