@@ -576,7 +576,45 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ W, int N, int
   dst[128] = make_uint4(L0.x, L0.y, L1.x, L1.y);
 }
 
+// All weights of one training step in ONE launch: thread -> (job, tile, chunk, lane) by binary search over the jobs'
+// first-unit table (a "unit" is one thread of pack_weight_split_kernel).
+__global__ void pack_weight_split_grouped_kernel(const gn_pack_job* __restrict__ jobs, int n_jobs, int total_units) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_units) return;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].unit_begin <= idx) lo = mid; else hi = mid - 1;
+  }
+  const gn_pack_job j = jobs[lo];
+  const int u = idx - j.unit_begin;
+  const int kc = (j.K + 31) >> 5;
+  const int lane = u & 63, tc = u >> 6, c = tc % kc, tile = tc / kc;
+  const int n = tile * 16 + (lane & 15), k0 = c * 32 + ((lane >> 4) << 3);
+  float x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    x[i] = (n < j.N && k < j.K) ? (j.trans ? j.W[(size_t)k * j.ldw + n] : j.W[(size_t)n * j.ldw + k]) : 0.f;
+  }
+  uint2 H0, M0, L0, H1, M1, L1;
+  split4(make_float4(x[0], x[1], x[2], x[3]), H0, M0, L0);
+  split4(make_float4(x[4], x[5], x[6], x[7]), H1, M1, L1);
+  uint4* dst = static_cast<uint4*>(j.out) + ((size_t)tc * 3) * 64 + lane;
+  dst[0] = make_uint4(H0.x, H0.y, H1.x, H1.y);
+  dst[64] = make_uint4(M0.x, M0.y, M1.x, M1.y);
+  dst[128] = make_uint4(L0.x, L0.y, L1.x, L1.y);
+}
+
 }  // namespace
+
+extern "C" int gn_pack_weight_split_grouped(const gn_pack_job* jobs, int n_jobs, int total_units, void* stream) {
+  if (n_jobs <= 0 || total_units <= 0) return 0;
+  hipLaunchKernelGGL(pack_weight_split_grouped_kernel, dim3(gn_cdiv(total_units, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), jobs, n_jobs, total_units);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
 
 #ifdef GN_CHAIN_TRACE
 extern "C" int gn_chain2_trace_read(unsigned long long* host) {

@@ -167,7 +167,9 @@ __global__ __launch_bounds__(1024) void tn_fold_grouped_kernel(const gn_tn_targe
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc += part[j][lane];
-    t.out[i] += acc;
+    // a column slice of a wider parameter (the three blocks of a concat-Dense weight): rows of `cols` elements, pitch `ld`
+    const int64_t o = t.cols > 0 ? (i / t.cols) * (int64_t)t.ld + (i % t.cols) : i;
+    t.out[o] += acc;
   }
 }
 

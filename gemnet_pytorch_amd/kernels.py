@@ -573,6 +573,31 @@ def pack_weight_split(W, trans=False):
     return out
 
 
+def pack_job_table(entries):
+    """Device job table (gn_pack_job) for `pack_weight_split_grouped`: entries = [(W, trans, packed uint8 tensor)].
+    -> (table tensor, total_units).  Host -> device copy: not inside a stream capture."""
+    import numpy as np
+    JOB = np.dtype([("W", "<u8"), ("out", "<u8"), ("N", "<i4"), ("K", "<i4"), ("ldw", "<i4"), ("trans", "<i4"),
+                    ("unit_begin", "<i4"), ("pad", "<i4")])
+    assert JOB.itemsize == 40
+    jobs = np.zeros(len(entries), dtype=JOB)
+    unit = 0
+    for i, (W, trans, packed) in enumerate(entries):
+        W = _rowmajor(W)
+        assert W.data_ptr() == entries[i][0].data_ptr(), "registered weights must have unit inner stride"
+        N, Kd = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
+        jobs[i] = (W.data_ptr(), packed.data_ptr(), N, Kd, W.stride(0), int(bool(trans)), unit, 0)
+        unit += -(-N // 16) * -(-Kd // 32) * 64
+    dev = entries[0][0].device
+    table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+    return table, unit
+
+
+def pack_weight_split_grouped(table, n_jobs, total_units):
+    check(_lib.load().gn_pack_weight_split_grouped(ptr(table), int(n_jobs), int(total_units), stream()),
+          "gn_pack_weight_split_grouped")
+
+
 def chain_split_supported(prog):
     """What gn_chain_split_f32 accepts: N % 16 == 0, slot 2 only as a parking slot."""
     for o in prog.ops:

@@ -87,6 +87,7 @@ class GemNet(torch.nn.Module):
         self._side = None
         self._cot = None      # cached force cotangents (see _cotangent)
         self._wcache = {}  # derived (transposed / contiguous) copies of frozen weights, see ops.weight_cache
+        self._packs = ops.PackRegistry()   # split-bf16 planes of the trainable weights, repacked once per training step
 
         AutomaticFit.reset()
 
@@ -368,7 +369,7 @@ class GemNet(torch.nn.Module):
         mode = self.matmul_precision or K_chain_mode()
         t2 = bool(graph) and ops.USE_TRAIN2 and not AutomaticFit.fitting_mode and mode != "f32"
         with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w), \
-                ops.train2(t2), \
+                ops.train2(t2, self._packs if (t2 and R.is_cuda) else None), \
                 ops.chain_mode(self.matmul_precision), torch.enable_grad() if not self.direct_forces else _nullcontext():
             E_mol, F_ca, V_ca = self._energy(R, plan)
 
@@ -434,15 +435,18 @@ class GemNet(torch.nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._wcache = {}  # .to()/.float()/.cuda() replace the parameters' storage
+        self._packs.clear()
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
         self._wcache = {}
+        self._packs.clear()
         return super().load_state_dict(*args, **kwargs)
 
     def __deepcopy__(self, memo):
         side, self._side = self._side, None  # HIP stream handles are not copyable
         cache, self._wcache = self._wcache, {}  # keyed by this instance's weight addresses
+        packs, self._packs = self._packs, ops.PackRegistry()
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -454,6 +458,7 @@ class GemNet(torch.nn.Module):
         finally:
             self._side = side
             self._wcache = cache
+            self._packs = packs
 
     @staticmethod
     def _check_inputs(R):

@@ -55,8 +55,12 @@ def wgrad_queue(queue):
 
 
 def _queueable(P):
-    return (_WGRAD_QUEUE is not None and not torch.is_grad_enabled() and P.is_leaf and P.requires_grad
-            and P.grad is not None and P.is_cuda and P.dim() == 2)
+    """May the weight gradient of P be deferred into the grouped launch?  Leaf parameters and their column-block views
+    (training/wgrad_queue.py::grad_target) in the final, non-differentiable backward."""
+    if _WGRAD_QUEUE is None or torch.is_grad_enabled():
+        return False
+    from .training.wgrad_queue import grad_target
+    return grad_target(P) is not None
 
 
 # ------------------------------------------------------------------------ gather <-> segsum
@@ -922,13 +926,59 @@ USE_TRAIN2 = os.environ.get("GEMNET_TRAIN2", "1") == "1"
 _STEP_PACKED = None     # per-forward cache of split-bf16 weight planes (the weights change every step)
 
 
+class PackRegistry:
+    """Split-bf16 planes of every (weight, orientation) a model's training step asks for, refreshed by ONE grouped launch
+    at the start of each step (gn_pack_weight_split_grouped) instead of one launch per weight and sweep (~220 per step).
+    The first step packs on demand and registers what it saw; from then on `begin_step` repacks all registered entries in
+    place (their buffers — and the device job table — are persistent: captured hipGraphs replay the same launch).
+    Keyed by the weight's address / shape / strides: `clear()` when the parameters move (GemNet._apply, load_state_dict)."""
+
+    def __init__(self):
+        self.entries = {}      # key -> (W, trans, packed uint8 tensor)
+        self.table = None      # device job table of the entries registered when it was built
+        self.n_table = 0
+        self.total_units = 0
+
+    def clear(self):
+        self.entries, self.table, self.n_table, self.total_units = {}, None, 0, 0
+
+    @staticmethod
+    def key(W, trans):
+        return (W.data_ptr(), tuple(W.shape), tuple(W.stride()), bool(trans))
+
+    def get(self, W, trans):
+        k = self.key(W, trans)
+        hit = self.entries.get(k)
+        if hit is None:
+            packed = K.pack_weight_split(W.detach(), trans=trans)
+            self.entries[k] = (W.detach(), bool(trans), packed)
+            return packed
+        return hit[2]
+
+    def begin_step(self):
+        """Repack every registered entry (one launch).  Entries registered after the table was built are packed on
+        demand in `get` until the table is rebuilt — outside of stream capture only (it needs a host -> device copy)."""
+        if not self.entries:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.n_table != len(self.entries):
+            if capturing:
+                raise RuntimeError("PackRegistry: run one eager training step of this model before capturing a hipGraph")
+            self.table, self.total_units = K.pack_job_table([(W, t, p) for W, t, p in self.entries.values()])
+            self.n_table = len(self.entries)
+        K.pack_weight_split_grouped(self.table, self.n_table, self.total_units)
+
+
 @contextlib.contextmanager
-def train2(enabled: bool):
+def train2(enabled: bool, registry=None):
+    """`registry`: the model's PackRegistry (GPU only); None packs per weight and step."""
     global _TRAIN2, _STEP_PACKED
     old, old_cache = _TRAIN2, _STEP_PACKED
     _TRAIN2 = bool(enabled)
     if enabled:
-        _STEP_PACKED = {}
+        if registry is not None:
+            registry.begin_step()
+        _STEP_PACKED = registry if registry is not None else {}
     try:
         yield
     finally:
@@ -940,22 +990,24 @@ def train2_enabled():
 
 
 def step_cache():
-    """The per-step dict of packed weights (None outside `train2`): a stack keeps a reference for its later sweeps."""
+    """The per-step store of packed weights (None outside `train2`): a stack keeps a reference for its later sweeps."""
     return _STEP_PACKED
 
 
 def step_packed(W, trans, cache=None):
     """Split-bf16 fragment form of a TRAINABLE weight (or of its transpose), packed once per training step and shared
     by the four sweeps of that step (ops_train.py); None on the f32 chain kernel / the host emulation.
-    `cache`: the dict a stack captured in its forward — the S3 / S4 sweeps run inside loss.backward(), after the
+    `cache`: the store a stack captured in its forward — the S3 / S4 sweeps run inside loss.backward(), after the
     `train2` context of the forward has closed."""
     if K.CHAIN_MODE == "f32" or not W.is_cuda:
         return None
     if cache is None:
         cache = _STEP_PACKED
-    key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()), bool(trans))
     if cache is None:
         return K.pack_weight_split(W.detach(), trans=trans)
+    if isinstance(cache, PackRegistry):
+        return cache.get(W, trans)
+    key = PackRegistry.key(W, trans)
     hit = cache.get(key)
     if hit is None:
         hit = cache[key] = K.pack_weight_split(W.detach(), trans=trans)

@@ -39,6 +39,11 @@ class FusedAdamWEMA:
                 if not any(s in name for s in ("atom_emb", "frequencies", "bias")):
                     wd[off:off + k] = weight_decay
                 off += pad(k)
+        # the parameters moved into the flat buffer: everything keyed by their old addresses is stale
+        if getattr(model, "_wcache", None):
+            model._wcache.clear()
+        if getattr(model, "_packs", None) is not None:
+            model._packs.clear()
         self.gscale, self.wd = gscale, wd
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)

@@ -18,8 +18,30 @@ from .._lib import check, ptr, stream
 PROB = np.dtype([("X", "<u8"), ("Y", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("ldx", "<i4"), ("ldy", "<i4"),
                  ("splitk", "<i4"), ("kchunk", "<i4"), ("wg_begin", "<i4"), ("ws_off", "<i8")])
 TARGET = np.dtype([("out", "<u8"), ("n", "<i8"), ("slice_begin", "<i4"), ("slice_end", "<i4"), ("wg_begin", "<i4"),
-                   ("pad", "<i4")])
-assert PROB.itemsize == 56 and TARGET.itemsize == 32
+                   ("cols", "<i4"), ("ld", "<i4"), ("pad", "<i4")])
+assert PROB.itemsize == 56 and TARGET.itemsize == 40
+
+
+def grad_target(P):
+    """Where the gradient of the 2-D weight-like tensor P accumulates: (address, rows, cols, ld) inside the `.grad` of a
+    leaf parameter — P itself, or the leaf P is a row-pitch-preserving 2-D view of (the column blocks `W[:, a:b]` of a
+    concat-Dense weight, embedding_block.py:60-75) — or None when P's gradient has to travel through autograd."""
+    if not (P.is_cuda and P.dim() == 2 and P.requires_grad):
+        return None
+    if P.is_leaf:
+        g = P.grad
+        if g is None or not g.is_contiguous():
+            return None
+        return (g.data_ptr(), P.shape[0], P.shape[1], P.shape[1])
+    base = P._base
+    if base is None or not base.is_leaf or base.dim() != 2 or not base.is_contiguous():
+        return None
+    g = base.grad
+    if g is None or not g.is_contiguous() or P.stride(1) != 1 or P.stride(0) != base.stride(0):
+        return None
+    off = P.storage_offset() - base.storage_offset()
+    return (g.data_ptr() + 4 * off, P.shape[0], P.shape[1], base.shape[1])
+
 
 
 def _rowmajor(t):
@@ -53,8 +75,11 @@ class WeightGradQueue:
         self._keep = None
 
     def add(self, param, X, Y):
-        """param.grad (M,N) += X^T @ Y with X (K,M), Y (K,N)."""
-        self.items.append((param, _rowmajor(X), _rowmajor(Y)))
+        """param.grad (M,N) += X^T @ Y with X (K,M), Y (K,N); `param`: a leaf parameter or a column-block view of one
+        (see `grad_target`, which must accept it)."""
+        tgt = grad_target(param)
+        assert tgt is not None and tgt[1:3] == (X.shape[1], Y.shape[1]), "not a queueable weight-gradient target"
+        self.items.append((tgt, _rowmajor(X), _rowmajor(Y), param))
 
     def _slot(self, nbytes, dev, capturing):
         if capturing:
@@ -89,25 +114,28 @@ class WeightGradQueue:
         by_param = {}
         wg = 0
         ws_off = 0
-        for i, (P, X, Y) in enumerate(items):
+        for i, (tgt, X, Y, _) in enumerate(items):
             K, M = X.shape
             N = Y.shape[1]
-            assert Y.shape[0] == K and tuple(P.shape) == (M, N) and P.grad is not None and P.grad.is_contiguous()
+            assert Y.shape[0] == K
             splitk = max(1, min(64, K // 512))
             kchunk = (-(-K // splitk) + 15) // 16 * 16
             splitk = -(-K // kchunk)
             tiles = -(-M // 64) * -(-N // 64)
             probs[i] = (X.data_ptr(), Y.data_ptr(), M, N, K, X.stride(0), Y.stride(0), splitk, kchunk, wg, ws_off)
-            by_param.setdefault(id(P), (P, []))[1].extend(ws_off + z * M * N for z in range(splitk))
+            # keyed by the target REGION: fresh view objects of one weight block must fold into one accumulator
+            by_param.setdefault(tgt, (tgt, []))[1].extend(ws_off + z * M * N for z in range(splitk))
             wg += tiles * splitk
             ws_off += splitk * M * N
         targets = np.zeros(len(by_param), dtype=TARGET)
         slices = []
         fold_wg = 0
-        for j, (P, offs) in enumerate(by_param.values()):
-            targets[j] = (P.grad.data_ptr(), P.numel(), len(slices), len(slices) + len(offs), fold_wg, 0)
+        for j, ((addr, rows, cols, ld), offs) in enumerate(by_param.values()):
+            strided = ld != cols
+            targets[j] = (addr, rows * cols, len(slices), len(slices) + len(offs), fold_wg, cols if strided else 0,
+                          ld if strided else 0, 0)
             slices.extend(offs)
-            fold_wg += -(-P.numel() // 64)
+            fold_wg += -(-(rows * cols) // 64)
         slice_off = np.asarray(slices, dtype=np.int64)
         blob = probs.tobytes() + targets.tobytes() + slice_off.tobytes()
         nbytes = len(blob)

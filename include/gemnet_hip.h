@@ -150,6 +150,14 @@ int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* stream);
  * planes in MFMA-fragment order; `out` holds gn_pack_weight_split_bytes(N,K) bytes (16-byte aligned). */
 int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream);
 int64_t gn_pack_weight_split_bytes(int N, int K);
+/* The same for ALL weights of a training step in one launch (the weights change every optimizer step,
+ * trainer.py:353-358): `jobs` is a DEVICE table sorted by unit_begin (first entry 0); job j owns the units
+ * [unit_begin, unit_begin + ceil(N/16) * ceil(K/32) * 64); total_units = the end of the last job. */
+typedef struct {
+  const float* W; void* out;
+  int N, K, ldw, trans, unit_begin, pad_;
+} gn_pack_job;
+int gn_pack_weight_split_grouped(const gn_pack_job* jobs, int n_jobs, int total_units, void* stream);
 
 /* C (M,N) = alpha * A^T B with A (K,M), B (K,N) row-major: the weight-gradient product dW = dY^T X of every
  * Dense (base_layers.py:5-48; autograd of torch.nn.Linear in the reference) and the weight adjoints of the double
@@ -164,7 +172,7 @@ int gn_gemm_tn_splitk(int M, int N, int K);
  *   probs[p]    one product: out_p (M,N) = X^T Y, X (K,M) row pitch ldx, Y (K,N) row pitch ldy, split over `splitk`
  *               slices of `kchunk` rows (multiple of 16); its workgroups are [wg_begin, wg_begin +
  *               ceil(M/64)*ceil(N/64)*splitk); partial z lands at ws + ws_off + z*M*N
- *   targets[t]  one accumulator (a parameter's .grad, n contiguous floats): out[i] += sum of ws[slice_off[k] + i]
+ *   targets[t]  one accumulator (a parameter's .grad, n floats — contiguous, or a column slice): out[i] += sum of ws[slice_off[k] + i]
  *               for k in [slice_begin, slice_end) in list order (deterministic); workgroups [wg_begin, +ceil(n/64))
  * probs and targets are sorted by wg_begin (first entry 0). */
 typedef struct {
@@ -175,7 +183,10 @@ typedef struct {
 typedef struct {
   float* out;
   int64_t n;
-  int slice_begin, slice_end, wg_begin, pad_;
+  int slice_begin, slice_end, wg_begin;
+  int cols;                 /* 0: out is n contiguous floats; > 0: rows of `cols` floats with row pitch `ld` (a column
+                             * slice of a wider parameter's .grad: the blocks of a concat-Dense weight) */
+  int ld, pad_;
 } gn_tn_target;
 int gn_gemm_tn_grouped_f32(const gn_tn_problem* probs, int n_prob, int total_wg, const gn_tn_target* targets,
                            int n_target, int total_fold_wg, const int64_t* slice_off, float* ws, void* stream);

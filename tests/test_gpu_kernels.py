@@ -383,6 +383,39 @@ def _adjoint_programs(M, width, g, dev):
     return build
 
 
+def _source_programs(M, width, g, dev):
+    """The second-order source terms (gn_chain_op.src_*) at every place they may sit: on a SCALE, after the mul stage of
+    a GEMM (ssilu'' of the global mul operand), on the second output of a GEMM and of a LOAD, with and without Q."""
+    def mk(*shape):
+        return rnd(g, *shape)
+    gin, W1, W2 = mk(M, width), mk(width, width) / 11, mk(width, width) / 11
+    z1, z2, z3 = mk(M, width), mk(M, width), mk(M, width)
+    P1, Q1, P2, Q2, P3 = mk(M, width), mk(M, width), mk(M, width), mk(M, width), mk(M, width)
+
+    def build(conv, idx):
+        t = {k: conv(v) for k, v in dict(g=gin, W1=W1, W2=W2, z1=z1, z2=z2, z3=z3, P1=P1, Q1=Q1, P2=P2, Q2=Q2,
+                                         P3=P3).items()}
+        outs = {k: conv(torch.zeros(M, width, dtype=torch.float64)) for k in ("a", "b", "c", "d", "e", "f")}
+        S = K.ChainProgram.source
+        p = K.ChainProgram(M)
+        # LOAD: slot 0 <- g, slot 1 <- g f'(z2) + P1 f''(z2) Q1
+        p.load(0, t["g"], y2=1, alpha2=1.0, Z2=t["z2"], mode2=0, add2=S(t["P1"], t["Q1"], d2=True))
+        p.store(1, outs["a"])
+        # GEMM stage-1 source: y = (x W2^T) f'(z1) * 0.9 + 1.3 P2 f''(z1) Q2, stored
+        p.gemm(t["W2"], a_slot=1, y_slot=1, mul=t["z1"], mul_mode=2, alpha=0.9, add=S(t["P2"], t["Q2"], d2=True, alpha=1.3),
+               out=outs["b"])
+        # GEMM second output with a plain (no ssilu'') source and no Q: y2 = y * 0.7 * z3 + 0.5 P3
+        p.gemm(t["W1"], a_slot=1, y_slot=0, res=0, beta=0.5, y2=1, alpha2=0.7, Z2=t["z3"], mode2=1,
+               add2=S(t["P3"], None, alpha=0.5), out2=outs["c"])
+        p.store(0, outs["d"])
+        # SCALE with a source: slot 0 <- slot 1 * 1.1 * f(z2) + P1 Q2 * 2
+        p.scale(0, 1, 1.1, Z=t["z2"], mode=2, add=S(t["P1"], t["Q2"], alpha=2.0), out=outs["e"])
+        # SCALE with the ssilu'' source of its own Z
+        p.scale(1, 0, 1.0, Z=t["z1"], mode=0, add=S(t["P2"], t["Q1"], d2=True), out=outs["f"])
+        return p, outs
+    return build
+
+
 # relative error budget of one chain program per arithmetic: f32 MFMA and the six-product split are fp32-equivalent
 CHAIN_TOL = {"f32": 1e-4, "split6": 1e-4, "split3": 2e-3, "bf16": 1e-1}
 
@@ -394,7 +427,7 @@ def test_chain_kernel_vs_interpreter(M, width, mode):
     MFMA kernel and on the split-operand bf16 kernel (packed weights), against the float64 interpreter."""
     tol = CHAIN_TOL[mode]
     worst = 0.0
-    for maker in (_stack_programs, _adjoint_programs):
+    for maker in (_stack_programs, _adjoint_programs) + ((_source_programs,) if mode != "f32" else ()):
         g = torch.Generator().manual_seed(M)
         build = maker(M, width, g, DEV)
         p_ref, o_ref = build(lambda t: t.clone(), lambda i: i)
@@ -407,6 +440,32 @@ def test_chain_kernel_vs_interpreter(M, width, mode):
             worst = max(worst, err)
             assert err <= 2 * tol, (maker.__name__, k, err)
     print(f"chain {mode} M={M} width={width}: max err / scale = {worst:.2e}")
+
+
+def test_source_terms_are_rejected_by_the_f32_chain_kernel():
+    """The f32-MFMA chain kernel has no second-order source terms: it must refuse such a program, never drop the term."""
+    g = torch.Generator().manual_seed(3)
+    build = _source_programs(64, 128, g, DEV)
+    p_dev, _ = build(lambda t: f32(t), lambda i: i.to(DEV))
+    with pytest.raises(RuntimeError):
+        K.chain(p_dev, mode="f32")
+
+
+def test_grouped_weight_pack_equals_single_packs():
+    """gn_pack_weight_split_grouped (all weights of a training step in one launch) == gn_pack_weight_split per weight,
+    bit for bit, for plain, transposed, sliced (row pitch > K) and ragged (N % 16, K % 32 != 0) matrices."""
+    g = torch.Generator().manual_seed(9)
+    big = f32(rnd(g, 128, 390))
+    mats = [(f32(rnd(g, 128, 128)), False), (f32(rnd(g, 128, 128)), True), (f32(rnd(g, 64, 16)), False),
+            (f32(rnd(g, 16, 64)), True), (big[:, 128:256], False), (big[:, 256:384], True), (f32(rnd(g, 128, 40)), False),
+            (f32(rnd(g, 48, 128)), False)]
+    singles = [K.pack_weight_split(W, trans=t) for W, t in mats]
+    outs = [torch.zeros_like(sp) for sp in singles]
+    table, units = K.pack_job_table([(W, t, o) for (W, t), o in zip(mats, outs)])
+    K.pack_weight_split_grouped(table, len(mats), units)
+    torch.cuda.synchronize()
+    for sp, o in zip(singles, outs):
+        assert torch.equal(sp, o)
 
 
 def test_split_six_products_is_fp32_equivalent():

@@ -1,0 +1,117 @@
+"""The fused force-training path (gemnet_pytorch_amd/ops_train.py: Dense stacks as twice-differentiable chain programs,
+sweeps S1..S4) on the CPU emulation of the launchers, float64:
+  * loss.backward() through the force reproduces the REFERENCE's parameter gradients (goldens: norms, +-1 probe
+    projections of every parameter, stored tensors) for GemNet-T / GemNet-Q, 1, 2 and 4 blocks;
+  * the composite closure (GEMNET_TRAIN2=0) still does — it remains the fallback for the f32 chain kernel;
+  * the path really runs the chain programs (launch counts), and `kernels.fuse_program` leaves the adjoint programs with
+    source terms unchanged in value."""
+from collections import Counter
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_kernels
+from conftest import check_grad_probes
+from oracle import gemnet_oracle as GO
+from gemnet_pytorch_amd import kernels as K
+from gemnet_pytorch_amd import ops
+from test_model_cpu import build
+from test_oracle_model import load_case
+
+
+def _run(g, tag, train2, count=None):
+    cfg, params, inputs = load_case(g, tag)
+    old = ops.USE_TRAIN2
+    ops.USE_TRAIN2 = train2
+    try:
+        with cpu_kernels.emulate():
+            saved = {}
+            if count is not None:
+                for n in cpu_kernels._NAMES:
+                    f = getattr(K, n)
+                    saved[n] = f
+                    setattr(K, n, (lambda *a, _f=f, _n=n, **k: (count.update([_n]), _f(*a, **k))[1]))
+            try:
+                model = build(cfg, params).train()
+                inputs["R"] = inputs["R"].double()
+                E, F = model(inputs)
+                loss = GO.training_loss(E[:, :1], F[:, 0] if F.dim() == 3 else F,
+                                        torch.tensor(g[f"{tag}.Et"]).double()[:, None], torch.tensor(g[f"{tag}.Ft"]).double())
+                loss.backward()
+            finally:
+                for n, f in saved.items():
+                    setattr(K, n, f)
+    finally:
+        ops.USE_TRAIN2 = old
+    return model, loss
+
+
+@pytest.mark.parametrize("train2", [True, False], ids=["train2", "composite"])
+@pytest.mark.parametrize("tag", ["t1", "q1", "t2", "t2s", "q2s"])
+def test_training_gradients_against_reference(golden_model, golden_model2, tag, train2):
+    g = golden_model2 if f"{tag}.E" in golden_model2 else golden_model
+    cnt = Counter()
+    model, loss = _run(g, tag, train2, cnt)
+    np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=1e-9)
+    named = dict(model.named_parameters())
+    names = [str(n) for n in g[f"{tag}.grad_names"]]
+    norms = np.array([0.0 if named[n].grad is None else float(named[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(norms, g[f"{tag}.grad_norms"], rtol=1e-7, atol=1e-12)
+    check_grad_probes(g, tag, {n: named[n].grad for n in names}, rtol=1e-7)
+    for n in names:
+        key = f"{tag}.grad.{n}"
+        if key in g:
+            np.testing.assert_allclose(named[n].grad.numpy(), g[key], rtol=1e-6, atol=1e-10)
+    # the stacks run as chain programs in the training form, and only there
+    assert (cnt["chain"] > 0) == train2, cnt
+    if train2:
+        assert cnt["pm"] < 0.5 * (cnt["pm"] + cnt["chain"] * 6), cnt
+
+
+def test_published_gemnet_t_second_order_gradients(golden_model2):
+    """t4s = the published 4-block GemNet-T configuration on a 32-atom molecule, fused training form."""
+    g = golden_model2
+    model, loss = _run(g, "t4s", True)
+    np.testing.assert_allclose(loss.item(), float(g["t4s.loss"]), rtol=1e-9)
+    named = dict(model.named_parameters())
+    names = [str(n) for n in g["t4s.grad_names"]]
+    check_grad_probes(g, "t4s", {n: named[n].grad for n in names}, rtol=1e-6)
+
+
+def test_fused_adjoint_programs_with_sources_equal_unfused():
+    """kernels.fuse_program folds SCALE ops — now also those that carry a second-order source term — into their
+    producers; the fused program computes the same values (float64 interpreter)."""
+    gen = torch.Generator().manual_seed(4)
+    M, w = 37, 128
+
+    def mk(*shape):
+        return torch.randn(*shape, generator=gen, dtype=torch.float64)
+    g, W1, W2 = mk(M, w), mk(w, w) / 11, mk(w, w) / 11
+    z = [mk(M, w) for _ in range(3)]
+    mu = [mk(M, w) for _ in range(3)]
+    zd = [mk(M, w) for _ in range(3)]
+    S = K.ChainProgram.source
+
+    def program():
+        outs = [torch.zeros(M, w, dtype=torch.float64) for _ in range(5)]
+        p = K.ChainProgram(M)
+        p.load(0, g)
+        p.scale(0, 0, 0.7, width=w)
+        p.scale(1, 0, 1.0, Z=z[2], add=S(mu[2], zd[2], d2=True), out=outs[0], width=w)
+        p.gemm(W2, a_slot=1, y_slot=1)
+        p.scale(1, 1, 1.0, Z=z[1], add=S(mu[1], zd[1], d2=True), out=outs[1], width=w)
+        p.gemm(W1, a_slot=1, y_slot=0, res=0, beta=1.0)
+        p.scale(0, 0, 0.5, out=outs[2], width=w)
+        p.scale(1, 0, 1.0, Z=z[0], add=S(mu[0], zd[0], d2=True), out=outs[3], width=w)
+        p.gemm(W2, a_slot=1, y_slot=-1, out=outs[4])
+        return p, outs
+    p0, o0 = program()
+    cpu_kernels.chain(p0)
+    p1, o1 = program()
+    fused = K.fuse_program(p1)
+    assert len(fused.ops) < len(p1.ops)
+    assert any(o.get("add") is not None or o.get("add2") is not None for o in fused.ops if o["kind"] != "scale")
+    cpu_kernels.chain(fused)
+    for a, b in zip(o0, o1):
+        torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
