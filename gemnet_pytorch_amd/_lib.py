@@ -94,6 +94,7 @@ SIGNATURES = {
     "gn_bil_expand_ang_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_dy_multi_ang_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
+    "gn_gather_mul_f32": [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_bil_fused_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _i, _vp],
     "gn_segsum_multi_f32": [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
@@ -102,6 +103,7 @@ SIGNATURES = {
     "gn_bil_reduce_t_grouped_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_dot_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_reduce_project_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "gn_bil_reduce_project2_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_fused_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _vp],
     "gn_bil_project_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_project_bwd_acc_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],

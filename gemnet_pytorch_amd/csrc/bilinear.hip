@@ -444,10 +444,15 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma49_kernel(
 //       lane (l15, lg) reads Y[t + lg][l15] and x[g(t + lg)][16 nt + l15] straight into fragment layout;
 //   K2  P[i,c] = sum_s B[s,i] Sm[s,c]      consumed from the K1 accumulators in place: in K-step r lane group lg
 //       supplies s = 4 lg + r for BOTH operands (its own D row r), so Sm never passes through LDS.
+// EXT (the tangent sweep of the training step, gn_bil_reduce_project2_f32): the K1 accumulators start from Sm_init[e]
+// (dSm = K1(dY, x) + K1(Y, dx) over two calls), K2 takes a second term from given blocks (P = B^T Sm + B2^T Sm2, i.e.
+// dP = B^T dSm + dB^T Sm) and is skipped altogether when P is null.
+template <bool EXT>
 __global__ __launch_bounds__(256) void bil_reduce_project_mfma7_kernel(
     const float* __restrict__ Y, const float* __restrict__ x, const int32_t* __restrict__ expand_idx,
     const int32_t* __restrict__ seg_off, const float* __restrict__ B, float* __restrict__ Sm,
-    float* __restrict__ P, int64_t E) {
+    float* __restrict__ P, int64_t E, const float* __restrict__ Sm_init, const float* __restrict__ B2,
+    const float* __restrict__ Sm2) {
   constexpr int S = 7, C = 64, I = 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -467,6 +472,16 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma7_kernel(
   v4f_b acc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc[nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
+  if (EXT && Sm_init) {   // D layout: row 4 lg + r (s), col 16 nt + l15 (c); rows s >= 7 stay zero
+    const float* __restrict__ si = Sm_init + e * (int64_t)S * C;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = si[min(4 * lg + r, S - 1) * C + 16 * nt + l15];
+        acc[nt][r] = (4 * lg + r) < S ? v : 0.f;
+      }
+  }
   const int tlast = max(t1 - 1, t0), scl = min(l15, S - 1);
   auto load = [&](int t, float& a, float (&b)[4]) {
     const int tq = t + lg;
@@ -498,6 +513,7 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma7_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (4 * lg + r < S) so[(4 * lg + r) * C + 16 * nt + l15] = acc[nt][r];
+  if (EXT && !P) return;
   v4f_b pacc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) pacc[nt] = (v4f_b){0.f, 0.f, 0.f, 0.f};
@@ -505,6 +521,22 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma7_kernel(
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bk[r], acc[nt][r], pacc[nt], 0, 0, 0);
+  if (EXT && B2) {   // + B2[e]^T Sm2[e]: the same K-steps with both operands read from memory in fragment layout
+    const float* __restrict__ b2 = B2 + e * (int64_t)S * I;
+    const float* __restrict__ s2 = Sm2 + e * (int64_t)S * C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int srw = min(4 * lg + r, S - 1);
+      const bool ok = (4 * lg + r) < S;
+      const float bv = b2[srw * I + l15];
+      const float bq = ok ? bv : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float sv = s2[srw * C + 16 * nt + l15];
+        pacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq, ok ? sv : 0.f, pacc[nt], 0, 0, 0);
+      }
+    }
+  }
   float* __restrict__ po = P + e * (int64_t)I * C;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -706,6 +738,8 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma7_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off,
     float* __restrict__ gB, float* __restrict__ dSm, float* __restrict__ dY, int64_t E, int gb_acc) {
   constexpr int S = 7, C = 64, I = 16, LD = C + 4;
+  const int dsm_acc = gb_acc & 2;     // bit 1 of the flag word: dSm += (the cross term dB mu_P of the second adjoint)
+  gb_acc &= 1;
   __shared__ __attribute__((aligned(16))) float dsl[4][8][LD];   // dSm of this wave's edge (row 7: MFMA padding)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -767,6 +801,7 @@ __global__ __launch_bounds__(256) void bil_project_bwd_mfma7_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int srw = 4 * lg + r;
+      if (dsm_acc && srw < S) d[nt][r] += dso[srw * C + 16 * nt + l15];
       if (srw < S) dso[srw * C + 16 * nt + l15] = d[nt][r];
       if (srw < 8) dsl[wave][srw][16 * nt + l15] = d[nt][r];   // row 7: padding, feeds the unstored column s = 7
     }
@@ -1280,8 +1315,8 @@ extern "C" int gn_bil_reduce_project_f32(const float* Y, const float* x, const i
   if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
   dim3 grid(gn_cdiv(E, epb)), block(256);
   if (S == 7 && C == 64 && I == 16) {
-    hipLaunchKernelGGL(bil_reduce_project_mfma7_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, Y, x, expand_idx, seg_off, B,
-                       Sm, P, E);
+    hipLaunchKernelGGL(bil_reduce_project_mfma7_kernel<false>, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, Y, x, expand_idx, seg_off,
+                       B, Sm, P, E, nullptr, nullptr, nullptr);
   } else if (S == 7) {
     hipLaunchKernelGGL(bil_reduce_project_kernel<7>, grid, block, smem, st, Y, x, expand_idx, seg_off, B, Sm, P, E, C, I);
   } else if (S == 49 && C == 32 && I == 32) {
@@ -1292,6 +1327,17 @@ extern "C" int gn_bil_reduce_project_f32(const float* Y, const float* x, const i
   } else {
     return (int)hipErrorInvalidValue;
   }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_reduce_project2_f32(const float* Y, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
+                                          const float* B, const float* Sm_init, const float* B2, const float* Sm2, float* Sm,
+                                          float* P, int64_t E, int S, int C, int I, void* stream) {
+  if (E <= 0) return 0;
+  if (!(S == 7 && C == 64 && I == 16) || ((B2 == nullptr) != (Sm2 == nullptr))) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bil_reduce_project_mfma7_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     Y, x, expand_idx, seg_off, B, Sm, P, E, Sm_init, B2, Sm2);
   GN_LAUNCH_CHECK();
   return 0;
 }
@@ -1432,6 +1478,9 @@ extern "C" int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, cons
   if (S <= 0 || C <= 0 || (C % 4) != 0 || I <= 0) return (int)hipErrorInvalidValue;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int gb_acc = (accumulate >> 1) & 1;
+  // bit 2: dSm += (spherical-basis kernel only; anything else must fail loudly, never drop the accumulation)
+  if ((accumulate & 4) && !(S == 7 && C == 64 && I == 16 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)))
+    return (int)hipErrorInvalidValue;
   if (S == 49 && C == 32 && I == 32 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)) {
     if (accumulate & 1)
       hipLaunchKernelGGL(bil_project_bwd_mfma49_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, dP, Sm, B, x,
@@ -1444,12 +1493,13 @@ extern "C" int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, cons
   }
   if (S == 7 && C == 64 && I == 16 && aligned16(dP) && aligned16(Sm) && aligned16(B) && aligned16(x)) {
     const dim3 grid(gn_cdiv(E, 4));
+    const int acc7 = gb_acc | (((accumulate >> 2) & 1) << 1);
     if (accumulate & 1)
       hipLaunchKernelGGL(bil_project_bwd_mfma7_kernel<true>, grid, dim3(256), 0, st, dP, Sm, B, x, expand_idx, seg_off, gB,
-                         dSm, dY, E, gb_acc);
+                         dSm, dY, E, acc7);
     else
       hipLaunchKernelGGL(bil_project_bwd_mfma7_kernel<false>, grid, dim3(256), 0, st, dP, Sm, B, x, expand_idx, seg_off, gB,
-                         dSm, dY, E, gb_acc);
+                         dSm, dY, E, acc7);
     GN_LAUNCH_CHECK();
     return 0;
   }

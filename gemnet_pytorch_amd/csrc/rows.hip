@@ -19,6 +19,20 @@ __global__ void gather_rows_v4(const float4* __restrict__ x, const int32_t* __re
   }
 }
 
+// y[t] = scale * x[idx[t]] (.) m[t]  (row gather fused with a Hadamard product: the operand of the weight gradient of
+// the radial-weighted aggregation, q[e] = scale * g[id_a[e]] (.) m[e])
+__global__ void gather_mul_v4(const float4* __restrict__ x, const int32_t* __restrict__ idx, const float4* __restrict__ m,
+                              float4* __restrict__ y, int64_t T, int C4, float scale) {
+  const int64_t n = T * C4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / C4;
+    const int c = (int)(i - t * C4);
+    const float4 a = x[(int64_t)idx[t] * C4 + c], b = m[i];
+    y[i] = make_float4(scale * a.x * b.x, scale * a.y * b.y, scale * a.z * b.z, scale * a.w * b.w);
+  }
+}
+
 __global__ void gather_rows_s(const float* __restrict__ x, const int32_t* __restrict__ idx,
                               float* __restrict__ y, int64_t T, int C) {
   const int64_t n = T * C;
@@ -170,6 +184,17 @@ extern "C" int gn_gather_rows_f32(const float* x, const int32_t* idx, float* y, 
   } else {
     hipLaunchKernelGGL(gather_rows_s, dim3(grid_for(T * C)), dim3(256), 0, st, x, idx, y, T, C);
   }
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_gather_mul_f32(const float* x, const int32_t* idx, const float* m, float* y, int64_t T, int C, float scale,
+                                 void* stream) {
+  if (T <= 0 || C <= 0) return 0;
+  if (C % 4 != 0 || !aligned16(x) || !aligned16(m) || !aligned16(y)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_mul_v4, dim3(grid_for(T * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(x), idx, reinterpret_cast<const float4*>(m),
+                     reinterpret_cast<float4*>(y), T, C / 4, scale);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -143,6 +143,17 @@ def gather(x, idx32):
     return y
 
 
+def gather_mul(x, idx32, m, scale=1.0):
+    """scale * x[idx] (.) m in one launch (gn_gather_mul_f32)."""
+    require_device(x, idx32, m)
+    x, m = _f32c(x), _f32c(m)
+    assert m.shape[0] == idx32.shape[0] and _rowsize(m) == _rowsize(x)
+    y = torch.empty_like(m)
+    check(_lib.load().gn_gather_mul_f32(ptr(x), ptr(idx32), ptr(m), ptr(y), idx32.shape[0], _rowsize(x), float(scale), stream()),
+          "gn_gather_mul_f32")
+    return y
+
+
 def segsum(y, perm, seg_off, n_rows):
     require_device(y, seg_off)
     y = _f32c(y)
@@ -704,13 +715,31 @@ def chain(prog, mode=None):
         check(_lib.load().gn_chain_f32(ctypes.byref(a), stream()), "gn_chain_f32")
 
 
-def bil_reduce_project(Y, x, B, sp):
-    """Fused K1+K2 -> (Sm (E,S,C), P (E,I,C)); B = rbf_W1 (E,S,I)."""
+def bil_train_supported(S, C, I):
+    """Shapes for which the bilinear layer has its fused twice-differentiable training form (ops_train._Bilinear2): the
+    spherical basis of the triplet interaction (the extended K1 + K2 kernel gn_bil_reduce_project2_f32)."""
+    return (S, C, I) == (7, 64, 16)
+
+
+def bil_reduce_project(Y, x, B, sp, Sm_init=None, B2=None, Sm2=None, want_P=True):
+    """Fused K1+K2 -> (Sm (E,S,C), P (E,I,C)); B = rbf_W1 (E,S,I).
+    Extended form (gn_bil_reduce_project2_f32, spherical-basis shapes only): Sm starts from `Sm_init` instead of zero,
+    P = B^T Sm + B2^T Sm2 (a second K2 term from given blocks), `want_P=False` skips K2 — the tangent sweep of the
+    training step: dSm = K1(dY, x) + K1(Y, dx), dP = B^T dSm + dB^T Sm."""
     require_device(Y, x, B)
     Y, x, B = _f32c(Y), _f32c(x), _f32c(B)
     S, C, I = B.shape[1], x.shape[1], B.shape[2]
     Sm = torch.empty((sp.n_reduce, S, C), device=x.device, dtype=torch.float32)
-    P = torch.empty((sp.n_reduce, I, C), device=x.device, dtype=torch.float32)
+    P = torch.empty((sp.n_reduce, I, C), device=x.device, dtype=torch.float32) if want_P else None
+    if Sm_init is not None or B2 is not None or not want_P:
+        assert bil_train_supported(S, C, I) and not is_angle_form(Y, S) and (B2 is None) == (Sm2 is None)
+        ts = [None if t is None else _f32c(t) for t in (Sm_init, B2, Sm2)]
+        assert ts[0] is None or ts[0].shape == Sm.shape
+        assert ts[1] is None or (ts[1].shape == B.shape and ts[2].shape == Sm.shape)
+        check(_lib.load().gn_bil_reduce_project2_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
+                                                     ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(Sm), ptr(P), sp.n_reduce,
+                                                     S, C, I, stream()), "gn_bil_reduce_project2_f32")
+        return Sm, P
     if is_angle_form(Y, S):   # Y_lm rebuilt in-kernel from (sin, cos) of the two angles
         check(_lib.load().gn_bil_reduce_project_ang_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
                                                         ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
@@ -799,9 +828,10 @@ def bil_dy_multi(dSm_list, x_list, sp, ang=None):
     return dY
 
 
-def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True, gB_accum=None):
+def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True, gB_accum=None, dSm_accum=None):
     """Fused adjoint of K2 and of K1 w.r.t. Y -> (gB (E,S,I), dSm (E,S,C), dY (T,S)); with `dY_accum` the Y
-    gradient is ADDED into that (T,S) buffer (and returned) instead of written to a fresh one; `gB_accum` likewise."""
+    gradient is ADDED into that (T,S) buffer (and returned) instead of written to a fresh one; `gB_accum` / `dSm_accum`
+    likewise (the cross terms of the training step's second adjoint land on the first-order ones)."""
     require_device(dP, Sm, B, x)
     dP, Sm, B, x = _f32c(dP), _f32c(Sm), _f32c(B), _f32c(x)
     E, S, C = Sm.shape
@@ -809,16 +839,20 @@ def bil_project_bwd(dP, Sm, B, x, sp, dY_accum=None, want_dY=True, gB_accum=None
     if gB_accum is not None:
         assert gB_accum.shape == (E, S, I) and gB_accum.is_contiguous() and gB_accum.dtype == torch.float32
     gB = gB_accum if gB_accum is not None else torch.empty((E, S, I), device=x.device, dtype=torch.float32)
-    dSm = torch.empty((E, S, C), device=x.device, dtype=torch.float32)
+    if dSm_accum is not None:
+        assert dSm_accum.shape == (E, S, C) and dSm_accum.is_contiguous() and dSm_accum.dtype == torch.float32
+        assert (S, C, I) == (7, 64, 16), "dSm accumulation exists for the spherical-basis kernel only"
+    dSm = dSm_accum if dSm_accum is not None else torch.empty((E, S, C), device=x.device, dtype=torch.float32)
     if dY_accum is not None:
         assert dY_accum.shape == (sp.size, S) and dY_accum.is_contiguous() and dY_accum.dtype == torch.float32
     if not want_dY:
         dY = None
     else:
         dY = dY_accum if dY_accum is not None else torch.empty((sp.size, S), device=x.device, dtype=torch.float32)
+    flags = int(dY_accum is not None) | (2 if gB_accum is not None else 0) | (4 if dSm_accum is not None else 0)
     check(_lib.load().gn_bil_project_bwd_acc_f32(ptr(dP), ptr(Sm), ptr(B), ptr(x), ptr(sp.expand.idx32),
                                                  ptr(sp.seg_off), ptr(gB), ptr(dSm), ptr(dY), E, S, C, I,
-                                                 int(dY_accum is not None) | (2 if gB_accum is not None else 0), stream()),
+                                                 flags, stream()),
           "gn_bil_project_bwd_acc_f32")
     return gB, dSm, dY
 

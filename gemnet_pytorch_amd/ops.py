@@ -615,6 +615,9 @@ class _RbfAggregate(torch.autograd.Function):
 
 def rbf_aggregate(m, rbf, W, ri, scale):
     """Fused path of `AtomUpdateBlock._aggregate` for constant weights; None when the shapes are not the fused ones."""
+    if _TRAIN2 and USE_AGGREGATE and K.rbf_aggregate_supported(m, rbf, W):
+        from . import ops_train
+        return ops_train.rbf_aggregate(m, rbf, W, ri, scale)
     if not (USE_AGGREGATE and constant_weights() and K.rbf_aggregate_supported(m, rbf, W)):
         return None
     return _RbfAggregate.apply(m, rbf, contiguous_weight(W), ri, float(scale))
@@ -829,6 +832,9 @@ def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
     if _FUSED:
         return _FusedBilinear.apply(rbf_W1, sph, x, W, sp, float(alpha))
     C, I, O = W.shape
+    if _TRAIN2 and USE_TRAIN2_BILINEAR and K.bil_train_supported(sph.shape[1], C, I):
+        from . import ops_train
+        return ops_train.bilinear(rbf_W1, sph, x, W, sp, alpha)
     Sm = bil_reduce(sph, x, sp)
     P = bmm(rbf_W1, Sm, True, False)
     W2 = W.permute(1, 0, 2).reshape(I * C, O)
@@ -923,6 +929,7 @@ def stacks_enabled():
 # on the composite ops above.  Set by GemNet.forward while it builds the force with create_graph=True.
 _TRAIN2 = False
 USE_TRAIN2 = os.environ.get("GEMNET_TRAIN2", "1") == "1"
+USE_TRAIN2_BILINEAR = os.environ.get("GEMNET_TRAIN2_BILINEAR", "1") == "1"
 _STEP_PACKED = None     # per-forward cache of split-bf16 weight planes (the weights change every step)
 
 

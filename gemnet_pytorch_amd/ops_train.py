@@ -549,3 +549,221 @@ class _Head2B(torch.autograd.Function):
 def dense_hadamard_down(x, rbf, Wa, Wr, Wd, act_a, act_d, alpha):
     y, _ = _Head2.apply((bool(act_a), bool(act_d), float(alpha)), x, rbf, Wa, Wr, Wd)
     return y
+
+
+# ================================================================================ radial-weighted edge -> atom aggregation
+class _Aggregate2(torch.autograd.Function):
+    """out[a] = scale * sum_{e -> a} m[e] (.) (W rbf[e]) (atom_update_block.py:60-68) with a trainable W, twice
+    differentiable.  The map is trilinear in (m, rbf, W), so every second-order term is the first-order kernel
+    (csrc/aggregate.hip) called with one operand replaced by its tangent:
+        S3   d g    = fwd(dm, rbf) + fwd(m, drbf)              sources (mbar_src, rbfbar_src) = bwd(g; dm, drbf)
+        S4   (mbar, rbfbar) = bwd(obar; m, rbf) accumulated into the sources
+        dW  += q(obar, m)^T rbf + q(g, dm)^T rbf + q(g, m)^T drbf,      q(u, v)[e] = scale * u[id_a[e]] (.) v[e]."""
+
+    @staticmethod
+    def forward(ctx, m, rbf, W, ri, scale):
+        perm, seg = ri.csr
+        m, rbf = m.contiguous(), rbf.contiguous()
+        Wc = W.detach().contiguous()
+        out = K.rbf_aggregate_fwd(m, rbf, Wc, perm, seg, ri.n_rows, scale)
+        rec = _Rec()
+        rec.s1 = dict(m=m, rbf=rbf)
+        tok = m.new_empty(0)
+        ctx.rec, ctx.ri, ctx.scale = rec, ri, scale
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(tok, W)
+        return out, tok
+
+    @staticmethod
+    def backward(ctx, g, g_tok):
+        tok, W = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (m, rbf, W, ri, scale)
+        if g is None:
+            return (None,) * 5
+        rec, ri, scale = ctx.rec, ctx.ri, ctx.scale
+        if torch.is_grad_enabled():
+            g_m, g_rbf = _Aggregate2B.apply(rec, ri, scale, (need[0], need[1]), g, tok, W)
+            return g_m, g_rbf, None, None, None
+        s3 = rec.s3
+        rec.s3 = None
+        s1 = rec.s1
+        g = g.contiguous()
+        Wc = W.detach().contiguous()
+        sm = s3["sm"] if s3 is not None else None
+        srbf = s3["srbf"] if s3 is not None else None
+        g_m, g_rbf = K.rbf_aggregate_bwd(g, s1["m"], s1["rbf"], Wc, ri.idx32, scale,
+                                         want_m=need[0] or sm is not None, want_rbf=need[1] or srbf is not None,
+                                         acc_m=sm, acc_rbf=srbf)
+        gW = None
+        if need[2] and ops._PARAM_GRADS:
+            gW = _wgrad(W, K.gather_mul(g, ri.idx32, s1["m"], scale), s1["rbf"])
+        return (g_m if need[0] else None), (g_rbf if need[1] else None), gW, None, None
+
+
+class _Aggregate2B(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rec, ri, scale, want, g, tok, W):
+        g = g.contiguous()
+        s1 = rec.s1
+        g_m, g_rbf = K.rbf_aggregate_bwd(g, s1["m"], s1["rbf"], W.detach().contiguous(), ri.idx32, scale,
+                                         want_m=want[0], want_rbf=want[1])
+        rec.s2, rec.s3 = dict(g=g), None
+        ctx.rec, ctx.ri, ctx.scale = rec, ri, scale
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(W)
+        return g_m, g_rbf
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, t_m, t_rbf):
+        (W,) = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (rec, ri, scale, want, g, tok, W)
+        if t_m is None and t_rbf is None:
+            return (None,) * 7
+        rec, ri, scale = ctx.rec, ctx.ri, ctx.scale
+        s1, g = rec.s1, rec.s2["g"]
+        perm, seg = ri.csr
+        Wc = W.detach().contiguous()
+        t_m = None if t_m is None else t_m.contiguous()
+        t_rbf = None if t_rbf is None else t_rbf.contiguous()
+        gd = None
+        if need[4]:
+            if t_m is not None:
+                gd = K.rbf_aggregate_fwd(t_m, s1["rbf"], Wc, perm, seg, ri.n_rows, scale)
+            if t_rbf is not None:
+                gd = _add(gd, K.rbf_aggregate_fwd(s1["m"], t_rbf, Wc, perm, seg, ri.n_rows, scale))
+        # the cross terms of the second adjoint: mbar += scale g[a] (.) (W drbf), rbfbar += scale W^T (g[a] (.) dm)
+        zm = t_m if t_m is not None else s1["m"]           # (unused operand when its output is not wanted)
+        zr = t_rbf if t_rbf is not None else s1["rbf"]
+        sm, srbf = K.rbf_aggregate_bwd(g, zm, zr, Wc, ri.idx32, scale, want_m=t_rbf is not None, want_rbf=t_m is not None)
+        rec.s3 = dict(sm=sm, srbf=srbf)
+        gW = None
+        if need[6] and ops._PARAM_GRADS:
+            if t_m is not None:
+                gW = _wgrad(W, K.gather_mul(g, ri.idx32, t_m, scale), s1["rbf"])
+            if t_rbf is not None:
+                gW = _add(gW, _wgrad(W, K.gather_mul(g, ri.idx32, s1["m"], scale), t_rbf))
+        return None, None, None, None, gd, None, gW
+
+
+def rbf_aggregate(m, rbf, W, ri, scale):
+    out, _ = _Aggregate2.apply(m, rbf, W, ri, float(scale))
+    return out
+
+
+# ============================================================================================ efficient bilinear layer
+class _Bilinear2(torch.autograd.Function):
+    """out[e] = alpha * vec(P[e]) W2,  P[e] = B[e]^T Sm[e],  Sm[e] = sum_{t in seg(e)} Y[t] (x) x[g(t)]   (efficient.py:159-189,
+    SURVEY.md Appendix D: K1, K2, K3) with a trainable W, twice differentiable, on the fused matrix-core kernels of the
+    force path (csrc/bilinear.hip).  The map is multilinear in (B, Y, x, W): with tangents (dB, dY, dx) and the first
+    adjoints mu_P = alpha g W2^T, mu_Sm = B mu_P of S2,
+        S3   dSm = K1(dY, x) + K1(Y, dx);   dP = dB^T Sm + B^T dSm;   d out = alpha dP W2
+        S4   Pbar = alpha obar W2^T;  Bbar = Sm Pbar^T + dSm mu_P^T;  Smbar = B Pbar + dB mu_P;
+             xbar = K1^T(Y, Smbar) + K1^T(dY, mu_Sm);   Ybar = dot(Smbar, x) + dot(mu_Sm, dx)
+        dW2  = alpha (P^T obar + dP^T g)
+    — the cross terms are the SAME kernels called with one operand replaced by its tangent."""
+
+    @staticmethod
+    def forward(ctx, B, Y, x, W, sp, alpha):
+        C, I, O = W.shape
+        B, Y, x = B.contiguous(), Y.contiguous(), x.contiguous()
+        W2 = W.detach().permute(1, 0, 2).reshape(I * C, O).contiguous()       # rows (i, c): one copy per step
+        Sm, P = K.bil_reduce_project(Y, x, B, sp)
+        out = K.gemm(P.reshape(-1, I * C), W2, False, True, alpha=alpha)
+        rec = _Rec()
+        rec.s1 = dict(B=B, Y=Y, x=x, W2=W2, Sm=Sm, P=P)
+        tok = x.new_empty(0)
+        ctx.rec, ctx.sp, ctx.alpha, ctx.dims = rec, sp, alpha, (C, I, O)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(tok, W)
+        return out, tok
+
+    @staticmethod
+    def backward(ctx, g, g_tok):
+        tok, W = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (B, Y, x, W, sp, alpha)
+        if g is None:
+            return (None,) * 6
+        rec, sp, alpha = ctx.rec, ctx.sp, ctx.alpha
+        C, I, O = ctx.dims
+        if torch.is_grad_enabled():
+            gB, gY, gx = _Bilinear2B.apply(rec, sp, alpha, ctx.dims, tuple(need[:3]), g, tok, W)
+            return gB, gY, gx, None, None, None
+        s1, s2, s3 = rec.s1, rec.s2, rec.s3
+        rec.s3 = None
+        g = g.contiguous()
+        Pb = K.gemm(g, s1["W2"], alpha=alpha).reshape(-1, I, C)
+        gB, Smb, _ = K.bil_project_bwd(Pb, s1["Sm"], s1["B"], s1["x"], sp, want_dY=False)
+        terms_d, terms_x = [Smb], [s1["x"]]
+        gx2 = None
+        if s3 is not None and s2 is not None:
+            Smd, tB = s3["Smd"], s3["tB"]
+            if Smd is not None or tB is not None:
+                zS = Smd if Smd is not None else torch.zeros_like(s1["Sm"])
+                zB = tB if tB is not None else torch.zeros_like(s1["B"])
+                gB, Smb, _ = K.bil_project_bwd(s2["mu_P"], zS, zB, s1["x"], sp, want_dY=False, gB_accum=gB, dSm_accum=Smb)
+            if s3["tx"] is not None:
+                terms_d.append(s2["mu_Sm"])
+                terms_x.append(s3["tx"])
+            if s3["tY"] is not None and need[2]:
+                gx2 = K.bil_reduce_t(s3["tY"], s2["mu_Sm"], sp)
+        gx = _add(K.bil_reduce_t(s1["Y"], Smb, sp), gx2) if need[2] else None
+        gY = K.bil_dy_multi(terms_d, terms_x, sp) if need[1] else None
+        gW = None
+        if need[3] and ops._PARAM_GRADS:
+            gW2 = K.gemm(s1["P"].reshape(-1, I * C), g, True, True, alpha=alpha)
+            gW = gW2.reshape(I, C, O).permute(1, 0, 2)
+        return (gB if need[0] else None), gY, gx, gW, None, None
+
+
+class _Bilinear2B(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rec, sp, alpha, dims, want, g, tok, W):
+        C, I, O = dims
+        s1 = rec.s1
+        g = g.contiguous()
+        mu_P = K.gemm(g, s1["W2"], alpha=alpha).reshape(-1, I, C)
+        gB, mu_Sm, gY = K.bil_project_bwd(mu_P, s1["Sm"], s1["B"], s1["x"], sp, want_dY=want[1])
+        gx = K.bil_reduce_t(s1["Y"], mu_Sm, sp) if want[2] else None
+        rec.s2, rec.s3 = dict(g=g, mu_P=mu_P, mu_Sm=mu_Sm), None
+        ctx.rec, ctx.sp, ctx.alpha, ctx.dims = rec, sp, alpha, dims
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(W)
+        return (gB if want[0] else None), gY, gx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, tB, tY, tx):
+        (W,) = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (rec, sp, alpha, dims, want, g, tok, W)
+        if tB is None and tY is None and tx is None:
+            return (None,) * 8
+        rec, sp, alpha = ctx.rec, ctx.sp, ctx.alpha
+        C, I, O = ctx.dims
+        s1, s2 = rec.s1, rec.s2
+        tB = None if tB is None else tB.contiguous()
+        tY = None if tY is None else tY.contiguous()
+        tx = None if tx is None else tx.contiguous()
+        # dSm = K1(dY, x) + K1(Y, dx) and dP = B^T dSm + dB^T Sm: the second K1 call starts from the first one's sum and
+        # takes the dB^T Sm term along (gn_bil_reduce_project2_f32)
+        Smd = Pd = None
+        if tY is not None and tx is not None:
+            Smd, _ = K.bil_reduce_project(tY, s1["x"], s1["B"], sp, want_P=False)
+            Smd, Pd = K.bil_reduce_project(s1["Y"], tx, s1["B"], sp, Sm_init=Smd, B2=tB, Sm2=s1["Sm"] if tB is not None else None)
+        elif tY is not None or tx is not None:
+            Ya, xa = (tY, s1["x"]) if tY is not None else (s1["Y"], tx)
+            Smd, Pd = K.bil_reduce_project(Ya, xa, s1["B"], sp, B2=tB, Sm2=s1["Sm"] if tB is not None else None)
+        else:
+            Pd = K.bmm(tB, s1["Sm"], True, False)
+        gd = K.gemm(Pd.reshape(-1, I * C), s1["W2"], False, True, alpha=alpha) if need[5] else None
+        rec.s3 = dict(Smd=Smd, tB=tB, tY=tY, tx=tx)
+        gW = None
+        if need[7] and ops._PARAM_GRADS:
+            gW2 = K.gemm(Pd.reshape(-1, I * C), s2["g"], True, True, alpha=alpha)
+            gW = gW2.reshape(I, C, O).permute(1, 0, 2)
+        return None, None, None, None, None, gd, None, gW
+
+
+def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
+    out, _ = _Bilinear2.apply(rbf_W1, sph, x, W, sp, float(alpha))
+    return out

@@ -260,6 +260,11 @@ int gn_index_gpu_stage2(const int32_t* mol_off, const int32_t* sq_off, int B, in
  *      `x[id4_expand_*]` :543,:548, `x_ac[id_swap]` :693, h[id] embedding_block.py:70-71 and
  *      torch_scatter.scatter(..., reduce="add") atom_update_block.py:67,172, gemnet.py:580) -- */
 int gn_gather_rows_f32(const float* x, const int32_t* idx, float* y, int64_t T, int C, void* stream);
+/* y[t, :] = scale * x[idx[t], :] (.) m[t, :] — a row gather fused with a Hadamard product (C % 4 == 0, 16-byte aligned):
+ * the operand q[e] = scale * g[id_a[e]] (.) m[e] of the weight gradient of dense_rbf in the training step
+ * (atom_update_block.py:60-68 under autograd). */
+int gn_gather_mul_f32(const float* x, const int32_t* idx, const float* m, float* y, int64_t T, int C, float scale,
+                      void* stream);
 /* x[n,:] = sum_{k in [seg_off[n], seg_off[n+1])} y[perm ? perm[k] : k, :]   (deterministic, no atomics) */
 int gn_segsum_rows_f32(const float* y, const int32_t* perm, const int32_t* seg_off, float* x,
                        int64_t N, int C, void* stream);
@@ -304,6 +309,14 @@ int gn_bil_dot_f32(const float* dSm, const float* x, const int32_t* expand_idx,
 int gn_bil_reduce_project_f32(const float* Y, const float* x, const int32_t* expand_idx,
                               const int32_t* seg_off, const float* B, float* Sm, float* P, int64_t E, int S,
                               int C, int I, void* stream);
+/* Extended K1 + K2 for the tangent sweep of the training step (trainer.py:346 through efficient.py:159-189), spherical
+ * basis shapes only ((S, C, I) = (7, 64, 16); anything else: hipErrorInvalidValue):
+ *   Sm[e] = Sm_init[e] + sum_{t in seg(e)} Y[t] (x) x[g(t)]        (Sm_init NULL: from zero)
+ *   P[e]  = B[e]^T Sm[e] + B2[e]^T Sm2[e]                          (B2 / Sm2 NULL together: no second term; P NULL: K2 skipped)
+ * so that dSm = K1(dY, x) + K1(Y, dx) and dP = B^T dSm + dB^T Sm take two launches and no elementwise adds. */
+int gn_bil_reduce_project2_f32(const float* Y, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
+                               const float* B, const float* Sm_init, const float* B2, const float* Sm2, float* Sm, float* P,
+                               int64_t E, int S, int C, int I, void* stream);
 /* K1 + K2 + K3 in one launch (efficient.py:173-188 incl. the final `torch.matmul(..., self.weight)`), for callers that
  * do not need P afterwards (inference / frozen weights):
  *   Sm as above (written: the adjoint needs it);  out[e,o] = alpha * sum_{i,c} P[e,i,c] * W2T[o, i*C + c]
@@ -319,7 +332,8 @@ int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, con
                            int64_t E, int S, int C, int I, void* stream);
 /* Same with `accumulate` bit 0: dY += (the Y gradient summed over the interaction blocks that share one basis tensor
  * — saves a (T,S)-sized add per block: 1.8 GB for the quadruplet basis at B = 32); bit 1: gB += (the radial part of the
- * basis is shared by the blocks in the same way). */
+ * basis is shared by the blocks in the same way); bit 2: dSm += (the cross term dB mu_P of the training step's second
+ * adjoint lands on B Pbar; spherical-basis shapes (7, 64, 16) only, else hipErrorInvalidValue). */
 int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, const float* B, const float* x,
                                const int32_t* expand_idx, const int32_t* seg_off, float* gB, float* dSm, float* dY,
                                int64_t E, int S, int C, int I, int accumulate, void* stream);

@@ -343,11 +343,22 @@ def _ang_to_Y(ang):
     return B.real_sph_harm_full(7, torch.atan2(ang[:, 0], ang[:, 1]), torch.atan2(ang[:, 2], ang[:, 3]))
 
 
-def bil_reduce_project(Y, x, Bm, sp):
+def bil_train_supported(S, C, I):
+    return True          # the emulation has no shape restriction: the training form is exercised for every test model
+
+
+def bil_reduce_project(Y, x, Bm, sp, Sm_init=None, B2=None, Sm2=None, want_P=True):
     if is_angle_form(Y, Bm.shape[1]):
         Y = _ang_to_Y(Y)
     Sm = bil_reduce(Y, x, sp)
-    return Sm, torch.bmm(Bm.transpose(1, 2), Sm)
+    if Sm_init is not None:
+        Sm = Sm + Sm_init
+    if not want_P:
+        return Sm, None
+    P = torch.bmm(Bm.transpose(1, 2), Sm)
+    if B2 is not None:
+        P = P + torch.bmm(B2.transpose(1, 2), Sm2)
+    return Sm, P
 
 
 def bil_dy_multi(dSm_list, x_list, sp, ang=None):
@@ -383,11 +394,13 @@ def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
     return Gc, Gbd
 
 
-def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True, gB_accum=None):
+def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True, gB_accum=None, dSm_accum=None):
     gB = torch.bmm(Sm, dP.transpose(1, 2))
     if gB_accum is not None:
         gB = gB_accum.add_(gB)
     dSm = torch.bmm(Bm, dP)
+    if dSm_accum is not None:
+        dSm = dSm_accum.add_(dSm)
     if not want_dY:
         return gB, dSm, None
     dY = bil_dot(dSm, x, sp)
@@ -451,6 +464,10 @@ def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
     return Sm, (P.reshape(P.shape[0], -1) @ W2T.t()) * alpha
 
 
+def gather_mul(x, idx32, m, scale=1.0):
+    return x[idx32.long()] * m * scale
+
+
 def rbf_aggregate_fwd(m, rbf, W, perm, seg_off, n_atoms, scale):
     return segsum(m * (rbf @ W.t()), perm, seg_off, n_atoms) * scale
 
@@ -466,7 +483,7 @@ def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=Tru
     return g_m, g_rbf
 
 
-_NAMES = ["bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["bil_train_supported", "gather_mul", "bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

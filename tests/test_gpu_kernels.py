@@ -853,3 +853,48 @@ def test_quad_angles_geometry_fwd_bwd():
         assert float((err / scale).median()) <= 1e-5 and float((err / scale).max()) <= 5e-3
     Gc, Gbd = K.quad_angles_bwd(f32(g_ang), f32(R), *dev_idx, packed=True)
     assert torch.equal(Gc, got[0]) and torch.equal(Gbd[:, 0:3], got[1]) and torch.equal(Gbd[:, 4:7], got[2])
+
+
+def test_bilinear_training_kernels_extended_forms():
+    """The two kernel extensions of the fused training step's bilinear layer (ops_train._Bilinear2):
+    gn_bil_reduce_project2_f32 (Sm starts from Sm_init, P takes a second K2 term B2^T Sm2, P optional) and the dSm
+    accumulation flag of gn_bil_project_bwd_acc_f32, against the float64 restatement on a ragged CSR plan."""
+    g = torch.Generator().manual_seed(77)
+    E, J, S, C, I = 301, 120, 7, 64, 16
+    counts = torch.randint(0, 40, (E,), generator=g)
+    counts[5] = 0
+    reduce_idx = torch.repeat_interleave(torch.arange(E), counts)
+    T = int(reduce_idx.shape[0])
+    expand_idx = torch.randint(0, J, (T,), generator=g)
+    sp_c = SegmentPlan(reduce_idx, expand_idx, E, J)
+    sp_d = SegmentPlan(reduce_idx.to(DEV), expand_idx.to(DEV), E, J)
+    Y, Y2, x, x2 = rnd(g, T, S), rnd(g, T, S), rnd(g, J, C), rnd(g, J, C)
+    B, B2, Sm2 = rnd(g, E, S, I), rnd(g, E, S, I), rnd(g, E, S, C)
+    # (a) two-call tangent form: Sm = K1(Y2, x) + K1(Y, x2), P = B^T Sm + B2^T Sm2
+    ref_a, _ = CK.bil_reduce_project(Y2, x, B, sp_c, want_P=False)
+    ref_Sm, ref_P = CK.bil_reduce_project(Y, x2, B, sp_c, Sm_init=ref_a, B2=B2, Sm2=Sm2)
+    Sm_a, none = K.bil_reduce_project(f32(Y2), f32(x), f32(B), sp_d, want_P=False)
+    assert none is None
+    close(Sm_a, ref_a, atol=2e-4 * float(ref_a.abs().max()))
+    Sm, P = K.bil_reduce_project(f32(Y), f32(x2), f32(B), sp_d, Sm_init=Sm_a, B2=f32(B2), Sm2=f32(Sm2))
+    close(Sm, ref_Sm, atol=2e-4 * float(ref_Sm.abs().max()))
+    close(P, ref_P, atol=2e-4 * float(ref_P.abs().max()))
+    # the plain form is unchanged by the template split
+    Sm0, P0 = K.bil_reduce_project(f32(Y), f32(x), f32(B), sp_d)
+    r0 = CK.bil_reduce_project(Y, x, B, sp_c)
+    close(Sm0, r0[0], atol=2e-4 * float(r0[0].abs().max())); close(P0, r0[1], atol=2e-4 * float(r0[1].abs().max()))
+    # (b) gB and dSm accumulated in place
+    dP = rnd(g, E, I, C)
+    base_gB, base_dSm = rnd(g, E, S, I), rnd(g, E, S, C)
+    rg, rd, _ = CK.bil_project_bwd(dP, ref_Sm, B, x, sp_c, want_dY=False, gB_accum=base_gB.clone(), dSm_accum=base_dSm.clone())
+    run_gB, run_dSm = f32(base_gB), f32(base_dSm)
+    gB, dSm, _ = K.bil_project_bwd(f32(dP), f32(ref_Sm), f32(B), f32(x), sp_d, want_dY=False, gB_accum=run_gB, dSm_accum=run_dSm)
+    assert gB is run_gB and dSm is run_dSm
+    close(gB, rg, atol=2e-4 * float(rg.abs().max())); close(dSm, rd, atol=2e-4 * float(rd.abs().max()))
+
+
+def test_gather_mul():
+    g = torch.Generator().manual_seed(8)
+    x, m = rnd(g, 50, 128), rnd(g, 700, 128)
+    idx = torch.randint(0, 50, (700,), generator=g, dtype=torch.int32)
+    close(K.gather_mul(f32(x), idx.to(DEV), f32(m), 0.37), x[idx.long()] * m * 0.37, rtol=1e-6, atol=1e-6)
