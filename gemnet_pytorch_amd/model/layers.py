@@ -399,6 +399,7 @@ class TensorBasisLayer(_RadialTables):
 def _up_pair_train(inter, x, plan):
     """(up_ca(x) + up_ac(x)[id_swap]) / sqrt2 (interaction_block.py:696-705) in the training form: each up projection one
     twice-differentiable launch (ops.dense -> ops_train.stack), the swap a row gather, the sum in the second epilogue."""
+    x = ops.accumulate_gradient(x)          # two fused consumers: one running gradient
     y_sw = ops.gather_rows(inter.up_projection_ac(x), plan.id_swap)
     return inter.up_projection_ca(x, res=y_sw, beta=INV_SQRT_2)
 

@@ -704,7 +704,7 @@ def accumulate_gradient(t, stream=None):
     returns the sum, so the autograd engine never launches its own elementwise adds (32 per forward+force step of the
     4-block model, 4-6 us each: tools/exp/grad_fanin.py, tools/exp/aten_ops.py).  Consumers on another HIP stream than
     the first one (the output blocks) do not take part: their gradient reaches `t` through autograd as before."""
-    if _FUSED and USE_GRAD_ACC and t.requires_grad:
+    if (_FUSED or _TRAIN2) and USE_GRAD_ACC and t.requires_grad:
         # a NEW running sum per call: a long-lived tensor (a leaf fed to a block again and again) must not count the
         # consumers of an earlier forward; the ops of that forward keep their reference to the sink they joined
         t._gn_acc = GradSink()

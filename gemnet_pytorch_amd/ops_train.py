@@ -51,6 +51,23 @@ def _wgrad(W, zb, a):
     return K.gemm(zb, a, True, True)
 
 
+def _wgrad_bilinear(W, Pm, g, alpha):
+    """Gradient of the bilinear weight W (C, I, O) from  dW2 = alpha * P2d^T g  with P (E, I, C), g (E, O):
+    dW[c, i, o] = alpha sum_e P[e, i, c] g[e, o].  Queued as I products (P[:, i, :]^T g -> the (C, O) block of i, rows
+    with pitch I * O) into the grouped launch when W is a leaf with a contiguous .grad; a tensor otherwise."""
+    C, I, O = W.shape
+    q = ops._WGRAD_QUEUE
+    if (q is not None and not torch.is_grad_enabled() and W.is_leaf and W.is_cuda and W.grad is not None
+            and W.grad.is_contiguous()):
+        ga = g if alpha == 1.0 else g * alpha
+        base = W.grad.data_ptr()
+        for i in range(I):
+            q.add_region((base + 4 * i * O, C, O, I * O), Pm[:, i, :], ga, keep=W)
+        return None
+    gW2 = K.gemm(Pm.reshape(-1, I * C), g, True, True, alpha=alpha)
+    return gW2.reshape(I, C, O).permute(1, 0, 2)
+
+
 def _add(a, b):
     if a is None:
         return b
@@ -80,6 +97,7 @@ class _Stack2(torch.autograd.Function):
         nL, nT = len(layers), len(spec["tails"])
         skips, Ws = rest[:nL], rest[nL:]
         M = x.shape[0]
+        ctx.acc = ops._acc_join(x)
         x = x.contiguous()
         rec = _Rec()
         z, a_in = {}, {}
@@ -135,25 +153,40 @@ class _Stack2(torch.autograd.Function):
         tok, *Ws = ctx.saved_tensors
         need = ctx.needs_input_grad      # (spec, x, res, res2, g1, g2, *skips, *Ws)
         n_in = 6 + nL + len(Ws)
+        acc = ctx.acc
         if g is None and all(t is None for t in g_tails):
-            return (None,) * n_in
+            return (None, acc.skip() if acc is not None else None) + (None,) * (n_in - 2)
         want = dict(x=need[1], res=need[2], res2=need[3], g1=need[4], g2=need[5], skips=tuple(need[6:6 + nL]))
+        prev, last = (acc.enter() if want["x"] else (acc.skip(), True)) if acc is not None else (None, True)
         if torch.is_grad_enabled():
             # the force graph is being built: S2 as a differentiable node
-            outs = _Stack2B.apply(ctx.rec, ctx.spec, ctx.has, want, (ctx.in_width, ctx.out_shape), g, *g_tails, tok, *Ws)
-            return (None, *outs, *([None] * len(Ws)))
+            outs = _Stack2B.apply(ctx.rec, ctx.spec, ctx.has, want, (ctx.in_width, ctx.out_shape), g, *g_tails, tok,
+                                  prev if want["x"] else None, *Ws)
+            gx = outs[0]
+            if acc is not None and want["x"]:
+                acc.leave(gx, last)
+                gx = gx if last else None
+            elif acc is not None:
+                gx = prev           # nothing of ours: hand the running sum on (acc.skip)
+            return (None, gx, *outs[1:], *([None] * len(Ws)))
         # final pass: S4 (first-order adjoint when no tangent sweep ran through this stack)
         s3 = ctx.rec.s3
         ctx.rec.s3 = None
         out, zbar = _stack_adjoint(ctx.rec, ctx.spec, ctx.has, want, (ctx.in_width, ctx.out_shape), g, g_tails, Ws,
-                                   second=s3, store="zbar")
+                                   second=s3, store="zbar", prev=prev if want["x"] else None, inplace=True)
+        gx = out[0]
+        if acc is not None and want["x"]:
+            acc.leave(gx, last)
+            gx = gx if last else None
+        elif acc is not None:
+            gx = prev
         gWs = [None] * len(Ws)
         if ops._PARAM_GRADS:
             a_in = ctx.rec.s1["a_in"]
             for i, key in enumerate(_gemm_keys(ctx.spec)):
                 if need[6 + nL + i]:
                     gWs[i] = _wgrad(Ws[i], zbar.get(key), a_in.get(key))
-        return (None, *out, *gWs)
+        return (None, gx, *out[1:], *gWs)
 
 
 def _gemm_keys(spec):
@@ -167,10 +200,12 @@ def _gemm_keys(spec):
     return keys
 
 
-def _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second, store):
+def _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second, store, prev=None, inplace=False):
     """The reverse sweep of a stack as one chain program.  S2 (second is None, store = "mu": mu_h per activation and
     mu_z per GEMM are written out for the later sweeps) and S4 (store = "zbar"; `second` = the record of the tangent
-    sweep, whose dz enter as source terms mu_h f''(z) dz).  Returns ((gx, g_res, g_res2, gg1, gg2, *g_skips), stored)."""
+    sweep, whose dz enter as source terms mu_h f''(z) dz).  Returns ((gx, g_res, g_res2, gg1, gg2, *g_skips), stored).
+    `prev`: running gradient of x (ops.accumulate_gradient) that the last GEMM adds in its epilogue — into a new tensor,
+    or (`inplace`, the non-differentiable S4) into `prev` itself."""
     first, layers, s = spec["first"], spec["layers"], spec["s"]
     has_res, has_res2, has_g1, has_g2, has_skips = has
     in_width, (M, width) = shapes
@@ -199,13 +234,20 @@ def _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second, store):
             prog.load(oth, gt)
             _gemm(prog, cache=rec.cache, W=Wof[("t", j)], trans=True, a_slot=oth, y_slot=cur, res=cur, beta=1.0)
     g_skips = [None] * len(layers)
+    park = spec.get("skip_is_x", -1)
+    if not (park >= 0 and in_width == width and has_skips[park] and want["skips"][park] and want["x"]):
+        park = -1
     for k in range(len(layers) - 1, -1, -1):
         L = layers[k]
         c = s
         if has_skips[k]:
-            if want["skips"][k]:
+            if k == park:
+                prog.scale(2, cur, L["skip_beta"], width=width)    # joins dL/dx in the last GEMM (res = slot 2)
+                c = s * L["skip_beta"]
+            elif want["skips"][k]:
                 g_skips[k] = _new(M, width, like)
                 prog.scale(cur, cur, L["skip_beta"], out=g_skips[k], width=width)
+                c = s
             else:
                 c = s * L["skip_beta"]
         mh2 = _new(M, width, like) if store == "mu" else None
@@ -245,8 +287,9 @@ def _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second, store):
         else:
             prog.scale(oth, cur, c, out=dz0, width=width)
         if want["x"]:
-            gx = _new(M, in_width, like)
-            _gemm(prog, cache=rec.cache, W=Wof["0"], trans=True, a_slot=oth, y_slot=-1, out=gx)
+            gx = prev if (inplace and prev is not None) else _new(M, in_width, like)
+            _gemm(prog, cache=rec.cache, W=Wof["0"], trans=True, a_slot=oth, y_slot=-1, out=gx,
+                  res=2 if park >= 0 else None, beta=1.0, res2=prev, beta2=1.0)
         K.chain(K.fuse_program(prog))
         if has_g1 and want["g1"]:
             gg1 = K.segsum(dz0, *first["i1"].csr, first["i1"].n_rows)
@@ -256,6 +299,8 @@ def _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second, store):
         gx = _new(M, width, like)
         prog.store(cur, gx)
         K.chain(K.fuse_program(prog))
+        if prev is not None:
+            gx = prev.add_(gx) if inplace else prev + gx
     if store == "mu":
         stored = dict(mu_h=mu_h, mu_z=stored)
     return (gx, g_res, g_res2, gg1, gg2, *g_skips), stored
@@ -267,8 +312,8 @@ class _Stack2B(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rec, spec, has, want, shapes, g, *rest):
         nT = len(spec["tails"])
-        g_tails, Ws = rest[:nT], rest[nT + 1:]
-        out, st = _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second=None, store="mu")
+        g_tails, prev, Ws = rest[:nT], rest[nT + 1], rest[nT + 2:]
+        out, st = _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second=None, store="mu", prev=prev)
         rec.s2 = st
         rec.s3 = None
         ctx.rec, ctx.spec, ctx.has, ctx.shapes, ctx.nT = rec, spec, has, shapes, nT
@@ -285,11 +330,12 @@ class _Stack2B(torch.autograd.Function):
         first, layers, s = spec["first"], spec["layers"], spec["s"]
         has_res, has_res2, has_g1, has_g2, has_skips = ctx.has
         in_width, (M, width) = ctx.shapes
-        need = ctx.needs_input_grad    # (rec, spec, has, want, shapes, g, *g_tails, tok, *Ws)
+        need = ctx.needs_input_grad    # (rec, spec, has, want, shapes, g, *g_tails, tok, prev, *Ws)
         n_lead = 5
         ts = [t for t in (t_x, t_res, t_res2, t_g1, t_g2, *t_skips) if t is not None]
         if not ts:
-            return (None,) * (n_lead + 1 + nT + 1 + len(Ws))
+            return (None,) * (n_lead + 1 + nT + 2 + len(Ws))
+        t_prev = t_x if need[n_lead + 1 + nT + 1] else None       # the running sum passes the cotangent through
         like = ts[0]
         z = rec.s1["z"]
         keys = _gemm_keys(spec)
@@ -335,6 +381,8 @@ class _Stack2B(torch.autograd.Function):
         for k, L in enumerate(layers):
             zd1, hd1, zd2, yk = (_new(M, width, like) for _ in range(4))
             tsk = t_skips[k] if has_skips[k] else None
+            if has_skips[k] and tsk is None and spec.get("skip_is_x", -1) == k:
+                tsk = t_x        # the skip IS the stack's input (its gradient rode on dL/dx in S2): same tangent
             _gemm(prog, cache=rec.cache, W=Wof[(k, 1)], a_slot=cur, y_slot=oth, pre_out=zd1, mul=z[(k, 1)], mul_mode=2, out=hd1)
             _gemm(prog, cache=rec.cache, W=Wof[(k, 2)], a_slot=oth, y_slot=cur, pre_out=zd2, mul=z[(k, 2)], mul_mode=2, res=cur, beta=s,
                   res2=None if tsk is None else tsk.contiguous(), beta2=L["skip_beta"] if tsk is not None else 1.0, out=yk)
@@ -359,10 +407,10 @@ class _Stack2B(torch.autograd.Function):
         if ops._PARAM_GRADS:
             mu_z = rec.s2["mu_z"]
             for i, key in enumerate(keys):
-                if need[n_lead + 1 + nT + 1 + i]:
+                if need[n_lead + 1 + nT + 2 + i]:
                     gWs[i] = _wgrad(Ws[i], mu_z.get(key), adot.get(key))
         g_y = y_prev if need[n_lead] else None
-        return (None,) * n_lead + (g_y, *t_tails, None, *gWs)
+        return (None,) * n_lead + (g_y, *t_tails, None, t_prev, *gWs)
 
 
 def _scale_last_gemm(prog, c):
@@ -393,6 +441,9 @@ def stack(x, first=None, layers=(), s=0.7071067811865475, tails=()):
         Ws += [L["W1"], L["W2"]]
     Ws += list(tails)
     skips = [L.get("skip") for L in layers]
+    # a skip connection fed by the stack's own input (m -> ... + m): its gradient joins dL/dx inside the adjoint programs
+    # (parked in the register slot) instead of travelling as a second (M, 128) tensor that autograd then adds
+    spec["skip_is_x"] = next((k for k, sk in enumerate(skips) if sk is x), -1) if first is not None else -1
     out = _Stack2.apply(spec, x, res, res2, g1, g2, *skips, *Ws)
     out = out[:-1]              # drop the ordering token
     return out if tails else out[0]
@@ -407,6 +458,7 @@ class _Head2(torch.autograd.Function):
     def forward(ctx, cfg, x, rbf, Wa, Wr, Wd):
         act_a, act_d, alpha = cfg
         M = x.shape[0]
+        ctx.acc_x, ctx.acc_rbf = ops._acc_join(x), ops._acc_join(rbf)
         x, rbf = x.contiguous(), rbf.contiguous()
         rec = _Rec()
         nh, nd = Wa.shape[0], Wd.shape[0]
@@ -432,14 +484,24 @@ class _Head2(torch.autograd.Function):
     def backward(ctx, g, g_tok):
         tok, Wa, Wr, Wd = ctx.saved_tensors
         need = ctx.needs_input_grad      # (cfg, x, rbf, Wa, Wr, Wd)
+        ax, ar = ctx.acc_x, ctx.acc_rbf
         if g is None:
-            return (None,) * 6
+            return (None, ax.skip() if ax is not None else None, ar.skip() if ar is not None else None, None, None, None)
+        px, last_x = ax.enter() if ax is not None else (None, True)
+        pr, last_r = ar.enter() if ar is not None else (None, True)
         if torch.is_grad_enabled():
-            gx, grbf = _Head2B.apply(ctx.rec, ctx.cfg, g, tok, Wa, Wr, Wd)
+            gx, grbf = _Head2B.apply(ctx.rec, ctx.cfg, g, tok, px, pr, Wa, Wr, Wd)
+        else:
+            s3 = ctx.rec.s3
+            ctx.rec.s3 = None
+            (gx, grbf), st = _head_adjoint(ctx.rec, ctx.cfg, g, (Wa, Wr, Wd), second=s3, store="zbar", prev=(px, pr), inplace=True)
+        if ax is not None:
+            ax.leave(gx, last_x)
+        if ar is not None:
+            ar.leave(grbf, last_r)
+        gx, grbf = (gx if last_x else None), (grbf if last_r else None)
+        if torch.is_grad_enabled():
             return None, gx, grbf, None, None, None
-        s3 = ctx.rec.s3
-        ctx.rec.s3 = None
-        (gx, grbf), st = _head_adjoint(ctx.rec, ctx.cfg, g, (Wa, Wr, Wd), second=s3, store="zbar")
         s1 = ctx.rec.s1
         gWa = gWr = gWd = None
         if ops._PARAM_GRADS:
@@ -452,9 +514,11 @@ class _Head2(torch.autograd.Function):
         return None, gx, grbf, gWa, gWr, gWd
 
 
-def _head_adjoint(rec, cfg, g, Ws, second, store):
+def _head_adjoint(rec, cfg, g, Ws, second, store, prev=(None, None), inplace=False):
     """Reverse sweep of the head: S2 (store = "mu") or S4 (store = "zbar", `second` = the tangent record).
-    -> ((gx, grbf), dict of the adjoints at z3, dh, r, xa, z1)."""
+    -> ((gx, grbf), dict of the adjoints at z3, dh, r, xa, z1).  `prev`: running gradients of (x, rbf) added in the
+    epilogues of the two GEMMs that produce ours (into new tensors, or — `inplace` — into the running sums)."""
+    px, pr = prev
     act_a, act_d, alpha = cfg
     Wa, Wr, Wd = Ws
     s1 = rec.s1
@@ -478,8 +542,8 @@ def _head_adjoint(rec, cfg, g, Ws, second, store):
     st["r"] = _new(M, nh, g)
     prog.scale(0, 1, alpha, Z=s1["xa"], mode=1, width=nh, out=st["r"],
                add=S(s2["dh"], sec["xad"], alpha=alpha) if sec is not None else None)          # adjoint of r
-    grbf = _new(M, Wr.shape[1], g)
-    _gemm(prog, Wr, trans=True, cache=rec.cache, a_slot=0, y_slot=-1, out=grbf)
+    grbf = pr if (inplace and pr is not None) else _new(M, Wr.shape[1], g)
+    _gemm(prog, Wr, trans=True, cache=rec.cache, a_slot=0, y_slot=-1, out=grbf, res=pr, beta=1.0)
     st["xa"] = _new(M, nh, g) if (store == "mu" or not act_a) else None
     prog.scale(1, 1, alpha, Z=s1["r"], mode=1, width=nh, out=st["xa"],
                add=S(s2["dh"], sec["rd"], alpha=alpha) if sec is not None else None)           # adjoint of xa
@@ -489,16 +553,16 @@ def _head_adjoint(rec, cfg, g, Ws, second, store):
                    add=S(s2["xa"], sec["zd1"], d2=True) if sec is not None else None)          # adjoint of z1
     else:
         st["z1"] = st["xa"]
-    gx = _new(M, Wa.shape[1], g)
-    _gemm(prog, Wa, trans=True, cache=rec.cache, a_slot=1, y_slot=-1, out=gx)
+    gx = px if (inplace and px is not None) else _new(M, Wa.shape[1], g)
+    _gemm(prog, Wa, trans=True, cache=rec.cache, a_slot=1, y_slot=-1, out=gx, res=px, beta=1.0)
     K.chain(K.fuse_program(prog))
     return (gx, grbf), st
 
 
 class _Head2B(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rec, cfg, g, tok, Wa, Wr, Wd):
-        out, st = _head_adjoint(rec, cfg, g, (Wa, Wr, Wd), second=None, store="mu")
+    def forward(ctx, rec, cfg, g, tok, px, pr, Wa, Wr, Wd):
+        out, st = _head_adjoint(rec, cfg, g, (Wa, Wr, Wd), second=None, store="mu", prev=(px, pr))
         st["g"] = g.contiguous()
         rec.s2, rec.s3 = st, None
         ctx.rec, ctx.cfg = rec, cfg
@@ -511,9 +575,11 @@ class _Head2B(torch.autograd.Function):
     def backward(ctx, t_x, t_rbf):
         rec, (act_a, act_d, alpha) = ctx.rec, ctx.cfg
         Wa, Wr, Wd = ctx.saved_tensors
-        need = ctx.needs_input_grad      # (rec, cfg, g, tok, Wa, Wr, Wd)
+        need = ctx.needs_input_grad      # (rec, cfg, g, tok, px, pr, Wa, Wr, Wd)
         if t_x is None and t_rbf is None:
-            return (None,) * 7
+            return (None,) * 9
+        t_px = t_x if need[4] else None          # the running sums pass their cotangents through
+        t_pr = t_rbf if need[5] else None
         s1, s2 = rec.s1, rec.s2
         like = t_x if t_x is not None else t_rbf
         M = like.shape[0]
@@ -537,13 +603,13 @@ class _Head2B(torch.autograd.Function):
         rec.s3 = dict(zd1=zd1, xad=xad, rd=rd, hd=hd, zd3=zd3)
         gWa = gWr = gWd = None
         if ops._PARAM_GRADS:
-            if need[4]:
-                gWa = _wgrad(Wa, s2["z1"], t_x)
-            if need[5]:
-                gWr = _wgrad(Wr, s2["r"], t_rbf)
             if need[6]:
+                gWa = _wgrad(Wa, s2["z1"], t_x)
+            if need[7]:
+                gWr = _wgrad(Wr, s2["r"], t_rbf)
+            if need[8]:
                 gWd = _wgrad(Wd, s2["z3"], hd)
-        return None, None, (yd if need[2] else None), None, gWa, gWr, gWd
+        return None, None, (yd if need[2] else None), None, t_px, t_pr, gWa, gWr, gWd
 
 
 def dense_hadamard_down(x, rbf, Wa, Wr, Wd, act_a, act_d, alpha):
@@ -556,13 +622,15 @@ class _Aggregate2(torch.autograd.Function):
     """out[a] = scale * sum_{e -> a} m[e] (.) (W rbf[e]) (atom_update_block.py:60-68) with a trainable W, twice
     differentiable.  The map is trilinear in (m, rbf, W), so every second-order term is the first-order kernel
     (csrc/aggregate.hip) called with one operand replaced by its tangent:
-        S3   d g    = fwd(dm, rbf) + fwd(m, drbf)              sources (mbar_src, rbfbar_src) = bwd(g; dm, drbf)
-        S4   (mbar, rbfbar) = bwd(obar; m, rbf) accumulated into the sources
+        S3   d g    = fwd(dm, rbf) + fwd(m, drbf)
+        S4   (mbar, rbfbar) = bwd(obar; m, rbf) + bwd(g; dm, drbf)       (two launches into one pair of buffers — the
+             running gradients of m and rbf when they have several fused consumers, ops.accumulate_gradient)
         dW  += q(obar, m)^T rbf + q(g, dm)^T rbf + q(g, m)^T drbf,      q(u, v)[e] = scale * u[id_a[e]] (.) v[e]."""
 
     @staticmethod
     def forward(ctx, m, rbf, W, ri, scale):
         perm, seg = ri.csr
+        ctx.acc_m, ctx.acc_rbf = ops._acc_join(m), ops._acc_join(rbf)
         m, rbf = m.contiguous(), rbf.contiguous()
         Wc = W.detach().contiguous()
         out = K.rbf_aggregate_fwd(m, rbf, Wc, perm, seg, ri.n_rows, scale)
@@ -578,35 +646,53 @@ class _Aggregate2(torch.autograd.Function):
     def backward(ctx, g, g_tok):
         tok, W = ctx.saved_tensors
         need = ctx.needs_input_grad      # (m, rbf, W, ri, scale)
+        am, ar = ctx.acc_m, ctx.acc_rbf
         if g is None:
-            return (None,) * 5
+            return (am.skip() if am is not None else None, ar.skip() if ar is not None else None, None, None, None)
         rec, ri, scale = ctx.rec, ctx.ri, ctx.scale
-        if torch.is_grad_enabled():
-            g_m, g_rbf = _Aggregate2B.apply(rec, ri, scale, (need[0], need[1]), g, tok, W)
-            return g_m, g_rbf, None, None, None
-        s3 = rec.s3
-        rec.s3 = None
-        s1 = rec.s1
-        g = g.contiguous()
-        Wc = W.detach().contiguous()
-        sm = s3["sm"] if s3 is not None else None
-        srbf = s3["srbf"] if s3 is not None else None
-        g_m, g_rbf = K.rbf_aggregate_bwd(g, s1["m"], s1["rbf"], Wc, ri.idx32, scale,
-                                         want_m=need[0] or sm is not None, want_rbf=need[1] or srbf is not None,
-                                         acc_m=sm, acc_rbf=srbf)
+        pm, last_m = am.enter() if am is not None else (None, True)
+        pr, last_r = ar.enter() if ar is not None else (None, True)
+        want_m, want_r = need[0] or am is not None, need[1] or ar is not None
         gW = None
-        if need[2] and ops._PARAM_GRADS:
-            gW = _wgrad(W, K.gather_mul(g, ri.idx32, s1["m"], scale), s1["rbf"])
-        return (g_m if need[0] else None), (g_rbf if need[1] else None), gW, None, None
+        if torch.is_grad_enabled():
+            g_m, g_rbf = _Aggregate2B.apply(rec, ri, scale, (want_m, want_r), g, tok, W, pm, pr)
+        else:
+            s3 = rec.s3
+            rec.s3 = None
+            s1 = rec.s1
+            g = g.contiguous()
+            Wc = W.detach().contiguous()
+            g_m, g_rbf = K.rbf_aggregate_bwd(g, s1["m"], s1["rbf"], Wc, ri.idx32, scale, want_m=want_m, want_rbf=want_r,
+                                             acc_m=pm, acc_rbf=pr)
+            if s3 is not None and rec.s2 is not None:
+                # the cross terms: mbar += scale g[a] (.) (W drbf), rbfbar += scale W^T (g[a] (.) dm)
+                t_m, t_rbf = s3["t_m"], s3["t_rbf"]
+                zm = t_m if t_m is not None else s1["m"]          # (placeholder operand of an output that is not produced)
+                zr = t_rbf if t_rbf is not None else s1["rbf"]
+                do_m, do_r = want_m and t_rbf is not None, want_r and t_m is not None
+                if do_m or do_r:
+                    g_m2, g_r2 = K.rbf_aggregate_bwd(rec.s2["g"], zm, zr, Wc, ri.idx32, scale, want_m=False, want_rbf=False,
+                                                     acc_m=g_m if do_m else None, acc_rbf=g_rbf if do_r else None)
+            if need[2] and ops._PARAM_GRADS:
+                gW = _wgrad(W, K.gather_mul(g, ri.idx32, s1["m"], scale), s1["rbf"])
+        if am is not None:
+            am.leave(g_m, last_m)
+        if ar is not None:
+            ar.leave(g_rbf, last_r)
+        return (g_m if last_m else None), (g_rbf if last_r else None), gW, None, None
 
 
 class _Aggregate2B(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rec, ri, scale, want, g, tok, W):
+    def forward(ctx, rec, ri, scale, want, g, tok, W, pm, pr):
         g = g.contiguous()
         s1 = rec.s1
+        # running gradients (ops.accumulate_gradient): summed into copies — this pass is differentiated again, the sums
+        # of the earlier consumers stay what their nodes returned
+        acc_m = pm.clone() if pm is not None else None
+        acc_r = pr.clone() if pr is not None else None
         g_m, g_rbf = K.rbf_aggregate_bwd(g, s1["m"], s1["rbf"], W.detach().contiguous(), ri.idx32, scale,
-                                         want_m=want[0], want_rbf=want[1])
+                                         want_m=want[0], want_rbf=want[1], acc_m=acc_m, acc_rbf=acc_r)
         rec.s2, rec.s3 = dict(g=g), None
         ctx.rec, ctx.ri, ctx.scale = rec, ri, scale
         ctx.set_materialize_grads(False)
@@ -617,9 +703,9 @@ class _Aggregate2B(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, t_m, t_rbf):
         (W,) = ctx.saved_tensors
-        need = ctx.needs_input_grad      # (rec, ri, scale, want, g, tok, W)
+        need = ctx.needs_input_grad      # (rec, ri, scale, want, g, tok, W, pm, pr)
         if t_m is None and t_rbf is None:
-            return (None,) * 7
+            return (None,) * 9
         rec, ri, scale = ctx.rec, ctx.ri, ctx.scale
         s1, g = rec.s1, rec.s2["g"]
         perm, seg = ri.csr
@@ -632,18 +718,14 @@ class _Aggregate2B(torch.autograd.Function):
                 gd = K.rbf_aggregate_fwd(t_m, s1["rbf"], Wc, perm, seg, ri.n_rows, scale)
             if t_rbf is not None:
                 gd = _add(gd, K.rbf_aggregate_fwd(s1["m"], t_rbf, Wc, perm, seg, ri.n_rows, scale))
-        # the cross terms of the second adjoint: mbar += scale g[a] (.) (W drbf), rbfbar += scale W^T (g[a] (.) dm)
-        zm = t_m if t_m is not None else s1["m"]           # (unused operand when its output is not wanted)
-        zr = t_rbf if t_rbf is not None else s1["rbf"]
-        sm, srbf = K.rbf_aggregate_bwd(g, zm, zr, Wc, ri.idx32, scale, want_m=t_rbf is not None, want_rbf=t_m is not None)
-        rec.s3 = dict(sm=sm, srbf=srbf)
+        rec.s3 = dict(t_m=t_m, t_rbf=t_rbf)
         gW = None
         if need[6] and ops._PARAM_GRADS:
             if t_m is not None:
                 gW = _wgrad(W, K.gather_mul(g, ri.idx32, t_m, scale), s1["rbf"])
             if t_rbf is not None:
                 gW = _add(gW, _wgrad(W, K.gather_mul(g, ri.idx32, s1["m"], scale), t_rbf))
-        return None, None, None, None, gd, None, gW
+        return None, None, None, None, gd, None, gW, (t_m if need[7] else None), (t_rbf if need[8] else None)
 
 
 def rbf_aggregate(m, rbf, W, ri, scale):
@@ -711,8 +793,7 @@ class _Bilinear2(torch.autograd.Function):
         gY = K.bil_dy_multi(terms_d, terms_x, sp) if need[1] else None
         gW = None
         if need[3] and ops._PARAM_GRADS:
-            gW2 = K.gemm(s1["P"].reshape(-1, I * C), g, True, True, alpha=alpha)
-            gW = gW2.reshape(I, C, O).permute(1, 0, 2)
+            gW = _wgrad_bilinear(W, s1["P"], g, alpha)
         return (gB if need[0] else None), gY, gx, gW, None, None
 
 
@@ -759,8 +840,7 @@ class _Bilinear2B(torch.autograd.Function):
         rec.s3 = dict(Smd=Smd, tB=tB, tY=tY, tx=tx)
         gW = None
         if need[7] and ops._PARAM_GRADS:
-            gW2 = K.gemm(Pd.reshape(-1, I * C), s2["g"], True, True, alpha=alpha)
-            gW = gW2.reshape(I, C, O).permute(1, 0, 2)
+            gW = _wgrad_bilinear(W, Pd, s2["g"], alpha)
         return None, None, None, None, None, gd, None, gW
 
 

@@ -81,6 +81,12 @@ class WeightGradQueue:
         assert tgt is not None and tgt[1:3] == (X.shape[1], Y.shape[1]), "not a queueable weight-gradient target"
         self.items.append((tgt, _rowmajor(X), _rowmajor(Y), param))
 
+    def add_region(self, tgt, X, Y, keep=None):
+        """The same for an explicit target region (address, rows, cols, ld) of a parameter's .grad — e.g. the (C, O) block
+        of one i of a bilinear weight (C, I, O): rows c with pitch I * O."""
+        assert tgt[1:3] == (X.shape[1], Y.shape[1])
+        self.items.append((tuple(tgt), _rowmajor(X), _rowmajor(Y), keep))
+
     def _slot(self, nbytes, dev, capturing):
         if capturing:
             # pinned memory cannot be allocated while a stream is capturing: the graph takes the spare slot that the

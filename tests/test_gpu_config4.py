@@ -89,7 +89,7 @@ def test_batch_additivity_against_single_molecules(shard, mode):
             # last bits (4e-3 relative) of single activations, and four blocks amplify those to the bf16 error level
             # itself (measured: 1.3e-2 here, 4.3e-2 against the default arithmetic): the bf16 bar is that noise floor
             assert d <= (1e-5 if mode == "default" else 0.1), (i, d)
-            assert float((Ei[0] - E[i]).abs().max()) <= 2e-5 * max(1.0, float(E.abs().max()))
+            assert float((Ei[0] - E[i]).abs().max()) <= (2e-5 if mode == "default" else 2e-3) * max(1.0, float(E.abs().max()))
     finally:
         model.matmul_precision = None
 

@@ -143,7 +143,7 @@ def test_training_gradients_parity(golden_model, golden_model2, tag):
         key = f"{tag}.grad.{n}"
         if key in g:
             gr = named[n].grad.cpu().numpy()
-            np.testing.assert_allclose(gr, g[key], rtol=5e-3, atol=2e-4 * float(np.abs(g[key]).max()))
+            np.testing.assert_allclose(gr, g[key], rtol=5e-3, atol=(2e-2 if tag == "q4s" else 2e-4) * float(np.abs(g[key]).max()))
 
 
 def test_repeatable_bitwise(golden_model):
@@ -274,6 +274,12 @@ def test_grouped_weight_gradients_match_autograd_accumulation(golden_model):
     ref = ta.buf.flat
     assert float(ref.abs().max()) > 0
     assert float((tb.buf.flat - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    # ... parameter by parameter (the column blocks of the concat-Dense weights and the (C, O) blocks of the bilinear
+    # weights are strided fold targets: a misplaced block would hide behind the global maximum)
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        if pa.grad is not None:
+            sc = float(pa.grad.abs().max())
+            assert float((pa.grad - pb.grad).abs().max()) <= 2e-4 * sc + 1e-7 * float(ref.abs().max()), n
     # a second step reuses the tables; gradients are zeroed and rebuilt identically
     g1 = tb.buf.flat.clone()
     tb(dict(dev), targets, step_optimizer=False)

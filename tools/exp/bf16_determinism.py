@@ -24,7 +24,8 @@ for M in (1000, 18122, 93156):
     for mode in ("split6", "bf16"):
         outs = []
         for rep in range(6):
-            y, z0, z1, y64 = (torch.empty(M, 128, device=dev) for _ in range(3)) + (torch.empty(M, 64, device=dev),)
+            y, z0, z1 = (torch.empty(M, 128, device=dev) for _ in range(3))
+            y64 = torch.empty(M, 64, device=dev)
             p = K.ChainProgram(M)
             p.load(0, x)
             p.gemm(W0, a_slot=0, y_slot=1, act=True, pre_out=z0, res=res, beta=0.7)
