@@ -95,6 +95,12 @@ SIGNATURES = {
     "gn_bil_dy_multi_ang_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_gather_mul_f32": [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
+    "gn_dist_fwd_f32": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "gn_dist_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "gn_dist_jvp_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "gn_angle_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "gn_angle_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "gn_angle_jvp_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_bil_fused_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _i, _vp],
     "gn_segsum_multi_f32": [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],

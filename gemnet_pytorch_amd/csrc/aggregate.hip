@@ -144,7 +144,9 @@ __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __r
           r0 += w0[4 * q] * b.x + w0[4 * q + 1] * b.y + w0[4 * q + 2] * b.z + w0[4 * q + 3] * b.w;
           r1 += w1[4 * q] * b.x + w1[4 * q + 1] * b.y + w1[4 * q + 2] * b.z + w1[4 * q + 3] * b.w;
         }
-        float2 o = make_float2(gx * r0, gy * r1);
+        // (__fmul_rn: the product is rounded before the running gradient is added — the accumulate form stays
+        // bit-identical to "write, then add" and does not depend on how many consumers share the buffer)
+        float2 o = make_float2(__fmul_rn(gx, r0), __fmul_rn(gy, r1));
         if (accum & 1) {   // running gradient of m (ops.accumulate_gradient): the same lane reads and rewrites its element
           o.x += pp[u].x; o.y += pp[u].y;
         }

@@ -411,6 +411,74 @@ def trip_basis_bwd(gY, R, tc, ta, tb):
     return Gc, Gb
 
 
+def dist_fwd(R, id_c, id_a):
+    """D (E,) = |R[id_a] - R[id_c]|   (gemnet.py:261-286)."""
+    require_device(R, id_c, id_a)
+    R = _f32c(R)
+    D = torch.empty(id_c.shape[0], device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_dist_fwd_f32(ptr(R), ptr(id_c), ptr(id_a), ptr(D), id_c.shape[0], stream()), "gn_dist_fwd_f32")
+    return D
+
+
+def dist_bwd(gD, R, id_c, id_a):
+    """-> W (E,3) = gD dD/dR_a: dE/dR = segsum(W, id_a) - segsum(W, id_c)."""
+    require_device(gD, R)
+    gD, R = _f32c(gD), _f32c(R)
+    W = torch.empty((id_c.shape[0], 3), device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_dist_bwd_f32(ptr(gD), ptr(R), ptr(id_c), ptr(id_a), ptr(W), id_c.shape[0], stream()), "gn_dist_bwd_f32")
+    return W
+
+
+def dist_jvp(R, tR, gD, id_c, id_a, want_D=True, want_H=True):
+    """Tangent pass of the distances along the position tangent tR (A,3): -> (Ddot (E,) | None, H (E,3) | None) with
+    H = d/dR_a [gD dD/dR_a] (tR[a] - tR[c])."""
+    require_device(R, tR)
+    R, tR = _f32c(R), _f32c(tR)
+    E = id_c.shape[0]
+    gD = None if gD is None else _f32c(gD)
+    Dd = torch.empty(E, device=R.device, dtype=torch.float32) if want_D else None
+    H = torch.empty((E, 3), device=R.device, dtype=torch.float32) if want_H else None
+    check(_lib.load().gn_dist_jvp_f32(ptr(R), ptr(tR), ptr(gD), ptr(id_c), ptr(id_a), ptr(Dd), ptr(H), E, stream()),
+          "gn_dist_jvp_f32")
+    return Dd, H
+
+
+def angle_fwd(R, tc, ta, tb):
+    """theta (T,) of the angle c <- a -> b   (gemnet.py:288-311, :420-451)."""
+    require_device(R, tc, ta, tb)
+    R = _f32c(R)
+    th = torch.empty(tc.shape[0], device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_angle_fwd_f32(ptr(R), ptr(tc), ptr(ta), ptr(tb), ptr(th), tc.shape[0], stream()), "gn_angle_fwd_f32")
+    return th
+
+
+def angle_bwd(g, R, tc, ta, tb):
+    """-> Gc, Gb (T,3) = g dtheta/dR_c, g dtheta/dR_b   (dtheta/dR_a = -(Gc + Gb))."""
+    require_device(g, R)
+    g, R = _f32c(g), _f32c(R)
+    T = tc.shape[0]
+    Gc = torch.empty((T, 3), device=R.device, dtype=torch.float32)
+    Gb = torch.empty((T, 3), device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_angle_bwd_f32(ptr(g), ptr(R), ptr(tc), ptr(ta), ptr(tb), ptr(Gc), ptr(Gb), T, stream()),
+          "gn_angle_bwd_f32")
+    return Gc, Gb
+
+
+def angle_jvp(R, tR, g, tc, ta, tb, want_theta=True, want_H=True):
+    """Tangent pass of the angles along tR (A,3): -> (thdot (T,) | None, Hc, Hb (T,3) | None): the directional
+    derivative of the first adjoint g dtheta/d(R_c, R_b)."""
+    require_device(R, tR)
+    R, tR = _f32c(R), _f32c(tR)
+    T = tc.shape[0]
+    g = None if g is None else _f32c(g)
+    thd = torch.empty(T, device=R.device, dtype=torch.float32) if want_theta else None
+    Hc = torch.empty((T, 3), device=R.device, dtype=torch.float32) if want_H else None
+    Hb = torch.empty((T, 3), device=R.device, dtype=torch.float32) if want_H else None
+    check(_lib.load().gn_angle_jvp_f32(ptr(R), ptr(tR), ptr(g), ptr(tc), ptr(ta), ptr(tb), ptr(thd), ptr(Hc), ptr(Hb), T,
+                                       stream()), "gn_angle_jvp_f32")
+    return thd, Hc, Hb
+
+
 class ChainProgram:
     """A program for gn_chain_f32: ops over the three LDS slots of a row tile (see include/gemnet_hip.h).
     Operands named `mul/res/res2` are either an int (LDS slot) or a tensor (global (M,N))."""

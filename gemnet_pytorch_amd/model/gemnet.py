@@ -229,6 +229,13 @@ class GemNet(torch.nn.Module):
                     t.record_stream(main)
             else:
                 sph3 = ops.share_gradient(ops.trip_basis(R, plan.t_c, plan.t_a, plan.t_b, self.num_spherical))
+        elif ops.train2_enabled() and not self.direct_forces:
+            # force training: distances and triplet angles as twice-differentiable kernels (ops_train._Dist2 / _Angle2),
+            # the bases on their closed derivative kernels
+            from .. import ops_train
+            D_ca, V_ca = ops_train.distances(R, plan.id_c, plan.id_a), None
+            rbf = self.rbf_basis(D_ca)
+            rad3, sph3 = b3(D_ca, ops_train.triplet_angles(R, plan.t_c, plan.t_a, plan.t_b))
         else:
             D_ca, V_ca = self.calculate_interatomic_vectors(R, plan.id_c, plan.id_a)
             rbf = self.rbf_basis(D_ca)
@@ -247,7 +254,11 @@ class GemNet(torch.nn.Module):
             sbf4 = (rad3, ops.share_gradient(ops.quad_basis(R, plan.q_c, plan.q_a, plan.q_b, plan.q_d, S, plan=plan,
                                                             angle_form=ang)))
         elif not T:
-            D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
+            if ops.train2_enabled() and not self.direct_forces:
+                from .. import ops_train
+                D_ab = ops_train.distances(R, plan.int_b, plan.int_a)
+            else:
+                D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
             Phi_cab, Phi_abd, Theta_cabd = self.calculate_angles(R, plan)
             cbf4 = self.cbf_basis(D_ab, Phi_abd, plan.intm_ab)           # (I, S*R)
             # the tensor basis shares cutoff and radial tables with cbf_basis3: reuse rad3

@@ -996,6 +996,26 @@ def train2_enabled():
     return _TRAIN2
 
 
+# Second-order position terms d/dR [J^T g] dR of the geometry ops (ops_train._Dist2B / _Angle2B): needed for the gradient
+# of the loss w.r.t. the POSITIONS through the force (loss.backward() on a leaf R), never for parameter gradients — the
+# data-parallel training step (training/ddp.py) asks for the parameters only and switches them off.
+_POSITION_2ND = True
+
+
+@contextlib.contextmanager
+def position_second_order_grads(enabled: bool):
+    global _POSITION_2ND
+    old, _POSITION_2ND = _POSITION_2ND, bool(enabled)
+    try:
+        yield
+    finally:
+        _POSITION_2ND = old
+
+
+def position_second_order():
+    return _POSITION_2ND
+
+
 def step_cache():
     """The per-step store of packed weights (None outside `train2`): a stack keeps a reference for its later sweeps."""
     return _STEP_PACKED

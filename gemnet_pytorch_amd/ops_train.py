@@ -847,3 +847,107 @@ class _Bilinear2B(torch.autograd.Function):
 def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
     out, _ = _Bilinear2.apply(rbf_W1, sph, x, W, sp, float(alpha))
     return out
+
+
+# =================================================================================== distances and triplet angles from R
+class _Dist2(torch.autograd.Function):
+    """D[e] = |R[a(e)] - R[c(e)]| (gemnet.py:261-286), twice differentiable on three kernels (csrc/geometry2.hip) — the
+    reference's gather / sub / pow / sum / sqrt and their two generations of autograd nodes are ~40 pointwise launches."""
+
+    @staticmethod
+    def forward(ctx, R, ri_c, ri_a):
+        ctx.save_for_backward(R)
+        ctx.ri = (ri_c, ri_a)
+        return K.dist_fwd(R, ri_c.idx32, ri_a.idx32)
+
+    @staticmethod
+    def backward(ctx, gD):
+        (R,) = ctx.saved_tensors
+        ri_c, ri_a = ctx.ri
+        if gD is None or not ctx.needs_input_grad[0]:
+            return None, None, None
+        if torch.is_grad_enabled():
+            return _Dist2B.apply(gD, R, ri_c, ri_a), None, None
+        W = K.dist_bwd(gD.contiguous(), R, ri_c.idx32, ri_a.idx32)
+        return K.segsum_multi([(W, *ri_a.csr, 1.0), (W, *ri_c.csr, -1.0)], ri_a.n_rows), None, None
+
+
+class _Dist2B(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gD, R, ri_c, ri_a):
+        gD = gD.contiguous()
+        ctx.save_for_backward(gD, R)
+        ctx.ri = (ri_c, ri_a)
+        W = K.dist_bwd(gD, R, ri_c.idx32, ri_a.idx32)
+        return K.segsum_multi([(W, *ri_a.csr, 1.0), (W, *ri_c.csr, -1.0)], ri_a.n_rows)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, tR):
+        gD, R = ctx.saved_tensors
+        ri_c, ri_a = ctx.ri
+        if tR is None:
+            return None, None, None, None
+        want_H = ctx.needs_input_grad[1] and ops.position_second_order()
+        Dd, H = K.dist_jvp(R, tR.contiguous(), gD, ri_c.idx32, ri_a.idx32, want_D=ctx.needs_input_grad[0], want_H=want_H)
+        gR = K.segsum_multi([(H, *ri_a.csr, 1.0), (H, *ri_c.csr, -1.0)], ri_a.n_rows) if want_H else None
+        return Dd, gR, None, None
+
+
+def distances(R, ri_c, ri_a):
+    return _Dist2.apply(R, ri_c, ri_a)
+
+
+class _Angle2(torch.autograd.Function):
+    """theta[t] = atan2(max(|u x v|, 1e-9), u . v), u = R[c] - R[a], v = R[b] - R[a] (gemnet.py:288-311, :420-451), twice
+    differentiable: value, first adjoint and the tangent pass (dual numbers through the adjoint) are one kernel each."""
+
+    @staticmethod
+    def forward(ctx, R, ri_c, ri_a, ri_b):
+        ctx.save_for_backward(R)
+        ctx.ri = (ri_c, ri_a, ri_b)
+        return K.angle_fwd(R, ri_c.idx32, ri_a.idx32, ri_b.idx32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (R,) = ctx.saved_tensors
+        ri_c, ri_a, ri_b = ctx.ri
+        if g is None or not ctx.needs_input_grad[0]:
+            return None, None, None, None
+        if torch.is_grad_enabled():
+            return _Angle2B.apply(g, R, ri_c, ri_a, ri_b), None, None, None
+        Gc, Gb = K.angle_bwd(g.contiguous(), R, ri_c.idx32, ri_a.idx32, ri_b.idx32)
+        return _atoms3(Gc, Gb, ri_c, ri_a, ri_b), None, None, None
+
+
+def _atoms3(Gc, Gb, ri_c, ri_a, ri_b):
+    """Per-triplet position terms (c: Gc, b: Gb, a: -(Gc + Gb)) -> atoms, one multi-term segmented sum."""
+    return K.segsum_multi([(Gc, *ri_c.csr, 1.0), (Gb, *ri_b.csr, 1.0), (Gc, *ri_a.csr, -1.0), (Gb, *ri_a.csr, -1.0)],
+                          ri_c.n_rows)
+
+
+class _Angle2B(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, R, ri_c, ri_a, ri_b):
+        g = g.contiguous()
+        ctx.save_for_backward(g, R)
+        ctx.ri = (ri_c, ri_a, ri_b)
+        Gc, Gb = K.angle_bwd(g, R, ri_c.idx32, ri_a.idx32, ri_b.idx32)
+        return _atoms3(Gc, Gb, ri_c, ri_a, ri_b)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, tR):
+        g, R = ctx.saved_tensors
+        ri_c, ri_a, ri_b = ctx.ri
+        if tR is None:
+            return None, None, None, None, None
+        want_H = ctx.needs_input_grad[1] and ops.position_second_order()
+        thd, Hc, Hb = K.angle_jvp(R, tR.contiguous(), g, ri_c.idx32, ri_a.idx32, ri_b.idx32,
+                                  want_theta=ctx.needs_input_grad[0], want_H=want_H)
+        gR = _atoms3(Hc, Hb, ri_c, ri_a, ri_b) if want_H else None
+        return thd, gR, None, None, None
+
+
+def triplet_angles(R, ri_c, ri_a, ri_b):
+    return _Angle2.apply(R, ri_c, ri_a, ri_b)

@@ -146,7 +146,7 @@ class TrainStep:
             torch.autograd.backward(loss, inputs=self.buf.params)
         else:
             from .. import ops
-            with ops.wgrad_queue(self.wgrad):
+            with ops.wgrad_queue(self.wgrad), ops.position_second_order_grads(False):
                 torch.autograd.backward(loss, inputs=self.buf.params)
             self.wgrad.flush()
         return loss.detach()

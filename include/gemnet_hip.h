@@ -386,6 +386,29 @@ int gn_trip_basis_fwd_f32(const float* R, const int32_t* tc, const int32_t* ta, 
 int gn_trip_basis_bwd_f32(const float* gY, const float* R, const int32_t* tc, const int32_t* ta,
                           const int32_t* tb, float* Gc, float* Gb, int64_t T, int S, void* stream);
 
+/* ---- twice-differentiable geometry of the force-training step (csrc/geometry2.hip) -----------------------------------
+ * calculate_interatomic_vectors (gemnet.py:261-286) and calculate_neighbor_angles / calculate_angles3 (gemnet.py:288-311,
+ * :420-451) as value / first adjoint / tangent kernels, so that `loss.backward()` through `autograd.grad(E, R,
+ * create_graph=True)` (trainer.py:338-346) needs no pointwise launches for the geometry:
+ *   D[e]      = |R[id_a[e]] - R[id_c[e]]|                       gn_dist_fwd_f32
+ *   W[e,:]    = gD[e] dD/dR_a   (dD/dR_c = -W)                  gn_dist_bwd_f32     (reduced onto atoms by gn_segsum_multi_f32)
+ *   Ddot[e]   = dD . (tR[a] - tR[c]);  H[e,:] = d/dR_a [gD dD/dR_a] (tR[a] - tR[c])      gn_dist_jvp_f32 (Ddot / H may be NULL)
+ *   theta[t]  = atan2(max(|u x v|, 1e-9), u . v), u = R[c] - R[a], v = R[b] - R[a]       gn_angle_fwd_f32
+ *   Gc, Gb    = g dtheta/dR_c, g dtheta/dR_b  (dtheta/dR_a = -(Gc + Gb))                  gn_angle_bwd_f32
+ *   thdot[t]  = dtheta . (du, dv);  (Hc, Hb)[t] = d/d(R_c, R_b) [g dtheta] (du, dv), du = tR[c] - tR[a], dv = tR[b] - tR[a]
+ *               — the directional derivative of the first adjoint, by dual numbers          gn_angle_jvp_f32 (thdot / Hc+Hb may be NULL;
+ *               g may be NULL when only thdot is wanted) */
+int gn_dist_fwd_f32(const float* R, const int32_t* id_c, const int32_t* id_a, float* D, int64_t E, void* stream);
+int gn_dist_bwd_f32(const float* gD, const float* R, const int32_t* id_c, const int32_t* id_a, float* W, int64_t E, void* stream);
+int gn_dist_jvp_f32(const float* R, const float* tR, const float* gD, const int32_t* id_c, const int32_t* id_a, float* Ddot,
+                    float* H, int64_t E, void* stream);
+int gn_angle_fwd_f32(const float* R, const int32_t* tc, const int32_t* ta, const int32_t* tb, float* theta, int64_t T,
+                     void* stream);
+int gn_angle_bwd_f32(const float* g, const float* R, const int32_t* tc, const int32_t* ta, const int32_t* tb, float* Gc,
+                     float* Gb, int64_t T, void* stream);
+int gn_angle_jvp_f32(const float* R, const float* tR, const float* g, const int32_t* tc, const int32_t* ta, const int32_t* tb,
+                     float* thdot, float* Hc, float* Hb, int64_t T, void* stream);
+
 /* Quadruplets c -> a - b <- d (gemnet.py:334-418: two neighbour angles, two vector rejections, the
  * dihedral) fused with the real Y_lm (basis_layers.py:269): Y[q,:] = Y_lm(Phi_cab, Theta_cabd) from
  * the four atom indices of each quadruplet. */

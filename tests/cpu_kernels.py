@@ -464,6 +464,61 @@ def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
     return Sm, (P.reshape(P.shape[0], -1) @ W2T.t()) * alpha
 
 
+def _angle(u, v):
+    x = (u * v).sum(1)
+    y = torch.linalg.cross(u, v, dim=-1).norm(dim=-1).clamp(min=1e-9)
+    return torch.atan2(y, x)
+
+
+def dist_fwd(R, id_c, id_a):
+    v = R[id_a.long()] - R[id_c.long()]
+    return torch.sqrt((v * v).sum(1))
+
+
+def dist_bwd(gD, R, id_c, id_a):
+    v = R[id_a.long()] - R[id_c.long()]
+    return gD[:, None] * v / torch.sqrt((v * v).sum(1))[:, None]
+
+
+def dist_jvp(R, tR, gD, id_c, id_a, want_D=True, want_H=True):
+    with torch.enable_grad():
+        v = (R[id_a.long()] - R[id_c.long()]).detach().clone().requires_grad_(True)
+        tv = (tR[id_a.long()] - tR[id_c.long()]).detach()
+        gg = (torch.ones(v.shape[0], dtype=R.dtype) if gD is None else gD.detach().clone()).requires_grad_(True)
+        D = torch.sqrt((v * v).sum(1))
+        (W,) = torch.autograd.grad(D, v, gg, create_graph=True)
+        s = (W * tv).sum()
+        Dd, H = torch.autograd.grad(s, (gg, v))
+    return (Dd if want_D else None), (H if want_H else None)
+
+
+def angle_fwd(R, tc, ta, tb):
+    Ra = R[ta.long()]
+    return _angle(R[tc.long()] - Ra, R[tb.long()] - Ra)
+
+
+def angle_bwd(g, R, tc, ta, tb):
+    with torch.enable_grad():
+        Ra = R[ta.long()]
+        u = (R[tc.long()] - Ra).detach().clone().requires_grad_(True)
+        v = (R[tb.long()] - Ra).detach().clone().requires_grad_(True)
+        Gc, Gb = torch.autograd.grad(_angle(u, v), (u, v), g)
+    return Gc, Gb
+
+
+def angle_jvp(R, tR, g, tc, ta, tb, want_theta=True, want_H=True):
+    with torch.enable_grad():
+        Ra, tRa = R[ta.long()], tR[ta.long()]
+        u = (R[tc.long()] - Ra).detach().clone().requires_grad_(True)
+        v = (R[tb.long()] - Ra).detach().clone().requires_grad_(True)
+        du, dv = (tR[tc.long()] - tRa).detach(), (tR[tb.long()] - tRa).detach()
+        gg = (torch.ones(u.shape[0], dtype=R.dtype) if g is None else g.detach().clone()).requires_grad_(True)
+        Gu, Gv = torch.autograd.grad(_angle(u, v), (u, v), gg, create_graph=True)
+        s = (Gu * du).sum() + (Gv * dv).sum()
+        thd, Hc, Hb = torch.autograd.grad(s, (gg, u, v))
+    return (thd if want_theta else None), (Hc if want_H else None), (Hb if want_H else None)
+
+
 def gather_mul(x, idx32, m, scale=1.0):
     return x[idx32.long()] * m * scale
 
@@ -483,7 +538,7 @@ def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=Tru
     return g_m, g_rbf
 
 
-_NAMES = ["bil_train_supported", "gather_mul", "bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["dist_fwd", "dist_bwd", "dist_jvp", "angle_fwd", "angle_bwd", "angle_jvp", "bil_train_supported", "gather_mul", "bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

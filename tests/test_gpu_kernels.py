@@ -898,3 +898,56 @@ def test_gather_mul():
     x, m = rnd(g, 50, 128), rnd(g, 700, 128)
     idx = torch.randint(0, 50, (700,), generator=g, dtype=torch.int32)
     close(K.gather_mul(f32(x), idx.to(DEV), f32(m), 0.37), x[idx.long()] * m * 0.37, rtol=1e-6, atol=1e-6)
+
+
+def test_twice_differentiable_geometry_kernels():
+    """csrc/geometry2.hip: distance and angle value / first adjoint / tangent kernels (the tangent pass differentiates
+    the first adjoint with dual numbers) against float64 autograd of the reference formulas, including a collinear
+    triplet (the max(|u x v|, 1e-9) clamp: zero gradient through y)."""
+    g = torch.Generator().manual_seed(21)
+    n = 40
+    R = torch.rand(n, 3, generator=g, dtype=torch.float64) * 4.0
+    R[3] = R[1] + 2.0 * (R[2] - R[1])                       # atoms 1, 2, 3 on a line
+    R32 = R.float().double()
+    tR = rnd(g, n, 3)
+    E, T = 500, 1500
+    idx = torch.stack([torch.randperm(n, generator=g)[:2] for _ in range(E)]).int()
+    ec, ea = idx[:, 0].contiguous(), idx[:, 1].contiguous()
+    tri = torch.stack([torch.randperm(n, generator=g)[:3] for _ in range(T)]).int()
+    tri[0] = torch.tensor([2, 1, 3])                        # collinear: c = 2, a = 1, b = 3
+    tc, ta, tb = (tri[:, i].contiguous() for i in range(3))
+    d = lambda t: t.to(DEV)                                  # noqa: E731
+    # distances
+    gD = rnd(g, E)
+    close(K.dist_fwd(f32(R), d(ec), d(ea)), CK.dist_fwd(R32, ec, ea), rtol=1e-6, atol=1e-6)
+    close(K.dist_bwd(f32(gD), f32(R), d(ec), d(ea)), CK.dist_bwd(gD, R32, ec, ea), rtol=1e-5, atol=1e-5)
+    Dd, H = K.dist_jvp(f32(R), f32(tR), f32(gD), d(ec), d(ea))
+    rDd, rH = CK.dist_jvp(R32, tR, gD, ec, ea)
+    close(Dd, rDd, rtol=1e-5, atol=1e-5)
+    close(H, rH, rtol=1e-4, atol=1e-4 * float(rH.abs().max()))
+    assert K.dist_jvp(f32(R), f32(tR), None, d(ec), d(ea), want_H=False)[1] is None
+    # angles
+    gth = rnd(g, T)
+    close(K.angle_fwd(f32(R), d(tc), d(ta), d(tb)), CK.angle_fwd(R32, tc, ta, tb), rtol=1e-5, atol=2e-6)
+    Gc, Gb = K.angle_bwd(f32(gth), f32(R), d(tc), d(ta), d(tb))
+    rGc, rGb = CK.angle_bwd(gth, R32, tc, ta, tb)
+    ok = torch.ones(T, dtype=torch.bool)
+    ok[0] = False                                            # the collinear triplet: checked separately (clamped branch)
+    sc = float(rGc[ok].abs().max())
+    close(Gc[ok.to(DEV)], rGc[ok], rtol=1e-3, atol=2e-4 * sc)
+    close(Gb[ok.to(DEV)], rGb[ok], rtol=1e-3, atol=2e-4 * sc)
+    assert torch.isfinite(Gc).all() and torch.isfinite(Gb).all()
+    thd, Hc, Hb = K.angle_jvp(f32(R), f32(tR), f32(gth), d(tc), d(ta), d(tb))
+    rthd, rHc, rHb = CK.angle_jvp(R32, tR, gth, tc, ta, tb)
+    close(thd[ok.to(DEV)], rthd[ok], rtol=1e-3, atol=2e-4 * float(rthd[ok].abs().max()))
+    # second derivatives of nearly straight / nearly folded angles are ill-conditioned in fp32: compare the well-
+    # conditioned triplets elementwise (sin(theta) >= 0.3) and require all of them finite
+    th = CK.angle_fwd(R32, tc, ta, tb)
+    well = ok & (torch.sin(th) >= 0.3)
+    assert int(well.sum()) > 1000
+    hs = float(rHc[well].abs().max())
+    close(Hc[well.to(DEV)], rHc[well], rtol=2e-3, atol=5e-4 * hs)
+    close(Hb[well.to(DEV)], rHb[well], rtol=2e-3, atol=5e-4 * hs)
+    assert torch.isfinite(Hc).all() and torch.isfinite(Hb).all() and torch.isfinite(thd).all()
+    t2, none_c, none_b = K.angle_jvp(f32(R), f32(tR), None, d(tc), d(ta), d(tb), want_H=False)
+    assert none_c is None and none_b is None and torch.equal(t2, thd)

@@ -115,3 +115,29 @@ def test_fused_adjoint_programs_with_sources_equal_unfused():
     cpu_kernels.chain(fused)
     for a, b in zip(o0, o1):
         torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["t2", "t1"])
+def test_position_gradient_of_the_force_loss(golden_model, tag):
+    """d loss / d R through the force (the second-order POSITION terms of the fused geometry ops, ops_train._Dist2B /
+    _Angle2B: d/dR [J^T g] dR by dual numbers on the GPU) equals the composite closure's; the caller's leaf R is used as
+    it is when it requires grad (as the reference does, gemnet.py:494)."""
+    g = golden_model
+    grads = {}
+    for train2 in (True, False):
+        cfg, params, inputs = load_case(g, tag)
+        old = ops.USE_TRAIN2
+        ops.USE_TRAIN2 = train2
+        try:
+            with cpu_kernels.emulate():
+                model = build(cfg, params).train()
+                R = inputs["R"].double().requires_grad_(True)
+                inputs["R"] = R
+                E, F = model(inputs)
+                loss = GO.training_loss(E[:, :1], F, torch.tensor(g[f"{tag}.Et"]).double()[:, None], torch.tensor(g[f"{tag}.Ft"]).double())
+                loss.backward()
+                grads[train2] = R.grad.clone()
+        finally:
+            ops.USE_TRAIN2 = old
+    assert float(grads[False].abs().max()) > 0
+    torch.testing.assert_close(grads[True], grads[False], rtol=1e-8, atol=1e-10 * float(grads[False].abs().max()))
