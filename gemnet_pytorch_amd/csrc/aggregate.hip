@@ -35,41 +35,34 @@ __global__ __launch_bounds__(256) void rbf_aggregate_fwd_kernel(const float* __r
   }
   const int beg = seg_off[a], end = seg_off[a + 1];
   float2 acc = make_float2(0.f, 0.f);
-  // NE edges per trip, every load of the group issued before the first use: a trip is a chain of dependent loads
-  // (perm -> row address -> 512 B row from HBM), and an atom has only ~4.4 edges per wave (17.7 per atom) to hide it
-  // behind — one trip per wave for the typical atom.  The per-edge products are added in the same order as in the
-  // one-edge form (edge i, i + 4, i + 8, ...), so the result does not depend on NE.
-  constexpr int NE = 4;
-  for (int i = beg + wave; i < end; i += 4 * NE) {
-    int ei[NE];
-    bool ok[NE];
+  // Two edges per trip, every load of the pair issued before the first use: the trip is a chain of dependent loads
+  // (perm -> row address -> 512 B row from HBM), and an atom has only ~4 edges per wave to hide it behind.
+  // The per-edge products are added in the same order as in the one-edge form (edge i, then edge i + 4).
+  for (int i = beg + wave; i < end; i += 8) {
+    const bool two = i + 4 < end;
+    const int e0 = perm ? perm[i] : i;
+    const int e1 = two ? (perm ? perm[i + 4] : i + 4) : e0;
+    const float2 m0 = *reinterpret_cast<const float2*>(m + (size_t)e0 * C + 2 * lane);
+    const float2 m1 = *reinterpret_cast<const float2*>(m + (size_t)e1 * C + 2 * lane);
+    float4 b0[R / 4], b1[R / 4];
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      ok[u] = i + 4 * u < end;
-      const int ii = ok[u] ? i + 4 * u : i;
-      ei[u] = perm ? perm[ii] : ii;
+    for (int q = 0; q < R / 4; ++q) {
+      b0[q] = *reinterpret_cast<const float4*>(rbf + (size_t)e0 * R + 4 * q);   // same address in every lane
+      b1[q] = *reinterpret_cast<const float4*>(rbf + (size_t)e1 * R + 4 * q);
     }
-    float2 mv[NE];
-    float4 bv[NE][R / 4];
+    float r0 = 0.f, r1 = 0.f, s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      mv[u] = *reinterpret_cast<const float2*>(m + (size_t)ei[u] * C + 2 * lane);
-#pragma unroll
-      for (int q = 0; q < R / 4; ++q)
-        bv[u][q] = *reinterpret_cast<const float4*>(rbf + (size_t)ei[u] * R + 4 * q);   // same address in every lane
+    for (int q = 0; q < R / 4; ++q) {
+      r0 += w0[4 * q] * b0[q].x + w0[4 * q + 1] * b0[q].y + w0[4 * q + 2] * b0[q].z + w0[4 * q + 3] * b0[q].w;
+      r1 += w1[4 * q] * b0[q].x + w1[4 * q + 1] * b0[q].y + w1[4 * q + 2] * b0[q].z + w1[4 * q + 3] * b0[q].w;
+      s0 += w0[4 * q] * b1[q].x + w0[4 * q + 1] * b1[q].y + w0[4 * q + 2] * b1[q].z + w0[4 * q + 3] * b1[q].w;
+      s1 += w1[4 * q] * b1[q].x + w1[4 * q + 1] * b1[q].y + w1[4 * q + 2] * b1[q].z + w1[4 * q + 3] * b1[q].w;
     }
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-      for (int q = 0; q < R / 4; ++q) {
-        r0 += w0[4 * q] * bv[u][q].x + w0[4 * q + 1] * bv[u][q].y + w0[4 * q + 2] * bv[u][q].z + w0[4 * q + 3] * bv[u][q].w;
-        r1 += w1[4 * q] * bv[u][q].x + w1[4 * q + 1] * bv[u][q].y + w1[4 * q + 2] * bv[u][q].z + w1[4 * q + 3] * bv[u][q].w;
-      }
-      if (ok[u]) {
-        acc.x += mv[u].x * r0;
-        acc.y += mv[u].y * r1;
-      }
+    acc.x += m0.x * r0;
+    acc.y += m0.y * r1;
+    if (two) {
+      acc.x += m1.x * s0;
+      acc.y += m1.y * s1;
     }
   }
   part[wave][lane] = acc;
@@ -110,64 +103,41 @@ __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __r
     for (int j = 0; j < 32; ++j) wt[j] = W[(size_t)(32 * part + j) * R + kq];
   }
   const int64_t stride = (int64_t)gridDim.x * 4;
-  // Two edges per trip (e and e + stride), all loads of the pair in flight before the first use: a trip is the dependent
-  // chain id_a -> g_out row (+ the m / rbf rows), and a wave only sees 2-3 edges.  Values per edge are computed exactly
-  // as in the one-edge form.
-  for (int64_t e0 = (int64_t)blockIdx.x * 4 + wave; e0 < E; e0 += 2 * stride) {
-    const bool two = e0 + stride < E;
-    const int64_t ee[2] = {e0, two ? e0 + stride : e0};
-    int aa[2];
+  for (int64_t e = (int64_t)blockIdx.x * 4 + wave; e < E; e += stride) {
+    const int a = id_a[e];
+    const float2 g = *reinterpret_cast<const float2*>(g_out + (size_t)a * C + 2 * lane);
+    const float gx = g.x * scale, gy = g.y * scale;
+    if (g_m) {
+      float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) aa[u] = id_a[ee[u]];
-    float2 gg[2], mm[2], pp[2];
-    float4 bb[2][R / 4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      gg[u] = *reinterpret_cast<const float2*>(g_out + (size_t)aa[u] * C + 2 * lane);
-      if (g_m) {
-#pragma unroll
-        for (int q = 0; q < R / 4; ++q) bb[u][q] = *reinterpret_cast<const float4*>(rbf + (size_t)ee[u] * R + 4 * q);
-        if (accum & 1) pp[u] = *reinterpret_cast<const float2*>(g_m + (size_t)ee[u] * C + 2 * lane);
+      for (int q = 0; q < R / 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(rbf + (size_t)e * R + 4 * q);
+        r0 += w0[4 * q] * b.x + w0[4 * q + 1] * b.y + w0[4 * q + 2] * b.z + w0[4 * q + 3] * b.w;
+        r1 += w1[4 * q] * b.x + w1[4 * q + 1] * b.y + w1[4 * q + 2] * b.z + w1[4 * q + 3] * b.w;
       }
-      if (g_rbf) mm[u] = *reinterpret_cast<const float2*>(m + (size_t)ee[u] * C + 2 * lane);
+      float2 o = make_float2(gx * r0, gy * r1);
+      if (accum & 1) {   // running gradient of m (ops.accumulate_gradient): the same lane reads and rewrites its element
+        const float2 p = *reinterpret_cast<const float2*>(g_m + (size_t)e * C + 2 * lane);
+        o.x += p.x; o.y += p.y;
+      }
+      *reinterpret_cast<float2*>(g_m + (size_t)e * C + 2 * lane) = o;
     }
+    if (g_rbf) {
+      const float2 me = *reinterpret_cast<const float2*>(m + (size_t)e * C + 2 * lane);
+      *reinterpret_cast<float2*>(&tsm[wave][2 * lane]) = make_float2(gx * me.x, gy * me.y);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u == 1 && !two) break;
-      const int64_t e = ee[u];
-      const float gx = gg[u].x * scale, gy = gg[u].y * scale;
-      if (g_m) {
-        float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-        for (int q = 0; q < R / 4; ++q) {
-          const float4 b = bb[u][q];
-          r0 += w0[4 * q] * b.x + w0[4 * q + 1] * b.y + w0[4 * q + 2] * b.z + w0[4 * q + 3] * b.w;
-          r1 += w1[4 * q] * b.x + w1[4 * q + 1] * b.y + w1[4 * q + 2] * b.z + w1[4 * q + 3] * b.w;
-        }
-        // (__fmul_rn: the product is rounded before the running gradient is added — the accumulate form stays
-        // bit-identical to "write, then add" and does not depend on how many consumers share the buffer)
-        float2 o = make_float2(__fmul_rn(gx, r0), __fmul_rn(gy, r1));
-        if (accum & 1) {   // running gradient of m (ops.accumulate_gradient): the same lane reads and rewrites its element
-          o.x += pp[u].x; o.y += pp[u].y;
-        }
-        *reinterpret_cast<float2*>(g_m + (size_t)e * C + 2 * lane) = o;
+      for (int j4 = 0; j4 < 8; ++j4) {
+        const float4 t = *reinterpret_cast<const float4*>(&tsm[wave][32 * part + 4 * j4]);
+        s += t.x * wt[4 * j4] + t.y * wt[4 * j4 + 1] + t.z * wt[4 * j4 + 2] + t.w * wt[4 * j4 + 3];
       }
-      if (g_rbf) {
-        *reinterpret_cast<float2*>(&tsm[wave][2 * lane]) = make_float2(gx * mm[u].x, gy * mm[u].y);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        float s = 0.f;
-#pragma unroll
-        for (int j4 = 0; j4 < 8; ++j4) {
-          const float4 t = *reinterpret_cast<const float4*>(&tsm[wave][32 * part + 4 * j4]);
-          s += t.x * wt[4 * j4] + t.y * wt[4 * j4 + 1] + t.z * wt[4 * j4 + 2] + t.w * wt[4 * j4 + 3];
-        }
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (lane < R) g_rbf[(size_t)e * R + lane] = (accum & 2) ? g_rbf[(size_t)e * R + lane] + s : s;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();   // all lanes have read tsm before the next edge overwrites it
-      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < R) g_rbf[(size_t)e * R + lane] = (accum & 2) ? g_rbf[(size_t)e * R + lane] + s : s;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();   // all lanes have read tsm before the next edge overwrites it
     }
   }
 }

@@ -188,7 +188,12 @@ class GemNet(torch.nn.Module):
     def _energy(self, R, plan):
         T = self.triplets_only
         b3 = self.cbf_basis3
-        side = self._side_stream(R.device) if self.overlap_output_blocks and R.is_cuda else None
+        # Output blocks on a side stream: triplets-only models.  For the quadruplet models the overlap buys 0.2 % (13.56 vs
+        # 13.59 ms, tools/exp/q_overlap_ab.py) and GemNet-Q with plain-bf16 stacks was NOT run-to-run reproducible with it
+        # (8e-2 eV/A at mean|F| = 5.6, energies included; reproducible with the output blocks in line, with serialized
+        # kernels, and in the default arithmetic — tools/exp/bf16_determinism.py, q_side_race.py): an ordering hazard
+        # between the two streams that only this timing exposes and that is not located yet.  Until it is, Q runs in line.
+        side = self._side_stream(R.device) if self.overlap_output_blocks and R.is_cuda and T else None
         # The head of the forward is a string of small launches (110 us at B = 32); only distances -> edge embedding ->
         # rbf3 are needed by the first kernel of block 0.  With a side stream the rest forks off: the triplet angles,
         # the atom embedding and its two concat-Dense terms need positions / atomic numbers only and run beside the edge

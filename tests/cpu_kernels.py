@@ -464,7 +464,7 @@ def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
     return Sm, (P.reshape(P.shape[0], -1) @ W2T.t()) * alpha
 
 
-def _angle(u, v):
+def _angle_uv(u, v):
     x = (u * v).sum(1)
     y = torch.linalg.cross(u, v, dim=-1).norm(dim=-1).clamp(min=1e-9)
     return torch.atan2(y, x)
@@ -494,7 +494,7 @@ def dist_jvp(R, tR, gD, id_c, id_a, want_D=True, want_H=True):
 
 def angle_fwd(R, tc, ta, tb):
     Ra = R[ta.long()]
-    return _angle(R[tc.long()] - Ra, R[tb.long()] - Ra)
+    return _angle_uv(R[tc.long()] - Ra, R[tb.long()] - Ra)
 
 
 def angle_bwd(g, R, tc, ta, tb):
@@ -502,7 +502,7 @@ def angle_bwd(g, R, tc, ta, tb):
         Ra = R[ta.long()]
         u = (R[tc.long()] - Ra).detach().clone().requires_grad_(True)
         v = (R[tb.long()] - Ra).detach().clone().requires_grad_(True)
-        Gc, Gb = torch.autograd.grad(_angle(u, v), (u, v), g)
+        Gc, Gb = torch.autograd.grad(_angle_uv(u, v), (u, v), g)
     return Gc, Gb
 
 
@@ -513,7 +513,7 @@ def angle_jvp(R, tR, g, tc, ta, tb, want_theta=True, want_H=True):
         v = (R[tb.long()] - Ra).detach().clone().requires_grad_(True)
         du, dv = (tR[tc.long()] - tRa).detach(), (tR[tb.long()] - tRa).detach()
         gg = (torch.ones(u.shape[0], dtype=R.dtype) if g is None else g.detach().clone()).requires_grad_(True)
-        Gu, Gv = torch.autograd.grad(_angle(u, v), (u, v), gg, create_graph=True)
+        Gu, Gv = torch.autograd.grad(_angle_uv(u, v), (u, v), gg, create_graph=True)
         s = (Gu * du).sum() + (Gv * dv).sum()
         thd, Hc, Hb = torch.autograd.grad(s, (gg, u, v))
     return (thd if want_theta else None), (Hc if want_H else None), (Hb if want_H else None)
