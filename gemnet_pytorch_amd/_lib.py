@@ -70,8 +70,8 @@ class ChainArgs(ctypes.Structure):
 SIGNATURES = {
     "gn_gemm_f32": [ctypes.POINTER(GemmArgs), _vp],
     "gn_gemm_f32_cfg": [ctypes.POINTER(GemmArgs), _i, _vp],
-    "gn_chain_f32": [ctypes.POINTER(ChainArgs), _vp],
-    "gn_chain_split_f32": [ctypes.POINTER(ChainArgs), _i, _vp],
+    "gn_chain_f32": [_vp, _vp],               # const gn_chain_args* (kernels.chain packs the block with `struct`)
+    "gn_chain_split_f32": [_vp, _i, _vp],
     "gn_pack_weight_split": [_vp, _i, _i, _i, _i, _vp, _vp],
     "gn_pack_weight_split_grouped": [_vp, _i, _i, _vp],
     "gn_gemm_tn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],

@@ -692,95 +692,161 @@ def chain_split_supported(prog):
     return True
 
 
+_CHAIN_PACK = None
+
+
+def _chain_packer():
+    """(struct.Struct of one gn_chain_op, field names, offset of ops[0], sizeof(op), sizeof(args)) derived from the ctypes
+    mirror — `chain()` fills the argument block with one pack_into per op instead of ~50 ctypes attribute stores
+    (171 us -> ~25 us of host time per launch: the eager / dynamic-shape path issues 50 of them per forward+force)."""
+    global _CHAIN_PACK
+    if _CHAIN_PACK is None:
+        import struct
+        from ._lib import ChainArgs, ChainOp
+        code = {ctypes.c_int: "i", ctypes.c_float: "f", ctypes.c_void_p: "P"}
+        names, fmt = [], "@"
+        for name, ct in ChainOp._fields_:
+            names.append(name)
+            fmt += code[ct]
+        st = struct.Struct(fmt)
+        # native alignment of `struct` == the C / ctypes layout: every field lands on its ctypes offset
+        probe = bytearray(ctypes.sizeof(ChainOp))
+        vals = list(range(1, len(names) + 1))
+        st.pack_into(probe, 0, *[float(v) if c == ctypes.c_float else v for v, (_, c) in zip(vals, ChainOp._fields_)])
+        chk = ChainOp.from_buffer_copy(bytes(probe))
+        assert all(getattr(chk, n) == (float(v) if c == ctypes.c_float else v)
+                   for v, (n, c) in zip(vals, ChainOp._fields_)) and st.size <= ctypes.sizeof(ChainOp)
+        _CHAIN_PACK = (st, names, ChainArgs.ops.offset, ctypes.sizeof(ChainOp), ctypes.sizeof(ChainArgs),
+                       {n: i for i, n in enumerate(names)})
+    return _CHAIN_PACK
+
+
 def chain(prog, mode=None):
     """Run a ChainProgram (one launch)."""
-    from ._lib import ChainArgs, GN_CHAIN_MAX_OPS, GN_OP_GEMM, GN_OP_LOAD, GN_OP_SCALE, GN_OP_STORE
+    from ._lib import GN_CHAIN_MAX_OPS, GN_OP_GEMM, GN_OP_LOAD, GN_OP_SCALE, GN_OP_STORE
     if len(prog.ops) > GN_CHAIN_MAX_OPS:
         raise ValueError("chain program too long")
     nprod = CHAIN_MODES[mode or CHAIN_MODE]
     if nprod and not chain_split_supported(prog):
         nprod = 0
+    st, names, ops_off, op_size, args_size, ix = _chain_packer()
     keep = []
-    a = ChainArgs()
-    a.M, a.n_ops = prog.M, len(prog.ops)
+    buf = bytearray(args_size)
     M = prog.M
+    import struct as _struct
+    _struct.pack_into("@ii", buf, 0, M, len(prog.ops))
+    nf = len(names)
+    f32 = torch.float32
 
     def mat(t, cols=None):
-        require_device(t)
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2, "chain operands: contiguous fp32 2-D"
+        if not t.is_cuda:
+            require_device(t)
+        assert t.dtype == f32 and t.dim() == 2 and t.is_contiguous(), "chain operands: contiguous fp32 2-D"
         if cols is not None:
             assert t.shape[1] == cols, (t.shape, cols)
-        return t
+        return t.data_ptr()
 
-    def source(c, src, stage, cols):
-        if src is None:
-            return
-        c.src_stage, c.src_mode, c.src_alpha = stage, int(src["mode"]), float(src["alpha"])
-        c.srcP = ptr(mat(src["P"], cols))
-        c.srcQ = ptr(mat(src["Q"], cols)) if src["Q"] is not None else None
-        has_src[0] = True
+    def p(t):
+        return 0 if t is None else t.data_ptr()
 
-    has_src = [False]
+    has_src = False
     for i, o in enumerate(prog.ops):
-        c = a.ops[i]
-        c.slot, c.a_slot, c.mul_slot, c.res_slot, c.res2_slot, c.y2_slot = -1, -1, -1, -1, -1, -1
-        c.src_stage = 0
-        if o["kind"] == "load":
-            src = mat(o["src"])
+        v = [0] * nf
+        for k in ("slot", "a_slot", "mul_slot", "res_slot", "res2_slot", "y2_slot"):
+            v[ix[k]] = -1
+        v[ix["alpha"]] = v[ix["beta"]] = v[ix["beta2"]] = v[ix["alpha2"]] = v[ix["src_alpha"]] = 0.0
+        kind = o["kind"]
+
+        def source(src, stage, cols):
+            v[ix["src_stage"]], v[ix["src_mode"]], v[ix["src_alpha"]] = stage, int(src["mode"]), float(src["alpha"])
+            v[ix["srcP"]] = mat(src["P"], cols)
+            v[ix["srcQ"]] = mat(src["Q"], cols) if src["Q"] is not None else 0
+
+        if kind == "load":
+            src = o["src"]
+            sp = mat(src)
             assert o["rows"] is not None or src.shape[0] == M
-            c.kind, c.slot, c.width, c.ld = GN_OP_LOAD, o["slot"], src.shape[1], src.stride(0)
-            c.src, c.rows = ptr(src), ptr(o["rows"])
-            c.alpha, c.y2_slot, c.alpha2, c.mode2 = o.get("alpha", 1.0), o.get("y2", -1), o.get("alpha2", 1.0), o.get("mode2", 0)
-            c.Z2 = ptr(mat(o["Z2"], src.shape[1])) if o.get("Z2") is not None else None
-            source(c, o.get("add2"), 2, src.shape[1])
-        elif o["kind"] == "scale":
+            w = src.shape[1]
+            v[ix["kind"]], v[ix["slot"]], v[ix["width"]], v[ix["ld"]] = GN_OP_LOAD, o["slot"], w, src.stride(0)
+            v[ix["src"]], v[ix["rows"]] = sp, p(o["rows"])
+            v[ix["alpha"]], v[ix["y2_slot"]] = o.get("alpha", 1.0), o.get("y2", -1)
+            v[ix["alpha2"]], v[ix["mode2"]] = o.get("alpha2", 1.0), o.get("mode2", 0)
+            if o.get("Z2") is not None:
+                v[ix["Z2"]] = mat(o["Z2"], w)
+            if o.get("add2") is not None:
+                source(o["add2"], 2, w)
+                has_src = True
+        elif kind == "scale":
             Z, out = o["Z"], o["out"]
             w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
-            c.kind, c.slot, c.a_slot, c.width, c.ld, c.alpha = GN_OP_SCALE, o["slot"], o["a_slot"], w, w, o["alpha"]
-            c.act = o.get("mode", 0)
-            c.src = ptr(mat(Z, w)) if Z is not None else None
-            c.out = ptr(mat(out, w)) if out is not None else None
-            source(c, o.get("add"), 1, w)
-        elif o["kind"] == "store":
-            out = mat(o["out"])
-            c.kind, c.slot, c.width, c.ld, c.out = GN_OP_STORE, o["slot"], out.shape[1], out.stride(0), ptr(out)
+            v[ix["kind"]], v[ix["slot"]], v[ix["a_slot"]] = GN_OP_SCALE, o["slot"], o["a_slot"]
+            v[ix["width"]], v[ix["ld"]], v[ix["alpha"]], v[ix["act"]] = w, w, o["alpha"], o.get("mode", 0)
+            if Z is not None:
+                v[ix["src"]] = mat(Z, w)
+            if out is not None:
+                v[ix["out"]] = mat(out, w)
+            if o.get("add") is not None:
+                source(o["add"], 1, w)
+                has_src = True
+        elif kind == "store":
+            out = o["out"]
+            v[ix["kind"]], v[ix["slot"]], v[ix["width"]], v[ix["ld"]] = GN_OP_STORE, o["slot"], out.shape[1], out.stride(0)
+            v[ix["out"]] = mat(out)
         else:
             W = o["W"]
             N, Kd = W.shape
             if nprod:
                 Wp = o.get("packed")     # with the packed planes given, `W` only carries the shape (any strides)
                 if Wp is None:
-                    Wp = pack_weight_split(mat(W))
+                    mat(W)
+                    Wp = pack_weight_split(W)
                 keep.append(Wp)
-                W = Wp
+                wptr = Wp.data_ptr()
             else:
-                W = mat(W)
-            c.kind, c.W, c.N, c.K, c.a_slot, c.slot = GN_OP_GEMM, ptr(W), N, Kd, o["a_slot"], o["slot"]
-            c.act, c.alpha, c.beta, c.beta2 = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
-            for name in ("gadd1", "gadd2"):
-                if o[name] is not None:
-                    mat(o[name], N)
-            c.gadd1, c.gidx1, c.gadd2, c.gidx2 = ptr(o["gadd1"]), ptr(o["gidx1"]), ptr(o["gadd2"]), ptr(o["gidx2"])
-            c.pre_out = ptr(mat(o["pre_out"], N)) if o["pre_out"] is not None else None
-            c.out = ptr(mat(o["out"], N)) if o["out"] is not None else None
-            c.mul_slot, t = _sel(o["mul"]); c.mul_g = ptr(mat(t, N)) if t is not None else None
-            c.res_slot, t = _sel(o["res"]); c.res_g = ptr(mat(t, N)) if t is not None else None
-            c.res_rows = ptr(o["res_rows"])
-            c.res2_slot, t = _sel(o["res2"]); c.res2_g = ptr(mat(t, N)) if t is not None else None
-            c.mul_mode, c.y2_slot, c.y2_src, c.mode2, c.alpha2 = o["mul_mode"], o["y2"], o["y2_src"], o["mode2"], o["alpha2"]
-            c.Z2 = ptr(mat(o["Z2"], N)) if o["Z2"] is not None else None
-            c.out2 = ptr(mat(o["out2"], N)) if o["out2"] is not None else None
+                wptr = mat(W)
+            v[ix["kind"]], v[ix["W"]], v[ix["N"]], v[ix["K"]] = GN_OP_GEMM, wptr, N, Kd
+            v[ix["a_slot"]], v[ix["slot"]] = o["a_slot"], o["slot"]
+            v[ix["act"]], v[ix["alpha"]], v[ix["beta"]], v[ix["beta2"]] = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
+            if o["gadd1"] is not None:
+                v[ix["gadd1"]], v[ix["gidx1"]] = mat(o["gadd1"], N), p(o["gidx1"])
+            if o["gadd2"] is not None:
+                v[ix["gadd2"]], v[ix["gidx2"]] = mat(o["gadd2"], N), p(o["gidx2"])
+            if o["pre_out"] is not None:
+                v[ix["pre_out"]] = mat(o["pre_out"], N)
+            if o["out"] is not None:
+                v[ix["out"]] = mat(o["out"], N)
+            for key, fs, fg in (("mul", "mul_slot", "mul_g"), ("res", "res_slot", "res_g"), ("res2", "res2_slot", "res2_g")):
+                x = o[key]
+                if x is None:
+                    continue
+                if isinstance(x, int):
+                    v[ix[fs]] = x
+                else:
+                    v[ix[fg]] = mat(x, N)
+            v[ix["res_rows"]] = p(o["res_rows"])
+            v[ix["mul_mode"]], v[ix["y2_slot"]], v[ix["y2_src"]] = o["mul_mode"], o["y2"], o["y2_src"]
+            v[ix["mode2"]], v[ix["alpha2"]] = o["mode2"], o["alpha2"]
+            if o["Z2"] is not None:
+                v[ix["Z2"]] = mat(o["Z2"], N)
+            if o["out2"] is not None:
+                v[ix["out2"]] = mat(o["out2"], N)
             if o["mul_mode"] > 1:
-                assert c.mul_slot < 0 and c.mul_g is not None, "mul_mode applies to a global mul operand"
-            source(c, o.get("add"), 1, N)
-            source(c, o.get("add2"), 2, N)
-    if has_src[0] and not nprod:
+                assert v[ix["mul_slot"]] < 0 and v[ix["mul_g"]], "mul_mode applies to a global mul operand"
+            if o.get("add") is not None:
+                source(o["add"], 1, N)
+                has_src = True
+            if o.get("add2") is not None:
+                source(o["add2"], 2, N)
+                has_src = True
+        st.pack_into(buf, ops_off + i * op_size, *v)
+    if has_src and not nprod:
         raise RuntimeError("chain programs with second-order source terms run on the split-operand kernel only "
                            "(CHAIN_MODE f32 / an unsupported shape): use the composite training path")
+    cbuf = (ctypes.c_char * args_size).from_buffer(buf)
     if nprod:
-        check(_lib.load().gn_chain_split_f32(ctypes.byref(a), nprod, stream()), "gn_chain_split_f32")
+        check(_lib.load().gn_chain_split_f32(ctypes.addressof(cbuf), nprod, stream()), "gn_chain_split_f32")
     else:
-        check(_lib.load().gn_chain_f32(ctypes.byref(a), stream()), "gn_chain_f32")
+        check(_lib.load().gn_chain_f32(ctypes.addressof(cbuf), stream()), "gn_chain_f32")
 
 
 def bil_train_supported(S, C, I):

@@ -750,10 +750,11 @@ class _Bilinear2(torch.autograd.Function):
         C, I, O = W.shape
         B, Y, x = B.contiguous(), Y.contiguous(), x.contiguous()
         W2 = W.detach().permute(1, 0, 2).reshape(I * C, O).contiguous()       # rows (i, c): one copy per step
+        W2T = W2.t().contiguous()   # (O, I*C): the K = 1024 products run the k-contiguous GEMM (37 vs 68 us at E = 18 k)
         Sm, P = K.bil_reduce_project(Y, x, B, sp)
-        out = K.gemm(P.reshape(-1, I * C), W2, False, True, alpha=alpha)
+        out = K.gemm(P.reshape(-1, I * C), W2T, alpha=alpha)
         rec = _Rec()
-        rec.s1 = dict(B=B, Y=Y, x=x, W2=W2, Sm=Sm, P=P)
+        rec.s1 = dict(B=B, Y=Y, x=x, W2=W2, W2T=W2T, Sm=Sm, P=P)
         tok = x.new_empty(0)
         ctx.rec, ctx.sp, ctx.alpha, ctx.dims = rec, sp, alpha, (C, I, O)
         ctx.set_materialize_grads(False)
@@ -836,7 +837,7 @@ class _Bilinear2B(torch.autograd.Function):
             Smd, Pd = K.bil_reduce_project(Ya, xa, s1["B"], sp, B2=tB, Sm2=s1["Sm"] if tB is not None else None)
         else:
             Pd = K.bmm(tB, s1["Sm"], True, False)
-        gd = K.gemm(Pd.reshape(-1, I * C), s1["W2"], False, True, alpha=alpha) if need[5] else None
+        gd = K.gemm(Pd.reshape(-1, I * C), s1["W2T"], alpha=alpha) if need[5] else None
         rec.s3 = dict(Smd=Smd, tB=tB, tY=tY, tx=tx)
         gW = None
         if need[7] and ops._PARAM_GRADS:
