@@ -189,7 +189,9 @@ class LaunchTimer:
         outs = out if isinstance(out, tuple) else (out,)
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
-    FAMILIES = ["rbf_aggregate_fwd", "rbf_aggregate_bwd", "gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
+    FAMILIES = ["rbf_aggregate_fwd", "rbf_aggregate_bwd", "gather_mul", "dist_fwd", "dist_bwd", "dist_jvp", "angle_fwd", "angle_bwd",
+                "angle_jvp", "pack_weight_split", "pack_weight_split_grouped",
+                "gemm", "gemm_tn", "bmm", "gather", "segsum", "ssilu", "pm", "dact_mul", "chain", "bil_reduce",
                 "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_fused_fwd", "bil_fused_bwd", "bil_project_bwd", "bil_dy_multi", "segsum_multi",
                 "bessel_rbf", "sph_radial", "ylm0",
                 "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
@@ -502,7 +504,10 @@ def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, w
         ts._graph = held
         log_families("training step", fam)
         out["roofline"] = roof
-        out["launches_per_step"] = int(sum(v["launches"] for v in fam.values()))
+        # launches through the C ABI (kernels.py launchers) of one eager step, + the grouped weight-gradient pair and the
+        # two optimizer launches; the remaining ATen launches (gradient fan-in adds of cross-stream consumers, geometry glue
+        # of the composite parts) are in profiles/r3_train_kernel_stats.csv
+        out["launches_per_step"] = int(sum(v["launches"] for v in fam.values())) + (2 if ts.wgrad is not None else 0) + 2
     del ts, model
     return out
 

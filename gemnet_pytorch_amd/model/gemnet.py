@@ -226,7 +226,8 @@ class GemNet(torch.nn.Module):
                     rad3.record_stream(side)
                     rbf_W1_3 = self.mlp_cbf3(rad3)
                     rbf_h = self.mlp_rbf_h(rbf)
-                    rbf_out = self.mlp_rbf_out(rbf)
+                    # consumed by the five output blocks, all on this (side) stream: one running gradient
+                    rbf_out = ops.accumulate_gradient(self.mlp_rbf_out(rbf), stream=side)
                     ev_b = torch.cuda.Event()
                     ev_b.record(side)
                 main.wait_event(ev_a)
@@ -291,7 +292,7 @@ class GemNet(torch.nn.Module):
         else:
             cbf3 = (ops.accumulate_gradient(self.mlp_cbf3(rad3)), sph3)
             rbf_h = ops.accumulate_gradient(self.mlp_rbf_h(rbf))
-            rbf_out = self.mlp_rbf_out(rbf)
+            rbf_out = ops.accumulate_gradient(self.mlp_rbf_out(rbf), stream=side)
 
         # OutputBlock i only feeds the final energy sum: it runs on a side stream, concurrently with
         # InteractionBlock i+1 (and, since autograd replays a node on its forward stream, so does its

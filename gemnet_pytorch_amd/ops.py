@@ -590,7 +590,7 @@ class _RbfAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, rbf, W, ri, scale):
         perm, seg = ri.csr
-        ctx.acc_m, ctx.acc_rbf = _acc_join(m), _acc_join(rbf)
+        ctx.acc_m, ctx.acc_rbf = _acc_join(m, cross=True), _acc_join(rbf)
         ctx.save_for_backward(m, rbf, W)
         ctx.ri, ctx.scale = ri, scale
         return K.rbf_aggregate_fwd(m, rbf, W, perm, seg, ri.n_rows, scale)
@@ -639,6 +639,8 @@ class GradSink:
         self.buf = None
         self.pending = []   # (dSm_b, x_b) of the consumers whose Y gradient is deferred to one combined pass
         self.stream = None  # accumulate_gradient: HIP stream of the participating consumers
+        self.cross = False  # consumers on several streams take part (events order their writes, see enter / leave)
+        self.buf_stream = self.buf_event = None
         self.task = None    # id of the backward pass (autograd graph task) the running state belongs to
 
     def arrive(self):
@@ -674,12 +676,26 @@ class GradSink:
         return out, prev, last
 
     def enter(self):
-        """-> (running sum so far or None, is this the last consumer of the pass); pair with `leave`."""
+        """-> (running sum so far or None, is this the last consumer of the pass); pair with `leave`.
+        A consumer on ANOTHER stream than the one that wrote the running sum last (an output block on the side stream
+        followed by the interaction block on the main stream) first orders itself behind that write and tells the
+        allocator that the buffer is in use on its stream too."""
         last = self.arrive()
-        return self.buf, last
+        buf = self.buf
+        if buf is not None and self.cross and buf.is_cuda:
+            cur = torch.cuda.current_stream(buf.device)
+            if self.buf_stream is not None and self.buf_stream != cur.cuda_stream:
+                cur.wait_event(self.buf_event)
+                buf.record_stream(cur)
+        return buf, last
 
     def leave(self, out, last):
         self.buf = None if last else out
+        if self.cross and not last and out is not None and out.is_cuda:
+            cur = torch.cuda.current_stream(out.device)
+            self.buf_stream = cur.cuda_stream
+            self.buf_event = torch.cuda.Event()
+            self.buf_event.record(cur)
 
     def skip(self):
         """A consumer that has no contribution in this pass (undefined incoming gradient)."""
@@ -716,14 +732,22 @@ def accumulate_gradient(t, stream=None):
     return t
 
 
-def _acc_join(t):
-    """Forward side of `accumulate_gradient`: register the calling fused op as a consumer of `t`."""
+USE_CROSS_ACC = os.environ.get("GEMNET_CROSS_ACC", "1") == "1"
+
+
+def _acc_join(t, cross=False):
+    """Forward side of `accumulate_gradient`: register the calling fused op as a consumer of `t`.  A consumer on another
+    stream than the sink's only takes part when it asks for it (`cross`: the output block's aggregation of the block
+    input m — its backward runs first, on the side stream, and the main-stream consumers then add into its result behind
+    an event instead of through a separate elementwise add of the autograd engine)."""
     acc = getattr(t, "_gn_acc", None)
     if acc is None:
         return None
     st = torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
     if acc.stream != st:
-        return None
+        if not (cross and USE_CROSS_ACC and constant_weights()):
+            return None
+        acc.cross = True
     acc.consumers += 1
     return acc
 
