@@ -732,7 +732,10 @@ def accumulate_gradient(t, stream=None):
     return t
 
 
-USE_CROSS_ACC = os.environ.get("GEMNET_CROSS_ACC", "1") == "1"
+# Off by default: measured on MI355X (same-box A/B pending in profiles/r3_ab.txt) the main-stream consumers then wait for
+# the output block's backward BEFORE they start instead of meeting it in one add at the end — the overlap of the side
+# stream is worth more than the five (E, 128) adds it saves (2.79 vs 2.71-2.74 ms per forward+force step).
+USE_CROSS_ACC = os.environ.get("GEMNET_CROSS_ACC", "0") == "1"
 
 
 def _acc_join(t, cross=False):
