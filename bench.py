@@ -463,7 +463,7 @@ def log_families(title, fam):
 
 
 # ------------------------------------------------------------------------------------------------ extra measurements
-def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, warmup=3, want_roofline=True):
+def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, warmup=3, want_roofline=True, graph=True):
     """The full training step (trainer.py:325-360): forward + force + loss + loss.backward() through the
     force + ONE flat-buffer RCCL all-reduce (world > 1) + shared-gradient rescale + global-norm clip + AdamW(amsgrad) + EMA.
     fwd/force/backward are one hipGraph; collective and optimizer launches follow it."""
@@ -473,9 +473,10 @@ def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, w
     model = GemNet(**cfg, scale_file=SCALE_FILE).to(inputs["R"].device)
     ts = TrainStep(model, world_size=world, fused_optimizer=True)
     inputs = {k: v for k, v in inputs.items() if k != "_plan"}
-    graphed = True
+    graphed = bool(graph)
     try:
-        ts.capture(inputs, targets)
+        if graph:
+            ts.capture(inputs, targets)
     except Exception as ex:  # noqa: BLE001
         log(f"[bench] training-step capture unavailable ({type(ex).__name__}: {ex}); eager")
         ts._graph, graphed = None, False
@@ -724,7 +725,7 @@ def main():
     extra = {}
     if args.mode == "train":   # explicit request: the training step IS the timed region
         tr = extra_train_step(cfg, 1234, inputs, targets, world, args.batch, steps=args.steps, warmup=args.warmup,
-                              want_roofline=not args.no_roofline and rank == 0)
+                              want_roofline=not args.no_roofline and rank == 0, graph=not args.no_graph)
         elapsed = tr["ms_per_step"] * 1e-3 * args.steps
         graph, roof = tr["hipgraph"], tr.pop("roofline", None)
         extra["train_step"] = tr
