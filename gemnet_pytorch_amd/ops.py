@@ -732,9 +732,9 @@ def accumulate_gradient(t, stream=None):
     return t
 
 
-# Off by default: measured on MI355X (same-box A/B pending in profiles/r3_ab.txt) the main-stream consumers then wait for
-# the output block's backward BEFORE they start instead of meeting it in one add at the end — the overlap of the side
-# stream is worth more than the five (E, 128) adds it saves (2.79 vs 2.71-2.74 ms per forward+force step).
+# Off by default: it removes five (E, 128) adds per step but the main-stream consumers then wait for the output block's
+# backward BEFORE they start instead of meeting it in one add at the end — same-box A/B on MI355X (profiles/r3_ab.txt):
+# 2.789 / 2.792 ms off vs 2.792 / 2.791 ms on.  No gain, so the simpler ordering stays.
 USE_CROSS_ACC = os.environ.get("GEMNET_CROSS_ACC", "0") == "1"
 
 
