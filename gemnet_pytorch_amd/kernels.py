@@ -696,9 +696,10 @@ _CHAIN_PACK = None
 
 
 def _chain_packer():
-    """(struct.Struct of one gn_chain_op, field names, offset of ops[0], sizeof(op), sizeof(args)) derived from the ctypes
-    mirror — `chain()` fills the argument block with one pack_into per op instead of ~50 ctypes attribute stores
-    (171 us -> ~25 us of host time per launch: the eager / dynamic-shape path issues 50 of them per forward+force)."""
+    """(struct.Struct of one gn_chain_op, default field values, offset of ops[0], sizeof(op), sizeof(args)) derived from
+    the ctypes mirror — `chain()` fills the argument block with one pack_into per op instead of ~50 ctypes attribute
+    stores (171 us -> ~60 us of host time per launch: the eager / dynamic-shape path issues 50 of them per forward+force).
+    The field indices become module globals F_<name>."""
     global _CHAIN_PACK
     if _CHAIN_PACK is None:
         import struct
@@ -716,129 +717,151 @@ def _chain_packer():
         chk = ChainOp.from_buffer_copy(bytes(probe))
         assert all(getattr(chk, n) == (float(v) if c == ctypes.c_float else v)
                    for v, (n, c) in zip(vals, ChainOp._fields_)) and st.size <= ctypes.sizeof(ChainOp)
-        _CHAIN_PACK = (st, names, ChainArgs.ops.offset, ctypes.sizeof(ChainOp), ctypes.sizeof(ChainArgs),
-                       {n: i for i, n in enumerate(names)})
+        default = [0.0 if c == ctypes.c_float else 0 for _, c in ChainOp._fields_]
+        for i, n in enumerate(names):
+            globals()["F_" + n] = i
+            if n in ("slot", "a_slot", "mul_slot", "res_slot", "res2_slot", "y2_slot"):
+                default[i] = -1
+        _CHAIN_PACK = (st, default, ChainArgs.ops.offset, ctypes.sizeof(ChainOp), ctypes.sizeof(ChainArgs),
+                       struct.Struct("@ii"))
     return _CHAIN_PACK
+
+
+def _mat(t, cols=None):
+    """Address of a contiguous fp32 2-D device tensor (the chain kernel's global operands)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()):
+        require_device(t)
+        raise AssertionError("chain operands: contiguous fp32 2-D")
+    if cols is not None and t.shape[1] != cols:
+        raise AssertionError((tuple(t.shape), cols))
+    return t.data_ptr()
+
+
+def _source(v, src, stage, cols):
+    v[F_src_stage], v[F_src_mode], v[F_src_alpha] = stage, int(src["mode"]), float(src["alpha"])
+    v[F_srcP] = _mat(src["P"], cols)
+    v[F_srcQ] = _mat(src["Q"], cols) if src["Q"] is not None else 0
 
 
 def chain(prog, mode=None):
     """Run a ChainProgram (one launch)."""
     from ._lib import GN_CHAIN_MAX_OPS, GN_OP_GEMM, GN_OP_LOAD, GN_OP_SCALE, GN_OP_STORE
-    if len(prog.ops) > GN_CHAIN_MAX_OPS:
+    ops = prog.ops
+    if len(ops) > GN_CHAIN_MAX_OPS:
         raise ValueError("chain program too long")
     nprod = CHAIN_MODES[mode or CHAIN_MODE]
     if nprod and not chain_split_supported(prog):
         nprod = 0
-    st, names, ops_off, op_size, args_size, ix = _chain_packer()
+    st, default, ops_off, op_size, args_size, hdr = _chain_packer()
     keep = []
     buf = bytearray(args_size)
     M = prog.M
-    import struct as _struct
-    _struct.pack_into("@ii", buf, 0, M, len(prog.ops))
-    nf = len(names)
-    f32 = torch.float32
-
-    def mat(t, cols=None):
-        if not t.is_cuda:
-            require_device(t)
-        assert t.dtype == f32 and t.dim() == 2 and t.is_contiguous(), "chain operands: contiguous fp32 2-D"
-        if cols is not None:
-            assert t.shape[1] == cols, (t.shape, cols)
-        return t.data_ptr()
-
-    def p(t):
-        return 0 if t is None else t.data_ptr()
-
+    hdr.pack_into(buf, 0, M, len(ops))
     has_src = False
-    for i, o in enumerate(prog.ops):
-        v = [0] * nf
-        for k in ("slot", "a_slot", "mul_slot", "res_slot", "res2_slot", "y2_slot"):
-            v[ix[k]] = -1
-        v[ix["alpha"]] = v[ix["beta"]] = v[ix["beta2"]] = v[ix["alpha2"]] = v[ix["src_alpha"]] = 0.0
+    off = ops_off
+    for o in ops:
+        v = default[:]
         kind = o["kind"]
-
-        def source(src, stage, cols):
-            v[ix["src_stage"]], v[ix["src_mode"]], v[ix["src_alpha"]] = stage, int(src["mode"]), float(src["alpha"])
-            v[ix["srcP"]] = mat(src["P"], cols)
-            v[ix["srcQ"]] = mat(src["Q"], cols) if src["Q"] is not None else 0
-
-        if kind == "load":
-            src = o["src"]
-            sp = mat(src)
-            assert o["rows"] is not None or src.shape[0] == M
-            w = src.shape[1]
-            v[ix["kind"]], v[ix["slot"]], v[ix["width"]], v[ix["ld"]] = GN_OP_LOAD, o["slot"], w, src.stride(0)
-            v[ix["src"]], v[ix["rows"]] = sp, p(o["rows"])
-            v[ix["alpha"]], v[ix["y2_slot"]] = o.get("alpha", 1.0), o.get("y2", -1)
-            v[ix["alpha2"]], v[ix["mode2"]] = o.get("alpha2", 1.0), o.get("mode2", 0)
-            if o.get("Z2") is not None:
-                v[ix["Z2"]] = mat(o["Z2"], w)
-            if o.get("add2") is not None:
-                source(o["add2"], 2, w)
-                has_src = True
-        elif kind == "scale":
-            Z, out = o["Z"], o["out"]
-            w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
-            v[ix["kind"]], v[ix["slot"]], v[ix["a_slot"]] = GN_OP_SCALE, o["slot"], o["a_slot"]
-            v[ix["width"]], v[ix["ld"]], v[ix["alpha"]], v[ix["act"]] = w, w, o["alpha"], o.get("mode", 0)
-            if Z is not None:
-                v[ix["src"]] = mat(Z, w)
-            if out is not None:
-                v[ix["out"]] = mat(out, w)
-            if o.get("add") is not None:
-                source(o["add"], 1, w)
-                has_src = True
-        elif kind == "store":
-            out = o["out"]
-            v[ix["kind"]], v[ix["slot"]], v[ix["width"]], v[ix["ld"]] = GN_OP_STORE, o["slot"], out.shape[1], out.stride(0)
-            v[ix["out"]] = mat(out)
-        else:
+        if kind == "gemm":
             W = o["W"]
             N, Kd = W.shape
             if nprod:
                 Wp = o.get("packed")     # with the packed planes given, `W` only carries the shape (any strides)
                 if Wp is None:
-                    mat(W)
+                    _mat(W)
                     Wp = pack_weight_split(W)
                 keep.append(Wp)
-                wptr = Wp.data_ptr()
+                v[F_W] = Wp.data_ptr()
             else:
-                wptr = mat(W)
-            v[ix["kind"]], v[ix["W"]], v[ix["N"]], v[ix["K"]] = GN_OP_GEMM, wptr, N, Kd
-            v[ix["a_slot"]], v[ix["slot"]] = o["a_slot"], o["slot"]
-            v[ix["act"]], v[ix["alpha"]], v[ix["beta"]], v[ix["beta2"]] = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
-            if o["gadd1"] is not None:
-                v[ix["gadd1"]], v[ix["gidx1"]] = mat(o["gadd1"], N), p(o["gidx1"])
-            if o["gadd2"] is not None:
-                v[ix["gadd2"]], v[ix["gidx2"]] = mat(o["gadd2"], N), p(o["gidx2"])
-            if o["pre_out"] is not None:
-                v[ix["pre_out"]] = mat(o["pre_out"], N)
-            if o["out"] is not None:
-                v[ix["out"]] = mat(o["out"], N)
-            for key, fs, fg in (("mul", "mul_slot", "mul_g"), ("res", "res_slot", "res_g"), ("res2", "res2_slot", "res2_g")):
-                x = o[key]
-                if x is None:
-                    continue
-                if isinstance(x, int):
-                    v[ix[fs]] = x
+                v[F_W] = _mat(W)
+            v[F_kind], v[F_N], v[F_K], v[F_a_slot], v[F_slot] = GN_OP_GEMM, N, Kd, o["a_slot"], o["slot"]
+            v[F_act], v[F_alpha], v[F_beta], v[F_beta2] = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
+            t = o["gadd1"]
+            if t is not None:
+                v[F_gadd1], v[F_gidx1] = _mat(t, N), o["gidx1"].data_ptr()
+            t = o["gadd2"]
+            if t is not None:
+                v[F_gadd2], v[F_gidx2] = _mat(t, N), o["gidx2"].data_ptr()
+            t = o["pre_out"]
+            if t is not None:
+                v[F_pre_out] = _mat(t, N)
+            t = o["out"]
+            if t is not None:
+                v[F_out] = _mat(t, N)
+            t = o["mul"]
+            if t is not None:
+                if isinstance(t, int):
+                    v[F_mul_slot] = t
                 else:
-                    v[ix[fg]] = mat(x, N)
-            v[ix["res_rows"]] = p(o["res_rows"])
-            v[ix["mul_mode"]], v[ix["y2_slot"]], v[ix["y2_src"]] = o["mul_mode"], o["y2"], o["y2_src"]
-            v[ix["mode2"]], v[ix["alpha2"]] = o["mode2"], o["alpha2"]
-            if o["Z2"] is not None:
-                v[ix["Z2"]] = mat(o["Z2"], N)
-            if o["out2"] is not None:
-                v[ix["out2"]] = mat(o["out2"], N)
-            if o["mul_mode"] > 1:
-                assert v[ix["mul_slot"]] < 0 and v[ix["mul_g"]], "mul_mode applies to a global mul operand"
-            if o.get("add") is not None:
-                source(o["add"], 1, N)
+                    v[F_mul_g] = _mat(t, N)
+            t = o["res"]
+            if t is not None:
+                if isinstance(t, int):
+                    v[F_res_slot] = t
+                else:
+                    v[F_res_g] = _mat(t, N)
+            t = o["res2"]
+            if t is not None:
+                if isinstance(t, int):
+                    v[F_res2_slot] = t
+                else:
+                    v[F_res2_g] = _mat(t, N)
+            t = o["res_rows"]
+            if t is not None:
+                v[F_res_rows] = t.data_ptr()
+            mm = o["mul_mode"]
+            v[F_mul_mode], v[F_y2_slot], v[F_y2_src], v[F_mode2], v[F_alpha2] = mm, o["y2"], o["y2_src"], o["mode2"], o["alpha2"]
+            t = o["Z2"]
+            if t is not None:
+                v[F_Z2] = _mat(t, N)
+            t = o["out2"]
+            if t is not None:
+                v[F_out2] = _mat(t, N)
+            if mm > 1:
+                assert v[F_mul_slot] < 0 and v[F_mul_g], "mul_mode applies to a global mul operand"
+            t = o.get("add")
+            if t is not None:
+                _source(v, t, 1, N)
                 has_src = True
-            if o.get("add2") is not None:
-                source(o["add2"], 2, N)
+            t = o.get("add2")
+            if t is not None:
+                _source(v, t, 2, N)
                 has_src = True
-        st.pack_into(buf, ops_off + i * op_size, *v)
+        elif kind == "load":
+            src = o["src"]
+            sp = _mat(src)
+            assert o["rows"] is not None or src.shape[0] == M
+            w = src.shape[1]
+            v[F_kind], v[F_slot], v[F_width], v[F_ld], v[F_src] = GN_OP_LOAD, o["slot"], w, src.stride(0), sp
+            t = o["rows"]
+            if t is not None:
+                v[F_rows] = t.data_ptr()
+            v[F_alpha], v[F_y2_slot], v[F_alpha2], v[F_mode2] = o.get("alpha", 1.0), o.get("y2", -1), o.get("alpha2", 1.0), o.get("mode2", 0)
+            t = o.get("Z2")
+            if t is not None:
+                v[F_Z2] = _mat(t, w)
+            t = o.get("add2")
+            if t is not None:
+                _source(v, t, 2, w)
+                has_src = True
+        elif kind == "scale":
+            Z, out = o["Z"], o["out"]
+            w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
+            v[F_kind], v[F_slot], v[F_a_slot], v[F_width], v[F_ld] = GN_OP_SCALE, o["slot"], o["a_slot"], w, w
+            v[F_alpha], v[F_act] = o["alpha"], o.get("mode", 0)
+            if Z is not None:
+                v[F_src] = _mat(Z, w)
+            if out is not None:
+                v[F_out] = _mat(out, w)
+            t = o.get("add")
+            if t is not None:
+                _source(v, t, 1, w)
+                has_src = True
+        else:   # store
+            out = o["out"]
+            v[F_kind], v[F_slot], v[F_width], v[F_ld], v[F_out] = GN_OP_STORE, o["slot"], out.shape[1], out.stride(0), _mat(out)
+        st.pack_into(buf, off, *v)
+        off += op_size
     if has_src and not nprod:
         raise RuntimeError("chain programs with second-order source terms run on the split-operand kernel only "
                            "(CHAIN_MODE f32 / an unsupported shape): use the composite training path")

@@ -384,7 +384,9 @@ class GemNet(torch.nn.Module):
         # force training: the Dense stacks as twice-differentiable single-launch Functions (ops_train.py), the rest on
         # the composite closure; the split-operand chain kernel only (its f32 sibling has no second-order source terms)
         mode = self.matmul_precision or K_chain_mode()
-        t2 = bool(graph) and ops.USE_TRAIN2 and not AutomaticFit.fitting_mode and mode != "f32"
+        # (one target: with several, each target's force pass would need its own record of the S2 / S3 sweeps per stack and
+        #  one source term per target in S4 — those models train on the composite closure)
+        t2 = bool(graph) and ops.USE_TRAIN2 and not AutomaticFit.fitting_mode and mode != "f32" and self.num_targets == 1
         with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w), \
                 ops.train2(t2, self._packs if (t2 and R.is_cuda) else None), \
                 ops.chain_mode(self.matmul_precision), torch.enable_grad() if not self.direct_forces else _nullcontext():

@@ -141,3 +141,34 @@ def test_position_gradient_of_the_force_loss(golden_model, tag):
             ops.USE_TRAIN2 = old
     assert float(grads[False].abs().max()) > 0
     torch.testing.assert_close(grads[True], grads[False], rtol=1e-8, atol=1e-10 * float(grads[False].abs().max()))
+
+
+def test_multi_target_models_train_on_the_composite_closure(golden_model2):
+    """num_targets = 2: one force pass per target over a shared graph (gemnet.py:599-609).  The fused training form keeps
+    ONE record of its sweeps per stack, so such models must not take it: the step runs on the composite closure and the
+    parameter gradients equal the ones with the fused form switched off."""
+    g = golden_model2
+    grads = {}
+    for train2 in (True, False):
+        cfg, params, inputs = load_case(g, "t1m")
+        old = ops.USE_TRAIN2
+        ops.USE_TRAIN2 = train2
+        cnt = Counter()
+        try:
+            with cpu_kernels.emulate():
+                f = K.chain
+                K.chain = lambda *a, _f=f, **k: (cnt.update(["chain"]), _f(*a, **k))[1]
+                try:
+                    model = build(cfg, params).train()
+                    inputs["R"] = inputs["R"].double()
+                    E, F = model(inputs)
+                    assert F.shape[1] == 2
+                    ((E ** 2).sum() + (F ** 2).sum()).backward()
+                finally:
+                    K.chain = f
+        finally:
+            ops.USE_TRAIN2 = old
+        assert cnt["chain"] == 0
+        grads[train2] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    for n in grads[False]:
+        torch.testing.assert_close(grads[True][n], grads[False][n], rtol=1e-10, atol=1e-12)
