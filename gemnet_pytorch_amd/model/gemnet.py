@@ -29,6 +29,8 @@ from .scaling import AutomaticFit
 
 
 _nullcontext = contextlib.nullcontext
+# A/B switch: one running gradient for rbf_out (five consumers on the side stream) instead of four engine-side adds
+_RBF_OUT_ACC = __import__("os").environ.get("GEMNET_RBF_OUT_ACC", "1") == "1"
 
 
 def K_chain_mode():
@@ -227,7 +229,9 @@ class GemNet(torch.nn.Module):
                     rbf_W1_3 = self.mlp_cbf3(rad3)
                     rbf_h = self.mlp_rbf_h(rbf)
                     # consumed by the five output blocks, all on this (side) stream: one running gradient
-                    rbf_out = ops.accumulate_gradient(self.mlp_rbf_out(rbf), stream=side)
+                    rbf_out = self.mlp_rbf_out(rbf)
+                    if _RBF_OUT_ACC:
+                        rbf_out = ops.accumulate_gradient(rbf_out, stream=side)
                     ev_b = torch.cuda.Event()
                     ev_b.record(side)
                 main.wait_event(ev_a)
@@ -292,7 +296,9 @@ class GemNet(torch.nn.Module):
         else:
             cbf3 = (ops.accumulate_gradient(self.mlp_cbf3(rad3)), sph3)
             rbf_h = ops.accumulate_gradient(self.mlp_rbf_h(rbf))
-            rbf_out = ops.accumulate_gradient(self.mlp_rbf_out(rbf), stream=side)
+            rbf_out = self.mlp_rbf_out(rbf)
+            if _RBF_OUT_ACC:
+                rbf_out = ops.accumulate_gradient(rbf_out, stream=side)
 
         # OutputBlock i only feeds the final energy sum: it runs on a side stream, concurrently with
         # InteractionBlock i+1 (and, since autograd replays a node on its forward stream, so does its

@@ -21,6 +21,7 @@ bound method, trainer.py:508).
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from .ddp import FlatGradBuffer, scale_shared_grads
 from .ema_decay import ExponentialMovingAverage
 from .schedules import LinearWarmupExponentialDecay, ReduceLROnPlateau
@@ -71,6 +72,7 @@ class Trainer:
                                  "force_nll", "force_var"] if mve
                                 else ["loss", "energy_mae", "force_mae", "force_rmse"])
         self._grads = None
+        self._wgrad = None
         self.reset_optimizer(learning_rate, weight_decay, warmup_steps, decay_steps, decay_rate, staircase,
                              decay_patience, decay_factor, decay_cooldown)
 
@@ -210,8 +212,19 @@ class Trainer:
 
         if self._grads is None:
             self._grads = FlatGradBuffer(self.model.parameters())
+            self._wgrad = None
+            if self._grads.params[0].is_cuda:
+                from .wgrad_queue import WeightGradQueue
+                self._wgrad = WeightGradQueue()   # all weight-gradient products of the step as one grouped launch
         self._grads.zero()
-        torch.autograd.backward(loss, inputs=self._grads.params)
+        # gradients w.r.t. the parameters only: the second-order POSITION terms of the fused geometry ops are not needed
+        if self._wgrad is None:
+            with ops.position_second_order_grads(False):
+                torch.autograd.backward(loss, inputs=self._grads.params)
+        else:
+            with ops.wgrad_queue(self._wgrad), ops.position_second_order_grads(False):
+                torch.autograd.backward(loss, inputs=self._grads.params)
+            self._wgrad.flush()
         self._grads.all_reduce()  # ONE collective (no-op in a single process)
         self.scale_shared_grads()
         if self.agc:
