@@ -29,8 +29,10 @@ from .scaling import AutomaticFit
 
 
 _nullcontext = contextlib.nullcontext
-# A/B switch: one running gradient for rbf_out (five consumers on the side stream) instead of four engine-side adds
-_RBF_OUT_ACC = __import__("os").environ.get("GEMNET_RBF_OUT_ACC", "1") == "1"
+# A/B switch: one running gradient for rbf_out (five consumers on the side stream) instead of four engine-side adds.
+# Off: same-box A/B on MI355X (profiles/r3_ab.txt) 2.777 / 2.747 ms with it, 2.729 / 2.685 ms without — the chained
+# in-place sums order the output blocks' adjoints behind each other, the engine's adds did not.
+_RBF_OUT_ACC = __import__("os").environ.get("GEMNET_RBF_OUT_ACC", "0") == "1"
 
 
 def K_chain_mode():
