@@ -20,6 +20,10 @@ PROB = np.dtype([("X", "<u8"), ("Y", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "
 TARGET = np.dtype([("out", "<u8"), ("n", "<i8"), ("slice_begin", "<i4"), ("slice_end", "<i4"), ("wg_begin", "<i4"),
                    ("cols", "<i4"), ("ld", "<i4"), ("pad", "<i4")])
 assert PROB.itemsize == 56 and TARGET.itemsize == 40
+# rows of the contraction per split-K slice.  A step queues ~480 products at once (1 900 output tiles of 64 x 64: the grid
+# is full without any split), and every slice costs a (M, N) partial written and folded again: see profiles/r3_ab.txt
+import os as _os
+SPLIT_ROWS = int(_os.environ.get("GEMNET_WGRAD_SPLIT_ROWS", "512"))
 
 
 def grad_target(P):
@@ -124,7 +128,7 @@ class WeightGradQueue:
             K, M = X.shape
             N = Y.shape[1]
             assert Y.shape[0] == K
-            splitk = max(1, min(64, K // 512))
+            splitk = max(1, min(64, K // SPLIT_ROWS))
             kchunk = (-(-K // splitk) + 15) // 16 * 16
             splitk = -(-K // kchunk)
             tiles = -(-M // 64) * -(-N // 64)
