@@ -23,7 +23,7 @@ assert PROB.itemsize == 56 and TARGET.itemsize == 40
 # rows of the contraction per split-K slice.  A step queues ~480 products at once (1 900 output tiles of 64 x 64: the grid
 # is full without any split), and every slice costs a (M, N) partial written and folded again: see profiles/r3_ab.txt
 import os as _os
-SPLIT_ROWS = int(_os.environ.get("GEMNET_WGRAD_SPLIT_ROWS", "512"))
+SPLIT_ROWS = int(_os.environ.get("GEMNET_WGRAD_SPLIT_ROWS", "2048"))
 
 
 def grad_target(P):

@@ -8,8 +8,10 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]))
 rows.sort()
-# a step = the kernels between two launches of the first kernel of the forward (edge_basis_fwd)
-starts = [i for i, r in enumerate(rows) if "edge_basis_fwd" in r[2]]
+# a step = the kernels between two launches of the first kernel of the forward (edge_basis_fwd; --marker=NAME for another
+# one: the training step starts with pack_weight_split_grouped)
+marker = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--marker=")), "edge_basis_fwd")
+starts = [i for i, r in enumerate(rows) if marker in r[2]]
 if len(starts) < 3:
     sys.exit("no steps found")
 a, b = starts[-2], starts[-1]
