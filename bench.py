@@ -212,6 +212,8 @@ class LaunchTimer:
                 finally:
                     self.depth -= 1
                 fl, by = self.cost(_name, args, kwargs, out)
+                if _name == "chain":   # the replay runs outside the sweep's arithmetic context (ops_train._sweep_mode)
+                    kwargs = dict(kwargs, mode=kwargs.get("mode") or self.K.CHAIN_MODE)
                 self.records.append((_name, _fn, args, kwargs, fl, by))
                 return out
 
@@ -333,8 +335,10 @@ def roofline_from(fam, mode="T"):
             out["mfma_busy_pct"] = mfma_busy(name, mode)
         if name == "chain" and K.CHAIN_MODE != "f32":
             # the Dense stacks execute on the bf16 pipe: fraction of THAT pipe's ceiling for this arithmetic
-            nprod = K.CHAIN_MODES[K.CHAIN_MODE]
-            out["executing_pipe"] = f"bf16 MFMA, {nprod} product(s) per fp32 product"
+            nprod = 3 if K.CHAIN_MODE == "h3" else K.CHAIN_MODES[K.CHAIN_MODE]
+            out["executing_pipe"] = (f"{'f16' if K.CHAIN_MODE == 'h3' else 'bf16'} MFMA, {nprod} product(s) per fp32 product"
+                                     + ("; the loss-scaled sweeps S3 / S4 of the training step run 6 bf16 products"
+                                        if K.CHAIN_MODE == "h3" and mode == "train" else ""))
             out["frac_of_executing_pipe"] = round(ach * nprod / PEAK_BF16_TFLOPS, 4)
             out["peak_executing_pipe_fp32_equiv"] = round(PEAK_BF16_TFLOPS / nprod, 1)
         if bound == "valu":
@@ -654,8 +658,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `extra` object (training step, isolated InteractionBlock, GemNet-Q, dynamic shapes)")
-    ap.add_argument("--chain-mode", choices=["f32", "split6", "split3", "bf16"], default=None,
-                    help="arithmetic of the Dense stacks (default: kernels.CHAIN_MODE = split6, fp32-equivalent)")
+    ap.add_argument("--chain-mode", choices=["f32", "split6", "h3", "split3", "bf16"], default=None,
+                    help="arithmetic of the Dense stacks (default: kernels.CHAIN_MODE = h3, fp32 operands as two fp16 planes)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: launch the ranks, shard the global batch, run one gloo all-reduce and print the JSON "
                          "skeleton (proves the N-rank launch path on a machine without GPUs; tests/test_bench_cpu.py)")
@@ -801,6 +805,7 @@ def main():
                        "mode": args.mode, "hipgraph": bool(graph), "per_gpu": sizes,
                        "dense_stack_arithmetic": {"f32": "v_mfma_f32_16x16x4_f32",
                                                   "split6": "fp32 operands as 3 bf16 planes, 6 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (fp32-equivalent: dropped terms < 2^-24)",
+                                                  "h3": "fp32 operands as 2 fp16 planes (hi + 2^-11 lo, 22 significand bits), 3 products on v_mfma_f32_16x16x32_f16, fp32 accumulate (operand rounding 2^-22: force MAE 1e-6 eV/A against float64)",
                                                   "split3": "3 bf16-plane products, fp32 accumulate",
                                                   "bf16": "bf16 operands, fp32 accumulate"}[K.CHAIN_MODE],
                        "parallelism": f"dp{world} (independent molecule shards, no data-path collective"

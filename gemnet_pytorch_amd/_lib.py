@@ -73,6 +73,7 @@ SIGNATURES = {
     "gn_chain_f32": [_vp, _vp],               # const gn_chain_args* (kernels.chain packs the block with `struct`)
     "gn_chain_split_f32": [_vp, _i, _vp],
     "gn_pack_weight_split": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "gn_pack_weight_split_fmt": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "gn_pack_weight_split_grouped": [_vp, _i, _i, _vp],
     "gn_gemm_tn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "gn_gemm_tn_splitk": [_i, _i, _i],

@@ -342,6 +342,7 @@ extern "C" int gn_chain_f32(const gn_chain_args* args, void* stream) {
     const gn_chain_op& o = args->ops[i];
     // the second-order source terms (training step) exist on the split-operand kernel only: fail loudly, never drop them
     if (o.src_stage != 0) return (int)hipErrorInvalidValue;
+    if (o.kind == GN_OP_GEMM && (o.act & ~1) != 0) return (int)hipErrorInvalidValue;   // pre_out = ssilu'(z): chain2.hip only
     if (o.kind == GN_OP_GEMM) {
       if (o.N <= 0 || o.N > SW || o.K <= 0 || o.K > SW || (o.K % 16) != 0) return (int)hipErrorInvalidValue;
       if (o.a_slot < 0 || o.a_slot >= NSLOT || o.slot >= NSLOT || o.y2_slot >= NSLOT) return (int)hipErrorInvalidValue;

@@ -30,6 +30,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 
 // Diagnosis switches of the trace build (never defined in the product library; GN_TRACE_DEFS of tools/chain2_trace.py):
 //   GN_EXP == 1  the MFMA phase without its LDS fragment reads (pipe time alone)
@@ -80,6 +82,86 @@ __device__ __forceinline__ float4 join4(const uint2 H, const uint2 M, const uint
                      (bf_lo(H.y) + bf_lo(M.y)) + bf_lo(L.y), (bf_hi(H.y) + bf_hi(M.y)) + bf_hi(L.y));
 }
 
+// The two-plane fp16 form (format H): x ~= hi + 2^-11 lo with hi = f16(x), lo = f16((x - hi) * 2^11) — 22 significand
+// bits; three products hh + 2^-11 (hl + lh) (the correction terms accumulate in their own registers and are scaled once),
+// the dropped ll term is below 2^-22 of the product.  Error-corrected half-precision GEMM in the manner of Ootomo & Yokota
+// (2022); fp16 keeps 11 bits per plane where bf16 keeps 8, so two planes and three MFMAs do the work of three and six.
+// Range: |x| < 65504 (larger values become inf and propagate: loud), full accuracy for |x| >= 2^-14 relative to the
+// largest operands of a dot product — activations and first-order adjoints of the model; NOT for quantities whose
+// magnitude follows an arbitrary loss scale (sweeps S3 / S4 of force training keep the bf16 planes).
+constexpr float H_UP = 2048.f, H_DOWN = 1.f / 2048.f;
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {
+  f32x2v v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2v));   // round to nearest even, a in the low half
+}
+// v_fma_mix_f32 reads an fp16 half-register as an fma operand (no separate conversion): 12 instead of 16 VALU ops per split,
+// 4 instead of 12 per join.  All of it exact: x - hi is representable in fp32 and so is every partial result.
+// fmix_lo / fmix_hi: fma(f16 low / high half of h, b, c)
+__device__ __forceinline__ float fmix_lo(uint32_t h, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fmix_hi(uint32_t h, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(b), "v"(c));
+  return d;
+}
+// fma(f16 half of l, b, f16 half of h)
+__device__ __forceinline__ float fmix2_lo(uint32_t l, float b, uint32_t h) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(l), "v"(b), "v"(h));
+  return d;
+}
+__device__ __forceinline__ float fmix2_hi(uint32_t l, float b, uint32_t h) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(l), "v"(b), "v"(h));
+  return d;
+}
+__device__ __forceinline__ void split4h(const float4 x, uint2& H, uint2& L) {
+  H.x = pk_f16(x.x, x.y); H.y = pk_f16(x.z, x.w);
+  L.x = pk_f16(fmix_lo(H.x, -H_UP, x.x * H_UP), fmix_hi(H.x, -H_UP, x.y * H_UP));
+  L.y = pk_f16(fmix_lo(H.y, -H_UP, x.z * H_UP), fmix_hi(H.y, -H_UP, x.w * H_UP));
+}
+__device__ __forceinline__ float4 join4h(const uint2 H, const uint2 L) {
+  return make_float4(fmix2_lo(L.x, H_DOWN, H.x), fmix2_hi(L.x, H_DOWN, H.x), fmix2_lo(L.y, H_DOWN, H.y), fmix2_hi(L.y, H_DOWN, H.y));
+}
+
+// Row scale of format H in LINEAR programs (no activation: adjoint sweeps, whose rows may be arbitrarily small):
+// sigma = 2^k with sigma * max|row| in [2^-4, 2^-3) — 2^18 of head room for what the program computes from the row before
+// fp16 overflows, elements down to 2^-10 of the row maximum at full accuracy.  Exact (power of two); 1 for a zero row.
+__device__ __forceinline__ float row_sigma(float m) {
+  const uint32_t e = __float_as_uint(m) >> 23;                 // m >= 0: biased exponent
+  const uint32_t ec = e < 4u ? 4u : (e > 250u ? 250u : e);
+  return m > 0.f ? __uint_as_float((250u - ec) << 23) : 1.f;    // 2^(123 - e)
+}
+// max over the w4 (8 / 16 / 32) consecutive lanes that hold one row, in every lane of the group: DPP butterflies inside the
+// 16-lane rows and one v_permlane16_swap across the row pair — the ds_bpermute form (__shfl_xor) cost 3.8 k cycles per LOAD
+__device__ __forceinline__ float group_max(float m, int w4) {
+#define GN2_DPP_MAX(ctrl) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), ctrl, 0xf, 0xf, true)))
+  GN2_DPP_MAX(0xB1);    // quad_perm [1,0,3,2]
+  GN2_DPP_MAX(0x4E);    // quad_perm [2,3,0,1]
+  GN2_DPP_MAX(0x141);   // row_half_mirror
+  if (w4 >= 16) GN2_DPP_MAX(0x140);   // row_mirror
+#undef GN2_DPP_MAX
+  if (w4 >= 32) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  return m;
+}
+__device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
+
+// 16 bytes per lane, global -> LDS at lds_base + 16 * lane, no registers (global_load_lds_dwordx4, M0 = LDS base).
+// Inline asm on purpose: with the builtin the compiler orders EVERY later ds_read behind the transfer (it cannot tell the
+// staging area from the operand planes) and the MFMA phase waited for the loads it was meant to hide (3.2 k -> 7.4 k cycles).
+// The consumer waits with an explicit s_waitcnt vmcnt(0); the compiler's own vmcnt bookkeeping stays conservative-correct
+// (returns are in order: extra transfers in flight only make its waits cover more).
+__device__ __forceinline__ void g2lds16(const float* gptr, uint32_t lds_base) {
+  const uint32_t base = __builtin_amdgcn_readfirstlane(lds_base);     // wave-uniform by construction
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(base) : "m0", "memory");
+}
+
 // s = src_alpha * phis(z) * p * q  (second-order source term, include/gemnet_hip.h); z is only read when mode == 1
 __device__ __forceinline__ float4 src_term(const float4 z, const float4 p, const float4 q, const int mode, const float a) {
   float4 s = make_float4(a * p.x * q.x, a * p.y * q.y, a * p.z * q.z, a * p.w * q.w);
@@ -91,11 +173,14 @@ __device__ __forceinline__ float4 src_term(const float4 z, const float4 p, const
 // ADJ: the program uses the register parking slot or second outputs (the adjoint programs); plain forward stacks run the
 // leaner variant (park / y2 registers would push the RT = 5 kernel into scratch, and a kernel with a scratch segment pays
 // ~1 us more per launch).
-template <int RT, int NPL, bool ADJ>
+// HF: the two-plane fp16 format (NPL = 2 there: both planes enter the MFMAs, three products)
+template <int RT, int NPL, bool ADJ, bool HF>
 __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) {
+  static_assert(!HF || NPL == 2, "format H has two planes");
   constexpr int BM = 16 * RT;
   constexpr int PLANE = BM * ROWB;          // bytes of one plane
-  constexpr int SLOT = 3 * PLANE;           // bytes of one slot (always three planes: exact fp32 content)
+  constexpr int SP = HF ? 2 : 3;            // planes of a slot (bf16: always three, exact fp32 content) and of a packed weight
+  constexpr int SLOT = SP * PLANE;          // bytes of one slot
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
@@ -108,17 +193,34 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
   // at the top of every GEMM op and must not wait for a scalar load of its descriptor from the kernarg segment
   __shared__ const void* gemm_W[GN_CHAIN_MAX_OPS + 2];
   __shared__ int gemm_NK[GN_CHAIN_MAX_OPS + 2];
+  // format H: row scales of the two LDS slots.  `rs` is the copy the row-linear ops (LOAD / SCALE / STORE) use, `sg` the
+  // register copy in accumulator layout (rows 16 t + l15) that the GEMM epilogues use and update without LDS traffic.
+  __shared__ float rs[2][16 * 5];
+  __shared__ int prog_linear;
   if (tid == 0) {
-    int g = 0;
+    int g = 0, lin = 1;
     for (int j = 0; j < P.n_ops; ++j)
       if (P.ops[j].kind == GN_OP_GEMM) {
         gemm_W[g] = P.ops[j].W;
         gemm_NK[g++] = (P.ops[j].N << 16) | P.ops[j].K;
+        if (P.ops[j].act & 1) lin = 0;
       }
     gemm_W[g] = gemm_W[g + 1] = nullptr;
     gemm_NK[g] = gemm_NK[g + 1] = 0;
+    prog_linear = lin;
   }
+  if (HF && tid < 2 * 16 * 5) (&rs[0][0])[tid] = 1.f;
   __syncthreads();
+#ifdef GN_H3_NOSCALE   // diagnosis build only (tools/chain2_trace.py): the cost of the row scales
+  const bool scaled = false;
+#else
+  const bool scaled = HF && prog_linear != 0;   // uniform
+#endif
+  float sg[2][HF ? RT : 1];
+#pragma unroll
+  for (int t = 0; t < (HF ? RT : 1); ++t) sg[0][t] = sg[1][t] = 1.f;
+  auto sg_get = [&](int slot, int t) -> float { return HF ? (slot ? sg[1][HF ? t : 0] : sg[0][HF ? t : 0]) : 1.f; };
+  auto sg_set = [&](int slot, int t, float v) { if (HF) { if (slot) sg[1][HF ? t : 0] = v; else sg[0][HF ? t : 0] = v; } };
 
   // weight fragments of one GEMM op: [k-chunk c][plane p] -> 8 bf16 (A operand rows = this wave's 16 weight rows)
   uint4 bcur[4][NPL];
@@ -126,13 +228,13 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
     // packed layout: [col tile][k-chunk][plane (3)][lane][8 bf16]
     const int nk = __builtin_amdgcn_readfirstlane(gemm_NK[ord]);
     const int N = nk >> 16, kc = ((nk & 0xffff) + 31) >> 5;
-    const uint4* __restrict__ base = reinterpret_cast<const uint4*>(gemm_W[ord]) + ((size_t)wave * kc * 3) * 64 + lane;
+    const uint4* __restrict__ base = reinterpret_cast<const uint4*>(gemm_W[ord]) + ((size_t)wave * kc * SP) * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
         dst[c][p] = make_uint4(0u, 0u, 0u, 0u);
-        if (wave * 16 < N && c < kc) dst[c][p] = base[(c * 3 + p) * 64];
+        if (wave * 16 < N && c < kc) dst[c][p] = base[(c * SP + p) * 64];
       }
   };
   // One fragment set: the NEXT GEMM's weights are requested right after the current op's MFMA phase (its fragments
@@ -150,33 +252,49 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
   for (int t = 0; t < (ADJ ? RT : 1); ++t) park[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto plane_ptr = [&](int slot, int p) -> unsigned char* { return smem + slot * SLOT + p * PLANE; };
+  // format H leaves LDS room for a per-wave staging area (RT KB per wave): the global factor of a GEMM epilogue (`mul_g`)
+  // is requested before the MFMA phase with global_load_lds (no registers) and read back lane-privately after it
+  unsigned char* const stage = smem + 2 * SLOT + wave * (RT * 1024);
+  const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)stage;   // LDS byte address
   // accumulator-layout element block of this lane in row block t: row 16t + l15, columns 16 wave + 4 lg .. +3
   // byte offset of columns col .. col+3 (col % 4 == 0) of row `row` inside a plane
   auto sw_off = [&](int row, int col) -> int { return row * ROWB + ((((col >> 3) ^ row) & 15) << 4) + ((col & 4) << 1); };
-  auto slot_read_acc = [&](int slot, int t) -> float4 {
-    const int off = sw_off(16 * t + l15, wave * 16 + (lg << 2));
-    const uint2 H = *reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off);
-    const uint2 Mi = *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off);
-    const uint2 L = *reinterpret_cast<const uint2*>(plane_ptr(slot, 2) + off);
-    return join4(H, Mi, L);
-  };
   auto slot_write = [&](int slot, int row, int col, const float4 v) {
-    uint2 H, Mi, L;
-    split4(v, H, Mi, L);
     const int off = sw_off(row, col);
-    *reinterpret_cast<uint2*>(plane_ptr(slot, 0) + off) = H;
-    *reinterpret_cast<uint2*>(plane_ptr(slot, 1) + off) = Mi;
-    *reinterpret_cast<uint2*>(plane_ptr(slot, 2) + off) = L;
+    if constexpr (HF) {
+      uint2 H, L;
+      split4h(v, H, L);
+      *reinterpret_cast<uint2*>(plane_ptr(slot, 0) + off) = H;
+      *reinterpret_cast<uint2*>(plane_ptr(slot, 1) + off) = L;
+    } else {
+      uint2 H, Mi, L;
+      split4(v, H, Mi, L);
+      *reinterpret_cast<uint2*>(plane_ptr(slot, 0) + off) = H;
+      *reinterpret_cast<uint2*>(plane_ptr(slot, 1) + off) = Mi;
+      *reinterpret_cast<uint2*>(plane_ptr(slot, 2) + off) = L;
+    }
   };
   auto slot_read = [&](int slot, int row, int col) -> float4 {
     const int off = sw_off(row, col);
-    return join4(*reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off),
-                 *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off),
-                 *reinterpret_cast<const uint2*>(plane_ptr(slot, 2) + off));
+    if constexpr (HF)
+      return join4h(*reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off),
+                    *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off));
+    else
+      return join4(*reinterpret_cast<const uint2*>(plane_ptr(slot, 0) + off),
+                   *reinterpret_cast<const uint2*>(plane_ptr(slot, 1) + off),
+                   *reinterpret_cast<const uint2*>(plane_ptr(slot, 2) + off));
+  };
+  auto mul4 = [](float4 v, float a) -> float4 { return make_float4(v.x * a, v.y * a, v.z * a, v.w * a); };
+  // accumulator-layout read of an LDS slot in TRUE scale
+  auto slot_read_acc = [&](int slot, int t) -> float4 {
+    const float4 v = slot_read(slot, 16 * t + l15, wave * 16 + (lg << 2));
+    return HF ? mul4(v, inv_pow2(sg_get(slot, t))) : v;
   };
 
   for (int oi = 0; oi < P.n_ops; ++oi) {
-    const gn_chain_op op = P.ops[oi];   // by value: the whole descriptor in one round of scalar loads, one wait
+    // by value: the whole descriptor in one round of scalar loads, one wait.  (Staging the descriptors in LDS and reading
+    // them back through v_readfirstlane was measured: the gap between ops grew from 0.6 - 0.9 k to 1.2 - 1.5 k cycles.)
+    const gn_chain_op op = P.ops[oi];
     const int kind = op.kind;
     GN2_STAMP(0);
     if (kind == GN_OP_LOAD) {
@@ -211,13 +329,27 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
           if (ADJ && y2_slot >= 0 && Z2) zz[i] = *reinterpret_cast<const float4*>(Z2 + gr * width + c);
         }
       }
+      float sig[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        v[i].x *= alpha; v[i].y *= alpha; v[i].z *= alpha; v[i].w *= alpha;
+        sig[i] = 1.f;
+      }
+      if (scaled && (w4 == 8 || w4 == 16 || w4 == 32)) {
+        // row maximum over the w4 consecutive lanes that hold the row (w4 divides the wave and NT); other widths: unscaled
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const float m = fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+          sig[i] = row_sigma(group_max(m, w4));
+        }
+      }
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
         const int f = tid + i * NT;
         if (f < BM * w4) {
           const int r = f / w4, c = (f - r * w4) << 2;
-          v[i].x *= alpha; v[i].y *= alpha; v[i].z *= alpha; v[i].w *= alpha;
-          slot_write(slot, r, c, v[i]);
+          slot_write(slot, r, c, HF ? mul4(v[i], sig[i]) : v[i]);
+          if (HF && c == 0) { rs[slot][r] = sig[i]; if (ADJ && y2_slot >= 0) rs[y2_slot][r] = sig[i]; }
           if (ADJ && y2_slot >= 0) {   // second tensor derived from the loaded rows: v * alpha2 * phi2(Z2)
             float4 u = make_float4(v[i].x * alpha2, v[i].y * alpha2, v[i].z * alpha2, v[i].w * alpha2);
             if (Z2 && in[i]) {
@@ -233,12 +365,19 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
               const float4 sv = src_term(zz[i], p, q, src_mode, src_alpha);
               u.x += sv.x; u.y += sv.y; u.z += sv.z; u.w += sv.w;
             }
-            slot_write(y2_slot, r, c, u);
+            slot_write(y2_slot, r, c, HF ? mul4(u, sig[i]) : u);
           }
         }
       }
       GN2_STAMP(3);
       lds_barrier();
+      if (HF) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          sg_set(slot, t, rs[slot][16 * t + l15]);
+          if (ADJ && y2_slot >= 0) sg_set(y2_slot, t, rs[y2_slot][16 * t + l15]);
+        }
+      }
       GN2_STAMP(4);
     } else if (kind == GN_OP_SCALE) {
       const int slot = op.slot, a_slot = op.a_slot, ld = op.ld, width = op.width;
@@ -261,8 +400,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         for (int f = tid; f < BM * w4; f += NT) {
           const int r = f / w4, c = (f - r * w4) << 2;
           const int64_t gr = row0 + r;
+          const float sc = HF ? rs[a_slot][r] : 1.f;       // the output inherits the row scale of its operand
           float4 v = slot_read(a_slot, r, c);
-          v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+          const float a_true = HF ? alpha * inv_pow2(sc) : alpha;
+          v.x *= a_true; v.y *= a_true; v.z *= a_true; v.w *= a_true;
           float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
           if (src && gr < M) {
             z = *reinterpret_cast<const float4*>(src + gr * ld + c);
@@ -276,10 +417,15 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
             const float4 sv = src_term(z, p, q, op.src_mode, op.src_alpha);
             v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
           }
-          slot_write(slot, r, c, v);
+          slot_write(slot, r, c, HF ? mul4(v, sc) : v);
+          if (HF && c == 0 && slot != a_slot) rs[slot][r] = sc;
           if (out && gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = v;
         }
         lds_barrier();
+        if (HF) {
+#pragma unroll
+          for (int t = 0; t < RT; ++t) sg_set(slot, t, sg_get(a_slot, t));
+        }
       }
     } else if (kind == GN_OP_STORE) {
       const int w4 = op.width >> 2, slot = op.slot, ld = op.ld;
@@ -287,11 +433,15 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       for (int f = tid; f < BM * w4; f += NT) {
         const int r = f / w4, c = (f - r * w4) << 2;
         const int64_t gr = row0 + r;
-        if (gr < M) *reinterpret_cast<float4*>(out + gr * ld + c) = slot_read(slot, r, c);
+        if (gr < M) {
+          const float4 v = slot_read(slot, r, c);
+          *reinterpret_cast<float4*>(out + gr * ld + c) = HF ? mul4(v, inv_pow2(rs[slot][r])) : v;
+        }
       }
       lds_barrier();
     } else {  // GN_OP_GEMM
-      const int N = op.N, K = op.K, a_slot = op.a_slot, y_slot = op.slot, act = op.act;
+      const int N = op.N, K = op.K, a_slot = op.a_slot, y_slot = op.slot, act = op.act & 1;
+      const bool pre_deriv = (op.act & 2) != 0;
       const float alpha = op.alpha, beta = op.beta, beta2 = op.beta2;
       const float* __restrict__ const gadd1 = op.gadd1;
       const float* __restrict__ const gadd2 = op.gadd2;
@@ -319,6 +469,19 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
 #endif
       GN2_STAMP(1);
 
+#ifdef GN_NO_STAGE     // diagnosis build only
+      const bool staged = false;
+#else
+      const bool staged = HF && active && mul_g != nullptr && mul_slot < 0;
+#endif
+      if (HF && staged) {
+        const int n0 = wave * 16 + (lg << 2);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const int64_t grow = row0 + 16 * t + l15;
+          if (grow < M) g2lds16(mul_g + (uint32_t)grow * (uint32_t)N + (uint32_t)n0, stage_lds + t * 1024);
+        }
+      }
       // hh | the cross terms hm + mh + hl + lh + mm (summed among themselves first)
       constexpr int NACC = 2;
       v4f acc[NACC][RT];
@@ -334,7 +497,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         // (c, t) — the compiler's own schedule waited on lgkmcnt(0) in front of every group of six MFMAs.
         // The widest instance (adjoint programs at RT = 5) has no registers left for the third plane's second buffer:
         // there the lo plane — used by one MFMA, issued last — is read at the top of its own step.
-        constexpr bool LATE_LO = ADJ && RT == 5 && NPL >= 3;
+        constexpr bool LATE_LO = ADJ && RT == 5 && NPL >= 3 && !HF;
         constexpr int PD = 1;   // steps of look-ahead (PD + 1 register buffers); 2 and 3 measured: no change
         uint4 xf[PD + 1][3];
         auto xload = [&](uint4 (&f)[3], int c, int t) {
@@ -373,6 +536,14 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
                 GN2_ACC(0)[0] += __uint_as_float(q.x); GN2_ACC(0)[1] += __uint_as_float(q.y); GN2_ACC(0)[2] += __uint_as_float(q.z); GN2_ACC(0)[3] += __uint_as_float(q.w); }
               continue;
 #endif
+              if constexpr (HF) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, bcur[c][0]), al = __builtin_bit_cast(f16x8, bcur[c][NPL >= 2 ? 1 : 0]);
+                const f16x8 yh = __builtin_bit_cast(f16x8, xf[cur][0]), yl = __builtin_bit_cast(f16x8, xf[cur][1]);
+                GN2_ACC(0) = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh, GN2_ACC(0), 0, 0, 0);
+                GN2_ACC(1) = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, GN2_ACC(1), 0, 0, 0);
+                GN2_ACC(2) = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, GN2_ACC(2), 0, 0, 0);
+                continue;
+              }
               const bf16x8 xh = __builtin_bit_cast(bf16x8, xf[cur][0]);
               bf16x8 xm, xl;
               if (NPL >= 2) xm = __builtin_bit_cast(bf16x8, xf[cur][1]);
@@ -394,8 +565,22 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
       float4 v[RT];            // the three partial sums collapse here: their registers are free for the prefetch below
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        const v4f s = NPL >= 2 ? acc[0][t] + acc[1][t] : acc[0][t];
+        const v4f s = HF ? acc[0][t] + acc[1][t] * H_DOWN : (NPL >= 2 ? acc[0][t] + acc[1][t] : acc[0][t]);
         v[t] = make_float4(s[0], s[1], s[2], s[3]);
+      }
+      // format H: the products are sigma_a times the true values; what this op leaves in LDS takes the smallest scale
+      // (= the largest magnitude) among its LDS operands.  Every wave keeps its register copy current, active or not.
+      float sy[HF ? RT : 1];
+      if (HF) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const float sa = sg_get(a_slot, t);
+          v[t] = mul4(v[t], inv_pow2(sa));
+          float m = sa;
+          if (res_slot == 0 || res_slot == 1) m = fminf(m, sg_get(res_slot, t));
+          if (res2_slot == 0 || res2_slot == 1) m = fminf(m, sg_get(res2_slot, t));
+          sy[HF ? t : 0] = m;
+        }
       }
 #undef GN2_ACC
       wload_op(bcur, gord);   // next GEMM's fragments (no-op after the last one): in flight under the epilogue
@@ -433,8 +618,17 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
                    if (ok[t]) q[t] = *reinterpret_cast<const float4*>(gadd2 + (size_t)gidx2[row0 + 16 * t + l15] * N + n0);)
           GN2_EACH(GN2_ADD(q[t]))
         }
-        if (pre_out) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(pre_out + off[t]) = v[t];)
-        if (act) GN2_EACH(v[t].x = gn_ssilu(v[t].x); v[t].y = gn_ssilu(v[t].y); v[t].z = gn_ssilu(v[t].z); v[t].w = gn_ssilu(v[t].w);)
+        if (pre_out && !pre_deriv) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(pre_out + off[t]) = v[t];)
+        if (act && pre_out && pre_deriv) {
+          // the activation and its derivative from ONE sigmoid; `pre_out` receives ssilu'(z): a first-order adjoint then
+          // multiplies by a stored factor instead of evaluating exp + rcp per element again (its epilogue was VALU-bound:
+          // 4.5 k cycles per op against 2.2 k, tools/chain2_trace.py --adj)
+          GN2_EACH(
+            float4 d;
+            gn_ssilu_pair(v[t].x, v[t].x, d.x); gn_ssilu_pair(v[t].y, v[t].y, d.y);
+            gn_ssilu_pair(v[t].z, v[t].z, d.z); gn_ssilu_pair(v[t].w, v[t].w, d.w);
+            if (ok[t]) *reinterpret_cast<float4*>(pre_out + off[t]) = d;)
+        } else if (act) GN2_EACH(v[t].x = gn_ssilu(v[t].x); v[t].y = gn_ssilu(v[t].y); v[t].z = gn_ssilu(v[t].z); v[t].w = gn_ssilu(v[t].w);)
         const bool want2 = ADJ && (y2_slot >= 0 || out2);
         // second output = v * alpha2 * phi2(Z2), written straight from the current value of v (no copy is kept):
         // before the `mul` stage when y2_src = 1, after the last stage otherwise
@@ -458,14 +652,20 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
             })
           }
           if (out2) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(out2 + off[t]) = q[t];)
-          if (y2_slot >= 0) GN2_EACH(slot_write(y2_slot, 16 * t + l15, n0, ok[t] ? q[t] : make_float4(0.f, 0.f, 0.f, 0.f));)
+          if (y2_slot >= 0) GN2_EACH(slot_write(y2_slot, 16 * t + l15, n0, ok[t] ? (HF ? mul4(q[t], sy[HF ? t : 0]) : q[t]) : make_float4(0.f, 0.f, 0.f, 0.f));)
         };
         if (want2 && y2_src) emit_y2();
         if (ADJ && mul_slot == 2) GN2_EACH(GN2_MUL(park[ADJ ? t : 0]))
         else if (mul_slot >= 0) GN2_EACH(const float4 q = slot_read_acc(mul_slot, t); GN2_MUL(q))
         else if (mul_g) {
           float4 q[RT];
-          GN2_EACH(q[t] = make_float4(1.f, 1.f, 1.f, 1.f); if (ok[t]) q[t] = *reinterpret_cast<const float4*>(mul_g + off[t]);)
+          if (HF && staged) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS writes of the staged loads have landed
+            GN2_EACH(q[t] = make_float4(1.f, 1.f, 1.f, 1.f);
+                     if (ok[t]) q[t] = *reinterpret_cast<const float4*>(stage + t * 1024 + lane * 16);)
+          } else {
+            GN2_EACH(q[t] = make_float4(1.f, 1.f, 1.f, 1.f); if (ok[t]) q[t] = *reinterpret_cast<const float4*>(mul_g + off[t]);)
+          }
           if (mul_mode == 2) GN2_EACH(q[t] = make_float4(gn_dssilu(q[t].x), gn_dssilu(q[t].y), gn_dssilu(q[t].z), gn_dssilu(q[t].w));)
           else if (mul_mode == 3) GN2_EACH(q[t] = make_float4(gn_ssilu(q[t].x), gn_ssilu(q[t].y), gn_ssilu(q[t].z), gn_ssilu(q[t].w));)
           GN2_EACH(GN2_MUL(q[t]))
@@ -498,7 +698,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         }
         if (out) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(out + off[t]) = v[t];)
         if (ADJ && y_slot == 2) GN2_EACH(park[ADJ ? t : 0] = v[t];)
-        else if (y_slot >= 0) GN2_EACH(slot_write(y_slot, 16 * t + l15, n0, ok[t] ? v[t] : make_float4(0.f, 0.f, 0.f, 0.f));)
+        else if (y_slot >= 0) GN2_EACH(slot_write(y_slot, 16 * t + l15, n0, ok[t] ? (HF ? mul4(v[t], sy[HF ? t : 0]) : v[t]) : make_float4(0.f, 0.f, 0.f, 0.f));)
         if (want2 && !y2_src) emit_y2();
 #undef GN2_EACH
 #undef GN2_ADD
@@ -510,6 +710,15 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
 #pragma unroll
         for (int t = 0; t < RT; ++t) slot_write(y_slot, 16 * t + l15, n0, make_float4(0.f, 0.f, 0.f, 0.f));
       }
+      if (HF) {
+        // nobody reads `rs` inside a GEMM op (the epilogue uses the registers): wave 0 refreshes the LDS copy
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const float m = sy[HF ? t : 0];
+          if (y_slot == 0 || y_slot == 1) { sg_set(y_slot, t, m); if (wave == 0 && lg == 0) rs[y_slot][16 * t + l15] = m; }
+          if (ADJ && y2_slot >= 0) { sg_set(y2_slot, t, m); if (wave == 0 && lg == 0) rs[y2_slot][16 * t + l15] = m; }
+        }
+      }
       GN2_STAMP(3);
       lds_barrier();
       GN2_STAMP(4);
@@ -517,45 +726,65 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
   }
 }
 
-template <int RT, int NPL, bool ADJ>
+template <int RT, int NPL, bool ADJ, bool HF>
 int launch_chain_split(const gn_chain_args* args, hipStream_t st) {
   constexpr int BM = 16 * RT;
-  constexpr size_t smem = (size_t)2 * 3 * BM * ROWB;
+  constexpr size_t smem = (size_t)2 * (HF ? 2 : 3) * BM * ROWB + (HF ? (size_t)8 * RT * 1024 : 0);
   static bool configured = false;   // idempotent attribute; a benign race sets it twice
   if (!configured) {
     if (smem > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_split_kernel<RT, NPL, ADJ>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_split_kernel<RT, NPL, ADJ, HF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
     configured = true;
   }
-  hipLaunchKernelGGL((chain_split_kernel<RT, NPL, ADJ>), dim3(gn_cdiv(args->M, BM)), dim3(NT), smem, st, *args);
+  hipLaunchKernelGGL((chain_split_kernel<RT, NPL, ADJ, HF>), dim3(gn_cdiv(args->M, BM)), dim3(NT), smem, st, *args);
   GN_LAUNCH_CHECK();
   return 0;
 }
 
-template <int NPL, bool ADJ>
+template <int NPL, bool ADJ, bool HF>
 int dispatch_rt(const gn_chain_args* args, hipStream_t st) {
   const int rt = gn_cdiv(args->M, 256 * 16);
   switch (rt <= 1 ? 1 : (rt >= 5 ? 5 : rt)) {
-    case 1: return launch_chain_split<1, NPL, ADJ>(args, st);
-    case 2: return launch_chain_split<2, NPL, ADJ>(args, st);
-    case 3: return launch_chain_split<3, NPL, ADJ>(args, st);
-    case 4: return launch_chain_split<4, NPL, ADJ>(args, st);
-    default: return launch_chain_split<5, NPL, ADJ>(args, st);
+    case 1: return launch_chain_split<1, NPL, ADJ, HF>(args, st);
+    case 2: return launch_chain_split<2, NPL, ADJ, HF>(args, st);
+    case 3: return launch_chain_split<3, NPL, ADJ, HF>(args, st);
+    case 4: return launch_chain_split<4, NPL, ADJ, HF>(args, st);
+    default: return launch_chain_split<5, NPL, ADJ, HF>(args, st);
   }
 }
 
-template <int NPL>
+template <int NPL, bool HF = false>
 int dispatch_adj(const gn_chain_args* args, bool adj, hipStream_t st) {
-  return adj ? dispatch_rt<NPL, true>(args, st) : dispatch_rt<NPL, false>(args, st);
+  return adj ? dispatch_rt<NPL, true, HF>(args, st) : dispatch_rt<NPL, false, HF>(args, st);
+}
+
+// eight consecutive k of one weight row -> the planes of (tile, chunk) unit tc: fmt 0 three bf16 planes, 1 two fp16 planes
+__device__ __forceinline__ void pack_unit(const float (&x)[8], uint4* __restrict__ out, int tc, int lane, int fmt) {
+  if (fmt == GN_SPLIT_F16X2) {
+    uint2 H0, L0, H1, L1;
+    split4h(make_float4(x[0], x[1], x[2], x[3]), H0, L0);
+    split4h(make_float4(x[4], x[5], x[6], x[7]), H1, L1);
+    uint4* dst = out + ((size_t)tc * 2) * 64 + lane;
+    dst[0] = make_uint4(H0.x, H0.y, H1.x, H1.y);
+    dst[64] = make_uint4(L0.x, L0.y, L1.x, L1.y);
+    return;
+  }
+  uint2 H0, M0, L0, H1, M1, L1;
+  split4(make_float4(x[0], x[1], x[2], x[3]), H0, M0, L0);
+  split4(make_float4(x[4], x[5], x[6], x[7]), H1, M1, L1);
+  uint4* dst = out + ((size_t)tc * 3) * 64 + lane;
+  dst[0] = make_uint4(H0.x, H0.y, H1.x, H1.y);
+  dst[64] = make_uint4(M0.x, M0.y, M1.x, M1.y);
+  dst[128] = make_uint4(L0.x, L0.y, L1.x, L1.y);
 }
 
 // W (N,K) row-major with pitch ldw (or, trans != 0, the (K,N) matrix whose transpose is the weight) -> fragment-major
 // planes [col tile][k-chunk][plane][lane][8]: lane (n = lane % 16, g = lane / 16) of (tile, chunk) holds
 // W[16 tile + n][32 chunk + 8 g + i], i = 0..7; rows >= N and columns >= K are zero.
-__global__ void pack_weight_split_kernel(const float* __restrict__ W, int N, int K, int ldw, int trans,
+__global__ void pack_weight_split_kernel(const float* __restrict__ W, int N, int K, int ldw, int trans, int fmt,
                                          uint4* __restrict__ out, int n_tiles, int kc) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (tile, chunk, lane)
   if (idx >= n_tiles * kc * 64) return;
@@ -567,13 +796,7 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ W, int N, int
     const int k = k0 + i;
     x[i] = (n < N && k < K) ? (trans ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k]) : 0.f;
   }
-  uint2 H0, M0, L0, H1, M1, L1;
-  split4(make_float4(x[0], x[1], x[2], x[3]), H0, M0, L0);
-  split4(make_float4(x[4], x[5], x[6], x[7]), H1, M1, L1);
-  uint4* dst = out + ((size_t)tc * 3) * 64 + lane;
-  dst[0] = make_uint4(H0.x, H0.y, H1.x, H1.y);
-  dst[64] = make_uint4(M0.x, M0.y, M1.x, M1.y);
-  dst[128] = make_uint4(L0.x, L0.y, L1.x, L1.y);
+  pack_unit(x, out, tc, lane, fmt);
 }
 
 // All weights of one training step in ONE launch: thread -> (job, tile, chunk, lane) by binary search over the jobs'
@@ -597,13 +820,7 @@ __global__ void pack_weight_split_grouped_kernel(const gn_pack_job* __restrict__
     const int k = k0 + i;
     x[i] = (n < j.N && k < j.K) ? (j.trans ? j.W[(size_t)k * j.ldw + n] : j.W[(size_t)n * j.ldw + k]) : 0.f;
   }
-  uint2 H0, M0, L0, H1, M1, L1;
-  split4(make_float4(x[0], x[1], x[2], x[3]), H0, M0, L0);
-  split4(make_float4(x[4], x[5], x[6], x[7]), H1, M1, L1);
-  uint4* dst = static_cast<uint4*>(j.out) + ((size_t)tc * 3) * 64 + lane;
-  dst[0] = make_uint4(H0.x, H0.y, H1.x, H1.y);
-  dst[64] = make_uint4(M0.x, M0.y, M1.x, M1.y);
-  dst[128] = make_uint4(L0.x, L0.y, L1.x, L1.y);
+  pack_unit(x, static_cast<uint4*>(j.out), tc, lane, j.fmt);
 }
 
 }  // namespace
@@ -626,21 +843,26 @@ extern "C" int64_t gn_pack_weight_split_bytes(int N, int K) {
   return (int64_t)gn_cdiv(N, 16) * gn_cdiv(K, 32) * 3 * 64 * 16;
 }
 
-extern "C" int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream) {
+extern "C" int gn_pack_weight_split_fmt(const float* W, int N, int K, int ldw, int trans, int fmt, void* out, void* stream) {
   if (N <= 0 || K <= 0) return 0;
+  if (fmt != GN_SPLIT_BF16X3 && fmt != GN_SPLIT_F16X2) return (int)hipErrorInvalidValue;
   const int n_tiles = gn_cdiv(N, 16), kc = gn_cdiv(K, 32);
   const int total = n_tiles * kc * 64;
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3(gn_cdiv(total, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), W, N, K, ldw, trans, static_cast<uint4*>(out), n_tiles, kc);
+                     static_cast<hipStream_t>(stream), W, N, K, ldw, trans, fmt, static_cast<uint4*>(out), n_tiles, kc);
   GN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream) {
+  return gn_pack_weight_split_fmt(W, N, K, ldw, trans, GN_SPLIT_BF16X3, out, stream);
 }
 
 extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* stream) {
   if (args->M <= 0 || args->n_ops <= 0) return 0;
   if (args->n_ops > GN_CHAIN_MAX_OPS) return (int)hipErrorInvalidValue;
   if (args->M > (1 << 24)) return (int)hipErrorInvalidValue;
-  if (nprod != 1 && nprod != 3 && nprod != 6) return (int)hipErrorInvalidValue;
+  if (nprod != 1 && nprod != 3 && nprod != 6 && nprod != GN_CHAIN_F16X2) return (int)hipErrorInvalidValue;
   for (int i = 0; i < args->n_ops; ++i) {
     const gn_chain_op& o = args->ops[i];
     if (o.kind == GN_OP_GEMM) {
@@ -674,6 +896,7 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
       adj = adj || o.slot == 2 || (o.kind == GN_OP_LOAD && o.y2_slot >= 0) || o.src_stage != 0;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nprod == GN_CHAIN_F16X2) return dispatch_adj<2, true>(args, adj, st);
   if (nprod == 6) return dispatch_adj<3>(args, adj, st);
   if (nprod == 3) return dispatch_adj<2>(args, adj, st);
   return dispatch_adj<1>(args, adj, st);

@@ -37,6 +37,13 @@ __device__ __forceinline__ float gn_dssilu(float x) {
   return s * (1.0f + x * (1.0f - s)) * GN_INV_06;
 }
 
+// f(x) and f'(x) from one sigmoid (x and y may alias)
+__device__ __forceinline__ void gn_ssilu_pair(float x, float& y, float& d) {
+  const float s = gn_sigmoid(x), xs = x * s;
+  d = (s + xs - xs * s) * GN_INV_06;
+  y = xs * GN_INV_06;
+}
+
 __device__ __forceinline__ float gn_d2ssilu(float x) {
   float s = gn_sigmoid(x);
   return s * (1.0f - s) * (2.0f + x * (1.0f - 2.0f * s)) * GN_INV_06;

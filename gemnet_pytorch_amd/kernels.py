@@ -508,16 +508,19 @@ class ChainProgram:
 
     def gemm(self, W, a_slot, y_slot=-1, act=False, alpha=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
              pre_out=None, mul=None, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0, out=None, packed=None,
-             mul_mode=1, y2=-1, y2_src=0, alpha2=1.0, Z2=None, mode2=0, out2=None, add=None, add2=None):
+             mul_mode=1, y2=-1, y2_src=0, alpha2=1.0, Z2=None, mode2=0, out2=None, add=None, add2=None, pre_deriv=False):
         """W: the (N,K) fp32 weight; `packed`: its split-bf16 fragment form (pack_weight_split(W)) if the caller
         caches it — the split-operand kernel packs on the fly otherwise.
         mul_mode (global `mul` only): 1 identity, 2 ssilu'(mul), 3 ssilu(mul).
         Second output: y2 (slot) / out2 (global) <- (y2_src ? activation output : final y) * alpha2 * phi2(Z2),
         phi2 by mode2: 0 ssilu', 1 identity, 2 ssilu (Z2 None: plain scale).
         add / add2: a source term (`source`) added to y after the mul and alpha stages (its ssilu'' factor reads the
-        GLOBAL mul operand) / to the second output (ssilu'' of Z2); at most one of them per op."""
+        GLOBAL mul operand) / to the second output (ssilu'' of Z2); at most one of them per op.
+        pre_deriv (with act and pre_out; split-operand kernel only): `pre_out` receives ssilu'(z) instead of z."""
         assert add is None or add2 is None, "one source term per op"
+        assert not pre_deriv or (act and pre_out is not None)
         self.ops.append(dict(kind="gemm", W=W, packed=packed, a_slot=a_slot, slot=y_slot, act=bool(act), alpha=float(alpha),
+                             pre_deriv=bool(pre_deriv),
                              add=add, add2=add2,
                              mul_mode=int(mul_mode), y2=int(y2), y2_src=int(y2_src), alpha2=float(alpha2), Z2=Z2,
                              mode2=int(mode2), out2=out2,
@@ -636,28 +639,51 @@ def _sel(x):
 
 # Arithmetic of the chain GEMMs: "f32" = v_mfma_f32_16x16x4_f32 (csrc/chain.hip); "split6" / "split3" / "bf16" =
 # bf16 matrix pipe with 6 / 3 / 1 products of split operands (csrc/chain2.hip; split6 is fp32-equivalent).
-CHAIN_MODES = {"f32": 0, "split6": 6, "split3": 3, "bf16": 1}
-CHAIN_MODE = os.environ.get("GEMNET_CHAIN_MODE", "split6")
+# nprod codes of gn_chain_split_f32: 6 / 3 / 1 products of bf16 planes; 2 = GN_CHAIN_F16X2, the two-plane fp16 form
+# (three products, csrc/chain2.hip "format H").  "h3" needs its weights packed with SPLIT_FORMAT 1.
+CHAIN_MODES = {"f32": 0, "split6": 6, "split3": 3, "bf16": 1, "h3": 2}
+SPLIT_FORMAT = {"split6": 0, "split3": 0, "bf16": 0, "h3": 1}
+CHAIN_MODE = os.environ.get("GEMNET_CHAIN_MODE", "h3")
+# The fp16 planes of "h3" cover the magnitudes the MODEL fixes (activations, first-order adjoints dE/d.): sweeps whose
+# scale follows the caller's loss (S3 / S4 and the energy-only final adjoint of force training, ops_train.py) run in this
+# mode instead when the stack's mode is "h3" — bf16 planes have the fp32 exponent range.
+CHAIN_MODE_LINEAR = os.environ.get("GEMNET_CHAIN_MODE_LINEAR", "split6")
+assert SPLIT_FORMAT.get(CHAIN_MODE_LINEAR) == 0, "GEMNET_CHAIN_MODE_LINEAR: one of the bf16-plane modes"
 
 
-def pack_weight_split(W, trans=False):
-    """(N,K) fp32 weight (or, trans, the (K,N) matrix whose transpose is the weight) -> packed bf16 planes (uint8)."""
+def linear_mode(mode):
+    """Arithmetic of the loss-scaled sweeps of a stack whose forward ran in `mode`."""
+    return CHAIN_MODE_LINEAR if mode == "h3" else mode
+
+
+def split_format(mode=None):
+    """Packed-weight format (GN_SPLIT_*) of a chain mode; None for the f32 kernel."""
+    return SPLIT_FORMAT.get(mode or CHAIN_MODE)
+
+
+def pack_weight_split(W, trans=False, fmt=None):
+    """(N,K) fp32 weight (or, trans, the (K,N) matrix whose transpose is the weight) -> packed planes (uint8) in the
+    format of the current chain mode (`fmt`: GN_SPLIT_BF16X3 = 0 three bf16 planes, GN_SPLIT_F16X2 = 1 two fp16 planes)."""
     require_device(W)
     W = _rowmajor(W)
+    if fmt is None:
+        fmt = split_format() or 0
     N, Kd = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
-    nbytes = -(-N // 16) * -(-Kd // 32) * 3 * 64 * 16
+    nbytes = -(-N // 16) * -(-Kd // 32) * (2 if fmt else 3) * 64 * 16
     out = torch.empty(nbytes, device=W.device, dtype=torch.uint8)
-    check(_lib.load().gn_pack_weight_split(ptr(W), N, Kd, W.stride(0), int(bool(trans)), ptr(out), stream()),
-          "gn_pack_weight_split")
+    check(_lib.load().gn_pack_weight_split_fmt(ptr(W), N, Kd, W.stride(0), int(bool(trans)), int(fmt), ptr(out), stream()),
+          "gn_pack_weight_split_fmt")
+    out._gn_fmt = fmt
     return out
 
 
 def pack_job_table(entries):
-    """Device job table (gn_pack_job) for `pack_weight_split_grouped`: entries = [(W, trans, packed uint8 tensor)].
+    """Device job table (gn_pack_job) for `pack_weight_split_grouped`: entries = [(W, trans, packed uint8 tensor)]; the
+    format of each job is the one its buffer was first packed in (`packed._gn_fmt`).
     -> (table tensor, total_units).  Host -> device copy: not inside a stream capture."""
     import numpy as np
     JOB = np.dtype([("W", "<u8"), ("out", "<u8"), ("N", "<i4"), ("K", "<i4"), ("ldw", "<i4"), ("trans", "<i4"),
-                    ("unit_begin", "<i4"), ("pad", "<i4")])
+                    ("unit_begin", "<i4"), ("fmt", "<i4")])
     assert JOB.itemsize == 40
     jobs = np.zeros(len(entries), dtype=JOB)
     unit = 0
@@ -665,7 +691,7 @@ def pack_job_table(entries):
         W = _rowmajor(W)
         assert W.data_ptr() == entries[i][0].data_ptr(), "registered weights must have unit inner stride"
         N, Kd = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
-        jobs[i] = (W.data_ptr(), packed.data_ptr(), N, Kd, W.stride(0), int(bool(trans)), unit, 0)
+        jobs[i] = (W.data_ptr(), packed.data_ptr(), N, Kd, W.stride(0), int(bool(trans)), unit, getattr(packed, "_gn_fmt", 0))
         unit += -(-N // 16) * -(-Kd // 32) * 64
     dev = entries[0][0].device
     table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
@@ -690,6 +716,35 @@ def chain_split_supported(prog):
         elif o["slot"] > 1 or o.get("y2", -1) > 1:
             return False
     return True
+
+
+def chain_is_linear(prog):
+    """No activation inside: an adjoint / tangent program, every LDS-resident value is linear in the loaded rows."""
+    return not any(o["kind"] == "gemm" and o["act"] for o in prog.ops)
+
+
+def h3_hazards(prog):
+    """Ops of a LINEAR program that the row-scaled fp16 form ("h3", csrc/chain2.hip) cannot take: the scale of a row
+    in LDS is fixed by the LOAD that brought it in and inherited by what is computed from it, so an op that ADDS a
+    global tensor of foreign magnitude (gathered rows, a global residual, a second-order source term) into a value that
+    stays in LDS may leave the fp16 range.  Non-linear programs (activations: O(1) by the model's normalisation) carry no
+    row scale and have no such restriction.  -> list of op indices."""
+    if not chain_is_linear(prog):
+        return []
+    bad = []
+    for i, o in enumerate(prog.ops):
+        if o["kind"] == "gemm":
+            stays = o["slot"] in (0, 1) or o.get("y2", -1) >= 0
+            foreign = (o["gadd1"] is not None or o["gadd2"] is not None or o.get("add") is not None
+                       or o.get("add2") is not None
+                       or any(o[k] is not None and not isinstance(o[k], int) for k in ("res", "res2")))
+            if stays and foreign:
+                bad.append(i)
+        elif o["kind"] == "scale" and o["slot"] in (0, 1) and o.get("add") is not None:
+            bad.append(i)
+        elif o["kind"] == "load" and o.get("add2") is not None:
+            bad.append(i)
+    return bad
 
 
 _CHAIN_PACK = None
@@ -752,6 +807,11 @@ def chain(prog, mode=None):
     nprod = CHAIN_MODES[mode or CHAIN_MODE]
     if nprod and not chain_split_supported(prog):
         nprod = 0
+    fmt = SPLIT_FORMAT.get(mode or CHAIN_MODE, 0)
+    if nprod == CHAIN_MODES["h3"] and h3_hazards(prog):
+        raise RuntimeError("chain: this linear program adds a global tensor into an LDS-resident value "
+                           f"(ops {h3_hazards(prog)}): not representable in the row-scaled fp16 form 'h3' — "
+                           "launch it in kernels.linear_mode('h3')")
     st, default, ops_off, op_size, args_size, hdr = _chain_packer()
     keep = []
     buf = bytearray(args_size)
@@ -769,13 +829,18 @@ def chain(prog, mode=None):
                 Wp = o.get("packed")     # with the packed planes given, `W` only carries the shape (any strides)
                 if Wp is None:
                     _mat(W)
-                    Wp = pack_weight_split(W)
+                    Wp = pack_weight_split(W, fmt=fmt)
+                elif getattr(Wp, "_gn_fmt", 0) != fmt:
+                    raise RuntimeError(f"chain: weight planes packed in format {getattr(Wp, '_gn_fmt', 0)} handed to a "
+                                       f"launch in mode {mode or CHAIN_MODE!r} (format {fmt})")
                 keep.append(Wp)
                 v[F_W] = Wp.data_ptr()
             else:
                 v[F_W] = _mat(W)
             v[F_kind], v[F_N], v[F_K], v[F_a_slot], v[F_slot] = GN_OP_GEMM, N, Kd, o["a_slot"], o["slot"]
-            v[F_act], v[F_alpha], v[F_beta], v[F_beta2] = int(o["act"]), o["alpha"], o["beta"], o["beta2"]
+            v[F_act], v[F_alpha], v[F_beta], v[F_beta2] = int(o["act"]) | (2 if o.get("pre_deriv") else 0), o["alpha"], o["beta"], o["beta2"]
+            if o.get("pre_deriv") and not nprod:
+                raise RuntimeError("chain: pre_deriv needs the split-operand kernel (not CHAIN_MODE 'f32')")
             t = o["gadd1"]
             if t is not None:
                 v[F_gadd1], v[F_gidx1] = _mat(t, N), o["gidx1"].data_ptr()

@@ -230,12 +230,17 @@ class GemNet(torch.nn.Module):
                     rad3.record_stream(side)
                     rbf_W1_3 = self.mlp_cbf3(rad3)
                     rbf_h = self.mlp_rbf_h(rbf)
-                    # consumed by the five output blocks, all on this (side) stream: one running gradient
-                    rbf_out = self.mlp_rbf_out(rbf)
-                    if _RBF_OUT_ACC:
-                        rbf_out = ops.accumulate_gradient(rbf_out, stream=side)
                     ev_b = torch.cuda.Event()
                     ev_b.record(side)
+                # The radial projection of the output blocks stays on the MAIN stream although all its consumers run on
+                # the side stream: produced there, hipGraph replays of the 8 x 64-atom batch in the "h3" arithmetic stopped
+                # matching the eager run (forces off by 1e-2 eV/A in 9 of 10 replays, energies identical; any one of:
+                # this projection on the main stream, unfused output-block aggregation, no fork — removes it; every kernel
+                # involved is bit-reproducible next to concurrent streams on its own: tools/exp/t_graph_race.py,
+                # h3_concurrency*.py, profiles/r3_t_graph_race.txt).  The ordering hazard behind it is not located.
+                rbf_out = self.mlp_rbf_out(rbf)
+                if _RBF_OUT_ACC:
+                    rbf_out = ops.accumulate_gradient(rbf_out, stream=side)
                 main.wait_event(ev_a)
                 for t in (sph3, h) + tuple(terms):
                     t.record_stream(main)

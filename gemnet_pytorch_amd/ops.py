@@ -978,7 +978,9 @@ class PackRegistry:
 
     @staticmethod
     def key(W, trans):
-        return (W.data_ptr(), tuple(W.shape), tuple(W.stride()), bool(trans))
+        # the packed format follows the chain mode of the requesting sweep ("h3": fp16 planes for S1 / S2, bf16 planes for
+        # the loss-scaled S3 / S4 — kernels.linear_mode): one entry per format
+        return (W.data_ptr(), tuple(W.shape), tuple(W.stride()), bool(trans), K.split_format())
 
     def get(self, W, trans):
         k = self.key(W, trans)
@@ -1085,7 +1087,7 @@ def packed_weight(W, trans):
         return None
     if not _frozen(W):
         return K.pack_weight_split(W.detach(), trans=trans)
-    return _cached(("pkt" if trans else "pk", W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version,
+    return _cached(("pkt" if trans else "pk", K.split_format(), W.data_ptr(), tuple(W.shape), tuple(W.stride())), W._version,
                    lambda: K.pack_weight_split(W.detach(), trans=trans))
 
 
@@ -1112,6 +1114,10 @@ class _Stack(torch.autograd.Function):
         x = x.contiguous()
         prog.load(0, x)
         cur, oth = 0, 1
+        # the backward below is first order and only ever needs ssilu'(z): the split-operand kernel stores that factor
+        # (from the sigmoid it evaluates anyway) in place of z, and the adjoint program multiplies instead of evaluating
+        # exp + rcp per element again (its epilogues were VALU-bound)
+        deriv = K.CHAIN_MODE != "f32"
         zs = []
         width = x.shape[1]
         n_out = (layers[-1]["W2"].shape[0] if layers else first["W"].shape[0])
@@ -1120,7 +1126,7 @@ class _Stack(torch.autograd.Function):
             W0 = contiguous_weight(first["W"])
             z0 = torch.empty((M, W0.shape[0]), device=dev, dtype=dt) if first["act"] else None
             rr = first.get("res_rows")
-            _gemm(prog, first["W"], a_slot=0, y_slot=1, act=first["act"],
+            _gemm(prog, first["W"], a_slot=0, y_slot=1, act=first["act"], pre_deriv=deriv and bool(first["act"]),
                       gadd1=g1, gidx1=None if g1 is None else first["i1"].idx32,
                       gadd2=g2, gidx2=None if g2 is None else first["i2"].idx32,
                       pre_out=z0, res=res, res_rows=None if rr is None else rr.idx32, beta=first["beta"],
@@ -1133,8 +1139,8 @@ class _Stack(torch.autograd.Function):
             z1 = torch.empty((M, width), device=dev, dtype=dt)
             z2 = torch.empty((M, width), device=dev, dtype=dt)
             last = k + 1 == len(layers)
-            _gemm(prog, L["W1"], a_slot=cur, y_slot=oth, act=True, pre_out=z1)
-            _gemm(prog, L["W2"], a_slot=oth, y_slot=cur, act=True, pre_out=z2, res=cur, beta=s,
+            _gemm(prog, L["W1"], a_slot=cur, y_slot=oth, act=True, pre_out=z1, pre_deriv=deriv)
+            _gemm(prog, L["W2"], a_slot=oth, y_slot=cur, act=True, pre_out=z2, pre_deriv=deriv, res=cur, beta=s,
                       res2=skips[k], beta2=L["skip_beta"], out=y if last else None)
             zs += [z1, z2]
         # tail projections y @ Wt^T of the final rows while they are still in LDS (the concat-Dense atom terms,
@@ -1145,6 +1151,11 @@ class _Stack(torch.autograd.Function):
             t = torch.empty((M, Wt_c.shape[0]), device=dev, dtype=dt)
             _gemm(prog, Wt, a_slot=cur, y_slot=-1, out=t)
             tails.append(t)
+        if deriv and x.is_cuda and not K.chain_split_supported(prog):   # falls back to the f32 chain kernel: plain z
+            deriv = False
+            for o in prog.ops:
+                o["pre_deriv"] = False
+        ctx.deriv = deriv
         K.chain(prog)
         ctx.set_materialize_grads(False)
         ctx.spec = spec
@@ -1180,6 +1191,7 @@ class _Stack(torch.autograd.Function):
         prog = K.ChainProgram(M)
         prog.load(0, g)
         cur, oth = 0, 1
+        zmode = 1 if ctx.deriv else 0        # the saved tensors hold ssilu'(z) (forward) resp. z
         for Wt, gt in zip(spec.get("tails", ()), g_tails):
             if gt is not None:   # dL/dy += gt @ Wt
                 prog.load(oth, gt.contiguous())
@@ -1202,9 +1214,9 @@ class _Stack(torch.autograd.Function):
                 else:
                     c = s * L["skip_beta"]
             prog.scale(cur, cur, c, width=width)                  # G = dL/d(x + f(x))
-            prog.scale(oth, cur, 1.0, Z=z2)                        # dz2
+            prog.scale(oth, cur, 1.0, Z=z2, mode=zmode)            # dz2
             _gemm(prog, L["W2"], trans=True, a_slot=oth, y_slot=oth)   # dh1 = dz2 @ W2
-            prog.scale(oth, oth, 1.0, Z=z1)                        # dz1
+            prog.scale(oth, oth, 1.0, Z=z1, mode=zmode)            # dz1
             _gemm(prog, L["W1"], trans=True, a_slot=oth, y_slot=cur, res=cur, beta=1.0)  # dx = dz1 @ W1 + G
         gx = g_res = g_res2 = gg1 = gg2 = None
         if first is not None:
@@ -1228,7 +1240,7 @@ class _Stack(torch.autograd.Function):
             src = cur
             if z0 is not None or c != 1.0 or want_dz:
                 # into the other slot: the producing GEMM then emits it as its second output (K.fuse_program)
-                prog.scale(oth, cur, c, Z=z0, out=dz0, width=width)
+                prog.scale(oth, cur, c, Z=z0, out=dz0, width=width, mode=zmode)
                 src = oth
             last = True
             if need[1]:

@@ -34,6 +34,22 @@ class _Rec:
         self.s2 = None    # dict: mu_h[site], mu_z[gemm], g, g_tails
         self.s3 = None    # dict: zdot[site], adot[gemm]
         self.cache = ops.step_cache()   # packed weights of this training step (shared by all four sweeps)
+        # arithmetic of the chain launches: S1 / S2 in the mode of the forward; the loss-scaled sweeps (S3, S4 and an
+        # energy-only final adjoint) in kernels.linear_mode of it — the forward's `ops.chain_mode` context has closed by then
+        self.mode = K.CHAIN_MODE
+
+
+def _sweep_mode(rec, linear):
+    return ops.chain_mode(K.linear_mode(rec.mode) if linear else rec.mode)
+
+
+def _linear_sweep(fn):
+    """Decorator of a `backward(ctx, ...)` that runs S3 of `ctx.rec`."""
+    def wrapped(ctx, *a):
+        with _sweep_mode(ctx.rec, True):
+            return fn(ctx, *a)
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
 
 
 def _new(M, N, like):
@@ -201,6 +217,11 @@ def _gemm_keys(spec):
 
 
 def _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second, store, prev=None, inplace=False):
+    with _sweep_mode(rec, store != "mu"):
+        return _stack_adjoint_(rec, spec, has, want, shapes, g, g_tails, Ws, second, store, prev, inplace)
+
+
+def _stack_adjoint_(rec, spec, has, want, shapes, g, g_tails, Ws, second, store, prev=None, inplace=False):
     """The reverse sweep of a stack as one chain program.  S2 (second is None, store = "mu": mu_h per activation and
     mu_z per GEMM are written out for the later sweeps) and S4 (store = "zbar"; `second` = the record of the tangent
     sweep, whose dz enter as source terms mu_h f''(z) dz).  Returns ((gx, g_res, g_res2, gg1, gg2, *g_skips), stored).
@@ -324,6 +345,7 @@ class _Stack2B(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_linear_sweep
     def backward(ctx, t_x, t_res, t_res2, t_g1, t_g2, *t_skips):
         rec, spec, nT = ctx.rec, ctx.spec, ctx.nT
         Ws = ctx.saved_tensors
@@ -515,6 +537,11 @@ class _Head2(torch.autograd.Function):
 
 
 def _head_adjoint(rec, cfg, g, Ws, second, store, prev=(None, None), inplace=False):
+    with _sweep_mode(rec, store != "mu"):
+        return _head_adjoint_(rec, cfg, g, Ws, second, store, prev, inplace)
+
+
+def _head_adjoint_(rec, cfg, g, Ws, second, store, prev=(None, None), inplace=False):
     """Reverse sweep of the head: S2 (store = "mu") or S4 (store = "zbar", `second` = the tangent record).
     -> ((gx, grbf), dict of the adjoints at z3, dh, r, xa, z1).  `prev`: running gradients of (x, rbf) added in the
     epilogues of the two GEMMs that produce ours (into new tensors, or — `inplace` — into the running sums)."""
@@ -572,6 +599,7 @@ class _Head2B(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_linear_sweep
     def backward(ctx, t_x, t_rbf):
         rec, (act_a, act_d, alpha) = ctx.rec, ctx.cfg
         Wa, Wr, Wd = ctx.saved_tensors

@@ -101,7 +101,8 @@ typedef struct {
   const float* src;         /* LOAD: source; SCALE: Z for ssilu'(Z) (NULL: plain scale) */
   const int32_t* rows;      /* LOAD: optional row gather */
   const float* W; int N; int K;
-  int act;
+  int act;                  /* GEMM: bit 0 = ScaledSiLU on z; bit 1 (gn_chain_split_f32 only, needs bit 0 and pre_out) =
+                               pre_out receives ssilu'(z) instead of z — the factor a first-order adjoint multiplies by */
   float alpha;
   const float* gadd1; const int32_t* gidx1;
   const float* gadd2; const int32_t* gidx2;
@@ -145,17 +146,29 @@ int gn_chain_f32(const gn_chain_args* args, void* stream);
  * (not at the fp32 matrix); N % 16 == 0, K % 4 == 0; slots 0/1 live in LDS, slot 2 is a register-resident parking
  * slot (written by a plain SCALE or as a GEMM's y_slot; readable as mul/res/res2 only).
  * Replaces: Dense/ResidualLayer stacks (base_layers.py:44-89) exactly like gn_chain_f32. */
+/* nprod = GN_CHAIN_F16X2: two fp16 planes instead, x ~= hi + 2^-11 lo (22 significand bits), three products
+ * hh + 2^-11 (hl + lh) — the error-corrected half-precision form; half the matrix-pipe time and two thirds of the LDS
+ * traffic of nprod = 6 at ~4x the operand rounding of fp32 (force MAE 1e-6 eV/A on the 4-block models).  Operands must
+ * stay below 65504 in magnitude (beyond: inf, which propagates) and lose relative accuracy below 2^-14 times the scale of
+ * their dot product: meant for activations and first-order adjoints, whose scale the model fixes — not for sweeps whose
+ * scale follows the loss.  `W` must have been packed with fmt = GN_SPLIT_F16X2. */
+#define GN_CHAIN_F16X2 2
 int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* stream);
 /* W (N,K) fp32 with row pitch ldw — or, trans != 0, the (K,N) matrix whose transpose is the weight — -> three bf16
  * planes in MFMA-fragment order; `out` holds gn_pack_weight_split_bytes(N,K) bytes (16-byte aligned). */
 int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream);
+/* fmt: GN_SPLIT_BF16X3 (the above) or GN_SPLIT_F16X2 (two fp16 planes, for nprod = GN_CHAIN_F16X2; uses the first two
+ * thirds of the same buffer size). */
+#define GN_SPLIT_BF16X3 0
+#define GN_SPLIT_F16X2 1
+int gn_pack_weight_split_fmt(const float* W, int N, int K, int ldw, int trans, int fmt, void* out, void* stream);
 int64_t gn_pack_weight_split_bytes(int N, int K);
 /* The same for ALL weights of a training step in one launch (the weights change every optimizer step,
  * trainer.py:353-358): `jobs` is a DEVICE table sorted by unit_begin (first entry 0); job j owns the units
  * [unit_begin, unit_begin + ceil(N/16) * ceil(K/32) * 64); total_units = the end of the last job. */
 typedef struct {
   const float* W; void* out;
-  int N, K, ldw, trans, unit_begin, pad_;
+  int N, K, ldw, trans, unit_begin, fmt;   /* fmt: GN_SPLIT_* */
 } gn_pack_job;
 int gn_pack_weight_split_grouped(const gn_pack_job* jobs, int n_jobs, int total_units, void* stream);
 

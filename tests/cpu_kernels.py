@@ -232,8 +232,12 @@ def trip_basis_bwd(gY, R, tc, ta, tb):
     return Gc, Gb
 
 
-def chain(prog):
-    """Interpret a ChainProgram on whole matrices (slots = (M, 128) tensors)."""
+def chain(prog, mode=None):
+    """Interpret a ChainProgram on whole matrices (slots = (M, 128) tensors).  Exact arithmetic; the launch rules of the
+    mode still apply (a program the device kernel would refuse must not pass on the emulation)."""
+    from gemnet_pytorch_amd import kernels as _K
+    if (mode or _K.CHAIN_MODE) == "h3" and _K.h3_hazards(prog):
+        raise RuntimeError(f"chain: ops {_K.h3_hazards(prog)} are not representable in mode 'h3'")
     M = prog.M
     dt = None
     for o in prog.ops:
@@ -296,7 +300,7 @@ def chain(prog):
             if o["gadd2"] is not None:
                 z = z + o["gadd2"][o["gidx2"].long()]
             if o["pre_out"] is not None:
-                o["pre_out"].copy_(z)
+                o["pre_out"].copy_(_act(z, 1) if o.get("pre_deriv") else z)
             y = _act(z, 0) if o["act"] else z
             a_val = y
             mul = sel(o["mul"], N)

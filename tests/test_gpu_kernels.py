@@ -417,10 +417,10 @@ def _source_programs(M, width, g, dev):
 
 
 # relative error budget of one chain program per arithmetic: f32 MFMA and the six-product split are fp32-equivalent
-CHAIN_TOL = {"f32": 1e-4, "split6": 1e-4, "split3": 2e-3, "bf16": 1e-1}
+CHAIN_TOL = {"f32": 1e-4, "split6": 1e-4, "h3": 1e-4, "split3": 2e-3, "bf16": 1e-1}
 
 
-@pytest.mark.parametrize("mode", ["f32", "split6", "split3", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "split6", "h3", "split3", "bf16"])
 @pytest.mark.parametrize("M,width", [(1000, 128), (33, 64), (18122, 128), (5000, 128), (9000, 64), (13000, 128)])
 def test_chain_kernel_vs_interpreter(M, width, mode):
     """Every op kind, aliasing slots, slot / register / global operands, all five tile heights (RT = 1..5), on the f32
@@ -431,8 +431,13 @@ def test_chain_kernel_vs_interpreter(M, width, mode):
         g = torch.Generator().manual_seed(M)
         build = maker(M, width, g, DEV)
         p_ref, o_ref = build(lambda t: t.clone(), lambda i: i)
-        CK.chain(p_ref)
         p_dev, o_dev = build(lambda t: f32(t), lambda i: i.to(DEV))
+        if mode == "h3" and K.h3_hazards(p_dev):
+            # second-order source terms / gathered adds into LDS-resident rows: refused, never computed out of range
+            with pytest.raises(RuntimeError):
+                K.chain(p_dev, mode=mode)
+            continue
+        CK.chain(p_ref, mode=mode)
         K.chain(p_dev, mode=mode)
         for k in o_ref:
             scale = max(1.0, float(o_ref[k].abs().max()))
@@ -451,16 +456,22 @@ def test_source_terms_are_rejected_by_the_f32_chain_kernel():
         K.chain(p_dev, mode="f32")
 
 
-def test_grouped_weight_pack_equals_single_packs():
+@pytest.mark.parametrize("fmt", [0, 1], ids=["bf16x3", "f16x2"])
+def test_grouped_weight_pack_equals_single_packs(fmt):
     """gn_pack_weight_split_grouped (all weights of a training step in one launch) == gn_pack_weight_split per weight,
-    bit for bit, for plain, transposed, sliced (row pitch > K) and ragged (N % 16, K % 32 != 0) matrices."""
+    bit for bit, for plain, transposed, sliced (row pitch > K) and ragged (N % 16, K % 32 != 0) matrices; both plane
+    formats, and a table that mixes them (the S1 / S2 and S3 / S4 entries of one weight in "h3" mode)."""
     g = torch.Generator().manual_seed(9)
     big = f32(rnd(g, 128, 390))
     mats = [(f32(rnd(g, 128, 128)), False), (f32(rnd(g, 128, 128)), True), (f32(rnd(g, 64, 16)), False),
             (f32(rnd(g, 16, 64)), True), (big[:, 128:256], False), (big[:, 256:384], True), (f32(rnd(g, 128, 40)), False),
             (f32(rnd(g, 48, 128)), False)]
-    singles = [K.pack_weight_split(W, trans=t) for W, t in mats]
+    fmts = [fmt if i % 3 else 1 - fmt for i in range(len(mats))]
+    singles = [K.pack_weight_split(W, trans=t, fmt=f) for (W, t), f in zip(mats, fmts)]
     outs = [torch.zeros_like(sp) for sp in singles]
+    for o, f in zip(outs, fmts):
+        o._gn_fmt = f
+    assert singles[1].numel() * (3 if fmts[1] else 2) == singles[0].numel() * (3 if fmts[0] else 2)   # 2 vs 3 planes
     table, units = K.pack_job_table([(W, t, o) for (W, t), o in zip(mats, outs)])
     K.pack_weight_split_grouped(table, len(mats), units)
     torch.cuda.synchronize()
@@ -492,7 +503,94 @@ def test_split_six_products_is_fp32_equivalent():
     assert torch.equal(rt, x)
 
 
-@pytest.mark.parametrize("mode", ["f32", "split6"])
+def test_two_plane_fp16_form_accuracy_and_range():
+    """Mode "h3" (two fp16 planes, three products).  A LINEAR program (adjoint sweeps) carries a power-of-two scale per
+    row: rows from 1e-8 to 1e4 all come out with the same relative accuracy (2^-22 operand rounding: within 4x of the
+    f32-MFMA result), the LOAD -> STORE round trip keeps 21 bits of every row's maximum.  A program with an activation
+    is unscaled (activations are O(1) by the model's normalisation): fp32-like accuracy at O(1), and a value beyond the
+    fp16 range comes out non-finite — never silently wrong."""
+    g = torch.Generator().manual_seed(6)
+    M = 4096
+    x, W = f32(rnd(g, M, 128)), f32(rnd(g, 128, 128) / 11)
+    scale = 10.0 ** (torch.rand(M, generator=g) * 12 - 8)
+    x = x * scale[:, None].to(DEV)
+    ref = x.double() @ W.double().t()
+    rel = {}
+    for mode in ("f32", "h3"):
+        y = torch.empty(M, 128, device=DEV)
+        p = K.ChainProgram(M)
+        p.load(0, x)
+        p.gemm(W, a_slot=0, y_slot=1, out=y)
+        K.chain(p, mode=mode)
+        rel[mode] = ((y.double() - ref).norm(dim=1) / ref.norm(dim=1)).cpu()
+    print(f"row-wise relative error, rows of scale 1e-8 .. 1e4: f32 MFMA max {float(rel['f32'].max()):.2e}, "
+          f"h3 max {float(rel['h3'].max()):.2e} median {float(rel['h3'].median()):.2e}")
+    assert float(rel["h3"].max()) <= 4.0 * float(rel["f32"].max())
+    rt = torch.empty(M, 128, device=DEV)
+    p = K.ChainProgram(M)
+    p.load(0, x)
+    p.store(0, rt)
+    K.chain(p, mode="h3")
+    assert float(((rt - x).abs().amax(dim=1) / x.abs().amax(dim=1)).max()) <= 2.0 ** -21
+    # two chained layers with the running row scale inherited through the first output and a slot residual
+    W2 = f32(rnd(g, 128, 128) / 11)
+    ref2 = (ref @ W2.double().t() + x.double()) * 0.5
+    y = torch.empty(M, 128, device=DEV)
+    p = K.ChainProgram(M)
+    p.load(0, x)
+    p.gemm(W, a_slot=0, y_slot=1)
+    p.gemm(W2, a_slot=1, y_slot=1, res=0, beta=0.5, out=y)
+    K.chain(p, mode="h3")
+    assert float(((y.double() - ref2).norm(dim=1) / ref2.norm(dim=1)).max()) <= 1e-6
+    # non-linear program: no row scale
+    xs = f32(rnd(g, M, 128))
+    refa = torch.nn.functional.silu(xs.double() @ W.double().t()) / 0.6
+    big = xs.clone()
+    big[5, 7] = 7.0e4
+    for inp, finite in ((xs, True), (big, False)):
+        y = torch.empty(M, 128, device=DEV)
+        p = K.ChainProgram(M)
+        p.load(0, inp)
+        p.gemm(W, a_slot=0, y_slot=1, act=True, out=y)
+        K.chain(p, mode="h3")
+        if finite:
+            close(y, refa.cpu(), rtol=1e-5, atol=1e-5)
+        else:
+            assert not bool(torch.isfinite(y[5]).all()) and bool(torch.isfinite(y[6]).all())
+
+
+@pytest.mark.parametrize("mode", ["split6", "h3", "bf16"])
+@pytest.mark.parametrize("M", [77, 18122])
+def test_chain_gemm_stores_the_activation_derivative(mode, M):
+    """act bit 1 of a chain GEMM: `pre_out` receives ssilu'(z) (what a first-order adjoint multiplies by) instead of z,
+    from the same sigmoid as the activation; the f32-MFMA kernel refuses the flag."""
+    g = torch.Generator().manual_seed(M)
+    x, W = f32(rnd(g, M, 128)), f32(rnd(g, 64, 128) / 6)
+    z = x.double().cpu() @ W.double().cpu().t()
+    sg = torch.sigmoid(z)
+    y, d = torch.empty(M, 64, device=DEV), torch.empty(M, 64, device=DEV)
+    p = K.ChainProgram(M)
+    p.load(0, x)
+    p.gemm(W, a_slot=0, y_slot=1, act=True, pre_out=d, pre_deriv=True, out=y)
+    K.chain(p, mode=mode)
+    tol = dict(rtol=2e-5, atol=2e-5) if mode != "bf16" else dict(rtol=5e-2, atol=5e-2)
+    close(y, z * sg / 0.6, **tol)
+    close(d, sg * (1 + z * (1 - sg)) / 0.6, **tol)
+    with pytest.raises(RuntimeError):
+        K.chain(p, mode="f32")
+
+
+def test_packed_weight_format_must_match_the_mode():
+    g = torch.Generator().manual_seed(6)
+    x, W = f32(rnd(g, 64, 128)), f32(rnd(g, 128, 128))
+    p = K.ChainProgram(64)
+    p.load(0, x)
+    p.gemm(W, a_slot=0, y_slot=1, out=torch.empty(64, 128, device=DEV), packed=K.pack_weight_split(W, fmt=0))
+    with pytest.raises(RuntimeError):
+        K.chain(p, mode="h3")
+
+
+@pytest.mark.parametrize("mode", ["f32", "split6", "h3"])
 @pytest.mark.parametrize("M", [300, 18122])
 def test_chain_gemm_accumulates_into_its_residual(mode, M):
     """A chain GEMM whose global residual IS its output (res / res2 = out): the running-gradient form used by
@@ -508,7 +606,8 @@ def test_chain_gemm_accumulates_into_its_residual(mode, M):
         p = K.ChainProgram(M)
         p.load(0, x)
         p.gemm(W16, a_slot=0, y_slot=-1, out=y16, res=run16, beta=1.0)
-        p.gemm(W, a_slot=0, y_slot=1, out=y, res2=run, beta2=1.0)
+        # (the row-scaled fp16 form takes a global residual only on a result that leaves LDS: kernels.h3_hazards)
+        p.gemm(W, a_slot=0, y_slot=-1 if mode == "h3" else 1, out=y, res2=run, beta2=1.0)
         K.chain(p, mode=mode)
         outs.append((y.clone(), y16.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

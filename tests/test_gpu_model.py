@@ -94,7 +94,7 @@ def test_relative_precision_on_unscaled_deep_fixtures(golden_model, tag):
     assert float(np.abs(E.detach().cpu().numpy() - Eref).max()) <= 2e-5 * max(1.0, float(np.abs(Eref).max()))
 
 
-@pytest.mark.parametrize("mode,bar", [("f32", 1e-5), ("split6", 1e-5), ("split3", 1e-3), ("bf16", None)])
+@pytest.mark.parametrize("mode,bar", [("f32", 1e-5), ("split6", 1e-5), ("h3", 1e-5), ("split3", 1e-3), ("bf16", None)])
 @pytest.mark.parametrize("tag", ["t4s", "q4s"])
 def test_matmul_arithmetic_modes(golden_model2, tag, mode, bar, monkeypatch):
     """The Dense stacks on the f32 MFMA, on the bf16 matrix pipe with 6 / 3 split-operand products, and with plain
@@ -159,7 +159,7 @@ def test_repeatable_bitwise(golden_model):
 def test_native_library_loaded():
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
-    assert lib.gn_abi_version() == 10
+    assert lib.gn_abi_version() == 11
     with open("/proc/self/maps") as f:
         assert "libgemnet_hip.so" in f.read()
 

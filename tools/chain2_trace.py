@@ -1,6 +1,6 @@
 """Phase timing inside gn_chain_split_f32 (diagnosis build with -DGN_CHAIN_TRACE): shader-clock stamps per op.
 
-    python tools/chain2_trace.py [--quick [--small]]            all modes / only split6 at M = 18122 (M = 1024)
+    python tools/chain2_trace.py [--quick [--small]] [--modes=split6,h3]   all modes / only split6 at M = 18122 (M = 1024)
     GN_TRACE_DEFS="-DGN_EXP=1" python tools/chain2_trace.py --quick   MFMA phase without its LDS reads (2: reads only)"""
 import ctypes, os, sys, subprocess, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,20 +21,27 @@ _lib.LIB_PATH = TRACE_LIB
 from gemnet_pytorch_amd import kernels as K
 lib = _lib.load()
 lib.gn_chain2_trace_read.argtypes = [ctypes.c_void_p]
-for mode in (("split6",) if QUICK else ("split6", "bf16")):
+MODES = [a.split("=")[1].split(",") for a in sys.argv if a.startswith("--modes=")]
+for mode in (MODES[0] if MODES else (("split6",) if QUICK else ("split6", "bf16"))):
   for M in (((1024,) if "--small" in sys.argv else (18122,)) if QUICK else (1024, 18122)):
-    for pre in ((0,) if QUICK else (0, 1)):
+    for pre in ((0, 1) if (MODES or not QUICK) else (0,)):
         n = 5
         x = torch.randn(M, 128, device="cuda")
         Ws = [torch.randn(128, 128, device="cuda") / 11 for _ in range(n)]
-        Wp = [K.pack_weight_split(w) for w in Ws]
-        zs = [torch.empty(M, 128, device="cuda") for _ in range(n)]
+        Wp = [K.pack_weight_split(w, fmt=K.SPLIT_FORMAT[mode]) for w in Ws]
+        zs = [torch.randn(M, 128, device="cuda") for _ in range(n)]
+        zs2 = [torch.empty(M, 128, device="cuda") for _ in range(n)]
         y = torch.empty(M, 128, device="cuda")
         p = K.ChainProgram(M); p.load(0, x)
         cur, oth = 0, 1
+        ADJ = "--adj" in sys.argv     # adjoint-like ops: a global f'(z) factor on every GEMM, pre-activation adjoint stored
         for i in range(n):
-            p.gemm(Ws[i], a_slot=cur, y_slot=oth, act=bool(pre), pre_out=zs[i] if pre else None, out=y if i == n - 1 else None,
-                   packed=Wp[i])
+            if ADJ:
+                p.gemm(Ws[i], a_slot=cur, y_slot=oth, mul=zs[i], mul_mode=2, pre_out=zs2[i] if pre else None,
+                       out=y if i == n - 1 else None, packed=Wp[i])
+            else:
+                p.gemm(Ws[i], a_slot=cur, y_slot=oth, act=bool(pre), pre_out=zs[i] if pre else None, out=y if i == n - 1 else None,
+                       packed=Wp[i])
             cur, oth = oth, cur
         for _ in range(5):
             K.chain(p, mode=mode)
