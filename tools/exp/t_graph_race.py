@@ -15,6 +15,12 @@ VARIANTS = {
     "no_fork": {"T_NO_FORK": "1"},
     "rbf_out_on_side": {"T_RBF_OUT_SIDE": "1"},
     "32x32": {"T_SIZE": "32x32"},
+    "16x48": {"T_SIZE": "16x48"},
+    "4x96": {"T_SIZE": "4x96"},
+    "64x16": {"T_SIZE": "64x16"},
+    "2x128": {"T_SIZE": "2x128"},
+    "12x40_split6": {"T_SIZE": "12x40", "GEMNET_CHAIN_MODE": "split6"},
+    "12x40": {"T_SIZE": "12x40"},
 }
 if len(sys.argv) == 1:
     for name, env in VARIANTS.items():
