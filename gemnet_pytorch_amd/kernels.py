@@ -509,7 +509,7 @@ class ChainProgram:
     def gemm(self, W, a_slot, y_slot=-1, act=False, alpha=1.0, gadd1=None, gidx1=None, gadd2=None, gidx2=None,
              pre_out=None, mul=None, res=None, res_rows=None, beta=1.0, res2=None, beta2=1.0, out=None, packed=None,
              mul_mode=1, y2=-1, y2_src=0, alpha2=1.0, Z2=None, mode2=0, out2=None, add=None, add2=None, pre_deriv=False):
-        """W: the (N,K) fp32 weight; `packed`: its split-bf16 fragment form (pack_weight_split(W)) if the caller
+        """W: the (N,K) fp32 weight; `packed`: its split fragment form (pack_weight_split(W), format of the launch mode) if the caller
         caches it — the split-operand kernel packs on the fly otherwise.
         mul_mode (global `mul` only): 1 identity, 2 ssilu'(mul), 3 ssilu(mul).
         Second output: y2 (slot) / out2 (global) <- (y2_src ? activation output : final y) * alpha2 * phi2(Z2),

@@ -405,7 +405,8 @@ def is_fused():
 @contextlib.contextmanager
 def chain_mode(mode):
     """Select the arithmetic of the Dense stacks (kernels.CHAIN_MODES) for the enclosed launches; None keeps the
-    current one.  The packed-weight cache is keyed per weight, not per mode: all split modes share one packed form."""
+    current one.  Packed weights are cached per weight and plane format (kernels.SPLIT_FORMAT: the bf16-plane modes share
+    one form, "h3" has its own)."""
     if mode is None:
         yield
         return
@@ -961,7 +962,7 @@ _STEP_PACKED = None     # per-forward cache of split-bf16 weight planes (the wei
 
 
 class PackRegistry:
-    """Split-bf16 planes of every (weight, orientation) a model's training step asks for, refreshed by ONE grouped launch
+    """Split planes (in the format of the requesting sweep, kernels.split_format) of every (weight, orientation) a model's training step asks for, refreshed by ONE grouped launch
     at the start of each step (gn_pack_weight_split_grouped) instead of one launch per weight and sweep (~220 per step).
     The first step packs on demand and registers what it saw; from then on `begin_step` repacks all registered entries in
     place (their buffers — and the device job table — are persistent: captured hipGraphs replay the same launch).
@@ -1051,7 +1052,7 @@ def step_cache():
 
 
 def step_packed(W, trans, cache=None):
-    """Split-bf16 fragment form of a TRAINABLE weight (or of its transpose), packed once per training step and shared
+    """Split fragment form (plane format of the current chain mode) of a TRAINABLE weight (or of its transpose), packed once per training step and shared
     by the four sweeps of that step (ops_train.py); None on the f32 chain kernel / the host emulation.
     `cache`: the store a stack captured in its forward — the S3 / S4 sweeps run inside loss.backward(), after the
     `train2` context of the forward has closed."""
@@ -1079,7 +1080,7 @@ def contiguous_weight(W):
 
 
 def packed_weight(W, trans):
-    """Split-bf16 fragment form (gn_pack_weight_split) of the weight W (trans: of W^T) for the split-operand chain
+    """Split fragment form (gn_pack_weight_split_fmt, plane format of the current chain mode) of the weight W (trans: of W^T) for the split-operand chain
     kernel.  Cached with the other derived forms when W is frozen; packed per call when W is trainable (a cache keyed
     by the address of a per-call temporary would hand a later weight the earlier one's planes); None when the chain
     runs on the f32 MFMA or on the host emulation."""
