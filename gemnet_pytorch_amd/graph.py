@@ -58,11 +58,14 @@ class SegmentPlan:
     def seg_off(self):
         return self.reduce.csr[1]
 
-    def set_row_groups(self, row_group: torch.Tensor, n_groups: int):
+    def set_row_groups(self, row_group: torch.Tensor, n_groups: int, max_rows=None):
         """Declare that r(t) and g(t) of every entry fall in the same group of rows (`row_group[row]`), as the
-        triplets c->a<-b do with the target atom a of both edges (data_container.py:262-300)."""
+        triplets c->a<-b do with the target atom a of both edges (data_container.py:262-300).
+        `max_rows`: a known upper bound of the rows per group (the largest in-degree of an atom) — without it the exact
+        maximum is read back from the device (a host sync: not possible inside a hipGraph capture)."""
         assert self.n_reduce == self.n_expand == int(row_group.shape[0])
         self._row_group, self._n_groups, self._groups = row_group, int(n_groups), None
+        self._max_rows = None if max_rows is None else int(max_rows)
 
     @property
     def groups(self):
@@ -78,7 +81,10 @@ class SegmentPlan:
             permT, segT = self.expand.csr
             rposT = rank[self.reduce.idx64[permT.to(torch.int64)]].to(torch.int32).contiguous()
             kseg = torch.stack([segT[:-1][rows], segT[1:][rows]], dim=1).to(torch.int32).contiguous()
-            max_rows = int((off[1:] - off[:-1]).max().item()) if rows.shape[0] else 0
+            if getattr(self, "_max_rows", None) is not None:
+                max_rows = self._max_rows
+            else:
+                max_rows = int((off[1:] - off[:-1]).max().item()) if rows.shape[0] else 0
             self._groups = (rows.to(torch.int32).contiguous(), off, kseg, rposT, max_rows)
         return self._groups
 
@@ -104,7 +110,8 @@ class GraphPlan:
         self.id_swap.inverse = self.id_swap  # id_swap is an involution (data_container.py:303-308)
         self.batch_seg = RowIndex(inputs["batch_seg"], self.n_mol, is_sorted=True)
         self.trip = SegmentPlan(inputs["id3_reduce_ca"], inputs["id3_expand_ba"], self.n_edges, self.n_edges)
-        self.trip.set_row_groups(id_a, self.n_atoms)  # reduce c->a and expand b->a share the target atom
+        # reduce c->a and expand b->a share the target atom; "max_in_degree": optional static bound (padded.py)
+        self.trip.set_row_groups(id_a, self.n_atoms, max_rows=inputs.get("max_in_degree"))
         # atom triples of each triplet for the angle c<-a->b (gemnet.py:442-444)
         r, x = inputs["id3_reduce_ca"], inputs["id3_expand_ba"]
         self.t_c, self.t_a, self.t_b = id_c[r], id_a[r], id_c[x]

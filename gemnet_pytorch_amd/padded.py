@@ -1,0 +1,196 @@
+"""Batches whose array sizes change from call to call, replayed from ONE captured hipGraph.
+
+The MD loop of the reference rebuilds the graph every step (ase_calculator.py:155-158) and the data provider hands out a
+new batch every step (data_provider.py:159-165): the number of edges and triplets differs by a few per cent from call to
+call, so a captured forward+force cannot be replayed and the eager path is bound by ~240 Python-side launches (8-12 ms for
+2.7 ms of kernels).  Here every batch is PADDED to fixed capacities with a dummy molecule and the one graph captured for
+those capacities is replayed:
+
+  * `A_pad = 3 G` dummy atoms in G groups (a, b, c) with a valid geometry of their own (1 A bonds, 90 degrees), far from
+    every real atom and assigned to an extra molecule whose energy and forces are dropped;
+  * pad edges come in quads  b->a, a->b, c->a, a->c  cycling over the groups (id_swap = the neighbour in the pair,
+    id_undir continues the numbering), pad triplets are the two orderings (c->a, b->a), (b->a, c->a) of the quads' forward
+    edges, as many as needed, sorted by reduce edge like the real ones — duplicates of an edge or of a triplet are just
+    more rows of the dummy molecule's sums;
+  * the index plan (CSR sorts, triplet groups) is built INSIDE the captured region from the static index buffers, so each
+    replay rebuilds it on the device for the indices of that batch; the one host read-back it needed (largest in-degree)
+    is replaced by the bound the caller knows (`max_in_degree`: atoms per molecule - 1).
+
+Molecules are independent (block-diagonal index arrays), every kernel of the path treats a row on its own and sums a
+segment in index order: the real molecules' energies and forces are those of the unpadded batch, bit for bit
+(tests/test_gpu_padded.py).  Triplets-only models, force by autograd, inference.
+"""
+import torch
+
+from .graph import GraphPlan
+
+PAD_EDGE_KEYS = ("id_c", "id_a", "id_swap", "id_undir")
+PAD_TRIP_KEYS = ("id3_reduce_ca", "id3_expand_ba")
+
+
+def _pad_edges(k, n_atoms, n_groups):
+    """Pad edge number k (0-based behind the real edges) -> (source atom, target atom).  Pairs (edge, reverse); the pairs
+    alternate b->a | c->a and cycle over the groups of three dummy atoms."""
+    pair, rev = k // 2, k % 2
+    typ, grp = pair % 2, (pair // 2) % max(n_groups, 1)
+    a = n_atoms + 3 * grp
+    other = a + 1 + typ                           # b or c
+    return torch.where(rev == 0, other, a), torch.where(rev == 0, a, other)
+
+
+def _pad_triplets(j, E, ep, tp):
+    """Pad triplet number j of tp -> (reduce edge, expand edge): the forward edges (even k) of the complete quads, spread
+    evenly and ALREADY sorted by reduce edge (f grows with j); the expand edge is the other forward edge of the quad —
+    same target atom a, the other source."""
+    n_fwd = 2 * (ep // 4)
+    f = (j * n_fwd) // max(tp, 1)
+    return E + 2 * f, E + 2 * (f ^ 1)
+
+
+def pad_indices(idx, n_atoms, e_cap, t_cap, n_groups, dtype=torch.int64):
+    """idx: the index dict of one batch (id_c, id_a, id_swap, id_undir, id3_reduce_ca, id3_expand_ba; any int dtype)
+    -> dict of the same keys padded to (e_cap, t_cap) as described in the module docstring.  Pure index arithmetic
+    (runs on any device, no host sync besides the shapes)."""
+    E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+    ep, tp = e_cap - E, t_cap - T
+    if ep < 0 or tp < 0:
+        raise ValueError(f"batch ({E} edges, {T} triplets) exceeds the capacities ({e_cap}, {t_cap})")
+    if ep % 2 or E % 2 or tp % 2:
+        raise ValueError("edge and triplet padding must be even (edges and triplets come in pairs)")
+    if tp and ep < 4:
+        raise ValueError("pad triplets need a complete quad of pad edges")
+    dev = idx["id_c"].device
+    k = torch.arange(ep, device=dev, dtype=torch.int64)
+    src, dst = _pad_edges(k, n_atoms, n_groups)
+    out = {
+        "id_c": torch.cat([idx["id_c"].to(dtype), src.to(dtype)]),
+        "id_a": torch.cat([idx["id_a"].to(dtype), dst.to(dtype)]),
+        "id_swap": torch.cat([idx["id_swap"].to(dtype), (E + (k ^ 1)).to(dtype)]),
+        "id_undir": torch.cat([idx["id_undir"].to(dtype), (E // 2 + k // 2).to(dtype)]),
+    }
+    red, exp = _pad_triplets(torch.arange(tp, device=dev, dtype=torch.int64), E, ep, tp)
+    out["id3_reduce_ca"] = torch.cat([idx["id3_reduce_ca"].to(dtype), red.to(dtype)])
+    out["id3_expand_ba"] = torch.cat([idx["id3_expand_ba"].to(dtype), exp.to(dtype)])
+    return out
+
+
+def dummy_positions(n_groups, like, offset=1.0e3):
+    """(3 G, 3) positions: group g = atoms a, b, c with |ab| = |ac| = 1 A and a right angle, 10 A between groups, `offset`
+    away from the origin (real molecules of a batch sit near it)."""
+    g = torch.arange(n_groups, device=like.device, dtype=like.dtype)
+    base = torch.stack([offset + 10.0 * g, torch.full_like(g, offset), torch.full_like(g, offset)], dim=1)
+    d = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], device=like.device, dtype=like.dtype)
+    return (base[:, None, :] + d[None, :, :]).reshape(-1, 3)
+
+
+class PaddedGraphRunner:
+    """runner = PaddedGraphRunner(model, Z, N, e_cap, t_cap);  E, F = runner(R, idx[, Z])   for every batch of this layout.
+
+    Z (A,), N (n_mol,): atomic numbers and molecule sizes (N fixed; Z may be replaced per call); e_cap / t_cap: capacities
+    (rounded up to even here); `max_in_degree`: bound of the incoming
+    edges of one atom (default max(N) - 1).  A batch that does not fit raises `ValueError` — size the capacities from the
+    first batches with a margin (`suggest_capacities`)."""
+
+    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None):
+        if not model.triplets_only or model.direct_forces:
+            raise NotImplementedError("padded replay: triplets-only models with forces by autograd")
+        self.model = model
+        dev = Z.device
+        self.A, self.n_mol = int(Z.shape[0]), int(N.shape[0])
+        self.e_cap, self.t_cap = (int(e_cap) + 1) // 2 * 2, (int(t_cap) + 1) // 2 * 2
+        self.deg = int(max_in_degree) if max_in_degree is not None else int(N.max().item()) - 1
+        # every group's atom a takes pad edges of both kinds: at most 2 * ceil(pad quads / G) incoming
+        self.G = int(n_groups) if n_groups is not None else max(1, -(-self.e_cap // (16 * max(self.deg, 2))))
+        Ap = 3 * self.G
+        i64 = torch.int64
+        self.inputs = {
+            "Z": torch.cat([Z.to(i64), torch.ones(Ap, dtype=i64, device=dev)]),
+            "N": torch.cat([N.to(i64), torch.tensor([Ap], dtype=i64, device=dev)]),
+            "R": torch.zeros(self.A + Ap, 3, device=dev, dtype=torch.float32),
+            "batch_seg": torch.cat([torch.repeat_interleave(torch.arange(self.n_mol, device=dev), N.to(i64)),
+                                    torch.full((Ap,), self.n_mol, dtype=i64, device=dev)]),
+            "max_in_degree": None,
+        }
+        self.inputs["R"][self.A:] = dummy_positions(self.G, self.inputs["R"])
+        for k in PAD_EDGE_KEYS:
+            self.inputs[k] = torch.zeros(self.e_cap, dtype=i64, device=dev)
+        for k in PAD_TRIP_KEYS:
+            self.inputs[k] = torch.zeros(self.t_cap, dtype=i64, device=dev)
+        k = torch.arange(self.e_cap, device=dev, dtype=i64)
+        self._pat_src, self._pat_dst = _pad_edges(k, self.A, self.G)
+        self._pat_swap, self._pat_pair = k ^ 1, k // 2
+        self._arange_t = torch.arange(self.t_cap, device=dev, dtype=i64)
+        self.graph = None
+        self.out = None
+
+    def padded_inputs(self):
+        """The static input buffers as one padded batch (a view of the runner's state: for tests)."""
+        return {k: v for k, v in self.inputs.items() if v is not None}
+
+    @staticmethod
+    def suggest_capacities(sizes, margin=0.06):
+        """sizes: [(E, T), ...] of a few batches -> (e_cap, t_cap).  Triplets get `margin` head room, edges a little more:
+        every pad triplet needs a pad edge to reduce into, and a pad edge with hundreds of triplets is a long tail for the
+        one wave that owns it (a real edge has ~18)."""
+        e = max(s[0] for s in sizes)
+        t = max(s[1] for s in sizes)
+        return int(e * (1 + 1.5 * margin)) // 4 * 4 + 8, int(t * (1 + margin)) // 2 * 2 + 2
+
+    def _fill(self, R, idx, Z=None):
+        """Write one batch into the static buffers: the real rows as they are, the pad rows from the patterns computed
+        once for the whole capacity (an edge's pattern only depends on its distance from the first pad edge)."""
+        if Z is not None:
+            self.inputs["Z"][:self.A].copy_(Z)
+        E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+        ep, tp = self.e_cap - E, self.t_cap - T
+        if ep < 0 or tp < 0:
+            raise ValueError(f"batch ({E} edges, {T} triplets) exceeds the capacities ({self.e_cap}, {self.t_cap})")
+        if ep % 2 or tp % 2 or (tp and ep < 4):
+            raise ValueError("edge and triplet padding must be even, and pad triplets need a complete quad of pad edges")
+        # in-degree of a group's atom a: both kinds of pairs land on it
+        if -(-(ep // 2) // self.G) > self.pad_degree_bound():
+            raise ValueError(f"{ep} pad edges over {self.G} dummy groups exceed the in-degree bound {self.pad_degree_bound()}")
+        buf = self.inputs
+        for k in PAD_EDGE_KEYS + PAD_TRIP_KEYS:
+            buf[k][:idx[k].shape[0]].copy_(idx[k])
+        if ep:
+            buf["id_c"][E:].copy_(self._pat_src[:ep])
+            buf["id_a"][E:].copy_(self._pat_dst[:ep])
+            torch.add(self._pat_swap[:ep], E, out=buf["id_swap"][E:])
+            torch.add(self._pat_pair[:ep], E // 2, out=buf["id_undir"][E:])
+        if tp:
+            red, exp = _pad_triplets(self._arange_t[:tp], E, ep, tp)
+            buf["id3_reduce_ca"][T:].copy_(red)
+            buf["id3_expand_ba"][T:].copy_(exp)
+        buf["R"][:self.A].copy_(R)
+
+    def pad_degree_bound(self):
+        return max(self.deg, 2)
+
+    def __call__(self, R, idx, Z=None):
+        """R (A, 3) float32 on the device, idx: the index dict of this batch, Z: its atomic numbers when they change from
+        batch to batch (same molecule sizes N) -> (E (n_mol, targets), F (A, [targets,] 3)); the results live in the
+        graph's static output buffers until the next call."""
+        self._fill(R, idx, Z)
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        E, F = self.out
+        return E.detach()[:self.n_mol], F.detach()[:self.A]
+
+    def _capture(self):
+        inputs = dict(self.inputs, max_in_degree=self.pad_degree_bound())
+        inputs.pop("_plan", None)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up off the default stream (autograd stream bookkeeping, lazy caches)
+            for _ in range(2):
+                self.model(dict(inputs))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cap = dict(inputs)                  # a fresh dict: the plan is built inside the capture, from the static buffers
+            self.out = self.model(cap)
+        self._cap_inputs = cap                  # keeps the plan's tensors (graph memory) referenced
+        self.graph = g

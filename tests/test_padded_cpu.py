@@ -1,0 +1,87 @@
+"""Padding of a batch to fixed capacities (gemnet_pytorch_amd/padded.py): the fabricated index rows are a valid graph of
+their own, and — on the CPU emulation of the launchers, float64 — the padded batch gives the real molecules the energies
+and forces of the unpadded one."""
+import numpy as np
+import torch
+
+import cpu_kernels
+from gemnet_pytorch_amd.padded import dummy_positions, pad_indices
+from test_model_cpu import build
+from test_oracle_model import load_case
+
+
+def _idx(inputs):
+    return {k: inputs[k] for k in ("id_c", "id_a", "id_swap", "id_undir", "id3_reduce_ca", "id3_expand_ba")}
+
+
+def test_pad_rows_form_a_valid_graph(golden_model2):
+    cfg, params, inputs = load_case(golden_model2, "t2s")
+    idx = _idx(inputs)
+    A = int(inputs["Z"].shape[0])
+    E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+    for e_cap, t_cap, G in ((E + 8, T + 2, 1), (E + 40, T + 300, 3), (E + 4, T, 2), (E, T, 1), (E + 6, T + 4, 2), (E + 2, T, 1)):
+        o = pad_indices(idx, A, e_cap, t_cap, G)
+        assert all(o[k].shape[0] == e_cap for k in ("id_c", "id_a", "id_swap", "id_undir"))
+        assert o["id3_reduce_ca"].shape[0] == t_cap == o["id3_expand_ba"].shape[0]
+        for k in idx:                                   # the real rows are untouched and come first
+            assert torch.equal(o[k][:idx[k].shape[0]], idx[k].to(torch.int64))
+        sw = o["id_swap"]
+        assert torch.equal(sw[sw], torch.arange(e_cap))                      # involution
+        assert torch.equal(o["id_c"][sw], o["id_a"]) and torch.equal(o["id_a"][sw], o["id_c"])
+        assert torch.equal(o["id_undir"][sw], o["id_undir"])                 # both directions share the undirected id
+        assert int(o["id_undir"].max()) == e_cap // 2 - 1 and torch.bincount(o["id_undir"]).eq(2).all()
+        r, x = o["id3_reduce_ca"], o["id3_expand_ba"]
+        assert bool((r[1:] >= r[:-1]).all())                                 # sorted by reduce edge
+        assert torch.equal(o["id_a"][r], o["id_a"][x])                       # c -> a <- b: same target atom
+        assert bool((o["id_c"][r] != o["id_c"][x]).all())                    # b != c: a proper angle
+        pad_atoms = torch.cat([o["id_c"][E:], o["id_a"][E:]])
+        assert pad_atoms.numel() == 0 or (int(pad_atoms.min()) >= A and int(pad_atoms.max()) < A + 3 * G)
+        assert bool((r[T:] >= E).all()) and bool((x[T:] >= E).all())         # pad triplets live on pad edges only
+
+
+def test_padded_batch_reproduces_the_unpadded_molecules(golden_model2):
+    cfg, params, inputs = load_case(golden_model2, "t2s")
+    A = int(inputs["Z"].shape[0])
+    with cpu_kernels.emulate():
+        model = build(cfg, params).eval()
+        base = dict(inputs, R=inputs["R"].double())
+        E0, F0 = model(base)
+        G = 2
+        idx = _idx(inputs)
+        E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+        pad = pad_indices(idx, A, E + 24, T + 50, G)
+        R = torch.cat([inputs["R"].double(), dummy_positions(G, inputs["R"].double(), offset=50.0)])
+        n_mol = int(inputs["N"].shape[0])
+        padded = dict(Z=torch.cat([inputs["Z"], torch.ones(3 * G, dtype=inputs["Z"].dtype)]), R=R,
+                      N=torch.cat([inputs["N"], torch.tensor([3 * G])]),
+                      batch_seg=torch.cat([inputs["batch_seg"], torch.full((3 * G,), n_mol, dtype=inputs["batch_seg"].dtype)]),
+                      max_in_degree=64, **pad)
+        E1, F1 = model(padded)
+    assert E1.shape[0] == n_mol + 1 and F1.shape[0] == A + 3 * G
+    np.testing.assert_allclose(E1[:n_mol].detach().numpy(), E0.detach().numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(F1[:A].detach().numpy(), F0.detach().numpy(), rtol=1e-11, atol=1e-12)
+    assert torch.isfinite(E1).all() and torch.isfinite(F1).all()
+
+
+def test_runner_fill_equals_pad_indices(golden_model2):
+    """The runner writes real rows and precomputed pad patterns straight into its static buffers: same arrays as the
+    reference construction `pad_indices`, for two batches of different sizes in turn (stale rows must not survive)."""
+    from gemnet_pytorch_amd.padded import PaddedGraphRunner
+
+    class _M:       # the runner only looks at these two attributes before a capture
+        triplets_only, direct_forces = True, False
+    cfg, params, inputs = load_case(golden_model2, "t2s")
+    idx = _idx(inputs)
+    E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+    runner = PaddedGraphRunner(_M(), inputs["Z"], inputs["N"], E + 42, T + 600, max_in_degree=64, n_groups=3)
+    fewer = dict(idx, id3_reduce_ca=idx["id3_reduce_ca"][:T - 6], id3_expand_ba=idx["id3_expand_ba"][:T - 6])
+    for batch in (idx, fewer, idx):
+        runner._fill(inputs["R"].float(), batch, Z=inputs["Z"])
+        ref = pad_indices(batch, runner.A, runner.e_cap, runner.t_cap, runner.G)
+        got = runner.padded_inputs()
+        for k, v in ref.items():
+            assert torch.equal(got[k], v), k
+        assert torch.equal(got["R"][:runner.A], inputs["R"].float())
+    with __import__("pytest").raises(ValueError):
+        runner._fill(inputs["R"].float(), dict(idx, id_c=torch.cat([idx["id_c"]] * 3), id_a=torch.cat([idx["id_a"]] * 3),
+                                               id_swap=torch.cat([idx["id_swap"]] * 3), id_undir=torch.cat([idx["id_undir"]] * 3)))
