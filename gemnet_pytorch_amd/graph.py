@@ -38,8 +38,10 @@ class RowIndex:
             if self.is_sorted:
                 self._csr = (None, _seg_offsets_sorted(self.idx64, self.n_rows))
             else:
-                perm = torch.argsort(self.idx64, stable=True)
-                seg = _seg_offsets_sorted(self.idx64[perm], self.n_rows)
+                # 32-bit keys: half the bytes through every pass of the device sort (the plan is rebuilt per batch on the
+                # dynamic-shape paths, inside the replayed graph of padded.py: four sorts of T keys were 0.5 ms of it)
+                perm = torch.argsort(self.idx32, stable=True)
+                seg = _seg_offsets_sorted(self.idx32[perm], self.n_rows)
                 self._csr = (perm.to(torch.int32).contiguous(), seg)
         return self._csr
 
@@ -158,8 +160,10 @@ class GraphPlan:
         return plan
 
     def row_indices(self):
+        """The row indices whose CSR some kernel of the path reads (id_swap's adjoint is a gather with its inverse;
+        id_undir only with coupled direct forces: built on first use there)."""
         out = [self.id_a, self.id_c, self.batch_seg, self.trip.reduce, self.trip.expand,
-               self.t_c, self.t_a, self.t_b, self.z_rows, self.id_undir]
+               self.t_c, self.t_a, self.t_b, self.z_rows]
         if not self.triplets_only:
             out += [self.int_a, self.int_b, self.intm_db, self.intm_ab, self.quad.reduce, self.quad.expand]
             out += list(self.quad_geom.values()) + [self.q_c, self.q_a, self.q_b, self.q_d]

@@ -178,6 +178,25 @@ class PaddedGraphRunner:
         E, F = self.out
         return E.detach()[:self.n_mol], F.detach()[:self.A]
 
+    def build_and_run(self, builder, R, Z=None, positions_ready=False):
+        """Index build (index_device.DeviceGraphBuilder) + padded replay with the build on a stream of its own: its size
+        read-back then waits for the build kernels only, not for the previous replay still running on the calling stream,
+        and the host can enqueue the next step while the GPU works.  `positions_ready`: R does not depend on work pending on
+        the calling stream (a new batch of a data provider); the default (False: an MD step's new positions) orders the
+        build behind the calling stream first."""
+        main = torch.cuda.current_stream(R.device)
+        if getattr(self, "_bstream", None) is None:
+            self._bstream = torch.cuda.Stream(device=R.device)
+        bs = self._bstream
+        if not positions_ready:
+            bs.wait_stream(main)
+        with torch.cuda.stream(bs):
+            idx = builder(R)
+        main.wait_stream(bs)
+        for t in idx.values():
+            t.record_stream(main)
+        return self(R, idx, Z)
+
     def _capture(self):
         inputs = dict(self.inputs, max_in_degree=self.pad_degree_bound())
         inputs.pop("_plan", None)

@@ -48,6 +48,13 @@ def test_padded_graph_replay_equals_eager_on_changing_batches():
             worst = max(worst, float((F - F0).abs().max()), float((E - E0).abs().max()))
             scale = float(F0.abs().max())
             assert float((F - F0).abs().max()) <= 1e-5 * scale and float((E - E0).abs().max()) <= 1e-5 * float(E0.abs().max())
+    # index build + replay in one call, the build on its own stream
+    builders = [DeviceGraphBuilder(N.cpu().numpy(), 5.0, 10.0, True, device=DEV) for _ in batches]
+    for rnd in range(2):
+        for (Zb, R, Nb, idx), (E0, F0), bld in zip(batches, ref, builders):
+            E, F = runner.build_and_run(bld, R, Z=Zb, positions_ready=bool(rnd))
+            torch.cuda.synchronize()
+            assert torch.equal(E, E0) and torch.equal(F, F0)
     print(f"padded replay vs eager over {len(batches)} batches {sizes} at capacities ({runner.e_cap}, {runner.t_cap}), "
           f"{runner.G} dummy groups: max abs deviation {worst:.3e}")
     with pytest.raises(ValueError):
