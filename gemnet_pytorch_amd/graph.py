@@ -23,7 +23,7 @@ class RowIndex:
     inverse      for permutations (id_swap): adjoint is a gather with the inverse permutation
     """
 
-    def __init__(self, idx: torch.Tensor, n_rows: int, is_sorted: bool = False, inverse=None):
+    def __init__(self, idx: torch.Tensor, n_rows: int, is_sorted: bool = False, inverse=None, csr_builder=None):
         self.idx64 = idx
         self.idx32 = idx.to(torch.int32).contiguous()
         self.n_rows = int(n_rows)
@@ -31,11 +31,14 @@ class RowIndex:
         self.is_sorted = is_sorted
         self.inverse = inverse
         self._csr = None
+        self._csr_builder = csr_builder   # () -> (perm, seg_off): a cheaper construction than the sort, same result
 
     @property
     def csr(self):
         if self._csr is None:
-            if self.is_sorted:
+            if self._csr_builder is not None:
+                self._csr = self._csr_builder()
+            elif self.is_sorted:
                 self._csr = (None, _seg_offsets_sorted(self.idx64, self.n_rows))
             else:
                 # 32-bit keys: half the bytes through every pass of the device sort (the plan is rebuilt per batch on the
@@ -44,6 +47,24 @@ class RowIndex:
                 seg = _seg_offsets_sorted(self.idx32[perm], self.n_rows)
                 self._csr = (perm.to(torch.int32).contiguous(), seg)
         return self._csr
+
+
+def expanded_csr(row_of_edge: RowIndex, seg_off_of_edge: torch.Tensor, n_items: int):
+    """CSR (perm, seg_off) by row of the items t (triplets) whose row is `row_of_edge[edge(t)]`, when the items are sorted
+    by their edge (`seg_off_of_edge`: item range of every edge): the rows' edge lists (the CSR of `row_of_edge`, a sort of
+    E keys) expanded into item ranges — the same permutation as the stable sort of the T item keys (edges of a row in
+    increasing order, the items of an edge in increasing order), without sorting T keys."""
+    perm_e, seg_e = row_of_edge.csr
+    so = seg_off_of_edge.to(torch.int64)
+    cnt = so[1:] - so[:-1]
+    order = perm_e.to(torch.int64) if perm_e is not None else torch.arange(cnt.shape[0], device=cnt.device)
+    c = cnt[order]
+    off = torch.zeros(c.shape[0] + 1, dtype=torch.int64, device=c.device)
+    torch.cumsum(c, 0, out=off[1:])
+    j = torch.arange(n_items, device=c.device, dtype=torch.int64)
+    k = torch.searchsorted(off[1:].contiguous(), j, right=True)      # slot of the edge that owns item j
+    perm = so[order[k]] + (j - off[k])
+    return perm.to(torch.int32).contiguous(), off[seg_e.to(torch.int64)].to(torch.int32).contiguous()
 
 
 class SegmentPlan:
@@ -116,8 +137,11 @@ class GraphPlan:
         self.trip.set_row_groups(id_a, self.n_atoms, max_rows=inputs.get("max_in_degree"))
         # atom triples of each triplet for the angle c<-a->b (gemnet.py:442-444)
         r, x = inputs["id3_reduce_ca"], inputs["id3_expand_ba"]
-        self.t_c, self.t_a, self.t_b = id_c[r], id_a[r], id_c[x]
-        self.t_c, self.t_a, self.t_b = (RowIndex(v, self.n_atoms) for v in (self.t_c, self.t_a, self.t_b))
+        # t_c, t_a follow the (sorted) reduce edge: their CSR by atom is the atoms' edge lists expanded into triplet ranges
+        T3 = int(r.shape[0])
+        self.t_c = RowIndex(id_c[r], self.n_atoms, csr_builder=lambda: expanded_csr(self.id_c, self.trip.seg_off, T3))
+        self.t_a = RowIndex(id_a[r], self.n_atoms, csr_builder=lambda: expanded_csr(self.id_a, self.trip.seg_off, T3))
+        self.t_b = RowIndex(id_c[x], self.n_atoms)
         self.z_rows = RowIndex(Z - 1, 93)
         self.id_undir = RowIndex(inputs["id_undir"], self.n_edges // 2)
         if "N" in inputs:

@@ -85,3 +85,27 @@ def test_runner_fill_equals_pad_indices(golden_model2):
     with __import__("pytest").raises(ValueError):
         runner._fill(inputs["R"].float(), dict(idx, id_c=torch.cat([idx["id_c"]] * 3), id_a=torch.cat([idx["id_a"]] * 3),
                                                id_swap=torch.cat([idx["id_swap"]] * 3), id_undir=torch.cat([idx["id_undir"]] * 3)))
+
+
+def test_triplet_atom_csr_by_expansion_equals_the_stable_sort(golden_model2):
+    """GraphPlan builds the CSR of the triplets' atoms c and a (adjoint of the angle kernel) by expanding the atoms' edge
+    lists into triplet ranges instead of sorting T keys: same permutation and offsets as the stable sort, also on a padded
+    batch (pad edges are not grouped by target atom)."""
+    from gemnet_pytorch_amd.graph import GraphPlan, RowIndex
+    for tag in ("t2s", "t4s"):
+        cfg, params, inputs = load_case(golden_model2, tag)
+        A = int(inputs["Z"].shape[0])
+        idx = _idx(inputs)
+        E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+        pad = pad_indices(idx, A, E + 26, T + 90, 3)
+        n_mol = int(inputs["N"].shape[0])
+        padded = dict(Z=torch.cat([inputs["Z"], torch.ones(9, dtype=inputs["Z"].dtype)]),
+                      N=torch.cat([inputs["N"], torch.tensor([9])]),
+                      batch_seg=torch.cat([inputs["batch_seg"], torch.full((9,), n_mol, dtype=inputs["batch_seg"].dtype)]), **pad)
+        for batch in (dict(inputs), padded):
+            plan = GraphPlan(batch, True)
+            for name in ("t_c", "t_a"):
+                ri = getattr(plan, name)
+                perm, seg = ri.csr
+                perm0, seg0 = RowIndex(ri.idx64, ri.n_rows).csr
+                assert torch.equal(perm, perm0) and torch.equal(seg, seg0), (tag, name)
