@@ -21,7 +21,7 @@ import contextlib
 import torch
 
 from .. import ops
-from ..graph import GraphPlan, RowIndex
+from ..graph import GraphPlan
 from .layers import (AtomEmbedding, BesselBasisLayer, Dense, EdgeEmbedding,
                      EfficientInteractionDownProjection, InteractionBlock,
                      InteractionBlockTripletsOnly, OutputBlock, SphericalBasisLayer, TensorBasisLayer)

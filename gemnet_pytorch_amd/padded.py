@@ -22,7 +22,6 @@ segment in index order: the real molecules' energies and forces are those of the
 """
 import torch
 
-from .graph import GraphPlan
 
 PAD_EDGE_KEYS = ("id_c", "id_a", "id_swap", "id_undir")
 PAD_TRIP_KEYS = ("id3_reduce_ca", "id3_expand_ba")

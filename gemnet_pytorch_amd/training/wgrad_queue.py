@@ -7,7 +7,6 @@ autograd graph: nothing reads it except the accumulation into `param.grad`.  Ins
 runs ONE grouped split-K launch and ONE grouped fold that adds straight into the flat gradient buffer
 (csrc/gemm_tn.hip, gn_gemm_tn_grouped_f32).  Fold order per parameter is enqueue order: deterministic.
 """
-import ctypes
 
 import numpy as np
 import torch
