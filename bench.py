@@ -647,6 +647,54 @@ def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12,
     return out
 
 
+def extra_train_dynamic(cfg, model_seed, n_mol, n_atoms, rank, n_batches=4, steps=8, warmup=3):
+    """The training step on a NEW batch every step (what a training loop sees: data_provider.py:159-165): eager TrainStep
+    per batch against PaddedTrainStep (every batch padded to fixed capacities, one captured hipGraph replayed)."""
+    from gemnet_pytorch_amd.index_device import DeviceGraphBuilder
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+    from gemnet_pytorch_amd.padded import PaddedGraphRunner
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    from gemnet_pytorch_amd.training.ddp import PaddedTrainStep, TrainStep
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator().manual_seed(1)
+    data = []
+    for b in range(n_batches):
+        ds = make_dataset(n_mol, n_atoms, config=2, first=(rank * n_batches + b + 1) * n_mol)
+        R = torch.tensor(ds["R"], device=dev, dtype=torch.float32)
+        idx = DeviceGraphBuilder(ds["N"], cfg["cutoff"], cfg["int_cutoff"], True, device=dev)(R)
+        data.append(dict(R=R, Z=torch.tensor(ds["Z"], device=dev).long(), N=torch.tensor(ds["N"], device=dev).long(), idx=idx,
+                         E=torch.randn(n_mol, 1, generator=g).to(dev), F=torch.randn(n_mol * n_atoms, 3, generator=g).to(dev)))
+    sizes = [(int(d["idx"]["id_c"].shape[0]), int(d["idx"]["id3_reduce_ca"].shape[0])) for d in data]
+    out = dict(batch_sizes=sizes, steps=steps, warmup=warmup)
+    state = {"i": 0}
+    for kind in ("eager", "padded_graph"):
+        torch.manual_seed(model_seed)
+        model = GemNet(**cfg, scale_file=SCALE_FILE).to(dev)
+        if kind == "eager":
+            ts = TrainStep(model, fused_optimizer=True)
+
+            def step():
+                d = data[state["i"] % n_batches]
+                state["i"] += 1
+                return ts(dict(Z=d["Z"], R=d["R"].clone(), N=d["N"], **d["idx"]), {"E": d["E"], "F": d["F"]})
+        else:
+            ts = PaddedTrainStep(model, data[0]["Z"], data[0]["N"], *PaddedGraphRunner.suggest_capacities(sizes), fused_optimizer=True)
+
+            def step():
+                d = data[state["i"] % n_batches]
+                state["i"] += 1
+                return ts.step(d["R"], d["idx"], d["E"], d["F"], Z=d["Z"])
+        state["i"] = 0
+        for _ in range(warmup):
+            step()
+        el = time_steps(step, steps, 0)
+        out[kind] = dict(ms_per_step=round(el / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / el, 1))
+        del ts, model
+    out["note"] = ("index arrays of every batch resident on the device (the loader's job); eager = ~600 launches issued from "
+                   "Python per step; padded_graph = pad + one hipGraph replay + optimizer")
+    return out
+
+
 def dry_run(args, rank, world):
     """The N-rank plumbing without a GPU: process group (gloo), the shard of the global batch, one all-reduce; rank 0
     prints the JSON skeleton.  Everything the real run does before touching the device."""
@@ -806,6 +854,7 @@ def main():
             guarded("train_step", lambda: extra_train_step(cfg, 1234, inputs, targets, 1, args.batch))
             guarded("interaction_block_fwd_bwd", lambda: extra_interaction_block(model, plan))
             guarded("dynamic_shape", lambda: extra_dynamic_shape(cfg, model, args.batch, args.atoms, rank))
+            guarded("train_step_dynamic", lambda: extra_train_dynamic(cfg, 1234, args.batch, args.atoms, rank))
             guarded("gemnet_q", lambda: extra_gemnet_q(args.batch, args.atoms, rank))
 
     cpu = None

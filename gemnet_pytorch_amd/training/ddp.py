@@ -135,10 +135,20 @@ class TrainStep:
         f_term = torch.norm(F - targets["F"], p=2, dim=1).sum() / A
         return (1 - self.rho) * e_term + self.rho * f_term
 
-    def _forward_backward(self, inputs, targets):
+    @staticmethod
+    def _local_counts(inputs):
+        """(molecules, atoms) of this rank's batch that enter the loss normalisation."""
+        return int(inputs["N"].shape[0]), int(inputs["Z"].shape[0])
+
+    def _outputs(self, inputs):
+        """(E (n_mol, targets), F (n_atoms, 3)) of the batch — a hook for subclasses that run a padded batch."""
         E, F = self.model(inputs)
         if F.dim() == 3:
             F = F[:, 0]
+        return E, F
+
+    def _forward_backward(self, inputs, targets):
+        E, F = self._outputs(inputs)
         loss = self.loss(E, F, targets)
         self.buf.zero()
         # restrict the double backward to the parameters: no gradient w.r.t. the positions
@@ -156,7 +166,7 @@ class TrainStep:
         hipGraph for this (static-shape) batch; the collective, clipping and optimizer stay eager.
         The graph reads the parameters in place, so optimizer updates are seen by every replay."""
         self.model.train()
-        local = (int(inputs["N"].shape[0]), int(inputs["Z"].shape[0]))
+        local = self._local_counts(inputs)
         self._pinned_counts = None
         self._use_pinned = False
         self._pinned_counts = (local, self._counts(*local, inputs["Z"].device))   # no collective inside the graph
@@ -212,3 +222,47 @@ class TrainStep:
                 self.opt.step()
         self.last_loss = loss
         return self.last_loss
+
+
+class PaddedTrainStep(TrainStep):
+    """The training step for batches whose array sizes change every step — what a real training loop sees
+    (data_provider.py:159-165) — replayed from ONE captured hipGraph: every batch is padded to fixed capacities with the
+    dummy molecule of `padded.py`, whose energy and forces are cut off before the loss (its rows then receive zero
+    cotangents: no contribution to any parameter gradient).  Same molecule-size layout N every step (the loader's batch
+    shape), atoms / geometry / targets change.
+
+        ts = PaddedTrainStep(model, Z, N, e_cap, t_cap, fused_optimizer=True)
+        loss = ts.step(R, idx, E_target, F_target, Z=Z_batch)
+
+    On a CPU model (host emulation of the launchers: tests) the padded batch runs eagerly."""
+
+    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, **kw):
+        super().__init__(model, **kw)
+        from ..padded import PaddedGraphRunner
+        self.pad = PaddedGraphRunner(model, Z, N, e_cap, t_cap, max_in_degree=max_in_degree, n_groups=n_groups)
+        dev = Z.device
+        self.inputs = dict(self.pad.inputs, max_in_degree=self.pad.pad_degree_bound())
+        self.targets = {"E": torch.zeros(self.pad.n_mol, model.num_targets, device=dev),
+                        "F": torch.zeros(self.pad.A, 3, device=dev)}
+        self._captured = False
+
+    def _local_counts(self, inputs):
+        return self.pad.n_mol, self.pad.A      # the dummy molecule does not count
+
+    def _outputs(self, inputs):
+        if not self._captured:
+            # the index plan must be built INSIDE the captured region (from the static buffers, so that every replay
+            # rebuilds it for the batch just written): no plan cached by an earlier eager call may survive into it.
+            # The plan of the capture run itself stays in the dict — its tensors are the graph's memory.
+            inputs.pop("_plan", None)
+        E, F = super()._outputs(inputs)
+        return E[:self.pad.n_mol], F[:self.pad.A]
+
+    def step(self, R, idx, E_target, F_target, Z=None, step_optimizer=True):
+        self.pad._fill(R, idx, Z)
+        self.targets["E"].copy_(E_target.reshape(self.targets["E"].shape))
+        self.targets["F"].copy_(F_target)
+        if R.is_cuda and not self._captured:
+            self.capture(self.inputs, self.targets)
+            self._captured = True
+        return self(self.inputs, self.targets, step_optimizer=step_optimizer)

@@ -109,3 +109,36 @@ def test_triplet_atom_csr_by_expansion_equals_the_stable_sort(golden_model2):
                 perm, seg = ri.csr
                 perm0, seg0 = RowIndex(ri.idx64, ri.n_rows).csr
                 assert torch.equal(perm, perm0) and torch.equal(seg, seg0), (tag, name)
+
+
+def test_padded_training_step_has_the_gradients_of_the_unpadded_batch(golden_model2):
+    """PaddedTrainStep (training/ddp.py) on the CPU emulation, float64: loss and every parameter gradient of the padded
+    batch equal those of the plain TrainStep on the unpadded batch — the dummy molecule is cut off before the loss."""
+    from gemnet_pytorch_amd.training.ddp import PaddedTrainStep, TrainStep
+    g = golden_model2
+    cfg, params, inputs = load_case(g, "t2s")
+    idx = _idx(inputs)
+    E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+    Et = torch.tensor(g["t2s.Et"]).double()[:, None]
+    Ft = torch.tensor(g["t2s.Ft"]).double()
+    grads = []
+    with cpu_kernels.emulate():
+        for padded in (False, True):
+            model = build(cfg, params).train()
+            if padded:
+                ts = PaddedTrainStep(model, inputs["Z"], inputs["N"], E + 30, T + 120, max_in_degree=64, n_groups=2)
+                for k in ("R",):
+                    ts.inputs[k] = ts.inputs[k].double()
+                ts.pad.inputs["R"] = ts.inputs["R"]
+                ts.inputs["R"][ts.pad.A:] = dummy_positions(2, ts.inputs["R"], offset=40.0)
+                ts.targets = {k: v.double() for k, v in ts.targets.items()}
+                loss = ts.step(inputs["R"].double(), idx, Et, Ft, Z=inputs["Z"], step_optimizer=False)
+            else:
+                ts = TrainStep(model)
+                loss = ts(dict(inputs, R=inputs["R"].double()), {"E": Et, "F": Ft}, step_optimizer=False)
+            grads.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = grads
+    np.testing.assert_allclose(l1, l0, rtol=1e-12)
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        np.testing.assert_allclose(g1[n].numpy(), g0[n].numpy(), rtol=1e-9, atol=1e-12 * float(g0[n].abs().max() + 1e-30), err_msg=n)
