@@ -85,38 +85,52 @@ def dummy_positions(n_groups, like, offset=1.0e3):
 class PaddedGraphRunner:
     """runner = PaddedGraphRunner(model, Z, N, e_cap, t_cap);  E, F = runner(R, idx[, Z])   for every batch of this layout.
 
-    Z (A,), N (n_mol,): atomic numbers and molecule sizes (N fixed; Z may be replaced per call); e_cap / t_cap: capacities
-    (rounded up to even here); `max_in_degree`: bound of the incoming
-    edges of one atom (default max(N) - 1).  A batch that does not fit raises `ValueError` — size the capacities from the
-    first batches with a margin (`suggest_capacities`)."""
+    Z (A,), N (n_mol,): atomic numbers and molecule sizes of a first batch; e_cap / t_cap: capacities (rounded up to even
+    here); `max_in_degree`: bound of the incoming edges of one atom (default max(N) - 1).
+    `a_cap` (optional): capacity of ATOMS — batches whose molecules differ in size from call to call (the same number of
+    molecules; a loader's batches): pass N (and Z) with every call; the atoms between the batch and `a_cap` are isolated
+    filler atoms of the dummy molecule.  Without it the layout N is fixed and only Z / R / the index arrays change.
+    A batch that does not fit raises `ValueError` — size the capacities from the first batches with a margin
+    (`suggest_capacities`)."""
 
-    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None):
+    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, a_cap=None):
         if not model.triplets_only or model.direct_forces:
             raise NotImplementedError("padded replay: triplets-only models with forces by autograd")
         self.model = model
         dev = Z.device
-        self.A, self.n_mol = int(Z.shape[0]), int(N.shape[0])
+        self.A, self.n_mol = int(Z.shape[0]), int(N.shape[0])          # A: atoms of the CURRENT batch
+        self.variable_atoms = a_cap is not None
+        self.a_cap = int(a_cap) if a_cap is not None else self.A
+        if self.a_cap < self.A:
+            raise ValueError("a_cap below the first batch")
         self.e_cap, self.t_cap = (int(e_cap) + 1) // 2 * 2, (int(t_cap) + 1) // 2 * 2
         self.deg = int(max_in_degree) if max_in_degree is not None else int(N.max().item()) - 1
         # every group's atom a takes pad edges of both kinds: at most 2 * ceil(pad quads / G) incoming
         self.G = int(n_groups) if n_groups is not None else max(1, -(-self.e_cap // (16 * max(self.deg, 2))))
         Ap = 3 * self.G
+        self.A_tot = self.a_cap + Ap
         i64 = torch.int64
+        n_fill = self.a_cap - self.A
         self.inputs = {
-            "Z": torch.cat([Z.to(i64), torch.ones(Ap, dtype=i64, device=dev)]),
-            "N": torch.cat([N.to(i64), torch.tensor([Ap], dtype=i64, device=dev)]),
-            "R": torch.zeros(self.A + Ap, 3, device=dev, dtype=torch.float32),
+            "Z": torch.cat([Z.to(i64), torch.ones(n_fill + Ap, dtype=i64, device=dev)]),
+            "N": torch.cat([N.to(i64), torch.tensor([n_fill + Ap], dtype=i64, device=dev)]),
+            "R": torch.zeros(self.A_tot, 3, device=dev, dtype=torch.float32),
             "batch_seg": torch.cat([torch.repeat_interleave(torch.arange(self.n_mol, device=dev), N.to(i64)),
-                                    torch.full((Ap,), self.n_mol, dtype=i64, device=dev)]),
+                                    torch.full((n_fill + Ap,), self.n_mol, dtype=i64, device=dev)]),
             "max_in_degree": None,
         }
-        self.inputs["R"][self.A:] = dummy_positions(self.G, self.inputs["R"])
+        # filler atoms: isolated, 10 A apart on a line of their own; the dummy groups behind them (fixed positions: only
+        # the rows of the current batch's atoms are rewritten per call)
+        fill = torch.arange(self.a_cap, device=dev, dtype=torch.float32)
+        self._R_fill = torch.stack([-1.0e3 - 10.0 * fill, torch.full_like(fill, -1.0e3), torch.full_like(fill, -1.0e3)], dim=1)
+        self.inputs["R"][:self.a_cap] = self._R_fill
+        self.inputs["R"][self.a_cap:] = dummy_positions(self.G, self.inputs["R"])
         for k in PAD_EDGE_KEYS:
             self.inputs[k] = torch.zeros(self.e_cap, dtype=i64, device=dev)
         for k in PAD_TRIP_KEYS:
             self.inputs[k] = torch.zeros(self.t_cap, dtype=i64, device=dev)
         k = torch.arange(self.e_cap, device=dev, dtype=i64)
-        self._pat_src, self._pat_dst = _pad_edges(k, self.A, self.G)
+        self._pat_src, self._pat_dst = _pad_edges(k, self.a_cap, self.G)
         self._pat_swap, self._pat_pair = k ^ 1, k // 2
         self._arange_t = torch.arange(self.t_cap, device=dev, dtype=i64)
         self.graph = None
@@ -135,9 +149,27 @@ class PaddedGraphRunner:
         t = max(s[1] for s in sizes)
         return int(e * (1 + 1.5 * margin)) // 4 * 4 + 8, int(t * (1 + margin)) // 2 * 2 + 2
 
-    def _fill(self, R, idx, Z=None):
+    def _fill(self, R, idx, Z=None, N=None):
         """Write one batch into the static buffers: the real rows as they are, the pad rows from the patterns computed
         once for the whole capacity (an edge's pattern only depends on its distance from the first pad edge)."""
+        A = int(R.shape[0])
+        if A != self.A:
+            if not self.variable_atoms or N is None or Z is None:
+                raise ValueError("the number of atoms changed: build the runner with a_cap and pass Z and N with every call")
+            if A > self.a_cap or int(N.shape[0]) != self.n_mol:
+                raise ValueError(f"batch of {A} atoms / {int(N.shape[0])} molecules exceeds a_cap = {self.a_cap} or changes the "
+                                 f"number of molecules ({self.n_mol})")
+        if N is not None:
+            buf = self.inputs
+            buf["N"][:self.n_mol].copy_(N)
+            buf["N"][self.n_mol:].fill_(self.A_tot - A)
+            buf["batch_seg"][:A].copy_(torch.repeat_interleave(torch.arange(self.n_mol, device=N.device), N.to(torch.int64),
+                                                                output_size=A))
+            buf["batch_seg"][A:].fill_(self.n_mol)
+            if A < self.A:      # atoms that were real in the previous batch become filler again
+                buf["R"][A:self.A].copy_(self._R_fill[A:self.A])
+                buf["Z"][A:self.A].fill_(1)
+            self.A = A
         if Z is not None:
             self.inputs["Z"][:self.A].copy_(Z)
         E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
@@ -166,18 +198,18 @@ class PaddedGraphRunner:
     def pad_degree_bound(self):
         return max(self.deg, 2)
 
-    def __call__(self, R, idx, Z=None):
+    def __call__(self, R, idx, Z=None, N=None):
         """R (A, 3) float32 on the device, idx: the index dict of this batch, Z: its atomic numbers when they change from
-        batch to batch (same molecule sizes N) -> (E (n_mol, targets), F (A, [targets,] 3)); the results live in the
-        graph's static output buffers until the next call."""
-        self._fill(R, idx, Z)
+        batch to batch, N: its molecule sizes when those change too (runner built with `a_cap`) -> (E (n_mol, targets),
+        F (A, [targets,] 3)); the results live in the graph's static output buffers until the next call."""
+        self._fill(R, idx, Z, N)
         if self.graph is None:
             self._capture()
         self.graph.replay()
         E, F = self.out
         return E.detach()[:self.n_mol], F.detach()[:self.A]
 
-    def build_and_run(self, builder, R, Z=None, positions_ready=False):
+    def build_and_run(self, builder, R, Z=None, positions_ready=False, N=None):
         """Index build (index_device.DeviceGraphBuilder) + padded replay with the build on a stream of its own: its size
         read-back then waits for the build kernels only, not for the previous replay still running on the calling stream,
         and the host can enqueue the next step while the GPU works.  `positions_ready`: R does not depend on work pending on
@@ -194,7 +226,7 @@ class PaddedGraphRunner:
         main.wait_stream(bs)
         for t in idx.values():
             t.record_stream(main)
-        return self(R, idx, Z)
+        return self(R, idx, Z, N)
 
     def _capture(self):
         inputs = dict(self.inputs, max_in_degree=self.pad_degree_bound())

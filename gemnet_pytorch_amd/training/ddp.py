@@ -227,27 +227,32 @@ class TrainStep:
 class PaddedTrainStep(TrainStep):
     """The training step for batches whose array sizes change every step — what a real training loop sees
     (data_provider.py:159-165) — replayed from ONE captured hipGraph: every batch is padded to fixed capacities with the
-    dummy molecule of `padded.py`, whose energy and forces are cut off before the loss (its rows then receive zero
-    cotangents: no contribution to any parameter gradient).  Same molecule-size layout N every step (the loader's batch
-    shape), atoms / geometry / targets change.
+    dummy molecule of `padded.py`, whose energy and forces never reach the loss (its rows then receive zero cotangents:
+    no contribution to any parameter gradient).  The number of molecules per batch is fixed; with `a_cap` the molecules
+    may differ in size from batch to batch (pass Z and N with every step), without it the layout N is fixed.
 
-        ts = PaddedTrainStep(model, Z, N, e_cap, t_cap, fused_optimizer=True)
-        loss = ts.step(R, idx, E_target, F_target, Z=Z_batch)
+        ts = PaddedTrainStep(model, Z, N, e_cap, t_cap, a_cap=..., fused_optimizer=True)
+        loss = ts.step(R, idx, E_target, F_target, Z=Z_batch, N=N_batch)
 
-    On a CPU model (host emulation of the launchers: tests) the padded batch runs eagerly."""
+    The loss is the one of `TrainStep.loss` written with a mask over the atom capacity (a slice would bake the first
+    batch's atom count into the graph); the atom count of the step (all ranks) is a device scalar filled before the
+    replay.  On a CPU model (host emulation of the launchers: tests) the padded batch runs eagerly."""
 
-    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, **kw):
+    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, a_cap=None, **kw):
         super().__init__(model, **kw)
         from ..padded import PaddedGraphRunner
-        self.pad = PaddedGraphRunner(model, Z, N, e_cap, t_cap, max_in_degree=max_in_degree, n_groups=n_groups)
+        self.pad = PaddedGraphRunner(model, Z, N, e_cap, t_cap, max_in_degree=max_in_degree, n_groups=n_groups, a_cap=a_cap)
         dev = Z.device
         self.inputs = dict(self.pad.inputs, max_in_degree=self.pad.pad_degree_bound())
-        self.targets = {"E": torch.zeros(self.pad.n_mol, model.num_targets, device=dev),
-                        "F": torch.zeros(self.pad.A, 3, device=dev)}
+        dt = next(model.parameters()).dtype
+        self.targets = {"E": torch.zeros(self.pad.n_mol, model.num_targets, device=dev, dtype=dt),
+                        "F": torch.zeros(self.pad.a_cap, 3, device=dev, dtype=dt)}
+        self.mask = torch.zeros(self.pad.a_cap, device=dev, dtype=dt)        # 1 for the atoms of the current batch
+        self.inv_atoms = torch.ones((), device=dev, dtype=dt)                # 1 / (atoms of the step, all ranks)
         self._captured = False
 
     def _local_counts(self, inputs):
-        return self.pad.n_mol, self.pad.A      # the dummy molecule does not count
+        return self.pad.n_mol, self.pad.a_cap
 
     def _outputs(self, inputs):
         if not self._captured:
@@ -256,12 +261,31 @@ class PaddedTrainStep(TrainStep):
             # The plan of the capture run itself stays in the dict — its tensors are the graph's memory.
             inputs.pop("_plan", None)
         E, F = super()._outputs(inputs)
-        return E[:self.pad.n_mol], F[:self.pad.A]
+        return E[:self.pad.n_mol], F[:self.pad.a_cap]
 
-    def step(self, R, idx, E_target, F_target, Z=None, step_optimizer=True):
-        self.pad._fill(R, idx, Z)
+    def loss(self, E, F, targets):
+        B = float(self.pad.n_mol * max(self.world_size, 1))
+        e_term = (E - targets["E"]).abs().sum() / (B * E.shape[1])
+        m = self.mask
+        # masked rows get a constant difference: the norm of an exact zero has no gradient (0 * nan), and they have no share
+        d = torch.where(m[:, None] > 0, F - targets["F"], torch.ones_like(F))
+        f_term = (torch.norm(d, p=2, dim=1) * m).sum() * self.inv_atoms
+        return (1 - self.rho) * e_term + self.rho * f_term
+
+    def step(self, R, idx, E_target, F_target, Z=None, N=None, step_optimizer=True):
+        self.pad._fill(R, idx, Z, N)
+        A = self.pad.A
         self.targets["E"].copy_(E_target.reshape(self.targets["E"].shape))
-        self.targets["F"].copy_(F_target)
+        self.targets["F"][:A].copy_(F_target)
+        self.targets["F"][A:].zero_()
+        self.mask[:A].fill_(1.0)
+        self.mask[A:].zero_()
+        if self.world_size > 1:
+            cnt = torch.full((), float(A), device=self.mask.device, dtype=torch.float64)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)          # device-side: no host sync, before the replay
+            self.inv_atoms.copy_(1.0 / cnt)
+        else:
+            self.inv_atoms.fill_(1.0 / A)
         if R.is_cuda and not self._captured:
             self.capture(self.inputs, self.targets)
             self._captured = True

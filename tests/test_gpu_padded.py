@@ -113,3 +113,54 @@ def test_padded_training_step_replays_one_graph_for_changing_batches():
     # AdamW moves every entry by ~lr per step whatever the gradient's size: an entry whose gradient is fp32 noise may go the
     # other way on the two sides (2 x 3 steps x lr 1e-3 at most); the trajectories stay together (losses above)
     assert drift <= 6.5e-3
+
+
+def _batch(n_mol, n_atoms, first, g=None):
+    ds = make_dataset(n_mol, n_atoms, config=2, first=first)
+    R = torch.tensor(ds["R"], device=DEV, dtype=torch.float32)
+    out = dict(Z=torch.tensor(ds["Z"], device=DEV).long(), R=R, N=torch.tensor(ds["N"], device=DEV).long(),
+               idx=DeviceGraphBuilder(ds["N"], 5.0, 10.0, True, device=DEV)(R))
+    if g is not None:
+        out["Et"] = torch.randn(n_mol, 1, generator=g).to(DEV)
+        out["Ft"] = torch.randn(n_mol * n_atoms, 3, generator=g).to(DEV)
+    return out
+
+
+def test_changing_molecule_sizes_through_one_graph():
+    """`a_cap`: batches of 8 molecules with 32, 24 and 28 atoms each (then the first again) through ONE captured graph —
+    forward+force bit-identical to the eager run on the unpadded batch; the training step within fp32 noise."""
+    import copy
+    from gemnet_pytorch_amd.training.ddp import PaddedTrainStep, TrainStep
+    cfg = dict(FULL, triplets_only=True, num_blocks=2)
+    torch.manual_seed(9)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV).eval()
+    model.requires_grad_(False)
+    g = torch.Generator().manual_seed(4)
+    batches = [_batch(8, n, 100 * (i + 1), g) for i, n in enumerate((32, 24, 28))]
+    sizes = [(int(b["idx"]["id_c"].shape[0]), int(b["idx"]["id3_reduce_ca"].shape[0])) for b in batches]
+    e_cap, t_cap = PaddedGraphRunner.suggest_capacities(sizes)
+    big = batches[0]
+    runner = PaddedGraphRunner(model, big["Z"], big["N"], e_cap, t_cap, a_cap=8 * 32, max_in_degree=31,
+                               n_groups=max(1, e_cap // (2 * 31)))
+    for b in batches + [batches[0]]:
+        E0, F0 = model(dict(Z=b["Z"], R=b["R"].clone(), N=b["N"], **b["idx"]))
+        E, F = runner(b["R"], b["idx"], Z=b["Z"], N=b["N"])
+        torch.cuda.synchronize()
+        assert torch.equal(E, E0.detach()) and torch.equal(F, F0.detach()), (float((F - F0).abs().max()),)
+    # training
+    model_a = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV)
+    model_b = copy.deepcopy(model_a)
+    pts = PaddedTrainStep(model_a, big["Z"], big["N"], e_cap, t_cap, a_cap=8 * 32, max_in_degree=31,
+                          n_groups=max(1, e_cap // (2 * 31)), fused_optimizer=True)
+    ets = TrainStep(model_b, fused_optimizer=True)
+    worst = 0.0
+    for b in batches + [batches[0]]:
+        la = pts.step(b["R"], b["idx"], b["Et"], b["Ft"], Z=b["Z"], N=b["N"], step_optimizer=False)
+        ga = pts.buf.flat.clone()
+        lb = ets(dict(Z=b["Z"], R=b["R"].clone(), N=b["N"], **b["idx"]), {"E": b["Et"], "F": b["Ft"]}, step_optimizer=False)
+        gb = ets.buf.flat.clone()
+        torch.cuda.synchronize()
+        assert abs(float(la) - float(lb)) <= 2e-5 * abs(float(lb)), (float(la), float(lb))
+        worst = max(worst, float((ga - gb).norm() / gb.norm()))
+    print(f"molecule sizes 32 / 24 / 28 through one graph ({sizes}): forward+force bit-identical, training gradients within {worst:.2e}")
+    assert worst <= 1e-3

@@ -142,3 +142,65 @@ def test_padded_training_step_has_the_gradients_of_the_unpadded_batch(golden_mod
     assert g0.keys() == g1.keys()
     for n in g0:
         np.testing.assert_allclose(g1[n].numpy(), g0[n].numpy(), rtol=1e-9, atol=1e-12 * float(g0[n].abs().max() + 1e-30), err_msg=n)
+
+
+def test_variable_atom_counts_through_one_set_of_buffers(golden_model, golden_model2):
+    """`a_cap`: batches whose molecules differ in size share the runner's static buffers — a 32-atom molecule, then a
+    12-atom one (the 20 atoms in between turn into isolated filler atoms of the dummy molecule again), then the first
+    again: energies and forces of the real atoms equal the unpadded runs (CPU emulation, float64)."""
+    from gemnet_pytorch_amd.padded import PaddedGraphRunner
+    cfg, params, small = load_case(golden_model, "t1")
+    _, _, big = load_case(golden_model, "t4")
+    with cpu_kernels.emulate():
+        model = build(cfg, params).eval()
+        ref = {}
+        for name, inp in (("small", small), ("big", big)):
+            E, F = model(dict(inp, R=inp["R"].double()))
+            ref[name] = (E.detach().clone(), F.detach().clone())
+        Eb, Tb = int(big["id_c"].shape[0]), int(big["id3_reduce_ca"].shape[0])
+        runner = PaddedGraphRunner(model, big["Z"], big["N"], Eb + 40, Tb + 200, max_in_degree=64, n_groups=6, a_cap=40)
+        runner.inputs["R"] = runner.inputs["R"].double()
+        runner._R_fill = runner._R_fill.double()
+        for name, inp in (("big", big), ("small", small), ("big", big)):
+            runner._fill(inp["R"].double(), _idx(inp), Z=inp["Z"], N=inp["N"])
+            padded = dict(runner.padded_inputs(), max_in_degree=64)
+            A = int(inp["Z"].shape[0])
+            assert int(padded["N"].sum()) == runner.A_tot and int(padded["N"][-1]) == runner.A_tot - A
+            assert torch.equal(padded["batch_seg"][:A], inp["batch_seg"]) and bool((padded["batch_seg"][A:] == 1).all())
+            E, F = model(padded)
+            E0, F0 = ref[name]
+            np.testing.assert_allclose(E[:1].detach().numpy(), E0.numpy(), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(F[:A].detach().numpy(), F0.numpy(), rtol=1e-10, atol=1e-12)
+            assert torch.isfinite(F).all() and float(F[A:runner.a_cap].abs().max()) == 0.0     # isolated filler atoms
+    import pytest
+    with pytest.raises(ValueError):
+        runner._fill(small["R"].double(), _idx(small))                  # a different atom count needs Z and N
+
+
+def test_padded_training_step_with_changing_molecule_sizes(golden_model):
+    """PaddedTrainStep with `a_cap`: a 32-atom batch, a 12-atom batch, the first again through one set of buffers — loss
+    and parameter gradients of each equal the plain TrainStep on the unpadded batch (CPU emulation, float64)."""
+    from gemnet_pytorch_amd.training.ddp import PaddedTrainStep, TrainStep
+    cfg, params, small = load_case(golden_model, "t1")
+    _, _, big = load_case(golden_model, "t4")
+    gen = torch.Generator().manual_seed(0)
+    tgt = {id(b): (torch.randn(1, 1, generator=gen).double(), torch.randn(int(b["Z"].shape[0]), 3, generator=gen).double())
+           for b in (small, big)}
+    Eb, Tb = int(big["id_c"].shape[0]), int(big["id3_reduce_ca"].shape[0])
+    with cpu_kernels.emulate():
+        model_p = build(cfg, params).train()
+        pts = PaddedTrainStep(model_p, big["Z"], big["N"], Eb + 40, Tb + 200, max_in_degree=64, n_groups=6, a_cap=40)
+        pts.inputs["R"] = pts.pad.inputs["R"] = pts.pad.inputs["R"].double()
+        pts.pad._R_fill = pts.pad._R_fill.double()
+        for batch in (big, small, big):
+            Et, Ft = tgt[id(batch)]
+            lp = pts.step(batch["R"].double(), _idx(batch), Et, Ft, Z=batch["Z"], N=batch["N"], step_optimizer=False)
+            gp = {n: p.grad.detach().clone() for n, p in model_p.named_parameters() if p.grad is not None}
+            model_e = build(cfg, params).train()
+            le = TrainStep(model_e)(dict(batch, R=batch["R"].double()), {"E": Et, "F": Ft}, step_optimizer=False)
+            ge = {n: p.grad.detach().clone() for n, p in model_e.named_parameters() if p.grad is not None}
+            np.testing.assert_allclose(float(lp), float(le), rtol=1e-12)
+            assert gp.keys() == ge.keys()
+            for n in ge:
+                np.testing.assert_allclose(gp[n].numpy(), ge[n].numpy(), rtol=1e-9,
+                                           atol=1e-12 * float(ge[n].abs().max() + 1e-30), err_msg=n)
