@@ -96,6 +96,55 @@ def test_two_rank_gradients_equal_single_process(tmp_path):
     np.testing.assert_allclose(float(np.load(tmp_path / "loss_0.npy")), loss_ref, rtol=1e-10)
 
 
+def _worker_padded(rank, world, port, shards, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_kernels
+    from gemnet_pytorch_amd.padded import dummy_positions
+    from gemnet_pytorch_amd.training.ddp import PaddedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with cpu_kernels.emulate():
+            model = _model()
+            inputs, targets = _batch(_make(4), shards[rank])
+            idx = {k: inputs[k] for k in ("id_c", "id_a", "id_swap", "id_undir", "id3_reduce_ca", "id3_expand_ba")}
+            E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+            # different capacities per rank on purpose: the padding is a local matter
+            ts = PaddedTrainStep(model, inputs["Z"], inputs["N"], E + 20 + 8 * rank, T + 60 + 10 * rank, max_in_degree=64,
+                                 n_groups=2, a_cap=int(inputs["Z"].shape[0]) + 5 * rank, world_size=world)
+            ts.inputs["R"] = ts.pad.inputs["R"] = ts.pad.inputs["R"].double()
+            ts.pad._R_fill = ts.pad._R_fill.double()
+            ts.inputs["R"][ts.pad.a_cap:] = dummy_positions(2, ts.inputs["R"], offset=60.0)
+            loss = ts.step(inputs["R"], idx, targets["E"], targets["F"], Z=inputs["Z"], N=inputs["N"], step_optimizer=False)
+        lt = loss.clone()
+        dist.all_reduce(lt)
+        np.save(os.path.join(out_dir, f"pgrad_{rank}.npy"), ts.buf.flat.numpy())
+        np.save(os.path.join(out_dir, f"ploss_{rank}.npy"), np.array(float(lt)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_padded_step_equals_single_process(tmp_path):
+    """PaddedTrainStep under world_size 2 (gloo): each rank pads its own shard (to its own capacities); the all-reduced
+    gradient and the summed loss equal the single-process TrainStep on the union batch."""
+    import cpu_kernels
+    dc = _make(4)
+    with cpu_kernels.emulate():
+        model = _model()
+        ts = TrainStep(model, world_size=1)
+        inputs, targets = _batch(dc, [0, 1, 2, 3])
+        loss_ref = float(ts(inputs, targets, step_optimizer=False))
+        ref = ts.buf.flat.clone().numpy()
+    shards = [[0, 3], [1, 2]]
+    mp.spawn(_worker_padded, args=(2, _free_port(), shards, str(tmp_path)), nprocs=2, join=True)
+    g0 = np.load(tmp_path / "pgrad_0.npy")
+    g1 = np.load(tmp_path / "pgrad_1.npy")
+    assert np.array_equal(g0, g1)
+    np.testing.assert_allclose(g0, ref, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(float(np.load(tmp_path / "ploss_0.npy")), loss_ref, rtol=1e-10)
+
+
 def test_flat_buffer_views():
     lin = torch.nn.Linear(3, 2)
     buf = FlatGradBuffer(lin.parameters())
