@@ -70,3 +70,57 @@ class ForceGraphs:
     def energies_forces(self):
         """Concatenated (E (nMol, T), F (nAtoms, ...)) of the last replay, sub-batch order."""
         return (torch.cat([o[0] for o in self.outputs]), torch.cat([o[1] for o in self.outputs]))
+
+
+class DynamicForceField:
+    """Energies and forces of ONE system for positions that change from call to call — the loop of the reference's ASE
+    calculator (ase_calculator.py:148-170: new neighbour list every step) — at hipGraph speed:
+
+        ff = DynamicForceField(model, Z, N_host, cutoff=5.0, int_cutoff=10.0)
+        E, F = ff(R)            # R (A, 3) float32 on the device
+
+    Every call builds the index arrays on the device (index_device.DeviceGraphBuilder, on a stream of its own), pads them to
+    the current capacities and replays the one captured graph (padded.PaddedGraphRunner: bit-identical to the eager run
+    on the unpadded arrays).  The capacities start `margin` above the first call's sizes; a call that outgrows them
+    captures a new graph with `margin` head room again (counted in `recaptures`).  Triplets-only models."""
+
+    def __init__(self, model, Z, N_host, cutoff, int_cutoff, margin=0.08, max_in_degree=None):
+        from .index_device import DeviceGraphBuilder
+        import numpy as np
+        self.model, self.Z = model, Z
+        self.N_host = np.asarray(N_host, dtype=np.int64).reshape(-1)
+        self.N = torch.as_tensor(self.N_host, device=Z.device)
+        self.builder = DeviceGraphBuilder(self.N_host, cutoff, int_cutoff, model.triplets_only, device=Z.device)
+        self.margin = float(margin)
+        self.deg = int(max_in_degree) if max_in_degree is not None else int(self.N_host.max()) - 1
+        self.runner = None
+        self.recaptures = 0
+        self._bstream = None
+
+    def _build(self, R):
+        main = torch.cuda.current_stream(R.device)
+        if self._bstream is None:
+            self._bstream = torch.cuda.Stream(device=R.device)
+        self._bstream.wait_stream(main)          # the new positions come from work on the calling stream (the integrator)
+        with torch.cuda.stream(self._bstream):
+            idx = self.builder(R)
+        main.wait_stream(self._bstream)
+        for t in idx.values():
+            t.record_stream(main)
+        return idx
+
+    def __call__(self, R):
+        from .padded import PaddedGraphRunner
+        idx = self._build(R)
+        E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+        r = self.runner
+        # pad triplets need a complete quad of pad edges; the pad edges must fit the dummy groups' in-degree bound
+        fits = r is not None and E + 4 <= r.e_cap and T <= r.t_cap and -(-((r.e_cap - E) // 2) // r.G) <= r.pad_degree_bound()
+        if not fits:
+            e_cap = int(E * (1 + 1.5 * self.margin)) // 2 * 2 + 8
+            t_cap = int(T * (1 + self.margin)) // 2 * 2 + 2
+            # dummy groups for the largest padding this runner may see (a later call with fewer edges pads more)
+            groups = max(1, -(-int(e_cap * min(1.0, 4 * self.margin)) // (2 * max(self.deg, 2))))
+            self.runner = PaddedGraphRunner(self.model, self.Z, self.N, e_cap, t_cap, max_in_degree=self.deg, n_groups=groups)
+            self.recaptures += self.runner is not r and r is not None
+        return self.runner(R, idx)

@@ -164,3 +164,33 @@ def test_changing_molecule_sizes_through_one_graph():
         worst = max(worst, float((ga - gb).norm() / gb.norm()))
     print(f"molecule sizes 32 / 24 / 28 through one graph ({sizes}): forward+force bit-identical, training gradients within {worst:.2e}")
     assert worst <= 1e-3
+
+
+def test_dynamic_force_field_follows_a_moving_system():
+    """runtime.DynamicForceField: positions drift from call to call (the neighbour list changes), the capacities start
+    tight so that the loop has to grow them at least once — every call equals the eager run on that call's arrays."""
+    from gemnet_pytorch_amd.runtime import DynamicForceField
+    cfg = dict(FULL, triplets_only=True, num_blocks=2)
+    torch.manual_seed(2)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV).eval()
+    model.requires_grad_(False)
+    ds = make_dataset(4, 32, config=2, first=50)
+    R0 = torch.tensor(ds["R"], device=DEV, dtype=torch.float32)
+    Z = torch.tensor(ds["Z"], device=DEV).long()
+    N = torch.tensor(ds["N"], device=DEV).long()
+    ff = DynamicForceField(model, Z, ds["N"], 5.0, 10.0, margin=0.03)
+    g = torch.Generator().manual_seed(0)
+    sizes = []
+    for step in range(8):
+        # breathe: scale the molecules about their centres (denser -> more edges), plus a little noise
+        c = R0.view(4, 32, 3).mean(dim=1, keepdim=True)
+        s = 1.0 - 0.008 * step
+        R = ((R0.view(4, 32, 3) - c) * s + c).reshape(-1, 3) + 0.01 * torch.randn(R0.shape, generator=g).to(DEV)
+        E, F = ff(R)
+        idx = DeviceGraphBuilder(ds["N"], 5.0, 10.0, True, device=DEV)(R)
+        E0, F0 = model(dict(Z=Z, R=R.clone(), N=N, **idx))
+        torch.cuda.synchronize()
+        sizes.append(int(idx["id_c"].shape[0]))
+        assert torch.equal(E, E0.detach()) and torch.equal(F, F0.detach()), (step, float((F - F0).abs().max()))
+    print(f"moving system: edges per step {sizes}, graphs re-captured {ff.recaptures} time(s)")
+    assert 1 <= ff.recaptures < 7 and len(set(sizes)) > 2      # grown at least once, replayed in between
