@@ -114,14 +114,14 @@ class PaddedGraphRunner:
         self.inputs = {
             "Z": torch.cat([Z.to(i64), torch.ones(n_fill + Ap, dtype=i64, device=dev)]),
             "N": torch.cat([N.to(i64), torch.tensor([n_fill + Ap], dtype=i64, device=dev)]),
-            "R": torch.zeros(self.A_tot, 3, device=dev, dtype=torch.float32),
+            "R": torch.zeros(self.A_tot, 3, device=dev, dtype=self._float_dtype(model)),
             "batch_seg": torch.cat([torch.repeat_interleave(torch.arange(self.n_mol, device=dev), N.to(i64)),
                                     torch.full((n_fill + Ap,), self.n_mol, dtype=i64, device=dev)]),
             "max_in_degree": None,
         }
         # filler atoms: isolated, 10 A apart on a line of their own; the dummy groups behind them (fixed positions: only
         # the rows of the current batch's atoms are rewritten per call)
-        fill = torch.arange(self.a_cap, device=dev, dtype=torch.float32)
+        fill = torch.arange(self.a_cap, device=dev, dtype=self.inputs["R"].dtype)
         self._R_fill = torch.stack([-1.0e3 - 10.0 * fill, torch.full_like(fill, -1.0e3), torch.full_like(fill, -1.0e3)], dim=1)
         self.inputs["R"][:self.a_cap] = self._R_fill
         self.inputs["R"][self.a_cap:] = dummy_positions(self.G, self.inputs["R"])
@@ -135,6 +135,14 @@ class PaddedGraphRunner:
         self._arange_t = torch.arange(self.t_cap, device=dev, dtype=i64)
         self.graph = None
         self.out = None
+
+    @staticmethod
+    def _float_dtype(model):
+        """fp32 on the device; the float64 CPU emulation of the tests keeps its own precision."""
+        try:
+            return next(model.parameters()).dtype
+        except (AttributeError, StopIteration, TypeError):
+            return torch.float32
 
     def padded_inputs(self):
         """The static input buffers as one padded batch (a view of the runner's state: for tests)."""

@@ -73,6 +73,8 @@ class Trainer:
                                 else ["loss", "energy_mae", "force_mae", "force_rmse"])
         self._grads = None
         self._wgrad = None
+        self._padded_caps = None     # enable_padded_graph(): capacities of the captured training step
+        self._pstep = None
         self.reset_optimizer(learning_rate, weight_decay, warmup_steps, decay_steps, decay_rate, staircase,
                              decay_patience, decay_factor, decay_cooldown)
 
@@ -203,10 +205,69 @@ class Trainer:
         return loss, report, out
 
     # ------------------------------------------------------------------------------------------ steps
+    def enable_padded_graph(self, a_cap, e_cap, t_cap, max_in_degree, n_groups=None):
+        """Run `train_on_batch` from ONE captured hipGraph although every batch has its own array sizes: each batch is
+        padded to these capacities (atoms, edges, triplets) with the dummy molecule of `padded.py` and the captured
+        forward + force + loss + backward is replayed; all-reduce, shared-gradient rescale, clipping, the optimizers,
+        schedulers, EMA and the metrics run as before.  Same loss values as the plain step (the objective is written
+        with a mask over the atom capacity); triplets-only models with forces by autograd, MAE / RMSE objectives (not the
+        mean-variance NLL).  Batches with the loader's number of molecules that fit the capacities take the graph; any other
+        batch (the partial last one) takes the plain step.  `max_in_degree`: largest molecule size - 1."""
+        if self.mve:
+            raise NotImplementedError("padded graph: MAE / RMSE objectives")
+        self._padded_caps = dict(a_cap=int(a_cap), e_cap=int(e_cap), t_cap=int(t_cap), max_in_degree=int(max_in_degree),
+                                 n_groups=n_groups)
+        self._pstep = None
+
+    def _padded_step_for(self, inputs):
+        """The padded step if this batch can take it, else None."""
+        caps = self._padded_caps
+        if caps is None or not self.model.triplets_only or self.model.direct_forces:
+            return None
+        n_mol, A = int(inputs["N"].shape[0]), int(inputs["Z"].shape[0])
+        E, T = int(inputs["id_c"].shape[0]), int(inputs["id3_reduce_ca"].shape[0])
+        if self._pstep is None:
+            if A > caps["a_cap"]:
+                return None
+            if self._grads is not None:
+                raise RuntimeError("enable_padded_graph before the first train_on_batch (the flat gradient buffer is shared)")
+            self._pstep = _TrainerPaddedStep(self, inputs["Z"], inputs["N"], **caps)
+            self._grads = self._pstep.buf
+        ps = self._pstep
+        pad = ps.pad
+        fits = (n_mol == pad.n_mol and A <= pad.a_cap and E + 4 <= pad.e_cap and T <= pad.t_cap
+                and -(-((pad.e_cap - E) // 2) // pad.G) <= pad.pad_degree_bound())
+        return ps if fits else None
+
+    def _train_on_batch_padded(self, ps, inputs, targets, metrics):
+        loss = ps.run(inputs, targets)
+        report = loss.detach().clone()
+        if self._world() > 1:
+            dist.all_reduce(report)
+        self._grads.all_reduce()
+        self.scale_shared_grads()
+        if self.agc:
+            self._adaptive_gradient_clipping(self.params_except_last, clip_factor=self.grad_clip_max)
+        else:
+            torch.nn.utils.clip_grad_norm_(self._grads.params, max_norm=self.grad_clip_max)
+        self.optimizers.step()
+        self.schedulers.step()
+        self.exp_decay.update()
+        with torch.no_grad():
+            A = int(inputs["Z"].shape[0])
+            E_pred, F_pred = ps.last_out[0].detach(), ps.last_out[1].detach()[:A]
+            e_term, f_term = ps.parts
+            parts = {"energy_mae": e_term, ("force_mae" if self.loss == "mae" else "force_rmse"): f_term}
+            self._update_metrics(metrics, report, targets, E_pred, None, F_pred, None, parts)
+        return report
+
     def train_on_batch(self, dataset_iter, metrics):
         self.model.train()
         inputs, targets = next(dataset_iter)
         inputs, targets = self.dict2device(inputs), self.dict2device(targets)
+        ps = self._padded_step_for(inputs)
+        if ps is not None:
+            return self._train_on_batch_padded(ps, inputs, targets, metrics)
         mean_energy, var_energy, mean_forces, var_forces = self.predict(inputs)
         loss, report, parts = self._objective(targets, mean_energy, var_energy, mean_forces, var_forces)
 
@@ -293,3 +354,66 @@ class Trainer:
                 getattr(self, k).load_state_dict(v)
             else:
                 setattr(self, k, v)
+
+
+def _padded_step_base():
+    from .ddp import PaddedTrainStep
+    return PaddedTrainStep
+
+
+class _TrainerPaddedStep(_padded_step_base()):
+    """`PaddedTrainStep` carrying the Trainer's objective (trainer.py:284-343 of the reference: (1 - rho) MAE(E) + rho
+    {MAE | mean L2}(F), every term a mean over this rank's molecules / atoms times its share of the global counts) in
+    masked form; only the captured part (forward, force, loss, backward) is used — the Trainer runs the rest of its step."""
+
+    def __init__(self, trainer, Z, N, a_cap, e_cap, t_cap, max_in_degree, n_groups=None):
+        super().__init__(trainer.model, Z, N, e_cap, t_cap, max_in_degree=max_in_degree, n_groups=n_groups, a_cap=a_cap,
+                         world_size=trainer._world(), rho_force=trainer.rho_force, optimizer=trainer.optimizers)
+        self.trainer = trainer
+        dev, dt = self.mask.device, self.mask.dtype
+        self.share = torch.ones(2, device=dev, dtype=dt)          # (B_r / B, A_r / A) of this rank in this step
+        self.inv_local = torch.ones((), device=dev, dtype=dt)     # 1 / A_r
+        self.parts = self.last_out = None
+
+    def _outputs(self, inputs):
+        self.last_out = super()._outputs(inputs)
+        return self.last_out
+
+    def loss(self, E, F, targets):
+        tr = self.trainer
+        m = self.mask
+        e_term = (E - targets["E"]).abs().mean()
+        diff = F - targets["F"]
+        if tr.loss == "mae":
+            f_term = (diff.abs() * m[:, None]).sum() * (self.inv_local / 3.0)
+        else:
+            d = torch.where(m[:, None] > 0, diff, torch.ones_like(diff))
+            f_term = (torch.norm(d, p=2, dim=1) * m).sum() * self.inv_local
+        self.parts = (e_term.detach(), f_term.detach())
+        return e_term * self.share[0] * (1 - tr.rho_force) + tr.rho_force * f_term * self.share[1]
+
+    def run(self, inputs, targets):
+        """Pad the batch into the static buffers and run / replay forward + force + loss + backward -> loss (this rank's
+        weighted objective; gradients in the flat buffer)."""
+        idx = {k: inputs[k] for k in ("id_c", "id_a", "id_swap", "id_undir", "id3_reduce_ca", "id3_expand_ba")}
+        self.pad._fill(inputs["R"], idx, inputs["Z"], inputs["N"])
+        A = self.pad.A
+        self.targets["E"].copy_(targets["E"].reshape(self.targets["E"].shape))
+        self.targets["F"][:A].copy_(targets["F"])
+        self.targets["F"][A:].zero_()
+        self.mask[:A].fill_(1.0)
+        self.mask[A:].zero_()
+        self.inv_local.fill_(1.0 / A)
+        if self.world_size > 1:
+            cnt = torch.tensor([self.pad.n_mol, A], dtype=torch.float64, device=self.mask.device)
+            tot = cnt.clone()
+            dist.all_reduce(tot)
+            self.share.copy_(cnt / tot)
+        self.model.train()
+        if inputs["R"].is_cuda:
+            if not self._captured:
+                self.capture(self.inputs, self.targets)
+                self._captured = True
+            self._graph.replay()
+            return self._graph_loss
+        return self._eager(self.inputs, self.targets)

@@ -37,8 +37,11 @@ def stream(dc, batches):
         i += 1
 
 
-@pytest.mark.parametrize("tag", CASES)
-def test_training_trajectory_matches_reference_trainer(golden_trainer, tag):
+@pytest.mark.parametrize("tag,padded", [(t, False) for t in CASES] + [("rmse", True), ("mae_agc", True)],
+                         ids=CASES + ["rmse-padded", "mae_agc-padded"])
+def test_training_trajectory_matches_reference_trainer(golden_trainer, tag, padded):
+    """`padded`: the same protocol with `Trainer.enable_padded_graph` — every batch padded to fixed capacities (the
+    captured-graph form of the step; eager on this CPU emulation) must reproduce the REFERENCE trainer's trajectory too."""
     g = golden_trainer
     cfg, kw = ast.literal_eval(str(g[f"{tag}.cfg"])), ast.literal_eval(str(g[f"{tag}.kw"]))
     seed, triplets_only = int(g[f"{tag}.seed"]), cfg["triplets_only"]
@@ -54,6 +57,12 @@ def test_training_trajectory_matches_reference_trainer(golden_trainer, tag):
         model._check_inputs = lambda R: None
         trainer = Trainer(model, **kw)
         trainer.dict2device = lambda d, device=None: d  # float64 CPU emulation
+        if padded:
+            shapes = [dc[b] for b in batches]
+            trainer.enable_padded_graph(a_cap=max(int(x["Z"].shape[0]) for x in shapes) + 3,
+                                        e_cap=max(int(x["id_c"].shape[0]) for x in shapes) + 24,
+                                        t_cap=max(int(x["id3_reduce_ca"].shape[0]) for x in shapes) + 80,
+                                        max_in_degree=64, n_groups=8)
         metrics = Metrics("train", trainer.tracked_metrics)
         it = stream(dc, batches)
         losses, lrs = [], []
@@ -62,6 +71,8 @@ def test_training_trajectory_matches_reference_trainer(golden_trainer, tag):
             lrs.append([s.get_last_lr()[0] for s in trainer.schedulers.wrapped])
         np.testing.assert_allclose(losses, g[f"{tag}.losses"], rtol=1e-7)
         np.testing.assert_allclose(lrs, g[f"{tag}.lrs"], rtol=1e-12)
+        if padded:
+            assert trainer._pstep is not None and trainer._pstep.parts is not None     # the padded step really ran
         res = metrics.result(append_tag=False)
         assert sorted(res) == [str(k) for k in g[f"{tag}.metric_names"]]
         np.testing.assert_allclose([float(res[k]) for k in sorted(res)], g[f"{tag}.metric_values"], rtol=1e-7)
