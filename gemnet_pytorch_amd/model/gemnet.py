@@ -17,6 +17,7 @@ second-order graph is built when it can be used — `self.training and torch.is_
 or when `self.force_graph` is set to True/False explicitly.
 """
 import contextlib
+import os
 
 import torch
 
@@ -32,7 +33,8 @@ _nullcontext = contextlib.nullcontext
 # A/B switch: one running gradient for rbf_out (five consumers on the side stream) instead of four engine-side adds.
 # Off: same-box A/B on MI355X (profiles/r3_ab.txt) 2.777 / 2.747 ms with it, 2.729 / 2.685 ms without — the chained
 # in-place sums order the output blocks' adjoints behind each other, the engine's adds did not.
-_RBF_OUT_ACC = __import__("os").environ.get("GEMNET_RBF_OUT_ACC", "0") == "1"
+_TRAIN_OVERLAP = os.environ.get("GEMNET_TRAIN_OVERLAP", "0") == "1"
+_RBF_OUT_ACC = os.environ.get("GEMNET_RBF_OUT_ACC", "0") == "1"
 
 
 def K_chain_mode():
@@ -197,7 +199,14 @@ class GemNet(torch.nn.Module):
         # (8e-2 eV/A at mean|F| = 5.6, energies included; reproducible with the output blocks in line, with serialized
         # kernels, and in the default arithmetic — tools/exp/bf16_determinism.py, q_side_race.py): an ordering hazard
         # between the two streams that only this timing exposes and that is not located yet.  Until it is, Q runs in line.
-        side = self._side_stream(R.device) if self.overlap_output_blocks and R.is_cuda and T else None
+        # FORCE TRAINING (the fused four-sweep form) runs them in line as well: the captured training step was not
+        # run-to-run reproducible with the side stream (flat gradient 3-7e-4 of its norm from replay to replay, both Dense
+        # arithmetics; the eager step, and the captured step with the output blocks in line — or with unfused output-block
+        # aggregation, or without the running-gradient sums — are bit-reproducible and bit-identical to each other:
+        # tools/exp/train_determinism.py, profiles/r3_train_determinism.txt).  Same unlocated hazard; GEMNET_TRAIN_OVERLAP=1
+        # restores the overlap for A/B runs.
+        overlap = self.overlap_output_blocks and (not ops.train2_enabled() or _TRAIN_OVERLAP)
+        side = self._side_stream(R.device) if overlap and R.is_cuda and T else None
         # The head of the forward is a string of small launches (110 us at B = 32); only distances -> edge embedding ->
         # rbf3 are needed by the first kernel of block 0.  With a side stream the rest forks off: the triplet angles,
         # the atom embedding and its two concat-Dense terms need positions / atomic numbers only and run beside the edge

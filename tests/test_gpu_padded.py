@@ -65,7 +65,7 @@ def test_padded_graph_replay_equals_eager_on_changing_batches():
 def test_padded_training_step_replays_one_graph_for_changing_batches():
     """PaddedTrainStep: the training step (forward + force + loss.backward() through the force) of batches with different
     edge / triplet counts from ONE captured hipGraph — loss and parameter gradients of every batch equal those of the
-    eager TrainStep on the unpadded batch (fp32 noise: the weight-gradient products split their longer contraction
+    eager TrainStep on the unpadded batch (to fp32 rounding: the weight-gradient products split their longer contraction
     differently), and three optimizer steps leave both models with the same parameters."""
     import copy
     from gemnet_pytorch_amd.training.ddp import PaddedTrainStep, TrainStep
@@ -104,7 +104,7 @@ def test_padded_training_step_replays_one_graph_for_changing_batches():
                 assert abs(float(la) - float(lb)) <= 2e-5 * abs(float(lb))
                 rel = float((ga - gb).norm() / gb.norm())
                 worst = max(worst, rel)
-                assert rel <= 1e-3, rel
+                assert rel <= 1e-5, rel
     pa = torch.cat([p.detach().reshape(-1) for p in model_a.parameters()])
     pb = torch.cat([p.detach().reshape(-1) for p in model_b.parameters()])
     drift = float((pa - pb).abs().max())
@@ -128,7 +128,7 @@ def _batch(n_mol, n_atoms, first, g=None):
 
 def test_changing_molecule_sizes_through_one_graph():
     """`a_cap`: batches of 8 molecules with 32, 24 and 28 atoms each (then the first again) through ONE captured graph —
-    forward+force bit-identical to the eager run on the unpadded batch; the training step within fp32 noise."""
+    forward+force bit-identical to the eager run on the unpadded batch; the training step to fp32 rounding."""
     import copy
     from gemnet_pytorch_amd.training.ddp import PaddedTrainStep, TrainStep
     cfg = dict(FULL, triplets_only=True, num_blocks=2)
@@ -163,7 +163,7 @@ def test_changing_molecule_sizes_through_one_graph():
         assert abs(float(la) - float(lb)) <= 2e-5 * abs(float(lb)), (float(la), float(lb))
         worst = max(worst, float((ga - gb).norm() / gb.norm()))
     print(f"molecule sizes 32 / 24 / 28 through one graph ({sizes}): forward+force bit-identical, training gradients within {worst:.2e}")
-    assert worst <= 1e-3
+    assert worst <= 1e-5
 
 
 def test_dynamic_force_field_follows_a_moving_system():
@@ -239,3 +239,31 @@ def test_trainer_with_padded_graph_follows_the_plain_trainer():
         assert abs(a - b) <= 2e-3 * abs(b), (lp, le)
     for k in me:
         assert abs(float(mp[k]) - float(me[k])) <= 2e-3 * abs(float(me[k])), (k, float(mp[k]), float(me[k]))
+
+
+def test_captured_training_step_is_bit_reproducible_and_equals_eager():
+    """The captured training step replayed four times from the same weights: identical flat gradients every time, and
+    identical to the eager step (the output blocks run in line during force training: with them on the side stream the
+    replays differed by 3-7e-4 of the gradient norm from run to run, tools/exp/train_determinism.py)."""
+    import copy
+    from gemnet_pytorch_amd.training.ddp import TrainStep
+    cfg = dict(FULL, triplets_only=True, num_blocks=2)
+    torch.manual_seed(9)
+    base = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    b = _batch(8, 32, 100, g)
+    inputs = dict(Z=b["Z"], R=b["R"].clone(), N=b["N"], **b["idx"])
+    targets = {"E": b["Et"], "F": b["Ft"]}
+    flat = {}
+    for kind in ("eager", "captured"):
+        ts = TrainStep(copy.deepcopy(base), fused_optimizer=True)
+        if kind == "captured":
+            ts.capture(inputs, targets)
+        runs = []
+        for _ in range(4):
+            ts(inputs, targets, step_optimizer=False)
+            torch.cuda.synchronize()
+            runs.append(ts.buf.flat.clone())
+        assert all(torch.equal(r, runs[0]) for r in runs[1:]), kind
+        flat[kind] = runs[0]
+    assert torch.equal(flat["eager"], flat["captured"])
