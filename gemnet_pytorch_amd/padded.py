@@ -18,7 +18,11 @@ those capacities is replayed:
 
 Molecules are independent (block-diagonal index arrays), every kernel of the path treats a row on its own and sums a
 segment in index order: the real molecules' energies and forces are those of the unpadded batch, bit for bit
-(tests/test_gpu_padded.py).  Triplets-only models, force by autograd, inference.
+(tests/test_gpu_padded.py).  With an atom capacity (`a_cap`) the molecules may differ in size from call to call as well: the
+atoms between the batch and the capacity are isolated filler atoms of the dummy molecule.  Triplets-only models with forces
+by autograd.  Callers: `runtime.DynamicForceField` (the MD loop), `training.ddp.PaddedTrainStep` and
+`Trainer.enable_padded_graph` (the training step in the same form), `bench.py` (`extra.dynamic_shape`,
+`extra.train_step_dynamic`).
 """
 import torch
 
