@@ -229,8 +229,8 @@ class Trainer:
         if self._pstep is None:
             if A > caps["a_cap"]:
                 return None
-            if self._grads is not None:
-                raise RuntimeError("enable_padded_graph before the first train_on_batch (the flat gradient buffer is shared)")
+            # the captured step writes the gradients into ITS flat buffer: from here on that buffer is the Trainer's (a plain
+            # step taken earlier — a first batch that did not fit — used one of its own; `.grad` is re-pointed)
             self._pstep = _TrainerPaddedStep(self, inputs["Z"], inputs["N"], **caps)
             self._grads = self._pstep.buf
         ps = self._pstep
