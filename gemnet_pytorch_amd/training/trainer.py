@@ -54,6 +54,8 @@ class MultiWrapper:
 
 class Trainer:
     _SUBSTATE = ("schedulers", "optimizers", "plateau_callback", "exp_decay")
+    # per-process execution state: never part of a checkpoint (the padded step holds the model, lambdas and a hipGraph)
+    _RUNTIME_ONLY = ("model", "params_except_last", "_grads", "_wgrad", "_pstep", "_padded_caps")
 
     def __init__(self, model, learning_rate: float = 1e-3, decay_steps: int = 100000, decay_rate: float = 0.96,
                  warmup_steps: int = 0, weight_decay: float = 0.001, staircase: bool = False,
@@ -205,18 +207,19 @@ class Trainer:
         return loss, report, out
 
     # ------------------------------------------------------------------------------------------ steps
-    def enable_padded_graph(self, a_cap, e_cap, t_cap, max_in_degree, n_groups=None):
+    def enable_padded_graph(self, a_cap, e_cap, t_cap, max_in_degree, n_groups=None, n_mol=None):
         """Run `train_on_batch` from ONE captured hipGraph although every batch has its own array sizes: each batch is
         padded to these capacities (atoms, edges, triplets) with the dummy molecule of `padded.py` and the captured
         forward + force + loss + backward is replayed; all-reduce, shared-gradient rescale, clipping, the optimizers,
         schedulers, EMA and the metrics run as before.  Same loss values as the plain step (the objective is written
         with a mask over the atom capacity); triplets-only models with forces by autograd, MAE / RMSE objectives (not the
         mean-variance NLL).  Batches with the loader's number of molecules that fit the capacities take the graph; any other
-        batch (the partial last one) takes the plain step.  `max_in_degree`: largest molecule size - 1."""
+        batch (the partial last one) takes the plain step.  `max_in_degree`: largest molecule size - 1; `n_mol`: the loader's
+        batch size (default: that of the first batch that fits)."""
         if self.mve:
             raise NotImplementedError("padded graph: MAE / RMSE objectives")
         self._padded_caps = dict(a_cap=int(a_cap), e_cap=int(e_cap), t_cap=int(t_cap), max_in_degree=int(max_in_degree),
-                                 n_groups=n_groups)
+                                 n_groups=n_groups, n_mol=None if n_mol is None else int(n_mol))
         self._pstep = None
 
     def _padded_step_for(self, inputs):
@@ -227,17 +230,31 @@ class Trainer:
         n_mol, A = int(inputs["N"].shape[0]), int(inputs["Z"].shape[0])
         E, T = int(inputs["id_c"].shape[0]), int(inputs["id3_reduce_ca"].shape[0])
         if self._pstep is None:
-            if A > caps["a_cap"]:
+            # the first batch that takes the graph fixes the number of molecules: with `n_mol` given, a partial batch
+            # that happens to come first does not (every later full batch would fall back to the plain step)
+            ok = A <= caps["a_cap"] and (caps.get("n_mol") is None or n_mol == caps["n_mol"])
+            if not self._all_ranks(ok):
                 return None
             # the captured step writes the gradients into ITS flat buffer: from here on that buffer is the Trainer's (a plain
             # step taken earlier — a first batch that did not fit — used one of its own; `.grad` is re-pointed)
-            self._pstep = _TrainerPaddedStep(self, inputs["Z"], inputs["N"], **caps)
+            self._pstep = _TrainerPaddedStep(self, inputs["Z"], inputs["N"],
+                                             **{k: v for k, v in caps.items() if k != "n_mol"})
             self._grads = self._pstep.buf
         ps = self._pstep
         pad = ps.pad
         fits = (n_mol == pad.n_mol and A <= pad.a_cap and E + 4 <= pad.e_cap and T <= pad.t_cap
                 and -(-((pad.e_cap - E) // 2) // pad.G) <= pad.pad_degree_bound())
-        return ps if fits else None
+        return ps if self._all_ranks(fits) else None
+
+    def _all_ranks(self, flag):
+        """`flag` on every rank?  The padded and the plain step issue different collectives (the plain objective
+        exchanges counts), so the choice between them has to be the same everywhere."""
+        if self._world() == 1:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=self._grads.params[0].device if self._grads is not None
+                         else next(self.model.parameters()).device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0)
 
     def _train_on_batch_padded(self, ps, inputs, targets, metrics):
         loss = ps.run(inputs, targets)
@@ -343,8 +360,8 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------ checkpoints
     def state_dict(self):
-        skip = ("model", "_grads") + self._SUBSTATE
-        state = {k: v for k, v in self.__dict__.items() if k not in skip and k != "params_except_last"}
+        skip = self._RUNTIME_ONLY + self._SUBSTATE
+        state = {k: v for k, v in self.__dict__.items() if k not in skip}
         state.update({attr: getattr(self, attr).state_dict() for attr in self._SUBSTATE})
         return state
 
@@ -352,7 +369,7 @@ class Trainer:
         for k, v in state_dict.items():
             if k in self._SUBSTATE:
                 getattr(self, k).load_state_dict(v)
-            else:
+            elif k not in self._RUNTIME_ONLY:   # a checkpoint written before these were excluded may carry them
                 setattr(self, k, v)
 
 
@@ -370,6 +387,9 @@ class _TrainerPaddedStep(_padded_step_base()):
         super().__init__(trainer.model, Z, N, e_cap, t_cap, max_in_degree=max_in_degree, n_groups=n_groups, a_cap=a_cap,
                          world_size=trainer._world(), rho_force=trainer.rho_force, optimizer=trainer.optimizers)
         self.trainer = trainer
+        # `loss` below carries its own per-step shares: the base class's count exchange (a collective + host sync inside
+        # `capture`, which ranks may reach on different steps) must never run
+        self.global_counts = (1, 1)
         dev, dt = self.mask.device, self.mask.dtype
         self.share = torch.ones(2, device=dev, dtype=dt)          # (B_r / B, A_r / A) of this rank in this step
         self.inv_local = torch.ones((), device=dev, dtype=dt)     # 1 / A_r

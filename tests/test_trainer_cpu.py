@@ -73,6 +73,18 @@ def test_training_trajectory_matches_reference_trainer(golden_trainer, tag, padd
         np.testing.assert_allclose(lrs, g[f"{tag}.lrs"], rtol=1e-12)
         if padded:
             assert trainer._pstep is not None and trainer._pstep.parts is not None     # the padded step really ran
+            # train.ipynb saves trainer.state_dict() at every checkpoint: the padded step (model, lambdas, a hipGraph on
+            # the device) must not be part of it, and loading such a state must not disturb a running trainer
+            import io
+            state = trainer.state_dict()
+            state.pop("dict2device")     # this test's own instance-level override (a lambda)
+            assert not {"_pstep", "_padded_caps", "_wgrad", "_grads", "model"} & set(state)
+            blob = io.BytesIO()
+            torch.save(state, blob)
+            blob.seek(0)
+            pstep = trainer._pstep
+            trainer.load_state_dict(dict(torch.load(blob, weights_only=False), _pstep="stale", _padded_caps=None))
+            assert trainer._pstep is pstep and trainer._padded_caps is not None
         res = metrics.result(append_tag=False)
         assert sorted(res) == [str(k) for k in g[f"{tag}.metric_names"]]
         np.testing.assert_allclose([float(res[k]) for k in sorted(res)], g[f"{tag}.metric_values"], rtol=1e-7)
