@@ -130,13 +130,16 @@ SIGNATURES = {
 }
 
 _lib = None
+# hbcheck.Recorder while a captured step is being checked for unordered memory accesses (debug tool, hbcheck.py): `ptr`
+# reports the tensors handed to a launch, `load` returns a proxy that reports the launch itself.  None otherwise.
+TRACE = None
 
 
 def load():
     """Load the HIP library (once).  Raises RuntimeError when it has not been built."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if TRACE is None else TRACE.proxy(_lib)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build the HIP extension first "
@@ -170,7 +173,24 @@ def stream():
 
 
 def ptr(t):
-    return None if t is None else _vp(t.data_ptr())
+    if t is None:
+        return None
+    if TRACE is not None:
+        TRACE.touch(t)
+    return _vp(t.data_ptr())
+
+
+def addr(t):
+    """Raw device address of a tensor (for argument blocks packed by hand); reported to the recorder like `ptr`."""
+    if TRACE is not None:
+        TRACE.touch(t)
+    return t.data_ptr()
+
+
+def note(reads=(), writes=()):
+    """Operands of the next launch that live in a device-resident table (invisible in the argument list)."""
+    if TRACE is not None:
+        TRACE.note(reads, writes)
 
 
 def require_device(*tensors):

@@ -110,12 +110,15 @@ template <int S>
 __global__ __launch_bounds__(1024) void bil_reduce_t_grouped_kernel(
     const float* __restrict__ Y, const float* __restrict__ dSm, const int32_t* __restrict__ grp_rows,
     const int32_t* __restrict__ grp_off, const int2* __restrict__ grp_kseg, const int32_t* __restrict__ permT,
-    const int32_t* __restrict__ rposT, float* __restrict__ dx) {
+    const int32_t* __restrict__ rposT, float* __restrict__ dx, int max_rows) {
   constexpr int C = 64, SC = S * C, NV = SC / 4;
   extern __shared__ float gtile[];  // [rows of the group][S*C]
   const int g = blockIdx.x;
   const int r0 = grp_off[g], n = grp_off[g + 1] - r0;
   if (n <= 0) return;
+  // the tile was sized for `max_rows` rows — a caller-supplied bound when the plan is built inside a hipGraph
+  // (padded.py: largest in-degree of an atom).  A group beyond it would write past the LDS allocation: abort loudly.
+  if (n > max_rows) __builtin_trap();
   for (int i = threadIdx.x; i < n * NV; i += 1024) {
     const int l = i / NV, v = i - l * NV;
     const float4 d = reinterpret_cast<const float4*>(dSm + (int64_t)grp_rows[r0 + l] * SC)[v];
@@ -1261,7 +1264,7 @@ extern "C" int gn_bil_reduce_t_grouped_f32(const float* Y, const float* dSm, con
     lds_max = 160 * 1024;
   }
   hipLaunchKernelGGL(bil_reduce_t_grouped_kernel<7>, dim3((unsigned)G), dim3(1024), lds, st, Y, dSm, grp_rows, grp_off,
-                     reinterpret_cast<const int2*>(grp_kseg), permT, rposT, dx);
+                     reinterpret_cast<const int2*>(grp_kseg), permT, rposT, dx, max_rows);
   GN_LAUNCH_CHECK();
   return 0;
 }

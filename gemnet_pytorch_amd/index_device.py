@@ -52,7 +52,7 @@ class DeviceGraphBuilder:
         e_arr = {k: new(self.cap) for k in ("id_a", "id_c", "id_undir", "id_swap")}
         i_arr = {k: new(self.cap if quad else 0) for k in ("id4_int_a", "id4_int_b")}
         sizes = (ctypes.c_int64 * 6)()
-        check(self.lib.gn_index_gpu_stage1(
+        check(_lib.load().gn_index_gpu_stage1(
             ptr(R), int(R.dtype == torch.float64), ptr(self.mol_off), ptr(self.sq_off), self.B, self.A, self.nmax,
             self.sum_n2, self.cutoff, self.int_cutoff, int(self.triplets_only), ptr(self.ws), ptr(batch_seg),
             ptr(e_arr["id_a"]), ptr(e_arr["id_c"]), ptr(e_arr["id_undir"]), ptr(e_arr["id_swap"]),
@@ -70,7 +70,7 @@ class DeviceGraphBuilder:
             q_arr.update(id4_reduce_intm_ca=new(Ica), id4_reduce_intm_ab=new(Ica),
                          id4_expand_intm_db=new(Idb), id4_expand_intm_ab=new(Idb))
         g = lambda d, k: ptr(d[k]) if k in d else None
-        check(self.lib.gn_index_gpu_stage2(
+        check(_lib.load().gn_index_gpu_stage2(
             ptr(self.mol_off), ptr(self.sq_off), self.B, self.A, self.sum_n2, int(self.triplets_only), ptr(self.ws),
             ptr(out["id_a"]), ptr(out["id_c"]), g(out, "id4_int_a"), g(out, "id4_int_b"), E, Eint,
             ptr(t_arr["id3_reduce_ca"]), ptr(t_arr["id3_expand_ba"]), ptr(t_arr["Kidx3"]),

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, check, ptr, require_device, stream
+from ._lib import GemmArgs, addr, check, ptr, require_device, stream
 
 
 def _f32c(t):
@@ -789,7 +789,7 @@ def _mat(t, cols=None):
         raise AssertionError("chain operands: contiguous fp32 2-D")
     if cols is not None and t.shape[1] != cols:
         raise AssertionError((tuple(t.shape), cols))
-    return t.data_ptr()
+    return addr(t)
 
 
 def _source(v, src, stage, cols):
@@ -834,7 +834,7 @@ def chain(prog, mode=None):
                     raise RuntimeError(f"chain: weight planes packed in format {getattr(Wp, '_gn_fmt', 0)} handed to a "
                                        f"launch in mode {mode or CHAIN_MODE!r} (format {fmt})")
                 keep.append(Wp)
-                v[F_W] = Wp.data_ptr()
+                v[F_W] = addr(Wp)
             else:
                 v[F_W] = _mat(W)
             v[F_kind], v[F_N], v[F_K], v[F_a_slot], v[F_slot] = GN_OP_GEMM, N, Kd, o["a_slot"], o["slot"]
@@ -843,10 +843,10 @@ def chain(prog, mode=None):
                 raise RuntimeError("chain: pre_deriv needs the split-operand kernel (not CHAIN_MODE 'f32')")
             t = o["gadd1"]
             if t is not None:
-                v[F_gadd1], v[F_gidx1] = _mat(t, N), o["gidx1"].data_ptr()
+                v[F_gadd1], v[F_gidx1] = _mat(t, N), addr(o["gidx1"])
             t = o["gadd2"]
             if t is not None:
-                v[F_gadd2], v[F_gidx2] = _mat(t, N), o["gidx2"].data_ptr()
+                v[F_gadd2], v[F_gidx2] = _mat(t, N), addr(o["gidx2"])
             t = o["pre_out"]
             if t is not None:
                 v[F_pre_out] = _mat(t, N)
@@ -873,7 +873,7 @@ def chain(prog, mode=None):
                     v[F_res2_g] = _mat(t, N)
             t = o["res_rows"]
             if t is not None:
-                v[F_res_rows] = t.data_ptr()
+                v[F_res_rows] = addr(t)
             mm = o["mul_mode"]
             v[F_mul_mode], v[F_y2_slot], v[F_y2_src], v[F_mode2], v[F_alpha2] = mm, o["y2"], o["y2_src"], o["mode2"], o["alpha2"]
             t = o["Z2"]
@@ -900,7 +900,7 @@ def chain(prog, mode=None):
             v[F_kind], v[F_slot], v[F_width], v[F_ld], v[F_src] = GN_OP_LOAD, o["slot"], w, src.stride(0), sp
             t = o["rows"]
             if t is not None:
-                v[F_rows] = t.data_ptr()
+                v[F_rows] = addr(t)
             v[F_alpha], v[F_y2_slot], v[F_alpha2], v[F_mode2] = o.get("alpha", 1.0), o.get("y2", -1), o.get("alpha2", 1.0), o.get("mode2", 0)
             t = o.get("Z2")
             if t is not None:
@@ -1016,7 +1016,7 @@ def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
     Gc = torch.empty((Q, 3), device=R.device, dtype=torch.float32)
     if packed:
         Gbd = torch.zeros((Q, 8), device=R.device, dtype=torch.float32)
-        base = Gbd.data_ptr()
+        base = addr(Gbd)
         check(_lib.load().gn_quad_angles_bwd_ld_f32(ptr(g_ang), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), 3,
                                                     base, 8, base + 16, 8, Q, stream()), "gn_quad_angles_bwd_ld_f32")
         return Gc, Gbd
@@ -1038,13 +1038,13 @@ def bil_dy_multi(dSm_list, x_list, sp, ang=None):
         ang = _f32c(ang)
         g_ang = torch.empty((sp.size, 4), device=ang.device, dtype=torch.float32)
         arr = ctypes.c_void_p * nb
-        check(_lib.load().gn_bil_dy_multi_ang_f32(arr(*[t.data_ptr() for t in dSm_list]), arr(*[t.data_ptr() for t in x_list]),
+        check(_lib.load().gn_bil_dy_multi_ang_f32(arr(*[addr(t) for t in dSm_list]), arr(*[addr(t) for t in x_list]),
                                                   nb, ptr(ang), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(g_ang), E, S, C,
                                                   stream()), "gn_bil_dy_multi_ang_f32")
         return g_ang
     dY = torch.empty((sp.size, S), device=x_list[0].device, dtype=torch.float32)
     arr = ctypes.c_void_p * nb
-    check(_lib.load().gn_bil_dy_multi_f32(arr(*[t.data_ptr() for t in dSm_list]), arr(*[t.data_ptr() for t in x_list]),
+    check(_lib.load().gn_bil_dy_multi_f32(arr(*[addr(t) for t in dSm_list]), arr(*[addr(t) for t in x_list]),
                                           nb, ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(dY), E, S, C, stream()),
           "gn_bil_dy_multi_f32")
     return dY
@@ -1129,7 +1129,7 @@ def quad_basis_bwd_packed(gY, R, qc, qa, qb, qd, S):
     Q = qc.shape[0]
     Gc = torch.empty((Q, 3), device=R.device, dtype=torch.float32)
     Gbd = torch.zeros((Q, 8), device=R.device, dtype=torch.float32)
-    base = Gbd.data_ptr()
+    base = addr(Gbd)
     check(_lib.load().gn_quad_basis_bwd_ld_f32(ptr(gY), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), 3,
                                                base, 8, base + 16, 8, Q, S, stream()), "gn_quad_basis_bwd_ld_f32")
     return Gc, Gbd

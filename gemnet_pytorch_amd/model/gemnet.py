@@ -35,6 +35,11 @@ _nullcontext = contextlib.nullcontext
 # in-place sums order the output blocks' adjoints behind each other, the engine's adds did not.
 _TRAIN_OVERLAP = os.environ.get("GEMNET_TRAIN_OVERLAP", "0") == "1"
 _RBF_OUT_ACC = os.environ.get("GEMNET_RBF_OUT_ACC", "0") == "1"
+# the two other configurations of the round-3 replay findings, kept reachable for the happens-before checker
+# (tools/hbcheck_run.py): quadruplet models with their output blocks on the side stream; the output blocks' radial
+# projection produced on the side stream of the forked head
+_Q_OVERLAP = os.environ.get("GEMNET_Q_OVERLAP", "0") == "1"
+_RBF_OUT_SIDE = os.environ.get("GEMNET_RBF_OUT_SIDE", "0") == "1"
 
 
 def K_chain_mode():
@@ -206,7 +211,7 @@ class GemNet(torch.nn.Module):
         # tools/exp/train_determinism.py, profiles/r3_train_determinism.txt).  Same unlocated hazard; GEMNET_TRAIN_OVERLAP=1
         # restores the overlap for A/B runs.
         overlap = self.overlap_output_blocks and (not ops.train2_enabled() or _TRAIN_OVERLAP)
-        side = self._side_stream(R.device) if overlap and R.is_cuda and T else None
+        side = self._side_stream(R.device) if overlap and R.is_cuda and (T or _Q_OVERLAP) else None
         # The head of the forward is a string of small launches (110 us at B = 32); only distances -> edge embedding ->
         # rbf3 are needed by the first kernel of block 0.  With a side stream the rest forks off: the triplet angles,
         # the atom embedding and its two concat-Dense terms need positions / atomic numbers only and run beside the edge
@@ -239,6 +244,8 @@ class GemNet(torch.nn.Module):
                     rad3.record_stream(side)
                     rbf_W1_3 = self.mlp_cbf3(rad3)
                     rbf_h = self.mlp_rbf_h(rbf)
+                    if _RBF_OUT_SIDE:
+                        rbf_out = self.mlp_rbf_out(rbf)
                     ev_b = torch.cuda.Event()
                     ev_b.record(side)
                 # The radial projection of the output blocks stays on the MAIN stream although all its consumers run on
@@ -247,7 +254,8 @@ class GemNet(torch.nn.Module):
                 # this projection on the main stream, unfused output-block aggregation, no fork — removes it; every kernel
                 # involved is bit-reproducible next to concurrent streams on its own: tools/exp/t_graph_race.py,
                 # h3_concurrency*.py, profiles/r3_t_graph_race.txt).  The ordering hazard behind it is not located.
-                rbf_out = self.mlp_rbf_out(rbf)
+                if not _RBF_OUT_SIDE:
+                    rbf_out = self.mlp_rbf_out(rbf)
                 if _RBF_OUT_ACC:
                     rbf_out = ops.accumulate_gradient(rbf_out, stream=side)
                 main.wait_event(ev_a)

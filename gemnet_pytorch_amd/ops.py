@@ -22,6 +22,7 @@ import os
 
 import torch
 
+from . import _lib
 from . import kernels as K
 
 _PARAM_GRADS = True
@@ -1003,6 +1004,9 @@ class PackRegistry:
                 raise RuntimeError("PackRegistry: run one eager training step of this model before capturing a hipGraph")
             self.table, self.total_units = K.pack_job_table([(W, t, p) for W, t, p in self.entries.values()])
             self.n_table = len(self.entries)
+        if _lib.TRACE is not None:      # operands of the grouped launch live in the device job table (hbcheck.py)
+            ents = list(self.entries.values())[:self.n_table]
+            _lib.note(reads=[W for W, _, _ in ents], writes=[p for _, _, p in ents])
         K.pack_weight_split_grouped(self.table, self.n_table, self.total_units)
 
 

@@ -161,10 +161,11 @@ class TrainStep:
             self.wgrad.flush()
         return loss.detach()
 
-    def capture(self, inputs, targets):
+    def capture(self, inputs, targets, check=False):
         """Capture forward + force + loss + double backward (thousands of small launches) into one
         hipGraph for this (static-shape) batch; the collective, clipping and optimizer stay eager.
-        The graph reads the parameters in place, so optimizer updates are seen by every replay."""
+        The graph reads the parameters in place, so optimizer updates are seen by every replay.
+        `check`: record the capture with the happens-before checker (hbcheck.py; the recorder is left in `self.hb`)."""
         self.model.train()
         local = self._local_counts(inputs)
         self._pinned_counts = None
@@ -181,7 +182,12 @@ class TrainStep:
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._graph_loss = self._forward_backward(inputs, targets)
+                if check:
+                    from .. import hbcheck
+                    with hbcheck.record() as self.hb:
+                        self._graph_loss = self._forward_backward(inputs, targets)
+                else:
+                    self._graph_loss = self._forward_backward(inputs, targets)
         finally:
             self._use_pinned = False
         self._graph_key = id(inputs)

@@ -64,7 +64,7 @@ class FusedAdamWEMA:
         cache = getattr(self._model, "_wcache", None)
         if cache:
             cache.clear()   # the kernel below rewrites the flat parameter buffer without touching tensor versions
-        check(self.lib.gn_adamw_ema_step_f32(
+        check(_lib.load().gn_adamw_ema_step_f32(
             ptr(self.flat_p), ptr(self.flat_g), ptr(self.gscale), ptr(self.wd), ptr(self.m), ptr(self.v),
             ptr(self.vmax), ptr(self.ema), self.n, ptr(self.partial), float(self.clip),
             float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),

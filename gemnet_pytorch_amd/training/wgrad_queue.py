@@ -156,7 +156,11 @@ class WeightGradQueue:
             slot.copied.record()
             slot.in_flight = True
         ws = torch.empty(ws_off, dtype=torch.float32, device=dev)
-        base = slot.dev.data_ptr()
+        base = _lib.addr(slot.dev)
+        # the operand addresses sit in the device table: tell a recorder (hbcheck.py) what this launch reads and writes
+        if _lib.TRACE is not None:
+            _lib.note(reads=[x for it in items for x in it[1:3]],
+                      writes=[(a, 4 * ((rows - 1) * ld + cols)) for (a, rows, cols, ld), _ in by_param.values()])
         o_t = probs.nbytes
         o_s = o_t + targets.nbytes
         check(_lib.load().gn_gemm_tn_grouped_f32(base, len(items), wg, base + o_t, len(by_param), fold_wg, base + o_s,

@@ -303,7 +303,8 @@ int gn_bil_reduce_t_f32(const float* Y, const float* dSm, const int32_t* reduce_
  * data_container.py:262-300).  Group g owns rows grp_rows[grp_off[g]..grp_off[g+1]); grp_kseg[i] = {k0,k1} is the
  * transposed segment (range of permT) of row grp_rows[i]; rposT[k] = position of r(permT[k]) inside its group.
  * A workgroup parks the group's dSm blocks in LDS (max_rows*S*C*4 <= 160 KB, else hipErrorInvalidValue and the
- * caller uses gn_bil_reduce_t_f32) so dSm is read from HBM once, not once per t.
+ * caller uses gn_bil_reduce_t_f32) so dSm is read from HBM once, not once per t.  max_rows is a promise: a group with more
+ * rows makes the kernel trap (the launch aborts) instead of writing past its LDS tile.
  * S = 7 and C = 64 only (else hipErrorInvalidValue).  Rows outside every group are not written. */
 int gn_bil_reduce_t_grouped_f32(const float* Y, const float* dSm, const int32_t* grp_rows, const int32_t* grp_off,
                                 const int32_t* grp_kseg, const int32_t* permT, const int32_t* rposT, float* dx,
