@@ -15,11 +15,84 @@
 // (emb_size_edge 128, emb_size_rbf 16); other shapes take the GEMM + segmented-sum path.
 #include "common.h"
 
+#ifdef GN_AGG_SELFCHECK
+// Diagnosis build only (tools/exp/agg_selfcheck.py; never defined in the product library).  The adjoint keeps 32 values
+// of the CONSTANT weight W per lane in registers for the whole launch; in a replayed multi-queue hipGraph some waves
+// produced g_m rows that are only explained by wrong w0[] values in one 16-lane row (profiles/r4_hb_forensics.txt).
+// The instrumented kernel re-reads W (volatile: a second, independent load) right after the first load and again at
+// every edge, compares with the registers and logs (kind, block, wave, lane, k, register bits, memory bits, HW_ID, XCC_ID):
+//   kind 1: the two loads at kernel start disagree          -> the LOAD returned wrong data
+//   kind 2: register != memory at the time of use           -> the REGISTER changed after a correct load
+//   kind 3: as 2, and a third load still agrees with the second (memory is stable, the register is the odd one)
+__device__ unsigned int gn_agg_selfcheck_n;
+__device__ unsigned int gn_agg_selfcheck_log[4096][10];
+__device__ __forceinline__ void agg_log(unsigned kind, unsigned lane, unsigned k, float reg, float mem, unsigned extra) {
+  const unsigned i = atomicAdd(&gn_agg_selfcheck_n, 1u);
+  if (i < 4096u) {
+    unsigned int* r = gn_agg_selfcheck_log[i];
+    r[0] = kind; r[1] = blockIdx.x; r[2] = threadIdx.x >> 6; r[3] = lane; r[4] = k;
+    r[5] = __float_as_uint(reg); r[6] = __float_as_uint(mem);
+    r[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave / simd / cu / sh / se
+    r[8] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    r[9] = extra;
+  }
+}
+// compare the 32 register-resident weights of this lane with a fresh (volatile) load; one log record per call: the mask of
+// mismatching k (bits 0-15: w0, 16-31: w1) in `k`, register / memory bits of the first mismatch; kind 2 -> 3 when a third
+// load of that element agrees with the second one
+__device__ __forceinline__ void agg_check(const float* W, const float (&w0)[16], const float (&w1)[16], int lane, unsigned kind,
+                                          unsigned extra) {
+  const volatile float* Wv = W;
+  unsigned mask = 0, first = 0;
+  float freg = 0.f, fmem = 0.f;
+  // (a quarter of the values: checking all 32 took the kernel from 114 to 238 VGPRs — and the symptom was gone)
+#pragma unroll
+  for (int k = 0; k < 16; k += GN_AGG_SELFCHECK) {
+    const float a0 = Wv[(size_t)(2 * lane) * 16 + k], a1 = Wv[(size_t)(2 * lane + 1) * 16 + k];
+    const bool m0 = __float_as_uint(a0) != __float_as_uint(w0[k]), m1 = __float_as_uint(a1) != __float_as_uint(w1[k]);
+    if (m0 && !mask) { first = k; freg = w0[k]; fmem = a0; }
+    if (m0) mask |= 1u << k;
+    if (m1 && !mask) { first = 16 + k; freg = w1[k]; fmem = a1; }
+    if (m1) mask |= 1u << (16 + k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (mask) {
+    if (kind == 2) {
+      const float again = first < 16 ? Wv[(size_t)(2 * lane) * 16 + first] : Wv[(size_t)(2 * lane + 1) * 16 + first - 16];
+      if (__float_as_uint(again) == __float_as_uint(fmem)) kind = 3;
+    }
+    agg_log(kind | (first << 8), lane, mask, freg, fmem, extra);
+  }
+}
+extern "C" int gn_agg_selfcheck_read(unsigned int* host, int reset) {
+  unsigned int n = 0;
+  hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(gn_agg_selfcheck_n), sizeof(n));
+  if (e != hipSuccess) return -1;
+  e = hipMemcpyFromSymbol(host, HIP_SYMBOL(gn_agg_selfcheck_log), sizeof(gn_agg_selfcheck_log));
+  if (e != hipSuccess) return -1;
+  if (reset) { unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(gn_agg_selfcheck_n), &z, sizeof(z)); }
+  return (int)n;
+}
+#endif
+
+// NO packed-FP32 VALU instructions in these two kernels.  On gfx950 (ROCm 7.2) the adjoint, compiled with v_pk_mul / v_pk_fma_f32,
+// returned wrong g_m values — always the low halves of the packed results in lanes 48..63, i.e. the even columns 96..126 of a
+// few rows — when its waves shared CUs with the Dense-stack chain kernels of ANOTHER branch of a replayed hipGraph: constant
+// inputs, no memory conflict (gemnet_pytorch_amd/hbcheck.py), never in a single-branch graph or alone.  Minimal repro (two
+// kernels, no model): tools/exp/graph_corun.py, 25 / 60 (fp16-plane stacks) and 45 / 60 (bf16-plane stacks) replays wrong;
+// with this attribute 0 / 60 (profiles/r4_corun_*.txt).  This was the mechanism behind the three "hipGraph replay != eager"
+// findings of round 3.  -DGN_AGG_PK restores the packed instructions for the repro.
+#if !defined(GN_AGG_PK) && defined(__HIP_DEVICE_COMPILE__)
+#define GN_AGG_ATTR __attribute__((target("no-packed-fp32-ops")))
+#else
+#define GN_AGG_ATTR
+#endif
+
 namespace {
 
 constexpr int C = 128, R = 16;
 
-__global__ __launch_bounds__(256) void rbf_aggregate_fwd_kernel(const float* __restrict__ m, const float* __restrict__ rbf,
+__global__ __launch_bounds__(256) GN_AGG_ATTR void rbf_aggregate_fwd_kernel(const float* __restrict__ m, const float* __restrict__ rbf,
                                                                 const float* __restrict__ W, const int32_t* __restrict__ perm,
                                                                 const int32_t* __restrict__ seg_off, float* __restrict__ out,
                                                                 float scale) {
@@ -82,7 +155,7 @@ __global__ __launch_bounds__(256) void rbf_aggregate_fwd_kernel(const float* __r
 //                 this wave's 512 B of LDS; lane (k = l % 16, part = l / 16) sums its 32 columns against W[c][k] held
 //                 in registers, two xor-shuffles fold the four parts (a 64-lane butterfly over 16 values took 96
 //                 ds_bpermute per edge: 27 us per launch instead of 11)
-__global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ m,
+__global__ __launch_bounds__(256) GN_AGG_ATTR void rbf_aggregate_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ m,
                                                                 const float* __restrict__ rbf, const float* __restrict__ W,
                                                                 const int32_t* __restrict__ id_a, float* g_m, float* g_rbf,
                                                                 int64_t E, float scale, int accum) {
@@ -102,11 +175,23 @@ __global__ __launch_bounds__(256) void rbf_aggregate_bwd_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < 32; ++j) wt[j] = W[(size_t)(32 * part + j) * R + kq];
   }
+#ifdef GN_AGG_SELFCHECK
+  agg_check(W, w0, w1, lane, 1, 0u);
+#endif
   const int64_t stride = (int64_t)gridDim.x * 4;
   for (int64_t e = (int64_t)blockIdx.x * 4 + wave; e < E; e += stride) {
     const int a = id_a[e];
+#ifdef GN_AGG_SELFCHECK
+    agg_check(W, w0, w1, lane, 2, (unsigned)e);
+#endif
     const float2 g = *reinterpret_cast<const float2*>(g_out + (size_t)a * C + 2 * lane);
+#ifdef GN_AGG_VSCALE   // experiment: the scale factor from a VGPR instead of an SGPR pair operand of the packed multiply
+    float sc;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(sc) : "s"(scale));
+    const float gx = g.x * sc, gy = g.y * sc;
+#else
     const float gx = g.x * scale, gy = g.y * scale;
+#endif
     if (g_m) {
       float r0 = 0.f, r1 = 0.f;
 #pragma unroll

@@ -431,6 +431,14 @@ class Recorder:
                 out.append((t, t.detach().clone()))
         return out
 
+    def dump(self, path):
+        """The captured graph as JSON: operations (index, name, stream, launch site, node ids, accesses) and edges."""
+        import json
+        with open(path, "w") as f:
+            json.dump(dict(ops=[dict(idx=o.idx, name=o.name, stream=o.stream, where=o.where, nodes=o.nodes,
+                                     reads=o.reads, writes=o.writes) for o in self.ops],
+                           edges=self.edges_, types={str(k): v for k, v in self.types_.items()}), f)
+
     def replay_diff(self, snap, limit=12):
         """Compare the current contents with `snap` (another replay): the operations, in issue order, that wrote a tensor
         whose contents differ, and for each whether any tensor it READ differs too.  An operation whose inputs are
@@ -442,7 +450,15 @@ class Recorder:
             by_op.setdefault(idx, []).append((kind, what, t))
         ops = {o.idx: o for o in self.ops}
         for idx in sorted(by_op):
-            w_bad = [what for kind, what, t in by_op[idx] if kind == "w" and differs.get(id(t))]
+            w_bad = []
+            for kind, what, t in by_op[idx]:
+                if kind == "w" and differs.get(id(t)):
+                    c = next(c for tt, c in snap if tt is t)
+                    d = (t != c)
+                    rows = d.reshape(d.shape[0], -1).any(dim=1).nonzero().flatten() if d.dim() > 0 and d.shape[0] else d.nonzero()
+                    w_bad.append(f"{what}: {int(d.sum())} of {d.numel()} elements in {rows.numel()} rows "
+                                 f"[{int(rows.min()) if rows.numel() else -1}..{int(rows.max()) if rows.numel() else -1}], "
+                                 f"max |d| {float((t.float() - c.float()).abs().max()):.2e} of max |x| {float(c.float().abs().max()):.2e}")
             if not w_bad:
                 continue
             r_bad = [what for kind, what, t in by_op[idx] if kind == "r" and differs.get(id(t))]

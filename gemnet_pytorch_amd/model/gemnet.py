@@ -33,13 +33,14 @@ _nullcontext = contextlib.nullcontext
 # A/B switch: one running gradient for rbf_out (five consumers on the side stream) instead of four engine-side adds.
 # Off: same-box A/B on MI355X (profiles/r3_ab.txt) 2.777 / 2.747 ms with it, 2.729 / 2.685 ms without — the chained
 # in-place sums order the output blocks' adjoints behind each other, the engine's adds did not.
-_TRAIN_OVERLAP = os.environ.get("GEMNET_TRAIN_OVERLAP", "0") == "1"
 _RBF_OUT_ACC = os.environ.get("GEMNET_RBF_OUT_ACC", "0") == "1"
-# the two other configurations of the round-3 replay findings, kept reachable for the happens-before checker
-# (tools/hbcheck_run.py): quadruplet models with their output blocks on the side stream; the output blocks' radial
-# projection produced on the side stream of the forked head
-_Q_OVERLAP = os.environ.get("GEMNET_Q_OVERLAP", "0") == "1"
-_RBF_OUT_SIDE = os.environ.get("GEMNET_RBF_OUT_SIDE", "0") == "1"
+# Side-stream placement switches.  All three were forced off in round 3 because hipGraph replays stopped matching the eager
+# run with them; round 4 located the cause below the library — packed-FP32 instructions of the fused aggregation adjoint
+# returning wrong lanes when its waves share CUs with the chain kernels of another graph branch (csrc/aggregate.hip,
+# tools/exp/graph_corun.py) — and removed it, so they are on again.  `=0` restores the in-line forms.
+_TRAIN_OVERLAP = os.environ.get("GEMNET_TRAIN_OVERLAP", "1") == "1"  # force training: output blocks on the side stream
+_Q_OVERLAP = os.environ.get("GEMNET_Q_OVERLAP", "1") == "1"          # quadruplet models: output blocks on the side stream
+_RBF_OUT_SIDE = os.environ.get("GEMNET_RBF_OUT_SIDE", "1") == "1"    # output-block radial projection in the forked head
 
 
 def K_chain_mode():
@@ -199,17 +200,8 @@ class GemNet(torch.nn.Module):
     def _energy(self, R, plan):
         T = self.triplets_only
         b3 = self.cbf_basis3
-        # Output blocks on a side stream: triplets-only models.  For the quadruplet models the overlap buys 0.2 % (13.56 vs
-        # 13.59 ms, tools/exp/q_overlap_ab.py) and GemNet-Q with plain-bf16 stacks was NOT run-to-run reproducible with it
-        # (8e-2 eV/A at mean|F| = 5.6, energies included; reproducible with the output blocks in line, with serialized
-        # kernels, and in the default arithmetic — tools/exp/bf16_determinism.py, q_side_race.py): an ordering hazard
-        # between the two streams that only this timing exposes and that is not located yet.  Until it is, Q runs in line.
-        # FORCE TRAINING (the fused four-sweep form) runs them in line as well: the captured training step was not
-        # run-to-run reproducible with the side stream (flat gradient 3-7e-4 of its norm from replay to replay, both Dense
-        # arithmetics; the eager step, and the captured step with the output blocks in line — or with unfused output-block
-        # aggregation, or without the running-gradient sums — are bit-reproducible and bit-identical to each other:
-        # tools/exp/train_determinism.py, profiles/r3_train_determinism.txt).  Same unlocated hazard; GEMNET_TRAIN_OVERLAP=1
-        # restores the overlap for A/B runs.
+        # Output blocks on a side stream (all model kinds, inference and force training; the round-3 restrictions are gone,
+        # see the switches at the top of the file).
         overlap = self.overlap_output_blocks and (not ops.train2_enabled() or _TRAIN_OVERLAP)
         side = self._side_stream(R.device) if overlap and R.is_cuda and (T or _Q_OVERLAP) else None
         # The head of the forward is a string of small launches (110 us at B = 32); only distances -> edge embedding ->
@@ -248,12 +240,7 @@ class GemNet(torch.nn.Module):
                         rbf_out = self.mlp_rbf_out(rbf)
                     ev_b = torch.cuda.Event()
                     ev_b.record(side)
-                # The radial projection of the output blocks stays on the MAIN stream although all its consumers run on
-                # the side stream: produced there, hipGraph replays of the 8 x 64-atom batch in the "h3" arithmetic stopped
-                # matching the eager run (forces off by 1e-2 eV/A in 9 of 10 replays, energies identical; any one of:
-                # this projection on the main stream, unfused output-block aggregation, no fork — removes it; every kernel
-                # involved is bit-reproducible next to concurrent streams on its own: tools/exp/t_graph_race.py,
-                # h3_concurrency*.py, profiles/r3_t_graph_race.txt).  The ordering hazard behind it is not located.
+                # (all consumers of the output blocks' radial projection run on the side stream: so does the projection)
                 if not _RBF_OUT_SIDE:
                     rbf_out = self.mlp_rbf_out(rbf)
                 if _RBF_OUT_ACC:

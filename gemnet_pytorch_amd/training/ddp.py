@@ -184,7 +184,7 @@ class TrainStep:
             with torch.cuda.graph(self._graph):
                 if check:
                     from .. import hbcheck
-                    with hbcheck.record() as self.hb:
+                    with hbcheck.record(keep=check == "keep") as self.hb:
                         self._graph_loss = self._forward_backward(inputs, targets)
                 else:
                     self._graph_loss = self._forward_backward(inputs, targets)

@@ -1,0 +1,104 @@
+"""-m gpu: the captured steps under the happens-before checker (gemnet_pytorch_amd/hbcheck.py) and the co-run regression of
+the round-4 finding.
+
+  * every pair of device operations of the captured forward+force (GemNet-T, GemNet-Q; output blocks and the head of the
+    forward on the side stream) and of the captured training step that touch overlapping memory, one of them writing, is
+    connected by a path of graph edges — read back from the runtime, not modelled; the recorder must have seen every node
+    of the graph and resolved every pointer;
+  * the replays of those graphs equal the eager result bit for bit (the reference runs one stream: gemnet.py:453-615);
+  * the fused aggregation kernels stay bit-exact next to the Dense-stack chain kernels of another graph branch
+    (tools/exp/graph_corun.py: with packed-FP32 instructions in the adjoint 25-54 of 60 replays were wrong on gfx950)."""
+import copy
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import SCALE_FILE
+from gemnet_pytorch_amd import hbcheck
+from gemnet_pytorch_amd.model.gemnet import GemNet
+from gemnet_pytorch_amd.synthetic import make_dataset
+from gemnet_pytorch_amd.training.data_container import DataContainer
+from gemnet_pytorch_amd.training.ddp import TrainStep
+from test_gpu_fullsize import FULL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def batch(n_mol, n_atoms, triplets_only):
+    ds = make_dataset(n_mol, n_atoms, config=2)
+    b = DataContainer.from_arrays(dict(ds), 5.0, 10.0, triplets_only=triplets_only)[list(range(n_mol))]
+    return {k: v.to(DEV) for k, v in b.items() if k not in ("E", "F")}
+
+
+def warm(fn):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+
+def assert_clean(rec, min_streams):
+    races = rec.races()
+    summary = rec.summary()
+    print(rec.format(races))
+    assert not races
+    assert summary["unrecorded_nodes"] == 0 and summary["unresolved_pointers"] == 0
+    assert summary["streams"] >= min_streams and summary["nodes"] >= summary["ops"] > 50
+
+
+@pytest.mark.parametrize("kind", ["T", "Q"])
+def test_captured_forward_force_has_no_unordered_conflict_and_replays_bitwise(kind):
+    cfg = dict(FULL, triplets_only=kind == "T")
+    torch.manual_seed(11)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV).eval()
+    model.requires_grad_(False)
+    assert model.overlap_output_blocks
+    inputs = batch(8, 64, cfg["triplets_only"])
+    E0, F0 = (t.detach().clone() for t in model(inputs))
+    warm(lambda: model(inputs))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        with hbcheck.record() as rec:
+            Eg, Fg = model(inputs)
+    assert_clean(rec, min_streams=2)        # the side stream is really in use (quadruplet models included)
+    for _ in range(10):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Eg, E0) and torch.equal(Fg, F0)
+
+
+def test_captured_training_step_has_no_unordered_conflict_and_replays_bitwise():
+    cfg = dict(FULL, triplets_only=True, num_blocks=2)
+    torch.manual_seed(9)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV)
+    inputs = batch(8, 32, True)
+    g = torch.Generator().manual_seed(4)
+    targets = {"E": torch.randn(8, 1, generator=g).to(DEV), "F": torch.randn(256, 3, generator=g).to(DEV)}
+    ts = TrainStep(copy.deepcopy(model), fused_optimizer=True)
+    ts(inputs, targets, step_optimizer=False)
+    torch.cuda.synchronize()
+    ref = ts.buf.flat.clone()
+    ts.capture(inputs, targets, check=True)
+    assert_clean(ts.hb, min_streams=2)      # output blocks of the training step on the side stream again
+    for _ in range(6):
+        ts(inputs, targets, step_optimizer=False)
+        torch.cuda.synchronize()
+        assert torch.equal(ts.buf.flat, ref)
+
+
+def test_aggregation_kernels_stay_exact_next_to_chain_kernels_of_another_graph_branch():
+    for mode in ("h3", "split6"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp", "graph_corun.py"), mode, "40"],
+                             capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+        print(out.stdout)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if "branch" in ln]
+        assert len(lines) == 2 and all("differ in 0/40 replays, aggregation outputs in 0/40" in ln for ln in lines), lines

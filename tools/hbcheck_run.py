@@ -49,7 +49,74 @@ def warm(fn):
     torch.cuda.synchronize()
 
 
-def force_case(name, kind, n_mol, n_atoms, flags=()):
+def diff_replays(name, rec, replay, n=6):
+    """Where do two replays part?  (recorder with keep=True: every intermediate of the captured step is still there)"""
+    replay()
+    torch.cuda.synchronize()
+    snap = rec.snapshot()
+    for k in range(n):
+        replay()
+        torch.cuda.synchronize()
+        cnt, text = rec.replay_diff(snap)
+        print(f"=== {name}: replay {k + 1} vs replay 0: {cnt} operations wrote differing tensors (first ones, in issue order):")
+        if cnt:
+            print(text, flush=True)
+
+
+def forensics(name, rec, replay, n=4):
+    """The aggregation adjoint g_m[e] = s g_out[id_a[e]] (.) (W rbf[e]) has no accumulator and single-writer inputs:
+    recompute it from the operands as they are AFTER a replay and look at the elements the replay got wrong."""
+    by_op = {}
+    for idx, kind, what, t in rec.touched:
+        by_op.setdefault(idx, {})[what.split(" ")[0]] = t
+    ops = [o for o in rec.ops if o.name == "gn_rbf_aggregate_bwd_f32"]
+    for k in range(n):
+        replay()
+        torch.cuda.synchronize()
+        for o in ops:
+            t = by_op[o.idx]
+            if "g_m" not in t:
+                continue
+            g_out, rbf, W, id_a, g_m = t["g_out"], t["rbf"], t["W"], t["id_a"].long(), t["g_m"]
+            ref = g_out[id_a].double() * (rbf.double() @ W.double().T)
+            ok = ref.abs() > 1e-6 * ref.abs().max()
+            scale = float((g_m.double()[ok] / ref[ok]).median())
+            err = (g_m.double() - scale * ref).abs()
+            bad = err > 1e-5 * float(ref.abs().max()) * abs(scale)
+            if not bool(bad.any()):
+                continue
+            rows = bad.any(dim=1).nonzero().flatten()
+            atoms = id_a[rows]
+            print(f"=== {name}: replay {k}: {o!r}: {int(bad.sum())} wrong elements in {rows.numel()} rows; scale {scale:.4g}")
+            print(f"      rows {rows.tolist()[:24]}")
+            print(f"      their target atoms {atoms.tolist()[:24]}")
+            for a in atoms.unique().tolist()[:3]:
+                all_rows = (id_a == a).nonzero().flatten()
+                print(f"      atom {a}: in-degree {all_rows.numel()}, wrong rows among them {int(bad[all_rows].any(dim=1).sum())}")
+            r = int(rows[0])
+            cols = bad[r].nonzero().flatten()
+            c0, c1 = int(cols.min()), int(cols.max()) + 1
+            a = int(id_a[r])
+            wr = (rbf[r].double() @ W.double().T)[c0:c1]
+            print(f"      row {r} (atom {a}), wrong columns {c0}..{c1 - 1}:")
+            print(f"        got      {[f'{v:.5e}' for v in g_m[r, c0:c1].tolist()]}")
+            print(f"        expected {[f'{v:.5e}' for v in (scale * ref[r, c0:c1]).tolist()]}")
+            print(f"        implied g_out[a] {[f'{v:.5e}' for v in (g_m[r, c0:c1].double() / (scale * wr)).tolist()]}")
+            print(f"        actual  g_out[a] {[f'{v:.5e}' for v in g_out[a, c0:c1].tolist()]}")
+            # is the implied g_out row some OTHER row of g_out (or of another block's g_out)?
+            imp = (g_m[r, c0:c1].double() / (scale * wr))
+            for o2 in ops:
+                g2 = by_op[o2.idx].get("g_out")
+                if g2 is None:
+                    continue
+                d = (g2[:, c0:c1].double() - imp[None, :]).abs().max(dim=1).values
+                j = int(d.argmin())
+                print(f"        nearest row of the g_out of op #{o2.idx}: row {j}, max |d| {float(d[j]):.3e}")
+            sys.stdout.flush()
+            break
+
+
+def force_case(name, kind, n_mol, n_atoms, flags=(), keep=False):
     for f in ("_Q_OVERLAP", "_RBF_OUT_SIDE"):
         setattr(G, f, f in flags)
     cfg = dict(FULL, triplets_only=kind == "T")
@@ -67,11 +134,14 @@ def force_case(name, kind, n_mol, n_atoms, flags=()):
     warm(lambda: model(inputs))
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        with hbcheck.record() as rec:
+        with hbcheck.record(keep=keep) as rec:
             Eg, Fg = model(inputs)
     races = rec.races()
     print(f"=== {name}: {len(races)} unordered conflicting pairs")
     print(rec.format(races))
+    import os
+    if os.environ.get("HB_DUMP"):
+        rec.dump(os.path.join(os.environ["HB_DUMP"], name + ".json"))
     bad = 0
     for _ in range(10):
         graph.replay()
@@ -79,10 +149,13 @@ def force_case(name, kind, n_mol, n_atoms, flags=()):
         bad += int(not (torch.equal(Fg, F0) and torch.equal(Eg, E0)))
     print(f"=== {name}: {bad} of 10 replays differ from the eager run (max |dF| of the last {float((Fg - F0).abs().max()):.3e})",
           flush=True)
+    if keep:
+        diff_replays(name, rec, graph.replay, n=2)
+        forensics(name, rec, graph.replay)
     return len(races), bad
 
 
-def train_case(name, overlap):
+def train_case(name, overlap, keep=False):
     G._TRAIN_OVERLAP = overlap
     cfg = dict(FULL, triplets_only=True, num_blocks=2)
     torch.manual_seed(9)
@@ -92,7 +165,7 @@ def train_case(name, overlap):
     ts(inputs, targets, step_optimizer=False)
     torch.cuda.synchronize()
     ref = ts.buf.flat.clone()
-    ts.capture(inputs, targets, check=True)
+    ts.capture(inputs, targets, check="keep" if keep else True)
     races = ts.hb.races()
     print(f"=== {name}: {len(races)} unordered conflicting pairs")
     print(ts.hb.format(races))
@@ -102,6 +175,8 @@ def train_case(name, overlap):
         torch.cuda.synchronize()
         devs.append(float((ts.buf.flat - ref).norm() / ref.norm()))
     print(f"=== {name}: flat gradient of 6 replays vs the eager step: {['%.1e' % d for d in devs]}", flush=True)
+    if keep:
+        diff_replays(name, ts.hb, ts._graph.replay)
     return len(races), sum(d != 0 for d in devs)
 
 
@@ -113,10 +188,13 @@ CASES = {
     "T64-rbfout-side": lambda: force_case("T64-rbfout-side", "T", 8, 64, ("_RBF_OUT_SIDE",)),
     "Q64-side": lambda: force_case("Q64-side", "Q", 8, 64, ("_Q_OVERLAP",)),
     "train-overlap": lambda: train_case("train-overlap", True),
+    # the same two with every intermediate kept: which operation's output differs first from replay to replay?
+    "T64-rbfout-side-diff": lambda: force_case("T64-rbfout-side-diff", "T", 8, 64, ("_RBF_OUT_SIDE",), keep=True),
+    "train-overlap-diff": lambda: train_case("train-overlap-diff", True, keep=True),
 }
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or [n for n in CASES if not n.endswith("-diff")]
     res = {}
     for n in names:
         try:
