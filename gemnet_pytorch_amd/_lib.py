@@ -146,6 +146,16 @@ def load():
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     lib.gn_abi_version.restype = _i
+    lib.gn_chain_wide_tile_rows.restype = _i
+    lib.gn_chain_wide_tile_rows.argtypes = [_i]
+    lib.gn_chain_wide_force_tile_rows.restype = _i
+    lib.gn_chain_wide_force_tile_rows.argtypes = [_i]
+    lib.gn_chain_wide_set_stagger.restype = _i
+    lib.gn_chain_wide_set_stagger.argtypes = [_i]
+    if os.environ.get("GN_CHAIN_STAGGER"):
+        lib.gn_chain_wide_set_stagger(int(os.environ["GN_CHAIN_STAGGER"]))
+    if os.environ.get("GN_CHAIN_TILE_ROWS"):
+        lib.gn_chain_wide_force_tile_rows(int(os.environ["GN_CHAIN_TILE_ROWS"]))
     lib.gn_optim_blocks.restype = _i
     lib.gn_optim_blocks.argtypes = [_i64]
     lib.gn_index_gpu_ws_bytes.restype = _i64

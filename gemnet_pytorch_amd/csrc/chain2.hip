@@ -375,7 +375,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         // The widest instance (adjoint programs at RT = 5) has no registers left for the third plane's second buffer:
         // there the lo plane — used by one MFMA, issued last — is read at the top of its own step.
         constexpr bool LATE_LO = ADJ && RT == 5 && NPL >= 3 && !HF;
-        constexpr int PD = 1;   // steps of look-ahead (PD + 1 register buffers); 2 and 3 measured: no change
+#ifndef GN_CHAIN_PD
+#define GN_CHAIN_PD 1
+#endif
+        constexpr int PD = HF ? GN_CHAIN_PD : 1;   // steps of look-ahead (PD + 1 register buffers); 2 and 3 measured with six bf16 products: no change
         uint4 xf[PD + 1][3];
         auto xload = [&](uint4 (&f)[3], int c, int t) {
           const unsigned char* xp = xb + (16 * t) * ROWB + ((((c << 2) | lg) ^ l15) << 4);
@@ -739,7 +742,8 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
   if (args->M <= 0 || args->n_ops <= 0) return 0;
   if (args->n_ops > GN_CHAIN_MAX_OPS) return (int)hipErrorInvalidValue;
   if (args->M > (1 << 24)) return (int)hipErrorInvalidValue;
-  if (nprod != 1 && nprod != 3 && nprod != 6 && nprod != GN_CHAIN_F16X2) return (int)hipErrorInvalidValue;
+  const bool wide = nprod == (GN_CHAIN_F16X2 | GN_CHAIN_WIDE);
+  if (nprod != 1 && nprod != 3 && nprod != 6 && nprod != GN_CHAIN_F16X2 && !wide) return (int)hipErrorInvalidValue;
   for (int i = 0; i < args->n_ops; ++i) {
     const gn_chain_op& o = args->ops[i];
     if (o.kind == GN_OP_GEMM) {
@@ -773,6 +777,15 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
       adj = adj || o.slot == 2 || (o.kind == GN_OP_LOAD && o.y2_slot >= 0) || o.src_stage != 0;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (wide) {      // chain3.hip: 4 waves x 32 columns, two workgroups per CU — it has no parking slot
+    bool park = false;
+    for (int i = 0; i < args->n_ops; ++i) {
+      const gn_chain_op& o = args->ops[i];
+      park = park || o.slot == 2 || (o.kind == GN_OP_GEMM && (o.mul_slot == 2 || o.res_slot == 2 || o.res2_slot == 2));
+    }
+    if (!park) return gn_chain_wide_dispatch(args, adj, st);
+    nprod = GN_CHAIN_F16X2;
+  }
   if (nprod == GN_CHAIN_F16X2) return dispatch_adj<2, true>(args, adj, st);
   if (nprod == 6) return dispatch_adj<3>(args, adj, st);
   if (nprod == 3) return dispatch_adj<2>(args, adj, st);

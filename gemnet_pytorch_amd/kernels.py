@@ -644,6 +644,14 @@ def _sel(x):
 CHAIN_MODES = {"f32": 0, "split6": 6, "split3": 3, "bf16": 1, "h3": 2}
 SPLIT_FORMAT = {"split6": 0, "split3": 0, "bf16": 0, "h3": 1}
 CHAIN_MODE = os.environ.get("GEMNET_CHAIN_MODE", "h3")
+# Kernel layout of the "h3" launches: "tall" = csrc/chain2.hip (one 8-wave workgroup per CU on row tiles of <= 80 rows, a wave
+# owns 16 columns), "wide" = csrc/chain3.hip (workgroups of 4 waves x 32 columns on row tiles of <= 48 rows, two per CU;
+# GN_CHAIN_WIDE).  Same results bit for bit (tests/test_gpu_kernels.py).  Measured on MI355X (profiles/r4_chain_layouts.txt):
+# the edge-row programs take the same time in both (a wave of either layout does the same amount of work per op, and two
+# co-resident workgroups neither help nor disturb each other), the atom-row programs are 25-35 % slower in the wide one —
+# "tall" stays the default; programs that use the parking slot always take it (the library decides).
+CHAIN_LAYOUT = os.environ.get("GEMNET_CHAIN_LAYOUT", "tall")
+GN_CHAIN_WIDE = 0x100
 # The fp16 planes of "h3" cover the magnitudes the MODEL fixes (activations, first-order adjoints dE/d.): sweeps whose
 # scale follows the caller's loss (S3 / S4 and the energy-only final adjoint of force training, ops_train.py) run in this
 # mode instead when the stack's mode is "h3" — bf16 planes have the fp32 exponent range.
@@ -931,6 +939,8 @@ def chain(prog, mode=None):
         raise RuntimeError("chain programs with second-order source terms run on the split-operand kernel only "
                            "(CHAIN_MODE f32 / an unsupported shape): use the composite training path")
     cbuf = (ctypes.c_char * args_size).from_buffer(buf)
+    if nprod == CHAIN_MODES["h3"] and CHAIN_LAYOUT == "wide":
+        nprod |= GN_CHAIN_WIDE
     if nprod:
         check(_lib.load().gn_chain_split_f32(ctypes.addressof(cbuf), nprod, stream()), "gn_chain_split_f32")
     else:

@@ -153,7 +153,16 @@ int gn_chain_f32(const gn_chain_args* args, void* stream);
  * their dot product: meant for activations and first-order adjoints, whose scale the model fixes — not for sweeps whose
  * scale follows the loss.  `W` must have been packed with fmt = GN_SPLIT_F16X2. */
 #define GN_CHAIN_F16X2 2
+/* nprod = GN_CHAIN_F16X2 | GN_CHAIN_WIDE: the same arithmetic in the "wide" kernel layout (csrc/chain3.hip): workgroups of 4
+ * waves x 32 output columns over row tiles of gn_chain_wide_tile_rows(M) rows (a multiple of 8, at most 48), two workgroups
+ * per CU — one workgroup's epilogue / LOAD / weight wait runs under the other's MFMA phase.  Same results bit for bit. */
+#define GN_CHAIN_WIDE 0x100
 int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* stream);
+int gn_chain_wide_tile_rows(int M);
+/* rows: a multiple of 8 in 8..48 fixes the tile height of the wide layout (tuning, tests); 0 restores the automatic choice */
+int gn_chain_wide_force_tile_rows(int rows);
+/* start-up offset of the second workgroup of a CU in the wide layout, in units of 64 cycles (0 = none; tuning) */
+int gn_chain_wide_set_stagger(int units_of_64_cycles);
 /* W (N,K) fp32 with row pitch ldw — or, trans != 0, the (K,N) matrix whose transpose is the weight — -> three bf16
  * planes in MFMA-fragment order; `out` holds gn_pack_weight_split_bytes(N,K) bytes (16-byte aligned). */
 int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream);

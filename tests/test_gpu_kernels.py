@@ -327,8 +327,9 @@ def test_trip_basis_fused_fwd_bwd_including_collinear():
     assert torch.isfinite(Gc).all() and torch.isfinite(Gb).all()
 
 
-def _stack_programs(M, width, g, dev):
-    """A residual-stack-like program with every op kind, slots aliasing and slot/global operands."""
+def _stack_programs(M, width, g, dev, park=True):
+    """A residual-stack-like program with every op kind, slots aliasing and slot/global operands.
+    park=False: the same without the register parking slot (such programs take the wide kernel layout, csrc/chain3.hip)."""
     def mk(*shape):
         return rnd(g, *shape)
     x, W0, W1, W2 = mk(M, 64), mk(width, 64) / 8, mk(width, width) / 11, mk(width, width) / 11
@@ -347,18 +348,19 @@ def _stack_programs(M, width, g, dev):
         p.gemm(t["W1"], a_slot=1, y_slot=0, act=True, pre_out=outs["z1"])
         p.gemm(t["W2"], a_slot=0, y_slot=1, act=True, pre_out=outs["z2"], res=1, beta=0.7, res2=t["skip"], beta2=0.6,
                out=outs["y"], mul=None)
-        p.scale(2, 1, 0.25, width=width)                      # park a scaled copy in the third slot ...
+        if park:
+            p.scale(2, 1, 0.25, width=width)                      # park a scaled copy in the third slot ...
         p.scale(0, 1, 0.3, Z=t["Z"], out=outs["sc"])
-        p.gemm(t["W1"], a_slot=0, y_slot=0, act=False, mul=1, alpha=1.5, res=2, beta=1.0)   # ... and add it back here
+        p.gemm(t["W1"], a_slot=0, y_slot=0, act=False, mul=1, alpha=1.5, res=2 if park else t["skip"], beta=1.0)   # ... and add it back here
         p.store(0, outs["st"])
         return p, outs
     return build
 
 
-def _adjoint_programs(M, width, g, dev):
+def _adjoint_programs(M, width, g, dev, park=True):
     """The fused-epilogue features of the adjoint programs: LOAD with scale + second tensor, a global mul with
     activation-derivative mode, second outputs (from the final value and from the pre-mul value, to a slot aliasing
-    the A operand and to global memory)."""
+    the A operand and to global memory).  park=False: without the register parking slot (wide kernel layout)."""
     def mk(*shape):
         return rnd(g, *shape)
     gin, W1, W2 = mk(M, width), mk(width, width) / 11, mk(width, width) / 11
@@ -369,13 +371,14 @@ def _adjoint_programs(M, width, g, dev):
         outs = {k: conv(torch.zeros(M, width, dtype=torch.float64)) for k in ("a", "b", "o2", "c", "d")}
         p = K.ChainProgram(M)
         p.load(0, t["g"], alpha=0.7, y2=1, alpha2=1.3, Z2=t["z2"], mode2=0)         # G, dz2 = G * 1.3 * f'(z2)
-        p.scale(2, 0, 0.5, width=width)
+        if park:
+            p.scale(2, 0, 0.5, width=width)
         p.gemm(t["W2"], a_slot=1, y_slot=1, mul=t["z1"], mul_mode=2, out=None)        # dz1 = (dz2 W2) f'(z1)
         p.gemm(t["W1"], a_slot=1, y_slot=0, res=0, alpha=2.0, beta=0.5, y2=1, alpha2=0.9, Z2=t["z3"], mode2=2,
                out2=outs["o2"])                                                       # G' and G' * 0.9 * f(z3)
         p.store(0, outs["a"])
         p.store(1, outs["b"])
-        p.gemm(t["W2"], a_slot=1, y_slot=1, mul=t["r"], mul_mode=1, alpha=1.1, res=2, beta=1.0,
+        p.gemm(t["W2"], a_slot=1, y_slot=1, mul=t["r"], mul_mode=1, alpha=1.1, res=2 if park else None, beta=1.0,
                y2=0, y2_src=1, alpha2=0.8, Z2=t["z1"], mode2=1)                      # two products of one GEMM
         p.store(0, outs["c"])
         p.store(1, outs["d"])
@@ -427,7 +430,9 @@ def test_chain_kernel_vs_interpreter(M, width, mode):
     MFMA kernel and on the split-operand bf16 kernel (packed weights), against the float64 interpreter."""
     tol = CHAIN_TOL[mode]
     worst = 0.0
-    for maker in (_stack_programs, _adjoint_programs) + ((_source_programs,) if mode != "f32" else ()):
+    import functools
+    nopark = (functools.partial(_stack_programs, park=False), functools.partial(_adjoint_programs, park=False))
+    for maker in (_stack_programs, _adjoint_programs) + nopark + ((_source_programs,) if mode != "f32" else ()):
         g = torch.Generator().manual_seed(M)
         build = maker(M, width, g, DEV)
         p_ref, o_ref = build(lambda t: t.clone(), lambda i: i)
@@ -443,8 +448,45 @@ def test_chain_kernel_vs_interpreter(M, width, mode):
             scale = max(1.0, float(o_ref[k].abs().max()))
             err = float((o_dev[k].double().cpu() - o_ref[k]).abs().max()) / scale
             worst = max(worst, err)
-            assert err <= 2 * tol, (maker.__name__, k, err)
+            assert err <= 2 * tol, (getattr(maker, '__name__', 'no-park variant'), k, err)
     print(f"chain {mode} M={M} width={width}: max err / scale = {worst:.2e}")
+
+
+@pytest.mark.parametrize("tile_rows", [0, 8, 24, 40, 48])
+@pytest.mark.parametrize("M,width", [(1000, 128), (33, 64), (18122, 128), (5000, 128), (9000, 64)])
+def test_wide_chain_layout_equals_tall_layout_bitwise(M, width, tile_rows):
+    """csrc/chain3.hip (4 waves x 32 columns, row tiles of any multiple of 8 rows up to 48, two workgroups per CU) against
+    csrc/chain2.hip (8 waves x 16 columns): the same products accumulated in the same order — every output bit for bit, for
+    forward stacks (activations, gathered adds, pre-activation / stored-derivative outputs) and first-order adjoint programs
+    (row scales, second outputs), ragged last tiles and half-used MFMA row blocks included."""
+    from gemnet_pytorch_amd import _lib
+    lib = _lib.load()
+    checked = 0
+    default_layout = K.CHAIN_LAYOUT
+    try:
+        import functools
+        for maker in (functools.partial(_stack_programs, park=False), functools.partial(_adjoint_programs, park=False),
+                      _adjoint_programs):
+            outs = {}
+            for layout in ("tall", "wide"):
+                g = torch.Generator().manual_seed(M)
+                build = maker(M, width, g, DEV)
+                p_dev, o_dev = build(lambda t: f32(t), lambda i: i.to(DEV))
+                if K.h3_hazards(p_dev):
+                    break
+                K.CHAIN_LAYOUT = layout
+                assert lib.gn_chain_wide_force_tile_rows(tile_rows if layout == "wide" else 0) == 0
+                K.chain(p_dev, mode="h3")
+                torch.cuda.synchronize()
+                outs[layout] = o_dev
+            if len(outs) == 2:
+                for k in outs["tall"]:
+                    assert torch.equal(outs["tall"][k], outs["wide"][k]), (k, tile_rows)
+                    checked += 1
+    finally:
+        K.CHAIN_LAYOUT = default_layout
+        lib.gn_chain_wide_force_tile_rows(0)
+    assert checked >= 10
 
 
 def test_source_terms_are_rejected_by_the_f32_chain_kernel():

@@ -27,12 +27,26 @@ groups = collections.OrderedDict()
 for p in progs:
     sig = (p.M, " ".join({"load": "L", "scale": "S", "gemm": "G", "store": "T"}[o["kind"]] + (str(o["W"].shape[0]) + "x" + str(o["W"].shape[1]) if o["kind"] == "gemm" else "") for o in p.ops))
     groups.setdefault(sig, []).append(p)
-tot = {"f32": 0.0, "split6": 0.0}
-print(f"{'M':>6s} {'n':>3s} {'f32 us':>8s} {'split6 us':>9s}  program")
+# columns: (label, chain mode, kernel layout, forced tile rows of the wide layout (0 = automatic))
+from gemnet_pytorch_amd import _lib
+lib = _lib.load()
+COLS = [("h3 tall", "h3", "tall", 0), ("h3 wide", "h3", "wide", 0)]
+COLS += [(f"wide/{r}", "h3", "wide", int(r)) for r in os.environ.get("TILE_ROWS", "").split(",") if r]
+# (label "stg N": the wide layout with the second workgroup of a CU started N x 64 cycles late; negative "rows" encodes it)
+COLS += [(f"stg {n}", "h3", "wide", -int(n)) for n in os.environ.get("STAGGER", "").split(",") if n]
+tot = {c[0]: 0.0 for c in COLS}
+def uses_park(p):
+    return any(o.get("slot") == 2 or any(isinstance(o.get(k), int) and o.get(k) == 2 for k in ("mul", "res", "res2")) for o in p.ops)
+print(f"{'M':>6s} {'n':>3s} " + " ".join(f"{c[0]:>9s}" for c in COLS) + "  park  program")
 for sig, ps in groups.items():
     t = {}
-    for mode in tot:
-        t[mode] = timeit(lambda: orig(ps[0], mode), iters=100)
-        tot[mode] += t[mode] * len(ps)
-    print(f"{sig[0]:6d} {len(ps):3d} {t['f32']:8.1f} {t['split6']:9.1f}  {sig[1]}")
+    for label, mode, layout, rows in COLS:
+        K.CHAIN_LAYOUT = layout
+        lib.gn_chain_wide_force_tile_rows(max(rows, 0))
+        lib.gn_chain_wide_set_stagger(max(-rows, 0))
+        t[label] = timeit(lambda: orig(ps[0], mode), iters=100)
+        tot[label] += t[label] * len(ps)
+    print(f"{sig[0]:6d} {len(ps):3d} " + " ".join(f"{t[c[0]]:9.1f}" for c in COLS) + f"  {'P' if uses_park(ps[0]) else '-':>4s}  {sig[1]}")
+lib.gn_chain_wide_force_tile_rows(0)
+lib.gn_chain_wide_set_stagger(0)
 print("total per step:", {k: round(v, 1) for k, v in tot.items()}, "us;", len(progs), "launches")
