@@ -15,7 +15,11 @@ Besides the headline, the same JSON line carries `extra` (never part of `value`;
   extra.train_step                 the full training step (with N > 1 GPUs: including the RCCL gradient all-reduce)
   extra.interaction_block_fwd_bwd  ONE InteractionBlock forward+backward, isolated: step/s and roofline fractions
   extra.gemnet_q                   BASELINE configs[2]: GemNet-Q forward+force with its own roofline
-  extra.dynamic_shape              a new batch every step: device index build + plan + eager forward+force
+  extra.dynamic_shape              a new batch every step: device index build + plan + eager forward+force, and the same
+                                   loop padded to fixed capacities and replayed from ONE hipGraph (padded.py)
+  extra.train_step_dynamic         the training step on a new batch every step: eager and padded-capacity hipGraph
+  extra.config4_shard              BASELINE configs[4], one GPU's shard: GemNet-Q, 64 molecules x 64 atoms, default and
+                                   bf16 Dense arithmetic, peak memory, roofline of the dominant family (--no-config4 skips)
 
 Extra objects on the JSON line:
   roofline      dominant kernel family of the step, measured live with HIP events around every launch
@@ -376,7 +380,11 @@ def cpu_baseline(cfg, n_atoms, budget_s=14.0, n_mol=8):
     return dict(value=round(n_mol * steps / dt, 3), unit="molecules/s", cores=cores, kind="port",
                 sample=f"{steps} steps of forward+force on {n_mol} molecules x {n_atoms} atoms "
                        f"(same generator/config as the GPU workload), torch CPU fp32, {cores} threads",
-                ms_per_step=round(dt / steps * 1e3, 1))
+                ms_per_step=round(dt / steps * 1e3, 1),
+                calibration="this is the build's own CPU restatement (oracle/, kind 'port').  The REFERENCE itself, imported in "
+                            "the build container (8 threads of an 8-vCPU Xeon, SURVEY.md section 5): forward+force 1.3 s per "
+                            "32-molecule batch = 24.6 molecules/s; the full training step (fwd + force + loss.backward) 3.8 s = "
+                            "8.4 molecules/s")
 
 
 def cpu_baseline_train(cfg, n_atoms, n_mol=8, budget_s=10.0, threads=32):
@@ -581,6 +589,61 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3):
                 steps=steps, warmup=warmup, per_gpu=sizes, hipgraph=True, roofline=roof)
 
 
+def extra_config4_shard(rank, n_mol=64, n_atoms=64, steps=3, warmup=2):
+    """BASELINE.json configs[4], ONE GPU's shard: GemNet-Q, 64 molecules x 64 atoms (batch 512 over 8 GPUs), forward+force —
+    126 M quadruplets, ~50 GiB; eager (the launch count is irrelevant at 127 ms per step).  Default Dense arithmetic and
+    `matmul_precision = "bf16"` (plain bf16 MFMA operands in the Dense stacks, fp32 accumulate, fp32 elsewhere: the
+    config's "bf16"), with the deviation of the latter and the roofline of the dominant launcher family."""
+    from gemnet_pytorch_amd.graph import GraphPlan
+    from gemnet_pytorch_amd.index_device import DeviceGraphBuilder
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    cfg = dict(GEMNET_T, triplets_only=False)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    free = torch.cuda.mem_get_info(dev)[0] / 2**30
+    if free < 80:
+        return {"skipped": f"needs ~50 GiB of device memory next to the other extras' pools; {free:.0f} GiB free"}
+    torch.manual_seed(1234)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(dev).eval()
+    model.requires_grad_(False)
+    ds = make_dataset(n_mol, n_atoms, config=4, first=rank * n_mol)
+    R = torch.tensor(ds["R"], device=dev)
+    idx = DeviceGraphBuilder(ds["N"], cfg["cutoff"], cfg["int_cutoff"], False, device=dev)(R)
+    inputs = dict(Z=torch.tensor(ds["Z"], device=dev).long(), R=R, N=torch.tensor(ds["N"], device=dev).long(), **idx)
+    plan = GraphPlan.from_inputs(inputs, False).warm()
+    sizes = dict(atoms=plan.n_atoms, edges=plan.n_edges, triplets=plan.trip.size, interaction_edges=plan.n_int,
+                 intermediate_triplets=plan.n_intm, quadruplets=plan.quad.size)
+    E, F = model(inputs)
+    scale = 1.0 / float(F.abs().mean())          # unit forces: they are linear in the output heads
+    with torch.no_grad():
+        for ob in model.out_blocks:
+            ob.out_energy.weight.mul_(scale)
+    model._wcache.clear()
+    torch.cuda.reset_peak_memory_stats(dev)
+    out = dict(per_gpu=sizes, steps=steps, warmup=warmup, hipgraph=False)
+    res = {}
+    for mode in (None, "bf16"):
+        model.matmul_precision = mode
+        step = lambda: model(inputs)  # noqa: E731
+        elapsed = time_steps(step, steps, warmup)
+        E, F = step()
+        res[mode or "default"] = (E.detach().clone(), F.detach().clone())
+        out[mode or "default"] = dict(ms_per_step=round(elapsed / steps * 1e3, 2), molecules_per_s=round(n_mol * steps / elapsed, 1))
+        if mode is None:
+            # (before the instrumented pass, which keeps every intermediate of the step alive)
+            out["peak_memory_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)
+            roof, fam = family_roofline(step, mode="config4")      # (no committed counter pass for this size: traffic null)
+            log_families("configs[4] shard forward+force", fam)
+            out["roofline"] = roof
+    (E0, F0), (E1, F1) = res["default"], res["bf16"]
+    out["bf16_vs_default"] = dict(force_mae_eV_per_A_at_unit_forces=float((F1 - F0).abs().mean()),
+                                  energy_max_abs=float((E1 - E0).abs().max()), max_abs_energy=float(E0.abs().max()))
+    model.matmul_precision = None
+    del model, inputs, plan, res
+    torch.cuda.empty_cache()
+    return out
+
+
 def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12, warmup=4):
     """A NEW batch every step (data_provider.py:159-165; ase_calculator.py:155-158 rebuilds the graph every MD step):
     positions resident in HBM -> device index construction (csrc/index_gpu.hip) -> GraphPlan (CSR groupings) -> eager
@@ -735,6 +798,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `extra` object (training step, isolated InteractionBlock, GemNet-Q, dynamic shapes)")
+    ap.add_argument("--no-config4", action="store_true", help="skip extra.config4_shard (64 x 64-atom GemNet-Q, ~50 GiB, ~20 s)")
     ap.add_argument("--chain-mode", choices=["f32", "split6", "h3", "split3", "bf16"], default=None,
                     help="arithmetic of the Dense stacks (default: kernels.CHAIN_MODE = h3, fp32 operands as two fp16 planes)")
     ap.add_argument("--dry-run", action="store_true",
@@ -856,6 +920,9 @@ def main():
             guarded("dynamic_shape", lambda: extra_dynamic_shape(cfg, model, args.batch, args.atoms, rank))
             guarded("train_step_dynamic", lambda: extra_train_dynamic(cfg, 1234, args.batch, args.atoms, rank))
             guarded("gemnet_q", lambda: extra_gemnet_q(args.batch, args.atoms, rank))
+            if not args.no_config4:
+                torch.cuda.empty_cache()
+                guarded("config4_shard", lambda: extra_config4_shard(rank))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "force":

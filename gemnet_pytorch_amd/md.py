@@ -1,0 +1,107 @@
+"""Molecular-dynamics entry point: the reference's `ase_calculator.Molecule` surface over the device-resident path.
+
+The reference's MD loop (ase_calculator.py:148-170, `GNNCalculator.calculate`) does, every step,
+
+    self.molecule.update(R=atoms.positions)        # new positions
+    inputs = self.molecule.get()                   # index construction on the host (data_container.py:244-489) + H2D copies
+    energy, forces = self.model.predict(inputs)    # forward + force, D2H
+
+`Molecule` builds the neighbour lists / triplets / quadruplets in numpy and scipy on the CPU each time.  `DeviceMolecule`
+has the same constructor and the same three methods the calculator uses (`update`, `get`, `to`) but `get()` hands back
+only positions, atomic numbers and the molecule layout, tagged as `MoleculeInputs`; `GemNet.predict` recognises the tag
+and serves the call from `runtime.DynamicForceField`: index construction on the device, padded to fixed capacities, ONE
+captured hipGraph replayed per step (bit-identical to the eager run on the unpadded arrays).  The calculator class itself
+is used unchanged:
+
+    from gemnet_pytorch_amd.md import DeviceMolecule as Molecule          # the only edited line of an MD script
+    calc = GNNCalculator(Molecule(R, Z, cutoff, int_cutoff, triplets_only), model=model, atoms=atoms)
+
+Models the padded replay does not cover (quadruplet interactions, direct forces) are served by the device index builder
++ the eager forward — still without the host-side index construction."""
+import numpy as np
+import torch
+
+
+class MoleculeInputs(dict):
+    """What `DeviceMolecule.get()` returns: {"R", "Z", "N"} (no index arrays) + the cutoffs that define the graph."""
+
+    def __init__(self, data, cutoff, int_cutoff, triplets_only):
+        super().__init__(data)
+        self.cutoff, self.int_cutoff, self.triplets_only = float(cutoff), float(int_cutoff), bool(triplets_only)
+
+
+class DeviceMolecule:
+    """Drop-in for the reference's `Molecule(R, Z, cutoff, int_cutoff, triplets_only)` (ase_calculator.py:23-104)."""
+
+    def __init__(self, R, Z, cutoff, int_cutoff, triplets_only=False):
+        R = np.asarray(R)
+        Z = np.asarray(Z)
+        assert R.shape == (len(Z), 3)
+        self.cutoff, self.int_cutoff, self.triplets_only = cutoff, int_cutoff, triplets_only
+        self.R = R
+        self.Z = Z
+        self.N = np.array([len(Z)], dtype=np.int32)
+        self.device = "cpu"
+        self._Z_dev = self._N_dev = None
+
+    def update(self, R):
+        """New positions (ase_calculator.py:86-97)."""
+        R = np.asarray(R) if not torch.is_tensor(R) else R
+        assert tuple(self.R.shape) == tuple(R.shape)
+        self.R = R
+
+    def to(self, device):
+        """Device of the tensors `get()` returns (ase_calculator.py:99-103)."""
+        self.device = device
+        self._Z_dev = self._N_dev = None
+
+    def get(self):
+        if self._Z_dev is None:   # constant over the trajectory: uploaded once
+            self._Z_dev = torch.as_tensor(np.asarray(self.Z), dtype=torch.int64).to(self.device)
+            self._N_dev = torch.as_tensor(self.N, dtype=torch.int64).to(self.device)
+        R = self.R if torch.is_tensor(self.R) else torch.as_tensor(np.asarray(self.R, dtype=np.float32))
+        return MoleculeInputs(dict(R=R.to(self.device, dtype=torch.float32), Z=self._Z_dev, N=self._N_dev),
+                              self.cutoff, self.int_cutoff, self.triplets_only)
+
+
+def predict_molecule(model, inputs):
+    """`GemNet.predict` for `MoleculeInputs`: -> (E, F) on the device, not detached from nothing (inference only)."""
+    R, Z, N = inputs["R"], inputs["Z"], inputs["N"]
+    if inputs.triplets_only != model.triplets_only:
+        raise ValueError("DeviceMolecule(triplets_only=...) does not match the model")
+    if not R.is_cuda:
+        # host tensors: the host index builder (include/gemnet_index.h) + the ordinary forward (raises without a device,
+        # like every other entry point: there is no CPU compute path)
+        from .training.data_container import DataContainer
+        dc = DataContainer.from_arrays(dict(R=R.numpy(), Z=Z.numpy(), N=N.numpy(), E=np.zeros((1, 1), np.float32),
+                                            F=np.zeros((R.shape[0], 3), np.float32)),
+                                       inputs.cutoff, inputs.int_cutoff, triplets_only=model.triplets_only)
+        b = dc[[0]]
+        return model({k: v for k, v in b.items() if k not in ("E", "F")})
+    key = (tuple(int(z) for z in Z.tolist()) if Z.numel() <= 4096 else id(Z), tuple(int(n) for n in N.tolist()),
+           inputs.cutoff, inputs.int_cutoff, R.device.index)
+    cache = model.__dict__.setdefault("_md_fields", {})
+    ff = cache.get(key)
+    was_training = model.training
+    if ff is None:
+        model.eval()
+        if model.triplets_only and not model.direct_forces:
+            from .runtime import DynamicForceField
+            for p in model.parameters():
+                p.requires_grad_(False)       # a force field: only dE/dR is ever asked for
+            ff = DynamicForceField(model, Z, N.cpu().numpy(), inputs.cutoff, inputs.int_cutoff)
+        else:
+            from .index_device import DeviceGraphBuilder
+            builder = DeviceGraphBuilder(N.cpu().numpy(), inputs.cutoff, inputs.int_cutoff, model.triplets_only, device=R.device)
+
+            def ff(R_, builder=builder):
+                idx = builder(R_)
+                return model(dict(R=R_, Z=Z, N=N, **idx))
+        if len(cache) >= 8:
+            cache.pop(next(iter(cache)))
+        cache[key] = ff
+    try:
+        model.eval()
+        return ff(R)
+    finally:
+        model.train(was_training)

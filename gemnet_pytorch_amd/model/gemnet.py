@@ -34,6 +34,7 @@ _nullcontext = contextlib.nullcontext
 # Off: same-box A/B on MI355X (profiles/r3_ab.txt) 2.777 / 2.747 ms with it, 2.729 / 2.685 ms without — the chained
 # in-place sums order the output blocks' adjoints behind each other, the engine's adds did not.
 _RBF_OUT_ACC = os.environ.get("GEMNET_RBF_OUT_ACC", "0") == "1"
+_H3_GUARD = os.environ.get("GEMNET_H3_GUARD", "1") == "1"     # see GemNet.forward
 # Side-stream placement switches.  All three were forced off in round 3 because hipGraph replays stopped matching the eager
 # run with them; round 4 located the cause below the library — packed-FP32 instructions of the fused aggregation adjoint
 # returning wrong lanes when its waves share CUs with the chain kernels of another graph branch (csrc/aggregate.hip,
@@ -367,6 +368,30 @@ class GemNet(torch.nn.Module):
         return E_mol, F_ca, V_ca
 
     def forward(self, inputs):
+        """E, F as the reference's `GemNet.forward` (gemnet.py:453-615).
+        Range guard of the default Dense arithmetic: the "h3" forward programs keep activations in two fp16 planes, so a
+        value beyond 65 504 becomes inf — fitted scale factors keep activations O(1), a model with
+        unfitted ones (the starting state of fit_scaling.py, foreign checkpoints) need not.  A non-finite result of an eager
+        forward in that arithmetic switches THIS model to the bf16-plane form ("split6": fp32 exponent range), says so, and
+        repeats the pass.  (One host read-back per eager forward; nothing is checked while a hipGraph is being captured: a
+        capture is preceded by eager warm-up passes of the same batch, which are.)"""
+        out = self._forward(inputs)
+        R = inputs["R"]
+        if (_H3_GUARD and R.is_cuda and (self.matmul_precision or K_chain_mode()) == "h3"
+                and not torch.cuda.is_current_stream_capturing()):
+            if not bool(torch.stack([torch.isfinite(t).all() for t in out]).all()):
+                import warnings
+                warnings.warn("gemnet_pytorch_amd: non-finite energies / forces from the fp16-plane Dense arithmetic ('h3': "
+                              "activations beyond 65504 overflow; are the scale factors fitted?) — this model now uses "
+                              "matmul_precision = 'split6' (bf16 planes, fp32 range); the pass is repeated", RuntimeWarning)
+                self.matmul_precision = "split6"
+                self._wcache = {}
+                if getattr(self, "_packs", None) is not None:
+                    self._packs.clear()
+                out = self._forward(inputs)
+        return out
+
+    def _forward(self, inputs):
         R = inputs["R"]
         self._check_inputs(R)
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
@@ -506,7 +531,14 @@ class GemNet(torch.nn.Module):
 
     # ----------------------------------------------------------------------------------- misc
     def predict(self, inputs):
-        E, F = self(inputs)
+        """(E, F) detached on the host, as the reference (gemnet.py:780-784).  Inputs from `md.DeviceMolecule.get()` (the MD
+        loop of ase_calculator.py:148-170) carry no index arrays: they are served by the device index builder + one
+        replayed hipGraph (md.predict_molecule)."""
+        from ..md import MoleculeInputs, predict_molecule
+        if isinstance(inputs, MoleculeInputs):
+            E, F = predict_molecule(self, inputs)
+        else:
+            E, F = self(inputs)
         return E.detach().cpu(), F.detach().cpu()
 
     def load_weights(self, path):

@@ -116,6 +116,45 @@ def test_matmul_arithmetic_modes(golden_model2, tag, mode, bar, monkeypatch):
         assert f_mae <= 0.2
 
 
+@pytest.mark.parametrize("train", [False, True], ids=["inference", "force-training"])
+def test_fp16_plane_overflow_falls_back_to_bf16_planes(golden_model2, train, monkeypatch):
+    """The default Dense arithmetic ("h3": two fp16 planes) cannot hold an activation beyond 65 504.  A model whose scale
+    factors do not keep activations O(1) — here: the input Dense of a residual stack blown up by 1e6, which fp32 and the
+    bf16 planes hold without trouble — must not return inf / nan silently: the eager forward notices, switches this model to "split6", warns, and returns what a split6 model returns."""
+    from gemnet_pytorch_amd import kernels as K
+    cfg, params, inputs = load_case(golden_model2, "t4s")
+    monkeypatch.setattr(K, "CHAIN_MODE", "h3")
+
+    def blown(model):
+        blk = model.int_blocks[1]
+        with torch.no_grad():
+            blk.dense_ca.weight.mul_(1e6)                    # activations of ~1 become ~1e6 > 65504
+        return model
+
+    ref = blown(build(cfg, params))
+    ref.matmul_precision = "split6"
+    ref = ref.train() if train else ref.eval()
+    E_ref, F_ref = ref(to_dev(inputs))
+    assert bool(torch.isfinite(F_ref).all())
+    model = blown(build(cfg, params))
+    model = model.train() if train else model.eval()
+    assert model.matmul_precision is None
+    with pytest.warns(RuntimeWarning, match="fp16-plane"):
+        E, F = model(to_dev(inputs))
+    assert model.matmul_precision == "split6"
+    assert bool(torch.isfinite(E).all()) and bool(torch.isfinite(F).all())
+    assert torch.equal(E, E_ref) and torch.equal(F, F_ref)
+    if train:
+        (F ** 2).sum().backward()      # the repeated pass left a usable autograd graph
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # without the guard the same input gives non-finite output (that is what it is for)
+    from gemnet_pytorch_amd.model import gemnet as G
+    monkeypatch.setattr(G, "_H3_GUARD", False)
+    raw = blown(build(cfg, params)).eval()
+    E2, F2 = raw(to_dev(inputs))
+    assert not bool(torch.isfinite(F2).all())
+
+
 @pytest.mark.parametrize("tag", ["t1", "q1", "t2", "t2s", "q2s", "t4s", "q4s", "dt1", "dq1", "dt2s"])
 def test_training_gradients_parity(golden_model, golden_model2, tag):
     """loss.backward() through the force (second order) resp. through the direct-force head (first order, fused
