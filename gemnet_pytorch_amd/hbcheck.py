@@ -188,7 +188,7 @@ def _where(skip_prefixes=("hbcheck.py", "_lib.py")):
     out = []
     for fr in reversed(traceback.extract_stack(limit=40)):
         base = os.path.basename(fr.filename)
-        if base in skip_prefixes or "torch/" in fr.filename or "/contextlib.py" in fr.filename:
+        if base in skip_prefixes or "-packages/torch/" in fr.filename or "/contextlib.py" in fr.filename:
             continue
         out.append(f"{base}:{fr.lineno}:{fr.name}")
         if len(out) == 4:
@@ -367,7 +367,14 @@ class Recorder:
         new = self._new_nodes()
         if not new:
             return
-        op = Op(len(self.ops), str(func), torch.cuda.current_stream().cuda_stream, _where())
+        where = _where()
+        if not where:      # issued by the autograd engine itself (gradient fan-in sums, AccumulateGrad): name the node at work
+            try:
+                node = torch._C._current_autograd_node()
+                where = "engine, after " + (node.name() if node is not None else "?")
+            except Exception:  # noqa: BLE001
+                where = "engine"
+        op = Op(len(self.ops), str(func), torch.cuda.current_stream().cuda_stream, where)
         op.nodes = new
         schema = getattr(func, "_schema", None)
         mutated = set()

@@ -16,7 +16,7 @@ is used unchanged:
     from gemnet_pytorch_amd.md import DeviceMolecule as Molecule          # the only edited line of an MD script
     calc = GNNCalculator(Molecule(R, Z, cutoff, int_cutoff, triplets_only), model=model, atoms=atoms)
 
-Models the padded replay does not cover (quadruplet interactions, direct forces) are served by the device index builder
+Models the padded replay does not cover (quadruplet interactions) are served by the device index builder
 + the eager forward — still without the host-side index construction."""
 import numpy as np
 import torch
@@ -85,7 +85,7 @@ def predict_molecule(model, inputs):
     was_training = model.training
     if ff is None:
         model.eval()
-        if model.triplets_only and not model.direct_forces:
+        if model.triplets_only:
             from .runtime import DynamicForceField
             for p in model.parameters():
                 p.requires_grad_(False)       # a force field: only dE/dR is ever asked for

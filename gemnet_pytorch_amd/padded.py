@@ -98,8 +98,8 @@ class PaddedGraphRunner:
     (`suggest_capacities`)."""
 
     def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, a_cap=None):
-        if not model.triplets_only or model.direct_forces:
-            raise NotImplementedError("padded replay: triplets-only models with forces by autograd")
+        if not model.triplets_only:
+            raise NotImplementedError("padded replay: triplets-only models (forces by autograd or by the direct-force head)")
         self.model = model
         dev = Z.device
         self.A, self.n_mol = int(Z.shape[0]), int(N.shape[0])          # A: atoms of the CURRENT batch
@@ -241,7 +241,7 @@ class PaddedGraphRunner:
         return self(R, idx, Z, N)
 
     def _capture(self):
-        inputs = dict(self.inputs, max_in_degree=self.pad_degree_bound())
+        inputs = dict(self.inputs, max_in_degree=self.pad_degree_bound(), _guard_rows=(self.n_mol, self.A))
         inputs.pop("_plan", None)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -266,6 +266,7 @@ class PaddedTrainStep(TrainStep):
             # rebuilds it for the batch just written): no plan cached by an earlier eager call may survive into it.
             # The plan of the capture run itself stays in the dict — its tensors are the graph's memory.
             inputs.pop("_plan", None)
+        inputs["_guard_rows"] = (self.pad.n_mol, self.pad.A)     # range guard of the fp16-plane arithmetic: the real rows
         E, F = super()._outputs(inputs)
         return E[:self.pad.n_mol], F[:self.pad.a_cap]
 

@@ -1,6 +1,6 @@
 """-m gpu: BASELINE.json configs[4], ONE GPU's shard at its full size — GemNet-Q (published 4-block configuration),
-64 molecules x 64 atoms (batch 512 over 8 GPUs), forward+force, default arithmetic (six split-bf16 products,
-fp32-equivalent) AND `matmul_precision = "bf16"` (plain bf16 MFMA operands, fp32 accumulate) — through the
+64 molecules x 64 atoms (batch 512 over 8 GPUs), forward+force, default arithmetic (two fp16 planes per operand, three
+products: fp32-equivalent) AND `matmul_precision = "bf16"` (plain bf16 MFMA operands, fp32 accumulate) — through the
 size-independent properties of tests/test_gpu_fullsize.py (the float64 reference does not finish 126 M quadruplets):
   * sum of forces = 0 per molecule,
   * batch additivity against per-molecule runs (the 64-atom single-molecule size is the golden-covered one: q4s/q2s are

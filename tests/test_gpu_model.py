@@ -248,9 +248,14 @@ def test_eval_forward_force_in_hipgraph(golden_model):
     assert torch.equal(E, Eg) and torch.equal(F, Fg)
 
 
-def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch):
-    """The LDS-resident stack path (gn_chain_f32, the default) gives the same E/F as per-layer GEMMs."""
+@pytest.mark.parametrize("mode,e_bar", [("f32", 2e-5), ("h3", 5e-5)])
+def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch, mode, e_bar):
+    """The LDS-resident stack path gives the same E/F as per-layer GEMMs (always the f32 MFMA): with the f32 chain kernel
+    (same arithmetic on both sides) and with the default two-plane fp16 chain kernel (22-bit operands on one side: the
+    energy of this unscaled fixture, |E| = 0.87, moves by 2.3e-5 — the force bar is the same for both)."""
+    from gemnet_pytorch_amd import kernels as K
     from gemnet_pytorch_amd import ops
+    monkeypatch.setattr(K, "CHAIN_MODE", mode)
     cfg, params, inputs = load_case(golden_model, "t2")
     model = build(cfg, params).eval()
     dev = to_dev(inputs)
@@ -260,7 +265,7 @@ def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch):
     E1, F1 = model(dev)
     fs = max(1.0, float(F0.abs().mean()))
     assert float((F1 - F0).abs().mean()) <= 1e-5 * fs
-    assert float((E1 - E0).abs().max()) <= 2e-5 * max(1.0, float(E0.abs().max()))
+    assert float((E1 - E0).abs().max()) <= e_bar * max(1.0, float(E0.abs().max()))
 
 
 def test_fused_trainer_step_matches_torch_optimizers(golden_model):

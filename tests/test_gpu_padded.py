@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def test_padded_graph_replay_equals_eager_on_changing_batches():
-    cfg = dict(FULL, triplets_only=True)
+@pytest.mark.parametrize("direct", [False, True], ids=["autograd-forces", "direct-forces"])
+def test_padded_graph_replay_equals_eager_on_changing_batches(direct):
+    cfg = dict(FULL, triplets_only=True, direct_forces=direct)
     torch.manual_seed(5)
     model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV).eval()
     model.requires_grad_(False)
