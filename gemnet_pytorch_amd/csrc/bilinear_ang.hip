@@ -196,6 +196,88 @@ __global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __res
   }
 }
 
+// ---- x-adjoint, fused per TARGET ATOM: no per-quadruplet rows in memory ----------------------------------------------
+// dx[j, :] = sum_{q: g(q) = j} Y[q, :] dSm[r(q)]   (interaction_block.py:517-566 backward through the gather of x).
+// expand_ang above writes the per-quadruplet rows dxt (Q x 32 floats: 1.15 GB at 9 M quadruplets) and a CSR segmented sum
+// reads them back (bil_expand_ang 0.42 ms + segsum 0.30 ms per block, 732 MB counted against 225 MB algorithmic).
+// A quadruplet c -> a <- b <- d reduces into the edge c -> a and expands from the intermediate triplet (a <- b <- d): both
+// end in atom a, and the intermediate triplets are sorted by a.  So ONE workgroup owns one atom: its rows dx[J_a] live in
+// LDS (|J_a| <= 848 rows of 32 floats), the workgroup walks the edges into a IN ORDER — all eight waves on the tiles of one
+// edge at a time: the quadruplets of one edge expand from distinct rows, so the adds of one step never collide, and a
+// barrier between the steps fixes the order of the sum (deterministic, no atomics) — and writes its rows once.
+// Inner tile = expand_ang's: Y rows of 32 quadruplets rebuilt in the wave's LDS tile, dSm[e] as B fragments in registers,
+// f32 MFMA 16x16x4.
+template <int NW, int TQ>
+__global__ __launch_bounds__(NW * 64) void bil_expand_atoms_ang_kernel(
+    const float4* __restrict__ ang, const float* __restrict__ dSm, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ a_perm, const int32_t* __restrict__ a_seg,
+    const int32_t* __restrict__ j_off, float* __restrict__ dx, int max_J) {
+  extern __shared__ __attribute__((aligned(16))) float alds[];   // dx rows [max_J][C], then the waves' Y tiles [NW][TQ * LDY]
+  const int a = blockIdx.x;
+  const int j0 = j_off[a], nJ = j_off[a + 1] - j0;
+  if (nJ <= 0) return;
+  if (nJ > max_J) __builtin_trap();      // the caller sized the LDS for max_J rows
+  float* __restrict__ dxl = alds;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  float* __restrict__ ys = alds + (size_t)max_J * C + wave * (TQ * LDY);
+  for (int i = threadIdx.x; i < nJ * (C / 4); i += NW * 64) reinterpret_cast<float4*>(dxl)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int e0 = a_seg[a], e1 = a_seg[a + 1];
+  for (int ei = e0; ei < e1; ++ei) {
+    const int e = a_perm ? a_perm[ei] : ei;
+    const int t0 = seg_off[e], t1 = seg_off[e + 1];
+    if (t0 + wave * TQ < t1) {             // (wave-uniform) this wave has a tile of the edge
+      const float* __restrict__ De = dSm + e * (int64_t)S * C;
+      float bd[13][2];   // dSm[4 kk + lg][16 nt + l15]
+#pragma unroll
+      for (int kk = 0; kk < 13; ++kk) {
+        const int sr = 4 * kk + lg;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float v = De[min(sr, S - 1) * C + 16 * nt + l15];
+          bd[kk][nt] = sr < S ? v : 0.f;
+        }
+      }
+      for (int tb = t0 + wave * TQ; tb < t1; tb += NW * TQ) {
+        const int nq = min(TQ, t1 - tb);
+        int jl = 0;
+        if (lane < nq) {
+          jl = expand_idx[tb + lane] - j0;
+          const float4 a4 = ang[tb + lane];
+          ylm7_row_T<float>(a4.x, a4.y, a4.z, a4.w, ys + lane * LDY);
+        }
+        wave_lds_sync();
+        for (int sub = 0; sub < nq; sub += 16) {
+          const float* __restrict__ yb = ys + min(sub + l15, nq - 1) * LDY + lg;
+          v4f_a c0 = (v4f_a){0.f, 0.f, 0.f, 0.f}, c1 = (v4f_a){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 13; ++kk) {
+            const float yv = yb[4 * kk];
+            const float av = (kk < 12 || lg == 0) ? yv : 0.f;
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bd[kk][0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bd[kk][1], c1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = sub + 4 * lg + r;
+            const int row = __shfl(jl, min(q, nq - 1), 64);
+            if (q < nq) {
+              float* __restrict__ o = dxl + row * C + l15;     // rows of one edge are distinct: no two lanes share an element
+              o[0] += c0[r];
+              o[16] += c1[r];
+            }
+          }
+        }
+        wave_lds_sync();
+      }
+    }
+    __syncthreads();     // every add of edge e has landed before an add of the next edge may touch the same row
+  }
+  float4* __restrict__ out = reinterpret_cast<float4*>(dx + (int64_t)j0 * C);
+  for (int i = threadIdx.x; i < nJ * (C / 4); i += NW * 64) out[i] = reinterpret_cast<const float4*>(dxl)[i];
+}
+
 // ---- angle gradient of all blocks that share the basis, one pass ------------------------------------------------------
 struct gn_dy_ang_args {
   const float* dS[4];
@@ -297,6 +379,29 @@ extern "C" int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const i
   if (S_ != S || C_ != C || !aligned16(ang)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(bil_expand_ang_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_expand_atoms_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, const int32_t* expand_idx,
+                                           const int32_t* a_perm, const int32_t* a_seg, const int32_t* j_off, float* dx,
+                                           int64_t n_atoms, int max_J, int S_, int C_, void* stream) {
+  if (n_atoms <= 0) return 0;
+  if (S_ != S || C_ != C || !aligned16(ang) || max_J < 1) return (int)hipErrorInvalidValue;
+  // 16 waves with tiles of 16 quadruplets (the same 13 568 floats of Y tiles as 8 waves x 32): twice the waves per step
+  constexpr int NW = 16, TQ = 16;
+  const size_t lds = ((size_t)max_J * C + (size_t)NW * TQ * LDY) * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  static bool configured = false;   // idempotent attribute; a benign race sets it twice
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_expand_atoms_ang_kernel<NW, TQ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((bil_expand_atoms_ang_kernel<NW, TQ>), dim3((unsigned)n_atoms), dim3(NW * 64), lds,
+                     static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(ang), dSm, seg_off, expand_idx, a_perm,
+                     a_seg, j_off, dx, max_J);
   GN_LAUNCH_CHECK();
   return 0;
 }

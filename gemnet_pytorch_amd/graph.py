@@ -81,6 +81,32 @@ class SegmentPlan:
     def seg_off(self):
         return self.reduce.csr[1]
 
+    def set_atom_blocks(self, reduce_atom: "RowIndex", expand_atom: torch.Tensor, n_atoms: int):
+        """Declare the quadruplet structure of GemNet-Q (data_container.py:331-397): r(t) — a reduce edge c -> a — and g(t)
+        — an intermediate triplet a <- b <- d — of every entry end in the same target atom, and the expand rows are sorted by
+        that atom.  `reduce_atom`: target atom of every reduce row (a RowIndex: its CSR groups the edges by atom);
+        `expand_atom`: target atom of every expand row (non-decreasing).  Enables the fused per-atom x-adjoint
+        (gn_bil_expand_atoms_ang_f32: no per-quadruplet rows in memory)."""
+        self._ab_src = (reduce_atom, expand_atom, int(n_atoms))
+        self._atom_blocks = None
+
+    @property
+    def atom_blocks(self):
+        """(a_perm int32 | None, a_seg int32 (A+1), j_off int32 (A+1), max_J) or None.  Built once per batch; the maximum is
+        read back from the device (a host sync: `GraphPlan.warm` does it outside of any capture)."""
+        src = getattr(self, "_ab_src", None)
+        if src is None:
+            return None
+        if self._atom_blocks is None:
+            reduce_atom, expand_atom, A = src
+            perm, seg = reduce_atom.csr
+            cnt = torch.bincount(expand_atom, minlength=A)
+            j_off = torch.zeros(A + 1, dtype=torch.int64, device=cnt.device)
+            torch.cumsum(cnt, 0, out=j_off[1:])
+            max_J = int(cnt.max().item()) if cnt.numel() else 0
+            self._atom_blocks = (perm, seg.to(torch.int32).contiguous(), j_off.to(torch.int32).contiguous(), max_J)
+        return self._atom_blocks
+
     def set_row_groups(self, row_group: torch.Tensor, n_groups: int, max_rows=None):
         """Declare that r(t) and g(t) of every entry fall in the same group of rows (`row_group[row]`), as the
         triplets c->a<-b do with the target atom a of both edges (data_container.py:262-300).
@@ -159,6 +185,8 @@ class GraphPlan:
             self.intm_db = RowIndex(exp_db, self.n_edges)
             self.intm_ab = RowIndex(exp_ab, self.n_int, is_sorted=True)
             self.quad = SegmentPlan(inputs["id4_reduce_ca"], inputs["id4_expand_abd"], self.n_edges, self.n_intm)
+            # reduce edge c -> a and intermediate triplet a <- b <- d share the target atom a; the latter are sorted by it
+            self.quad.set_atom_blocks(self.id_a, i_a[exp_ab], self.n_atoms)
             A = self.n_atoms
             self.quad_geom = {
                 # a - b <- d per intermediate triplet (gemnet.py:385-388)
@@ -200,6 +228,8 @@ class GraphPlan:
             for ri in self.row_indices():
                 ri.csr
             self.trip.groups
+            if not self.triplets_only:
+                self.quad.atom_blocks
             self._warmed = True
         return self
 

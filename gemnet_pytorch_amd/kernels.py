@@ -268,6 +268,16 @@ def bil_reduce(Y, x, sp):
     return Sm
 
 
+# The fused per-atom x-adjoint of the tensor basis (gn_bil_expand_atoms_ang_f32: one workgroup per target atom sums the atom's
+# expand rows in LDS, edge by edge — no 1.15 GB of per-quadruplet rows written and read back).  Exact and deterministic
+# (tests/test_gpu_kernels.py), but measured SLOWER than the two-pass form on MI355X (profiles/r4_q_atom_blocks.txt: the
+# bil_reduce_t family of a GemNet-Q step 3.39-3.54 ms against 3.18 ms): one workgroup per CU (its LDS holds the atom's rows)
+# walking ~18 edges behind a barrier each cannot hide what 20 independent waves per CU hide in the two-pass kernels.  Off by
+# default; GEMNET_ATOM_BLOCKS=1 selects it.
+USE_ATOM_BLOCKS = os.environ.get("GEMNET_ATOM_BLOCKS", "0") == "1"
+ATOM_BLOCK_MAX_ROWS = 848
+
+
 def bil_reduce_t(Y, D, sp):
     """dx[j,c] = sum_{t: g(t)=j} sum_s Y[t,s] D[r(t),s,c]."""
     require_device(Y, D)
@@ -275,6 +285,15 @@ def bil_reduce_t(Y, D, sp):
     S, C = D.shape[1], D.shape[2]
     permT, segT = sp.expand.csr
     if is_angle_form(Y, S):
+        ab = sp.atom_blocks if USE_ATOM_BLOCKS else None
+        if ab is not None and 0 < ab[3] <= ATOM_BLOCK_MAX_ROWS and C == 32:
+            # quadruplets: the rows of one target atom summed in LDS, no per-quadruplet rows in memory
+            a_perm, a_seg, j_off, max_J = ab
+            dx = torch.empty((sp.n_expand, C), device=Y.device, dtype=torch.float32)   # j_off partitions the rows: all written
+            check(_lib.load().gn_bil_expand_atoms_ang_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(sp.expand.idx32), ptr(a_perm),
+                                                          ptr(a_seg), ptr(j_off), ptr(dx), a_seg.shape[0] - 1, int(max_J), S, C,
+                                                          stream()), "gn_bil_expand_atoms_ang_f32")
+            return dx
         dxt = torch.empty((sp.size, C), device=Y.device, dtype=torch.float32)
         check(_lib.load().gn_bil_expand_ang_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(dxt), sp.n_reduce, S, C, stream()),
               "gn_bil_expand_ang_f32")

@@ -242,6 +242,17 @@ int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_
 /* per-quadruplet x-adjoint rows as gn_bil_expand_f32, Y given as angles */
 int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,
                           void* stream);
+/* The same x-adjoint SUMMED over the expand rows, without the per-quadruplet rows in memory: dx[j] = sum_{q: g(q) = j}
+ * Y[q] dSm[r(q)].  Needs the quadruplet structure of GemNet (data_container.py:331-397): reduce edge and expand row of a
+ * quadruplet end in the same target atom, and the expand rows (intermediate triplets) are sorted by that atom —
+ * a_perm / a_seg: the reduce edges grouped by target atom (CSR over n_atoms; a_perm NULL = already grouped), j_off: first
+ * expand row of every atom (n_atoms + 1).  One workgroup per atom keeps its rows in LDS: max_J >= the largest
+ * j_off[a+1] - j_off[a], (max_J * 32 + 13 568) * 4 bytes <= 160 KB (max_J <= 848), else hipErrorInvalidValue (the caller
+ * uses gn_bil_expand_ang_f32 + gn_segsum_rows_f32); an atom with more rows than max_J traps.  Deterministic (the edges of
+ * an atom are summed in a_perm order).  Every row of dx that belongs to an atom is written; S = 49, C = 32. */
+int gn_bil_expand_atoms_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, const int32_t* expand_idx,
+                                const int32_t* a_perm, const int32_t* a_seg, const int32_t* j_off, float* dx,
+                                int64_t n_atoms, int max_J, int S, int C, void* stream);
 /* gradient w.r.t. the two angles of all nb <= 4 blocks sharing the basis (gn_bil_dy_multi_f32 contracted with dY/d angle) */
 int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float* const* x_list, int nb, const float* ang,
                             const int32_t* expand_idx, const int32_t* seg_off, float* g_ang, int64_t E, int S, int C,

@@ -967,6 +967,40 @@ def test_tensor_basis_angle_form_kernels(E, J, mk):
         close(got, g_ref, atol=3e-5 * max(1.0, float(g_ref.abs().max())))
 
 
+@pytest.mark.parametrize("n_mol,n_atoms", [(3, 12), (2, 32)])
+def test_fused_per_atom_x_adjoint_of_the_tensor_basis(n_mol, n_atoms, monkeypatch):
+    """gn_bil_expand_atoms_ang_f32 — one workgroup per target atom, the atom's expand rows summed in LDS edge by edge, no
+    per-quadruplet rows in memory — on the real quadruplet structure of a GemNet-Q batch (the only structure it is defined
+    for: reduce edge and intermediate triplet of a quadruplet end in the same atom) against the float64 restatement on the
+    explicit (Q, 49) harmonics and against the two-pass form (gn_bil_expand_ang_f32 + segmented sum); run twice: bitwise."""
+    from gemnet_pytorch_amd.graph import GraphPlan
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    from gemnet_pytorch_amd.training.data_container import DataContainer
+    ds = make_dataset(n_mol, n_atoms, config=2)
+    b = DataContainer.from_arrays(dict(ds), 5.0, 10.0, triplets_only=False)[list(range(n_mol))]
+    inputs = {k: v for k, v in b.items() if k not in ("E", "F")}
+    cpu = GraphPlan.from_inputs(dict(inputs), False).quad
+    dev_plan = GraphPlan.from_inputs({k: v.to(DEV) for k, v in inputs.items()}, False).warm()
+    dev = dev_plan.quad
+    a_perm, a_seg, j_off, max_J = dev.atom_blocks
+    assert 0 < max_J <= K.ATOM_BLOCK_MAX_ROWS and int(j_off[-1]) == dev.n_expand
+    g = torch.Generator().manual_seed(n_atoms)
+    Q, S, C = cpu.size, 49, 32
+    th, ph = torch.rand(Q, generator=g, dtype=torch.float64) * 3.1, torch.rand(Q, generator=g, dtype=torch.float64) * 3.1
+    ang = torch.stack([torch.sin(th), torch.cos(th), torch.sin(ph), torch.cos(ph)], 1)
+    D = rnd(g, dev.n_reduce, S, C)
+    ref = CK.bil_reduce_t(ang, D, cpu)
+    monkeypatch.setattr(K, "USE_ATOM_BLOCKS", True)
+    got = K.bil_reduce_t(f32(ang), f32(D), dev)
+    close(got, ref, atol=2e-5 * max(1.0, float(ref.abs().max())))
+    assert torch.equal(got, K.bil_reduce_t(f32(ang), f32(D), dev))
+    monkeypatch.setattr(K, "USE_ATOM_BLOCKS", False)
+    two_pass = K.bil_reduce_t(f32(ang), f32(D), dev)
+    close(got, two_pass.double().cpu(), atol=2e-5 * max(1.0, float(ref.abs().max())))
+    print(f"{n_mol} x {n_atoms}: {Q} quadruplets, max |J_a| {max_J}; fused vs float64 {float((got.double().cpu() - ref).abs().max()):.2e}, "
+          f"two-pass vs float64 {float((two_pass.double().cpu() - ref).abs().max()):.2e}")
+
+
 def test_quad_angles_geometry_fwd_bwd():
     """gn_quad_angles_fwd / bwd: (sin, cos) of Phi_cab, Theta_cabd per quadruplet and the force contributions of a
     gradient given w.r.t. the two angles, against autograd on the float64 geometry (gemnet.py:334-418)."""
