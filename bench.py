@@ -272,7 +272,7 @@ class LaunchTimer:
 
 PEAK_SPLIT6_TFLOPS = 2500.0 / 6   # fp32-equivalent ceiling of six bf16 products on the 2.5 PF dense bf16 pipe
 PEAK_BF16_TFLOPS = 2500.0
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
 
 
 def _profile_json(name):
@@ -285,7 +285,7 @@ def _profile_json(name):
 
 def pmc_traffic(name, mode):
     """(HBM-side bytes per launch, source) of a launcher family from the COMMITTED rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes of the same workload `mode` ("T" forward+force, "Q", "train"): profiles/r3_traffic_<mode>.json,
+    WRITE_SIZE passes of the same workload `mode` ("T" forward+force, "Q", "train"): profiles/<round>_traffic_<mode>.json,
     written by tools/gpu_artifacts.sh + tools/pmc_summary.py on the builder's GPU box (gfx950 FETCH_SIZE correction
     applied).  Not measured in this run: the counters need rocprofv3 around the process.  (None, None) when that
     family / mode was not profiled."""
@@ -299,7 +299,7 @@ def pmc_traffic(name, mode):
 
 def mfma_busy(name, mode):
     """MFMA-busy percentage of the family's kernels (SQ_VALU_MFMA_BUSY_CYCLES / (duration x clock x SIMDs)) from the
-    committed SQ counter pass (profiles/r3_mfma_busy.json); None when not profiled."""
+    committed SQ counter pass (profiles/<round>_mfma_busy.json); None when not profiled."""
     tab = _profile_json(f"{PROFILE_ROUND}_mfma_busy.json")
     try:
         return float(tab[mode][name]["mfma_busy_pct"])
@@ -518,7 +518,7 @@ def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, w
         out["roofline"] = roof
         # launches through the C ABI (kernels.py launchers) of one eager step, + the grouped weight-gradient pair and the
         # two optimizer launches; the remaining ATen launches (gradient fan-in adds of cross-stream consumers, geometry glue
-        # of the composite parts) are in profiles/r3_train_kernel_stats.csv
+        # of the composite parts) are in profiles/r4_train_kernel_stats.csv
         out["launches_per_step"] = int(sum(v["launches"] for v in fam.values())) + (2 if ts.wgrad is not None else 0) + 2
     del ts, model
     return out
@@ -898,6 +898,10 @@ def main():
         if not args.no_roofline and rank == 0:
             roof, fam = family_roofline(step)
             log_families("forward+force", fam)
+            # the WHOLE step against the same roof: algorithmic flops of every launcher family of one step / the timed step
+            step_flops = sum(v["flops"] for v in fam.values())
+            roof["step_algorithmic_gflop"] = round(step_flops / 1e9, 2)
+            roof["step_frac"] = round(step_flops / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
 
     # ---- the numbers SURVEY.md 8(d) asks for besides the headline (never part of `value`)
     if not args.no_extras and args.mode == "force":

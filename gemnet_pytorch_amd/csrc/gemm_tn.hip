@@ -139,8 +139,8 @@ __global__ __launch_bounds__(TNT) void gemm_tn_grouped_kernel(const gn_tn_proble
   float* __restrict__ o = ws + p.ws_off + (size_t)z * p.M * p.N;
   const bool va = (p.ldx % 4 == 0) && (p.M % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
   const bool vb = (p.ldy % 4 == 0) && (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0);
-  if (va && vb) tn_tile<true, true>(p.X, p.Y, o, p.M, p.N, p.ldx, p.ldy, p.N, tm * TBM, tn * TBN, kbeg, kend, 1.0f, As, Bs);
-  else tn_tile<false, false>(p.X, p.Y, o, p.M, p.N, p.ldx, p.ldy, p.N, tm * TBM, tn * TBN, kbeg, kend, 1.0f, As, Bs);
+  if (va && vb) tn_tile<true, true>(p.X, p.Y, o, p.M, p.N, p.ldx, p.ldy, p.N, tm * TBM, tn * TBN, kbeg, kend, p.alpha, As, Bs);
+  else tn_tile<false, false>(p.X, p.Y, o, p.M, p.N, p.ldx, p.ldy, p.N, tm * TBM, tn * TBN, kbeg, kend, p.alpha, As, Bs);
 }
 
 // Grouped fold: target t owns elements [0, n_t) and a list of partial slices (offsets into ws); one workgroup

@@ -75,10 +75,9 @@ def _wgrad_bilinear(W, Pm, g, alpha):
     q = ops._WGRAD_QUEUE
     if (q is not None and not torch.is_grad_enabled() and W.is_leaf and W.is_cuda and W.grad is not None
             and W.grad.is_contiguous()):
-        ga = g if alpha == 1.0 else g * alpha
         base = W.grad.data_ptr()
-        for i in range(I):
-            q.add_region((base + 4 * i * O, C, O, I * O), Pm[:, i, :], ga, keep=W)
+        for i in range(I):      # (alpha rides on the queued product: no scaled copy of g)
+            q.add_region((base + 4 * i * O, C, O, I * O), Pm[:, i, :], g, keep=W, alpha=alpha)
         return None
     gW2 = K.gemm(Pm.reshape(-1, I * C), g, True, True, alpha=alpha)
     return gW2.reshape(I, C, O).permute(1, 0, 2)

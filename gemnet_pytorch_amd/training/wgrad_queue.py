@@ -15,10 +15,10 @@ from .. import _lib
 from .._lib import check, ptr, stream
 
 PROB = np.dtype([("X", "<u8"), ("Y", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("ldx", "<i4"), ("ldy", "<i4"),
-                 ("splitk", "<i4"), ("kchunk", "<i4"), ("wg_begin", "<i4"), ("ws_off", "<i8")])
+                 ("splitk", "<i4"), ("kchunk", "<i4"), ("wg_begin", "<i4"), ("ws_off", "<i8"), ("alpha", "<f4"), ("pad", "<i4")])
 TARGET = np.dtype([("out", "<u8"), ("n", "<i8"), ("slice_begin", "<i4"), ("slice_end", "<i4"), ("wg_begin", "<i4"),
                    ("cols", "<i4"), ("ld", "<i4"), ("pad", "<i4")])
-assert PROB.itemsize == 56 and TARGET.itemsize == 40
+assert PROB.itemsize == 64 and TARGET.itemsize == 40
 # rows of the contraction per split-K slice.  A step queues ~480 products at once (1 900 output tiles of 64 x 64: the grid
 # is full without any split), and every slice costs a (M, N) partial written and folded again: see profiles/r3_ab.txt
 import os as _os
@@ -77,18 +77,18 @@ class WeightGradQueue:
         self._captured = []
         self._keep = None
 
-    def add(self, param, X, Y):
-        """param.grad (M,N) += X^T @ Y with X (K,M), Y (K,N); `param`: a leaf parameter or a column-block view of one
+    def add(self, param, X, Y, alpha=1.0):
+        """param.grad (M,N) += alpha X^T @ Y with X (K,M), Y (K,N); `param`: a leaf parameter or a column-block view of one
         (see `grad_target`, which must accept it)."""
         tgt = grad_target(param)
         assert tgt is not None and tgt[1:3] == (X.shape[1], Y.shape[1]), "not a queueable weight-gradient target"
-        self.items.append((tgt, _rowmajor(X), _rowmajor(Y), param))
+        self.items.append((tgt, _rowmajor(X), _rowmajor(Y), param, float(alpha)))
 
-    def add_region(self, tgt, X, Y, keep=None):
+    def add_region(self, tgt, X, Y, keep=None, alpha=1.0):
         """The same for an explicit target region (address, rows, cols, ld) of a parameter's .grad — e.g. the (C, O) block
         of one i of a bilinear weight (C, I, O): rows c with pitch I * O."""
         assert tgt[1:3] == (X.shape[1], Y.shape[1])
-        self.items.append((tuple(tgt), _rowmajor(X), _rowmajor(Y), keep))
+        self.items.append((tuple(tgt), _rowmajor(X), _rowmajor(Y), keep, float(alpha)))
 
     def _slot(self, nbytes, dev, capturing):
         if capturing:
@@ -123,7 +123,7 @@ class WeightGradQueue:
         by_param = {}
         wg = 0
         ws_off = 0
-        for i, (tgt, X, Y, _) in enumerate(items):
+        for i, (tgt, X, Y, _, alpha) in enumerate(items):
             K, M = X.shape
             N = Y.shape[1]
             assert Y.shape[0] == K
@@ -131,7 +131,7 @@ class WeightGradQueue:
             kchunk = (-(-K // splitk) + 15) // 16 * 16
             splitk = -(-K // kchunk)
             tiles = -(-M // 64) * -(-N // 64)
-            probs[i] = (X.data_ptr(), Y.data_ptr(), M, N, K, X.stride(0), Y.stride(0), splitk, kchunk, wg, ws_off)
+            probs[i] = (X.data_ptr(), Y.data_ptr(), M, N, K, X.stride(0), Y.stride(0), splitk, kchunk, wg, ws_off, alpha, 0)
             # keyed by the target REGION: fresh view objects of one weight block must fold into one accumulator
             by_param.setdefault(tgt, (tgt, []))[1].extend(ws_off + z * M * N for z in range(splitk))
             wg += tiles * splitk

@@ -191,7 +191,7 @@ int gn_gemm_tn_splitk(int M, int N, int K);
 
 /* Grouped form: ALL weight-gradient products of one training step (the ~300 dW = X^T Y leaves of the double
  * backward, trainer.py:346) as one launch + one fold launch.  Device-resident tables built by the caller:
- *   probs[p]    one product: out_p (M,N) = X^T Y, X (K,M) row pitch ldx, Y (K,N) row pitch ldy, split over `splitk`
+ *   probs[p]    one product: out_p (M,N) = alpha X^T Y, X (K,M) row pitch ldx, Y (K,N) row pitch ldy, split over `splitk`
  *               slices of `kchunk` rows (multiple of 16); its workgroups are [wg_begin, wg_begin +
  *               ceil(M/64)*ceil(N/64)*splitk); partial z lands at ws + ws_off + z*M*N
  *   targets[t]  one accumulator (a parameter's .grad, n floats — contiguous, or a column slice): out[i] += sum of ws[slice_off[k] + i]
@@ -201,6 +201,8 @@ typedef struct {
   const float* X; const float* Y;
   int M, N, K, ldx, ldy, splitk, kchunk, wg_begin;
   int64_t ws_off;
+  float alpha;              /* factor of this product (out_p = alpha X^T Y) */
+  int pad_;
 } gn_tn_problem;
 typedef struct {
   float* out;
