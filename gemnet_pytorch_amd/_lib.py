@@ -151,6 +151,10 @@ def load():
     lib.gn_chain_wide_tile_rows.argtypes = [_i]
     lib.gn_chain_wide_force_tile_rows.restype = _i
     lib.gn_chain_wide_force_tile_rows.argtypes = [_i]
+    lib.gn_bil_ang_set_f16.restype = _i
+    lib.gn_bil_ang_set_f16.argtypes = [_i]
+    if os.environ.get("GEMNET_ANG_F16"):
+        lib.gn_bil_ang_set_f16(int(os.environ["GEMNET_ANG_F16"]))
     lib.gn_chain_wide_set_stagger.restype = _i
     lib.gn_chain_wide_set_stagger.argtypes = [_i]
     if os.environ.get("GN_CHAIN_STAGGER"):

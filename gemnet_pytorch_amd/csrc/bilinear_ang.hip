@@ -30,6 +30,35 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // ---- K1 + K2 ----------------------------------------------------------------------------------------------------------
+// F16: K1 on the fp16 matrix pipe with split operands.  The f32-input MFMA runs at the f32 VECTOR rate (chain2.hip): a
+// tile of 32 quadruplets costs 64 v_mfma_f32_16x16x4_f32 = 2 k cycles of a pipe that the Y_lm rebuild (VALU) cannot overlap
+// within one wave.  A tile of 32 quadruplets is exactly one K = 32 chunk of v_mfma_f32_16x16x32_f16: Y and the gathered x rows
+// are split in registers into hi = f16(v) and lo = f16(v - hi) (UNSCALED: both operands are O(1) — harmonics and activations
+// — so the fp16 subnormals the hardware keeps bound the error at 6e-8 absolute, below fp32 rounding of the sum) and
+// hh + hl + lh accumulate into the same fp32 registers: 24 MFMAs of 16 cycles per tile instead of 64 of 32.  The same
+// number of LDS reads and gathered loads as the f32 form; the gathers are issued before the Y rebuild and land under it.
+typedef _Float16 h8_a __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8(const float (&v)[8], h8_a& hi, h8_a& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)v[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(v[i] - (float)h);
+  }
+}
+
+// the scaled form of chain2.hip: lo = f16((v - hi) 2^11) keeps 22 significand bits for every element down to 1.2e-4 of the
+// largest one; its products accumulate in registers of their own and are scaled back once
+__device__ __forceinline__ void split8s(const float (&v)[8], h8_a& hi, h8_a& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)v[i];
+    hi[i] = h;
+    lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
+  }
+}
+
+template <bool F16>
 __global__ __launch_bounds__(256) void bil_reduce_project_ang_kernel(
     const float4* __restrict__ ang, const float* __restrict__ x, const int32_t* __restrict__ expand_idx,
     const int32_t* __restrict__ seg_off, const float* __restrict__ B, float* __restrict__ Sm, float* __restrict__ P,
@@ -52,6 +81,52 @@ __global__ __launch_bounds__(256) void bil_reduce_project_ang_kernel(
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
   for (int tb = t0; tb < t1; tb += TQ) {
     const int nq = min(TQ, t1 - tb);
+    if constexpr (F16) {
+      int gq = 0;
+      float4 a4 = make_float4(0.f, 1.f, 0.f, 1.f);
+      if (lane < nq) {
+        gq = expand_idx[tb + lane];
+        a4 = ang[tb + lane];
+      }
+      // B operand: x[g(q)][16 nt + l15] for the 8 quadruplets q = 8 lg + i of this lane's K group — requested now, used
+      // after the Y rebuild
+      float xb[2][8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = 8 * lg + i;
+        const bool ok = q < nq;
+        const float* __restrict__ xr = x + (int64_t)__shfl(gq, min(q, nq - 1), 64) * C + l15;
+        const float x0 = xr[0], x1 = xr[16];
+        xb[0][i] = ok ? x0 : 0.f;
+        xb[1][i] = ok ? x1 : 0.f;
+      }
+      if (lane < nq) ylm7_row_T<float>(a4.x, a4.y, a4.z, a4.w, ys + lane * LDY);
+      wave_lds_sync();
+      h8_a bh[2], bl[2];
+      split8(xb[0], bh[0], bl[0]);
+      split8(xb[1], bh[1], bl[1]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        // A operand: Y[q = 8 lg + i][s = 16 mt + l15]; tile 3 carries only s = 48
+        float ya[8];
+        const int sc = 16 * mt + l15;
+        const bool s_ok = sc < S;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int q = 8 * lg + i;
+          const float v = ys[min(q, nq - 1) * LDY + min(sc, S - 1)];
+          ya[i] = (s_ok && q < nq) ? v : 0.f;
+        }
+        h8_a ah, al;
+        split8(ya, ah, al);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    } else {
     int gq = 0;                          // expand row of quadruplet tb + lane: one coalesced load per tile,
     if (lane < nq) {                     // handed to the lanes that need it by a wave shuffle (no dependent index load)
       gq = expand_idx[tb + lane];
@@ -95,6 +170,7 @@ __global__ __launch_bounds__(256) void bil_reduce_project_ang_kernel(
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1[nt], acc[mt][nt], 0, 0, 0);
       }
+    }
     }
     wave_lds_sync();   // every fragment read of this tile has returned before the next tile overwrites it
   }
@@ -143,10 +219,14 @@ __global__ __launch_bounds__(256) void bil_reduce_project_ang_kernel(
 }
 
 // ---- x-adjoint, grouped by reduce edge: dxt[seg(e)] (K4 x C) = Yseg (K4 x S) @ dSm[e] (S x C) -------------------------
+// F16 (bit 2 of gn_bil_ang_set_f16): the product on the fp16 matrix pipe — Y (O(1)) and sigma dSm[e] (one exact power-of-two
+// scale per edge: the block is a cotangent of arbitrary magnitude) split into hi + 2^-11 lo planes, the correction products
+// in accumulators of their own (chain2.hip "format H"): 24 MFMAs of 16 cycles per tile of 32 quadruplets instead of 52 of 32.
+template <bool F16>
 __global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __restrict__ ang, const float* __restrict__ dSm,
                                                              const int32_t* __restrict__ seg_off, float* __restrict__ dxt,
                                                              int64_t E) {
-  constexpr int TQ = 32;   // 27 KB of LDS per workgroup: 5 workgroups per CU
+  constexpr int TQ = 32;
   __shared__ float ysm[4][TQ * LDY];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -154,6 +234,88 @@ __global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __res
   if (e >= E) return;
   float* __restrict__ ys = ysm[wave];
   const float* __restrict__ De = dSm + e * (int64_t)S * C;
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  if constexpr (F16) {
+    // B operand: dSm[e][s = 32 kc + 8 lg + i][c = 16 nt + l15], i < 8 (s >= 49: zero)
+    float bv[2][2][8];
+    float vmax = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sr = 32 * kc + 8 * lg + i;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float v = De[min(sr, S - 1) * C + 16 * nt + l15];
+          bv[kc][nt][i] = sr < S ? v : 0.f;
+          vmax = fmaxf(vmax, fabsf(bv[kc][nt][i]));
+        }
+      }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    float sigma = 1.f, inv_sigma = 1.f;
+    {
+      const uint32_t ex = __float_as_uint(vmax) >> 23;
+      const uint32_t ec = ex < 2u ? 2u : (ex > 250u ? 250u : ex);
+      if (vmax > 0.f) {
+        sigma = __uint_as_float((252u - ec) << 23);      // sigma max|dSm[e]| in [0.25, 0.5)
+        inv_sigma = __uint_as_float((2u + ec) << 23);
+      }
+    }
+    h8_a bh[2][2], bl[2][2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[kc][nt][i] *= sigma;
+        split8s(bv[kc][nt], bh[kc][nt], bl[kc][nt]);
+      }
+    for (int tb = t0; tb < t1; tb += TQ) {
+      const int nq = min(TQ, t1 - tb);
+      if (lane < nq) {
+        const float4 a4 = ang[tb + lane];
+        ylm7_row_T<float>(a4.x, a4.y, a4.z, a4.w, ys + lane * LDY);
+      }
+      wave_lds_sync();
+      for (int sub = 0; sub < nq; sub += 16) {
+        // A operand: Y[q = sub + l15][s = 32 kc + 8 lg + i]
+        const float* __restrict__ yb = ys + min(sub + l15, nq - 1) * LDY;
+        v4f_a c0 = (v4f_a){0.f, 0.f, 0.f, 0.f}, c1 = c0, x0 = c0, x1 = c0;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          float ya[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int sr = 32 * kc + 8 * lg + i;
+            const float v = yb[min(sr, S - 1)];
+            ya[i] = sr < S ? v : 0.f;
+          }
+          h8_a ah, al;
+          split8s(ya, ah, al);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kc][0], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kc][1], c1, 0, 0, 0);
+          x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kc][0], x0, 0, 0, 0);
+          x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kc][1], x1, 0, 0, 0);
+          x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kc][0], x0, 0, 0, 0);
+          x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kc][1], x1, 0, 0, 0);
+        }
+        c0 = (c0 + x0 * (1.f / 2048.f)) * inv_sigma;
+        c1 = (c1 + x1 * (1.f / 2048.f)) * inv_sigma;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = sub + 4 * lg + r;
+          if (q < nq) {
+            float* __restrict__ o = dxt + (int64_t)(tb + q) * C + l15;
+            o[0] = c0[r];
+            o[16] = c1[r];
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+    return;
+  }
   float bd[13][2];   // dSm[4 kk + lg][16 nt + l15]
 #pragma unroll
   for (int kk = 0; kk < 13; ++kk) {
@@ -164,7 +326,6 @@ __global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __res
       bd[kk][nt] = sr < S ? v : 0.f;
     }
   }
-  const int t0 = seg_off[e], t1 = seg_off[e + 1];
   for (int tb = t0; tb < t1; tb += TQ) {
     const int nq = min(TQ, t1 - tb);
     if (lane < nq) {
@@ -289,6 +450,12 @@ struct gn_dy_ang_args {
 // the four waves, which split the edge's quadruplets in tiles of 16.  (One wave per edge with the 4 x 32 B fragments in
 // registers — the layout of bil_dy_multi_mfma49 — needs 256 VGPRs once the angle contraction is added: one wave per
 // SIMD, and the gathered x rows were fully exposed: 3.1 ms instead of 1.6 ms at 9 M quadruplets.)
+// F16: the contraction dY[q, s] = sum_b sum_c x_b[g(q), c] dSm_b[e, s, c] on the fp16 matrix pipe with split operands (see
+// bil_reduce_project_ang_kernel): K = c = 32 is one chunk of v_mfma_f32_16x16x32_f16, 12 MFMAs of 16 cycles per block and
+// 16-quadruplet tile instead of 32 f32 MFMAs of 32 cycles.  x is an activation (O(1)); dSm is a COTANGENT of arbitrary
+// magnitude (1e-6 on the quadruplet path of a force pass): the staged blocks of the edge are scaled by one exact power of two
+// (largest |value| of all nb blocks -> [0.25, 0.5)) before the split, the dY rows by its inverse afterwards.
+template <bool F16>
 __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_args a, const float4* __restrict__ ang,
                                                                const int32_t* __restrict__ expand_idx,
                                                                const int32_t* __restrict__ seg_off, float4* __restrict__ g_ang,
@@ -300,14 +467,33 @@ __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_a
   const int64_t e = blockIdx.x;
   const int nb = a.nb;
   float* __restrict__ dy = dsm + nb * S * LDD + wave * 16 * LDY;
+  __shared__ float wmax[4];
+  float vmax = 0.f;
   for (int b = 0; b < nb; ++b) {                      // stage dSm_b[e] (49 x 32): 392 float4 per block
     const float4* __restrict__ src = reinterpret_cast<const float4*>(a.dS[b] + e * (int64_t)S * C);
     for (int i = threadIdx.x; i < S * C / 4; i += 256) {
       const int r = i >> 3, c4i = i & 7;
-      *reinterpret_cast<float4*>(dsm + (b * S + r) * LDD + 4 * c4i) = src[i];
+      const float4 v = src[i];
+      *reinterpret_cast<float4*>(dsm + (b * S + r) * LDD + 4 * c4i) = v;
+      if (F16) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
   }
+  if (F16) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0) wmax[wave] = vmax;
+  }
   __syncthreads();
+  float sigma = 1.f, inv_sigma = 1.f;
+  if (F16) {
+    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const uint32_t ex = __float_as_uint(m) >> 23;                      // m >= 0: biased exponent; m 2^(125 - ex) in [0.25, 0.5)
+    const uint32_t ec = ex < 2u ? 2u : (ex > 250u ? 250u : ex);
+    if (m > 0.f) {
+      sigma = __uint_as_float((252u - ec) << 23);
+      inv_sigma = __uint_as_float((2u + ec) << 23);
+    }
+  }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
   const int t0 = seg_off[e], t1 = seg_off[e + 1];
@@ -318,6 +504,39 @@ __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_a
     v4f_a c4[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) c4[nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+    if constexpr (F16) {
+      v4f_a cx[4];      // the correction products hl + lh (operands' lo planes carry a factor 2^11)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) cx[nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < nb; ++b) {
+        // A operand: x_b[g(q = l15)][c = 8 lg .. 8 lg + 7] — 32 contiguous bytes of the gathered row
+        float xa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* __restrict__ xr = a.x[b] + g * C + 8 * lg;
+          const float4 u0 = *reinterpret_cast<const float4*>(xr), u1 = *reinterpret_cast<const float4*>(xr + 4);
+          xa[0] = u0.x; xa[1] = u0.y; xa[2] = u0.z; xa[3] = u0.w; xa[4] = u1.x; xa[5] = u1.y; xa[6] = u1.z; xa[7] = u1.w;
+        }
+        h8_a ah, al;
+        split8s(xa, ah, al);
+        const float* __restrict__ db = dsm + b * S * LDD;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          // B operand: sigma dSm_b[e][s = 16 nt + l15][c = 8 lg .. 8 lg + 7]; rows >= 49 contribute nothing
+          const int sr = 16 * nt + l15;
+          const float* __restrict__ row = db + min(sr, S - 1) * LDD + 8 * lg;
+          const float4 u0 = *reinterpret_cast<const float4*>(row), u1 = *reinterpret_cast<const float4*>(row + 4);
+          const float sc = sr < S ? sigma : 0.f;
+          const float bv[8] = {u0.x * sc, u0.y * sc, u0.z * sc, u0.w * sc, u1.x * sc, u1.y * sc, u1.z * sc, u1.w * sc};
+          h8_a bh, bl;
+          split8s(bv, bh, bl);
+          c4[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c4[nt], 0, 0, 0);
+          cx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, cx[nt], 0, 0, 0);
+          cx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, cx[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) c4[nt] = (c4[nt] + cx[nt] * (1.f / 2048.f)) * inv_sigma;
+    } else {
     for (int b = 0; b < nb; ++b) {
       float4 ax0 = z4, ax1 = z4;
       if (ok) {
@@ -339,6 +558,7 @@ __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_a
           c4[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ax1, q), comp(b1, q), c4[nt], 0, 0, 0);
         }
       }
+    }
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -362,13 +582,27 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// Matrix-pipe arithmetic of the angle-form kernels, a bit mask: 1 = K1 of gn_bil_reduce_project_ang_f32, 2 = the contraction
+// of gn_bil_dy_multi_ang_f32, 4 = gn_bil_expand_ang_f32 on v_mfma_f32_16x16x32_f16 with split fp16 operands; a cleared bit =
+// the f32-input MFMA.  Default 5: measured on MI355X (profiles/r4_q_f16.txt) K1 -25 %, the x-adjoint rows see there, the
+// angle gradient no faster in the exact (scaled-lo) form — its time is the per-quadruplet derivative recurrences, not the MFMAs.
+static int g_ang_f16 = 5;
+extern "C" int gn_bil_ang_set_f16(int mask) {
+  g_ang_f16 = mask & 7;
+  return 0;
+}
+
 extern "C" int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx,
                                              const int32_t* seg_off, const float* B, float* Sm, float* P, int64_t E, int S_,
                                              int C_, int I_, void* stream) {
   if (E <= 0) return 0;
   if (S_ != S || C_ != C || I_ != I || !aligned16(ang)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(bil_reduce_project_ang_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const float4*>(ang), x, expand_idx, seg_off, B, Sm, P, E);
+  if (g_ang_f16 & 1)
+    hipLaunchKernelGGL(bil_reduce_project_ang_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(ang), x, expand_idx, seg_off, B, Sm, P, E);
+  else
+    hipLaunchKernelGGL(bil_reduce_project_ang_kernel<false>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(ang), x, expand_idx, seg_off, B, Sm, P, E);
   GN_LAUNCH_CHECK();
   return 0;
 }
@@ -377,8 +611,12 @@ extern "C" int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const i
                                      int C_, void* stream) {
   if (E <= 0) return 0;
   if (S_ != S || C_ != C || !aligned16(ang)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(bil_expand_ang_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
+  if (g_ang_f16 & 4)
+    hipLaunchKernelGGL(bil_expand_ang_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
+  else
+    hipLaunchKernelGGL(bil_expand_ang_kernel<false>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
   GN_LAUNCH_CHECK();
   return 0;
 }
@@ -419,8 +657,12 @@ extern "C" int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float
     if (b < nb && (!aligned16(a.dS[b]) || !aligned16(a.x[b]))) return (int)hipErrorInvalidValue;
   }
   const size_t smem = ((size_t)nb * S * (C + 4) + 4 * 16 * LDY) * sizeof(float);   // 42 KB at nb = 4
-  hipLaunchKernelGGL(bil_dy_multi_ang_kernel, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream), a,
-                     reinterpret_cast<const float4*>(ang), expand_idx, seg_off, reinterpret_cast<float4*>(g_ang), E);
+  if (g_ang_f16 & 2)
+    hipLaunchKernelGGL(bil_dy_multi_ang_kernel<true>, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream), a,
+                       reinterpret_cast<const float4*>(ang), expand_idx, seg_off, reinterpret_cast<float4*>(g_ang), E);
+  else
+    hipLaunchKernelGGL(bil_dy_multi_ang_kernel<false>, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream), a,
+                       reinterpret_cast<const float4*>(ang), expand_idx, seg_off, reinterpret_cast<float4*>(g_ang), E);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -942,8 +942,18 @@ def test_gemm_accumulates_in_place():
     assert out is run and torch.equal(run, ref)
 
 
+@pytest.fixture(params=[5, 7, 0], ids=["f16-K1+expand (default)", "f16-all", "f32-mfma"])
+def ang_arithmetic(request):
+    """gn_bil_ang_set_f16: which of the angle-form kernels run their products on the fp16 matrix pipe (split operands)."""
+    from gemnet_pytorch_amd import _lib
+    lib = _lib.load()
+    lib.gn_bil_ang_set_f16(request.param)
+    yield request.param
+    lib.gn_bil_ang_set_f16(5)
+
+
 @pytest.mark.parametrize("E,J,mk", [(60, 300, 80), (9, 40, 700), (33, 120, 3)])
-def test_tensor_basis_angle_form_kernels(E, J, mk):
+def test_tensor_basis_angle_form_kernels(E, J, mk, ang_arithmetic):
     """The *_ang kernels (Y_lm rebuilt in LDS from (sin, cos) of the two angles, 16 B per quadruplet) against the
     float64 restatements working on the explicit (Q,49) harmonics: K1 + K2 forward, the x-adjoint, and the gradient
     w.r.t. the two angles of several blocks at once; segments of 0 .. 700 quadruplets (tiles of 64 and 16)."""
@@ -960,11 +970,22 @@ def test_tensor_basis_angle_form_kernels(E, J, mk):
     close(P, P_ref, atol=2e-5 * max(1.0, float(P_ref.abs().max())))
     dx_ref = CK.bil_reduce_t(ang, D, cpu)
     close(K.bil_reduce_t(f32(ang), f32(D), dev), dx_ref, atol=2e-5 * max(1.0, float(dx_ref.abs().max())))
+    for scale in (1e-9, 3e-6, 1e5):     # a cotangent of any magnitude: the split-fp16 product scales the block per edge
+        rows = torch.logspace(0, -3, E, dtype=torch.float64)[:, None, None]       # and edges of very different size
+        close(K.bil_reduce_t(f32(ang), f32(D * scale * rows), dev), CK.bil_reduce_t(ang, D * scale * rows, cpu),
+              atol=2e-5 * scale * float(dx_ref.abs().max()), rtol=2e-4)
     Ds, xs = [rnd(g, E, S, C) for _ in range(3)], [rnd(g, J, C) for _ in range(3)]
     for nb in (1, 3):
         g_ref = CK.bil_dy_multi(Ds[:nb], xs[:nb], cpu, ang=ang)
         got = K.bil_dy_multi([f32(d) for d in Ds[:nb]], [f32(v) for v in xs[:nb]], dev, ang=f32(ang))
         close(got, g_ref, atol=3e-5 * max(1.0, float(g_ref.abs().max())))
+        # the cotangent blocks may have ANY magnitude (1e-6 on the quadruplet path of a force pass): the split-fp16 form scales
+        # them per edge by a power of two — same relative accuracy from 1e-9 to 1e5, blocks of very different size mixed
+        for scale in (1e-9, 3e-6, 1e5):
+            sc = [scale * (10.0 ** (-2 * i)) for i in range(nb)]
+            got_s = K.bil_dy_multi([f32(d * c) for d, c in zip(Ds[:nb], sc)], [f32(v) for v in xs[:nb]], dev, ang=f32(ang))
+            ref_s = CK.bil_dy_multi([d * c for d, c in zip(Ds[:nb], sc)], xs[:nb], cpu, ang=ang)
+            close(got_s, ref_s, atol=3e-5 * float(ref_s.abs().max()), rtol=0)
 
 
 @pytest.mark.parametrize("n_mol,n_atoms", [(3, 12), (2, 32)])
