@@ -112,7 +112,7 @@ SIGNATURES = {
     "gn_bil_dot_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_reduce_project_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_reduce_project2_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
-    "gn_bil_fused_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _vp],
+    "gn_bil_fused_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _vp],
     "gn_bil_project_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_project_bwd_acc_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
     "gn_bessel_rbf_f32": [_vp, _vp, _vp, _i64, _i, _f, _i, _i, _i, _vp],

@@ -556,13 +556,24 @@ __global__ __launch_bounds__(256) void bil_reduce_project_mfma7_kernel(
 // (tools/k3fused_bench.py; 32-edge tiles with 8 waves: 111 us, 16-edge tiles with 8 waves: 75 us).
 constexpr int FTE = 16, FLDP = 1024 + 4;
 
+// HP: K3 on the fp16 matrix pipe with split operands.  On the f32-input MFMA the 16 x 1024 x 64 product of a workgroup is
+// 1024 v_mfma_f32_16x16x4_f32 = 8.2 k cycles of every SIMD's matrix pipe (the f32 vector rate, chain2.hip); with P written to
+// LDS as two fp16 planes (hi, 2^11 lo: the K2 epilogue splits its 16 values per lane) and the weight given PRE-SPLIT in
+// fragment order (gn_pack_weight_split_fmt(W2T, 64, 1024, GN_SPLIT_F16X2): no conversion in the kernel) it is 384
+// v_mfma_f32_16x16x32_f16 = 1.5 k cycles.  Computed transposed (A = 16 rows of W2T, B = the P rows of the 16 edges), so a lane
+// ends with four consecutive output columns of one edge: one float4 store.
+typedef _Float16 h8_b __attribute__((ext_vector_type(8)));
+constexpr int FPH = 1024 + 8;      // fp16 elements per P-plane row (2 064 B: the 16 rows of a b128 read fall in distinct banks)
+
+template <bool HP>
 __global__ __launch_bounds__(1024) void bil_fused_fwd_mfma7_kernel(const float* __restrict__ Y, const float* __restrict__ x,
                                                      const int32_t* __restrict__ expand_idx,
                                                      const int32_t* __restrict__ seg_off, const float* __restrict__ B,
-                                                     const float* __restrict__ W2T, float* __restrict__ Sm,
+                                                     const float* __restrict__ W2T, const uint4* __restrict__ W2Tp,
+                                                     float* __restrict__ Sm,
                                                      float* __restrict__ out, int64_t E, float alpha) {
   constexpr int S = 7, C = 64, I = 16;
-  extern __shared__ __attribute__((aligned(16))) float Pl[];   // [FFTE][FFLDP] + partial tiles
+  extern __shared__ __attribute__((aligned(16))) float Pl[];   // [FFTE][FFLDP] (HP: two fp16 planes [FTE][FPH]) + partial tiles
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, lg = lane >> 4;
   const int64_t e0 = (int64_t)blockIdx.x * FTE;
@@ -623,12 +634,57 @@ __global__ __launch_bounds__(1024) void bil_fused_fwd_mfma7_kernel(const float* 
         for (int nt = 0; nt < 4; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bk[r], acc[nt][r], pacc[nt], 0, 0, 0);
     }
     // P[e][i = 4 lg + r][c = 16 nt + l15] -> K3 row, k = i * 64 + c  (zeros for the rows past E)
+    if constexpr (HP) {
+      _Float16* __restrict__ ph = reinterpret_cast<_Float16*>(Pl) + row * FPH;
+      _Float16* __restrict__ pl = ph + FTE * FPH;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) prow[(4 * lg + r) * C + 16 * nt + l15] = pacc[nt][r];
+        for (int r = 0; r < 4; ++r) {
+          const float v = pacc[nt][r];
+          const _Float16 h = (_Float16)v;
+          const int k = (4 * lg + r) * C + 16 * nt + l15;
+          ph[k] = h;
+          pl[k] = (_Float16)((v - (float)h) * 2048.f);
+        }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prow[(4 * lg + r) * C + 16 * nt + l15] = pacc[nt][r];
+    }
   }
   __syncthreads();
+  if constexpr (HP) {
+    // wave (kq, nt): output columns 16 nt .. 16 nt + 15 of all 16 edges over the k-chunks 8 kq .. 8 kq + 7
+    const int kq = wave >> 2, nt = wave & 3;
+    const _Float16* __restrict__ ph = reinterpret_cast<const _Float16*>(Pl) + l15 * FPH + 8 * lg;
+    const _Float16* __restrict__ pl = ph + FTE * FPH;
+    const uint4* __restrict__ wp = W2Tp + ((size_t)(nt * 32 + 8 * kq) * 2) * 64 + lane;     // [tile][chunk][plane][lane]
+    float* red = reinterpret_cast<float*>(reinterpret_cast<_Float16*>(Pl) + 2 * FTE * FPH);  // [3 kq][4 nt][64 lanes][4]
+    v4f_b ch = (v4f_b){0.f, 0.f, 0.f, 0.f}, cx = ch;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const h8_b ah = __builtin_bit_cast(h8_b, wp[(2 * c) * 64]);
+      const h8_b al = __builtin_bit_cast(h8_b, wp[(2 * c + 1) * 64]);
+      const h8_b bh = *reinterpret_cast<const h8_b*>(ph + 32 * (8 * kq + c));
+      const h8_b bl = *reinterpret_cast<const h8_b*>(pl + 32 * (8 * kq + c));
+      ch = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, ch, 0, 0, 0);
+      cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, cx, 0, 0, 0);
+      cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, cx, 0, 0, 0);
+    }
+    v4f_b c0 = ch + cx * (1.f / 2048.f);
+    if (kq > 0) *reinterpret_cast<v4f_b*>(red + (((kq - 1) * 4 + nt) * 64 + lane) * 4) = c0;
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+      for (int z = 0; z < 3; ++z) c0 += *reinterpret_cast<const v4f_b*>(red + ((z * 4 + nt) * 64 + lane) * 4);
+      // D^T layout: row = output column 16 nt + 4 lg + r, col = edge l15
+      const int64_t e = e0 + l15;
+      if (e < E) *reinterpret_cast<float4*>(out + e * 64 + 16 * nt + 4 * lg) = make_float4(alpha * c0[0], alpha * c0[1], alpha * c0[2], alpha * c0[3]);
+    }
+    return;
+  }
   // K3: out[16 x 64] = Pl[16 x 1024] @ W2T^T; wave (kq, nt) owns one 16 x 16 tile over a quarter of K; the quarters meet
   // in LDS.  K-step (j, comp): lane group lg supplies k = 16 j + 4 lg + comp for both operands (float4 along k).
   const int kq = wave >> 2, nt = wave & 3;
@@ -1346,20 +1402,29 @@ extern "C" int gn_bil_reduce_project2_f32(const float* Y, const float* x, const 
 }
 
 extern "C" int gn_bil_fused_fwd_f32(const float* Y, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
-                                    const float* B, const float* W2T, float* Sm, float* out, int64_t E, int S, int C,
-                                    int I, int O, float alpha, void* stream) {
+                                    const float* B, const float* W2T, const void* W2T_planes, float* Sm, float* out, int64_t E,
+                                    int S, int C, int I, int O, float alpha, void* stream) {
   if (E <= 0) return 0;
-  if (S != 7 || C != 64 || I != 16 || O != 64 || !aligned16(W2T)) return (int)hipErrorInvalidValue;
-  const size_t lds = ((size_t)FTE * FLDP + 3 * 4 * 64 * 4) * sizeof(float);
+  if (S != 7 || C != 64 || I != 16 || O != 64 || !aligned16(W2T) || !aligned16(W2T_planes)) return (int)hipErrorInvalidValue;
+  const size_t lds_f = ((size_t)FTE * FLDP + 3 * 4 * 64 * 4) * sizeof(float);
+  const size_t lds_h = (size_t)2 * FTE * FPH * 2 + (size_t)3 * 4 * 64 * 4 * sizeof(float);
+  const size_t lds = W2T_planes ? lds_h : lds_f;
   static bool configured = false;   // idempotent attribute; a benign race sets it twice
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_fwd_mfma7_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_fwd_mfma7_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_fwd_mfma7_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL(bil_fused_fwd_mfma7_kernel, dim3(gn_cdiv(E, FTE)), dim3(1024), lds, static_cast<hipStream_t>(stream), Y, x,
-                     expand_idx, seg_off, B, W2T, Sm, out, E, alpha);
+  if (W2T_planes)
+    hipLaunchKernelGGL(bil_fused_fwd_mfma7_kernel<true>, dim3(gn_cdiv(E, FTE)), dim3(1024), lds, static_cast<hipStream_t>(stream),
+                       Y, x, expand_idx, seg_off, B, W2T, static_cast<const uint4*>(W2T_planes), Sm, out, E, alpha);
+  else
+    hipLaunchKernelGGL(bil_fused_fwd_mfma7_kernel<false>, dim3(gn_cdiv(E, FTE)), dim3(1024), lds, static_cast<hipStream_t>(stream),
+                       Y, x, expand_idx, seg_off, B, W2T, nullptr, Sm, out, E, alpha);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -1002,15 +1002,22 @@ def bil_reduce_project(Y, x, B, sp, Sm_init=None, B2=None, Sm2=None, want_P=True
     return Sm, P
 
 
-def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
+USE_K3_F16 = os.environ.get("GEMNET_K3_F16", "1") == "1"
+
+
+def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0, W2T_planes=None):
     """K1+K2+K3 in one launch -> (Sm (E,S,C), out (E,O)); W2T (O, I*C) = the bilinear weight, k-contiguous.
+    W2T_planes: pack_weight_split(W2T, fmt=1) — K3 then runs on the fp16 matrix pipe with split operands.
     Spherical basis only (S, C, I, O) = (7, 64, 16, 64); see `bil_fused_fwd_supported`."""
     require_device(Y, x, B, W2T)
     Y, x, B, W2T = _f32c(Y), _f32c(x), _f32c(B), _f32c(W2T)
     S, C, I, O = Y.shape[1], x.shape[1], B.shape[2], W2T.shape[0]
     Sm = torch.empty((sp.n_reduce, S, C), device=x.device, dtype=torch.float32)
     out = torch.empty((sp.n_reduce, O), device=x.device, dtype=torch.float32)
+    if W2T_planes is not None:
+        assert getattr(W2T_planes, "_gn_fmt", None) == 1 and W2T_planes.numel() == 4 * 32 * 2 * 64 * 16
     check(_lib.load().gn_bil_fused_fwd_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B), ptr(W2T),
+                                           ptr(W2T_planes) if USE_K3_F16 else None,
                                            ptr(Sm), ptr(out), sp.n_reduce, S, C, I, O, float(alpha), stream()),
           "gn_bil_fused_fwd_f32")
     return Sm, out

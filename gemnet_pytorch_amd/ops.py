@@ -772,7 +772,8 @@ class _FusedBilinear(torch.autograd.Function):
         if ctx.ang and (C, I) != (32, 32):
             raise ValueError("the angle-form tensor basis needs emb_size_quad = emb_size_sbf = 32")
         if not keep_p and not ctx.ang and K.bil_fused_fwd_supported(sph.shape[1], C, I, O):
-            Sm, out = K.bil_fused_fwd(sph, x, rbf_W1, bilinear_weight(W, True), sp, alpha)   # K1 + K2 + K3, P stays in LDS
+            Sm, out = K.bil_fused_fwd(sph, x, rbf_W1, bilinear_weight(W, True), sp, alpha,   # K1 + K2 + K3, P stays in LDS
+                                      W2T_planes=bilinear_weight_planes(W))
             P = None
         else:
             Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)
@@ -854,6 +855,16 @@ def bilinear_weight(W, transposed_form):
     if not _frozen(W):
         return make()
     return _cached(("bilT" if transposed_form else "bil", W.data_ptr(), tuple(W.shape)), W._version, make)
+
+
+def bilinear_weight_planes(W):
+    """W2^T of a FROZEN bilinear weight as two fp16 planes in MFMA fragment order (K3 of the fused forward on the fp16 matrix
+    pipe, kernels.bil_fused_fwd); None for a trainable weight (its planes would have to be repacked every step) and off the
+    device."""
+    if not (_frozen(W) and W.is_cuda and K.USE_K3_F16):
+        return None
+    return _cached(("bilTp", W.data_ptr(), tuple(W.shape)), W._version,
+                   lambda: K.pack_weight_split(bilinear_weight(W, True), fmt=1))
 
 
 def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):

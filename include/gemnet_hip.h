@@ -364,9 +364,13 @@ int gn_bil_reduce_project2_f32(const float* Y, const float* x, const int32_t* ex
  *   Sm as above (written: the adjoint needs it);  out[e,o] = alpha * sum_{i,c} P[e,i,c] * W2T[o, i*C + c]
  * W2T = the (C,I,O) bilinear weight permuted to (O, I*C), k-contiguous, 16-byte aligned.
  * S = 7, C = 64, I = 16, O = 64 only (else hipErrorInvalidValue: use gn_bil_reduce_project_f32 + gn_gemm_f32). */
+/* W2T_planes (optional, NULL = K3 on the f32-input MFMA): the same weight as two fp16 planes in fragment order,
+ * gn_pack_weight_split_fmt(W2T, 64, 1024, 1024, 0, GN_SPLIT_F16X2, ...): K3 then runs as three v_mfma_f32_16x16x32_f16
+ * products per fp32 product (P split into hi + 2^-11 lo planes in LDS), 5 x less matrix-pipe time, same result to fp32
+ * rounding (22-bit operands: |P| < 65 504). */
 int gn_bil_fused_fwd_f32(const float* Y, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
-                         const float* B, const float* W2T, float* Sm, float* out, int64_t E, int S, int C, int I, int O,
-                         float alpha, void* stream);
+                         const float* B, const float* W2T, const void* W2T_planes, float* Sm, float* out, int64_t E, int S,
+                         int C, int I, int O, float alpha, void* stream);
 /* Fused adjoint: gB[e,s,i] = sum_c Sm[e,s,c] dP[e,i,c]; dSm[e,s,c] = sum_i B[e,s,i] dP[e,i,c];
  * dY[t,s] = sum_c dSm[r(t),s,c] x[g(t),c].  x rows 16-byte aligned, C % 4 == 0. */
 int gn_bil_project_bwd_f32(const float* dP, const float* Sm, const float* B, const float* x,

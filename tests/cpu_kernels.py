@@ -463,7 +463,7 @@ def quad_basis_bwd_packed(gY, R, qc, qa, qb, qd, S):
     return Gc, Gbd
 
 
-def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0):
+def bil_fused_fwd(Y, x, B, W2T, sp, alpha=1.0, W2T_planes=None):
     Sm, P = bil_reduce_project(Y, x, B, sp)
     return Sm, (P.reshape(P.shape[0], -1) @ W2T.t()) * alpha
 

@@ -838,6 +838,18 @@ def test_bilinear_forward_fused_with_the_final_projection(E, mk):
     close(out, rout, atol=3e-4 * max(1.0, float(rout.abs().max())))
     Sm2, P2 = K.bil_reduce_project(f32(Y), f32(x), f32(Bm), dev)
     assert torch.equal(Sm, Sm2)
+    # K3 on the fp16 matrix pipe (the weight given as two fp16 planes in fragment order, P split in LDS): the same product to
+    # fp32 rounding, Sm bit for bit; also with activations of 1e3 (P ~ 1e5 would leave fp16: 2e4 still inside)
+    planes = K.pack_weight_split(f32(W2T), fmt=1)
+    Sm3, out3 = K.bil_fused_fwd(f32(Y), f32(x), f32(Bm), f32(W2T), dev, alpha=0.6, W2T_planes=planes)
+    assert torch.equal(Sm3, Sm)
+    close(out3, rout, atol=3e-4 * max(1.0, float(rout.abs().max())))
+    err16 = float((out3.double().cpu() - rout).abs().max())
+    err32 = float((out.double().cpu() - rout).abs().max())
+    print(f"K3 f32 MFMA max err {err32:.2e}, split fp16 {err16:.2e} (|out| max {float(rout.abs().max()):.2e})")
+    assert err16 <= 4 * err32 + 1e-6 * float(rout.abs().max())
+    _, out4 = K.bil_fused_fwd(f32(Y), f32(x * 300.0), f32(Bm), f32(W2T), dev, alpha=0.6, W2T_planes=planes)
+    close(out4, rout * 300.0, atol=3e-4 * 300.0 * max(1.0, float(rout.abs().max())))
     with pytest.raises(RuntimeError):
         K.bil_fused_fwd(f32(Y), f32(x)[:, :32].contiguous(), f32(Bm), f32(W2T)[:, :512].contiguous(), dev)
 
