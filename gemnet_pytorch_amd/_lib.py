@@ -104,7 +104,7 @@ SIGNATURES = {
     "gn_angle_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_angle_jvp_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_segsum_rows_f32": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
-    "gn_bil_fused_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _i, _vp],
+    "gn_bil_fused_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _i, _vp],
     "gn_segsum_multi_f32": [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gn_bil_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_reduce_t_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],

@@ -1437,7 +1437,13 @@ extern "C" int gn_bil_fused_fwd_f32(const float* Y, const float* x, const int32_
 // W2 = the bilinear weight as (I*C, O), o contiguous.  Same products in the same order as the two-launch form: the
 // results are bit-identical (tests/test_gpu_kernels.py).
 namespace {
+// HP: phase 1 on the fp16 matrix pipe with split operands, computed transposed (A = 16 rows of the pre-split weight W2,
+// gn_pack_weight_split_fmt(W2, 1024, 64, GN_SPLIT_F16X2); B = the g rows of the 16 edges): 24 v_mfma_f32_16x16x32_f16 per wave
+// instead of 64 f32 MFMAs of twice the length.  g is a COTANGENT: every edge's row gets one exact power-of-two scale (row
+// maximum -> [0.25, 0.5)) before the split, and the lane that ends up with four consecutive k of that edge multiplies it back.
+template <bool HP>
 __global__ __launch_bounds__(1024) void bil_fused_bwd_mfma7_kernel(const float* __restrict__ g, const float* __restrict__ W2,
+                                                      const uint4* __restrict__ W2p,
                                                       const float* __restrict__ Sm, const float* __restrict__ B,
                                                       float* __restrict__ gB, float* __restrict__ dSm, int64_t E,
                                                       float alpha, int gb_acc) {
@@ -1449,7 +1455,59 @@ __global__ __launch_bounds__(1024) void bil_fused_bwd_mfma7_kernel(const float* 
   auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
   // ---- phase 1: dP tile = g tile (16 x 64) @ W2^T (64 x 1024).  Wave w owns the 64 columns k = 64 w .. 64 w + 63
   // (= i = w, all c) as four 16 x 16 tiles; K-step (j, comp): lane group lg supplies o = 16 j + 4 lg + comp.
-  {
+  if constexpr (HP) {
+    const int64_t er = min(e0 + l15, E - 1);   // rows past E: duplicates, never used
+    // B operand: g[e = l15][o = 32 c + 8 lg + i]
+    float gv[2][8];
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float* __restrict__ gr = g + er * 64 + 32 * c + 8 * lg;
+      const float4 u0 = *reinterpret_cast<const float4*>(gr), u1 = *reinterpret_cast<const float4*>(gr + 4);
+      gv[c][0] = u0.x; gv[c][1] = u0.y; gv[c][2] = u0.z; gv[c][3] = u0.w;
+      gv[c][4] = u1.x; gv[c][5] = u1.y; gv[c][6] = u1.z; gv[c][7] = u1.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(gv[c][i]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));       // the four lanes (lg) that hold the row of edge l15
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sigma = 1.f, inv_sigma = 1.f;
+    {
+      const uint32_t ex = __float_as_uint(m) >> 23;
+      const uint32_t ec = ex < 2u ? 2u : (ex > 250u ? 250u : ex);
+      if (m > 0.f) {
+        sigma = __uint_as_float((252u - ec) << 23);
+        inv_sigma = __uint_as_float((2u + ec) << 23);
+      }
+    }
+    h8_b bh[2], bl[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = gv[c][i] * sigma;
+        const _Float16 h = (_Float16)v;
+        bh[c][i] = h;
+        bl[c][i] = (_Float16)((v - (float)h) * 2048.f);
+      }
+    const float post = alpha * inv_sigma;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const uint4* __restrict__ wp = W2p + ((size_t)(4 * wave + nt) * 2 * 2) * 64 + lane;   // [k tile][chunk][plane][lane]
+      v4f_b ch = (v4f_b){0.f, 0.f, 0.f, 0.f}, cx = ch;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const h8_b ah = __builtin_bit_cast(h8_b, wp[(2 * c) * 64]);
+        const h8_b al = __builtin_bit_cast(h8_b, wp[(2 * c + 1) * 64]);
+        ch = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[c], ch, 0, 0, 0);
+        cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[c], cx, 0, 0, 0);
+        cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[c], cx, 0, 0, 0);
+      }
+      // D^T: row = k = 64 w + 16 nt + 4 lg + r, col = edge l15
+      const v4f_b d = (ch + cx * (1.f / 2048.f)) * post;
+      *reinterpret_cast<float4*>(dPl + l15 * LDP + 64 * wave + 16 * nt + 4 * lg) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+  } else {
     const int64_t er = min(e0 + l15, E - 1);   // rows past E: duplicates, never used
     float4 ga[4];
 #pragma unroll
@@ -1520,21 +1578,31 @@ __global__ __launch_bounds__(1024) void bil_fused_bwd_mfma7_kernel(const float* 
 
 }  // namespace
 
-extern "C" int gn_bil_fused_bwd_f32(const float* g, const float* W2, const float* Sm, const float* B, float* gB, float* dSm,
-                                    int64_t E, int S, int C, int I, int O, float alpha, int accumulate, void* stream) {
+extern "C" int gn_bil_fused_bwd_f32(const float* g, const float* W2, const void* W2_planes, const float* Sm, const float* B,
+                                    float* gB, float* dSm, int64_t E, int S, int C, int I, int O, float alpha, int accumulate,
+                                    void* stream) {
   if (E <= 0) return 0;
   if (S != 7 || C != 64 || I != 16 || O != 64) return (int)hipErrorInvalidValue;
   if (!aligned16(g) || !aligned16(W2) || !aligned16(Sm) || !aligned16(B)) return (int)hipErrorInvalidValue;
+  if (!aligned16(W2_planes)) return (int)hipErrorInvalidValue;
   constexpr size_t lds = (size_t)16 * (1024 + 4) * sizeof(float);
   static bool configured = false;   // idempotent attribute; a benign race sets it twice
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_bwd_mfma7_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_bwd_mfma7_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_bwd_mfma7_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL(bil_fused_bwd_mfma7_kernel, dim3((unsigned)gn_cdiv(E, 16)), dim3(1024), lds,
-                     static_cast<hipStream_t>(stream), g, W2, Sm, B, gB, dSm, E, alpha, (accumulate >> 1) & 1);
+  if (W2_planes)
+    hipLaunchKernelGGL(bil_fused_bwd_mfma7_kernel<true>, dim3((unsigned)gn_cdiv(E, 16)), dim3(1024), lds,
+                       static_cast<hipStream_t>(stream), g, W2, static_cast<const uint4*>(W2_planes), Sm, B, gB, dSm, E, alpha,
+                       (accumulate >> 1) & 1);
+  else
+    hipLaunchKernelGGL(bil_fused_bwd_mfma7_kernel<false>, dim3((unsigned)gn_cdiv(E, 16)), dim3(1024), lds,
+                       static_cast<hipStream_t>(stream), g, W2, nullptr, Sm, B, gB, dSm, E, alpha, (accumulate >> 1) & 1);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -1119,9 +1119,10 @@ def bil_fused_bwd_supported(S, C, I, O):
     return (S, C, I, O) == (7, 64, 16, 64)
 
 
-def bil_fused_bwd(g, W2, Sm, B, alpha=1.0, gB_accum=None):
+def bil_fused_bwd(g, W2, Sm, B, alpha=1.0, gB_accum=None, W2_planes=None):
     """Adjoint of the bilinear tail in one launch -> (gB (E,S,I), dSm (E,S,C)); W2 (I*C, O) = the bilinear weight
-    (gn_bil_fused_bwd_f32: dP = alpha g W2^T stays in LDS).  `gB_accum`: running gradient gB is added to (and returned)."""
+    (gn_bil_fused_bwd_f32: dP = alpha g W2^T stays in LDS).  `gB_accum`: running gradient gB is added to (and returned).
+    W2_planes: pack_weight_split(W2, fmt=1) — the first product then runs on the fp16 matrix pipe with split operands."""
     require_device(g, W2, Sm, B)
     g, W2, Sm, B = _f32c(g), _f32c(W2), _f32c(Sm), _f32c(B)
     E, S, C = Sm.shape
@@ -1131,7 +1132,10 @@ def bil_fused_bwd(g, W2, Sm, B, alpha=1.0, gB_accum=None):
         assert gB_accum.shape == (E, S, I) and gB_accum.is_contiguous() and gB_accum.dtype == torch.float32
     gB = gB_accum if gB_accum is not None else torch.empty((E, S, I), device=g.device, dtype=torch.float32)
     dSm = torch.empty((E, S, C), device=g.device, dtype=torch.float32)
-    check(_lib.load().gn_bil_fused_bwd_f32(ptr(g), ptr(W2), ptr(Sm), ptr(B), ptr(gB), ptr(dSm), E, S, C, I, O, float(alpha),
+    if W2_planes is not None:
+        assert getattr(W2_planes, "_gn_fmt", None) == 1 and W2_planes.numel() == 64 * 2 * 2 * 64 * 16
+    check(_lib.load().gn_bil_fused_bwd_f32(ptr(g), ptr(W2), ptr(W2_planes) if USE_K3_F16 else None, ptr(Sm), ptr(B), ptr(gB),
+                                           ptr(dSm), E, S, C, I, O, float(alpha),
                                            2 if gB_accum is not None else 0, stream()), "gn_bil_fused_bwd_f32")
     return gB, dSm
 

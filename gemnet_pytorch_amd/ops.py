@@ -808,7 +808,8 @@ class _FusedBilinear(torch.autograd.Function):
         elif sink is not None and need[1] and tuple(Sm.shape[1:]) in ((49, 32), (7, 64)) and sink.consumers <= 4:
             # gB and dSm now, the Y gradient of all consumers of this basis in ONE pass when the last one arrives
             if fused_tail:
-                gB, dSm = K.bil_fused_bwd(g, bilinear_weight(W, False), Sm, rbf_W1, alpha, gB_accum=prevB)
+                gB, dSm = K.bil_fused_bwd(g, bilinear_weight(W, False), Sm, rbf_W1, alpha, gB_accum=prevB,
+                                          W2_planes=bilinear_weight_planes(W, False))
             else:
                 gB, dSm, _ = K.bil_project_bwd(dP, Sm, rbf_W1, x, sp, want_dY=False, gB_accum=prevB)
             last = sink.arrive()
@@ -857,14 +858,14 @@ def bilinear_weight(W, transposed_form):
     return _cached(("bilT" if transposed_form else "bil", W.data_ptr(), tuple(W.shape)), W._version, make)
 
 
-def bilinear_weight_planes(W):
-    """W2^T of a FROZEN bilinear weight as two fp16 planes in MFMA fragment order (K3 of the fused forward on the fp16 matrix
-    pipe, kernels.bil_fused_fwd); None for a trainable weight (its planes would have to be repacked every step) and off the
-    device."""
+def bilinear_weight_planes(W, transposed_form=True):
+    """W2^T (or W2) of a FROZEN bilinear weight as two fp16 planes in MFMA fragment order (K3 of the fused forward / its
+    transpose in the fused adjoint on the fp16 matrix pipe, kernels.bil_fused_fwd / bil_fused_bwd); None for a trainable
+    weight (its planes would have to be repacked every step) and off the device."""
     if not (_frozen(W) and W.is_cuda and K.USE_K3_F16):
         return None
-    return _cached(("bilTp", W.data_ptr(), tuple(W.shape)), W._version,
-                   lambda: K.pack_weight_split(bilinear_weight(W, True), fmt=1))
+    return _cached(("bilTp" if transposed_form else "bilp", W.data_ptr(), tuple(W.shape)), W._version,
+                   lambda: K.pack_weight_split(bilinear_weight(W, transposed_form), fmt=1))
 
 
 def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):

@@ -387,9 +387,12 @@ int gn_bil_project_bwd_acc_f32(const float* dP, const float* Sm, const float* B,
  * leaves LDS):  dP[e,(i,c)] = alpha * sum_o g[e,o] W2[(i,c),o];  gB[e] = Sm[e] dP[e]^T;  dSm[e] = B[e] dP[e].
  * W2 = the bilinear weight as (I*C, O) row-major (efficient.py:159-189 differentiated).  (S, C, I, O) = (7, 64, 16, 64)
  * only (else hipErrorInvalidValue); `accumulate` bit 1: gB += (as gn_bil_project_bwd_acc_f32).  Bit-identical to
- * gn_gemm_f32 + gn_bil_project_bwd_f32(dY = NULL). */
-int gn_bil_fused_bwd_f32(const float* g, const float* W2, const float* Sm, const float* B, float* gB, float* dSm,
-                         int64_t E, int S, int C, int I, int O, float alpha, int accumulate, void* stream);
+ * gn_gemm_f32 + gn_bil_project_bwd_f32(dY = NULL) when W2_planes is NULL.  W2_planes (optional): W2 as two fp16 planes in
+ * fragment order, gn_pack_weight_split_fmt(W2, 1024, 64, 64, 0, GN_SPLIT_F16X2, ...): the first product then runs on
+ * v_mfma_f32_16x16x32_f16 with split operands (g under one exact power-of-two scale per edge row: any magnitude), same result
+ * to fp32 rounding. */
+int gn_bil_fused_bwd_f32(const float* g, const float* W2, const void* W2_planes, const float* Sm, const float* B, float* gB,
+                         float* dSm, int64_t E, int S, int C, int I, int O, float alpha, int accumulate, void* stream);
 /* gn_bil_project_bwd*_f32 accept dY == NULL (gB and dSm only).  The deferred Y gradient of up to 4 blocks that
  * share one basis tensor (S = 49, C = 32 or S = 7, C = 64; else hipErrorInvalidValue) is then produced in one pass:
  *   dY[t,s] = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c]        (dSm_list / x_list: host arrays of nb device pointers) */

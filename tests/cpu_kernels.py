@@ -418,7 +418,7 @@ def bil_fused_bwd_supported(S, C, I, O):
     return (S, C, I, O) == (7, 64, 16, 64)
 
 
-def bil_fused_bwd(g, W2, Sm, Bm, alpha=1.0, gB_accum=None):
+def bil_fused_bwd(g, W2, Sm, Bm, alpha=1.0, gB_accum=None, W2_planes=None):
     E, S, C = Sm.shape
     I = Bm.shape[2]
     dP = (alpha * (g @ W2.t())).reshape(E, I, C)

@@ -708,6 +708,21 @@ def test_bilinear_tail_adjoint_one_launch(E):
     run = base.clone()
     gB2, _ = K.bil_fused_bwd(gr, W2, Sm, Bm, 0.7, gB_accum=run)
     assert gB2 is run and torch.equal(run, base + gB0)
+    # the first product on the fp16 matrix pipe (W2 pre-split, g under one power-of-two scale per edge row): the same result to
+    # fp32 rounding for cotangents of ANY magnitude, rows of very different size mixed
+    planes = K.pack_weight_split(W2, fmt=1)
+    e32 = [float((gB1.double().cpu() - ref[0]).abs().max()), float((dSm1.double().cpu() - ref[1]).abs().max())]
+    for scale in (1.0, 1e-9, 3e-6, 1e5):
+        rows = torch.logspace(0, -4, E, dtype=torch.float64)[:, None]
+        gs = gr.double().cpu() * scale * rows
+        rs = CK.bil_fused_bwd(gs, W2.double().cpu(), Sm.double().cpu(), Bm.double().cpu(), 0.7)
+        gB3, dSm3 = K.bil_fused_bwd(f32(gs), W2, Sm, Bm, 0.7, W2_planes=planes)
+        # per edge: error relative to that edge's own magnitude (the row scale makes it independent of the others)
+        for got, want, bar in ((gB3, rs[0], e32[0]), (dSm3, rs[1], e32[1])):
+            err = (got.double().cpu() - want).abs().flatten(1).max(dim=1).values
+            mag = want.abs().flatten(1).max(dim=1).values.clamp_min(1e-300)
+            ref_mag = float(ref[0 if got is gB3 else 1].abs().max())
+            assert float((err / mag).max()) <= 4 * bar / ref_mag + 2e-6, (scale, float((err / mag).max()))
 
 
 def test_quad_basis_fused_fwd_bwd():
