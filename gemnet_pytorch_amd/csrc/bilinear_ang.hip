@@ -587,9 +587,10 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // the f32-input MFMA.  Default 5: measured on MI355X (profiles/r4_q_f16.txt) K1 -25 %, the x-adjoint rows see there, the
 // angle gradient no faster in the exact (scaled-lo) form — its time is the per-quadruplet derivative recurrences, not the MFMAs.
 static int g_ang_f16 = 5;
-extern "C" int gn_bil_ang_set_f16(int mask) {
-  g_ang_f16 = mask & 7;
-  return 0;
+extern "C" int gn_bil_ang_set_f16(int mask) {   // -> the previous mask; mask < 0: query only
+  const int prev = g_ang_f16;
+  if (mask >= 0) g_ang_f16 = mask & 7;
+  return prev;
 }
 
 extern "C" int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx,

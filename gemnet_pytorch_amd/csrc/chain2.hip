@@ -51,8 +51,10 @@ using namespace gn_split;
 // leaner variant (park / y2 registers would push the RT = 5 kernel into scratch, and a kernel with a scratch segment pays
 // ~1 us more per launch).
 // HF: the two-plane fp16 format (NPL = 2 there: both planes enter the MFMAs, three products)
+// `meta` (computed by the launcher's pass over the program): bits 0-7 index of the first GEMM op (0xff: none), bit 8 the
+// program is linear (no GEMM applies an activation) — what the prologue needs before the op table exists.
 template <int RT, int NPL, bool ADJ, bool HF>
-__global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) {
+__global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, const int meta) {
   static_assert(!HF || NPL == 2, "format H has two planes");
   constexpr int BM = 16 * RT;
   constexpr int PLANE = BM * ROWB;          // bytes of one plane
@@ -66,32 +68,46 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
   const int lg = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int M = P.M;
-  // weight pointer / shape of the GEMM ops in program order, staged in LDS once: the next op's fragments are requested
-  // at the top of every GEMM op and must not wait for a scalar load of its descriptor from the kernarg segment
+  // weight pointer / shape of the GEMM ops in program order, staged in LDS: the next op's fragments are requested at the
+  // top of every GEMM op and must not wait for a scalar load of its descriptor from the kernarg segment
   __shared__ const void* gemm_W[GN_CHAIN_MAX_OPS + 2];
   __shared__ int gemm_NK[GN_CHAIN_MAX_OPS + 2];
   // format H: row scales of the two LDS slots.  `rs` is the copy the row-linear ops (LOAD / SCALE / STORE) use, `sg` the
   // register copy in accumulator layout (rows 16 t + l15) that the GEMM epilogues use and update without LDS traffic.
+  // (Every op that writes a slot writes the scales of all its rows: no initial state.)
   __shared__ float rs[2][16 * 5];
-  __shared__ int prog_linear;
-  if (tid == 0) {
-    int g = 0, lin = 1;
-    for (int j = 0; j < P.n_ops; ++j)
-      if (P.ops[j].kind == GN_OP_GEMM) {
-        gemm_W[g] = P.ops[j].W;
-        gemm_NK[g++] = (P.ops[j].N << 16) | P.ops[j].K;
-        if (P.ops[j].act & 1) lin = 0;
-      }
-    gemm_W[g] = gemm_W[g + 1] = nullptr;
-    gemm_NK[g] = gemm_NK[g + 1] = 0;
-    prog_linear = lin;
+#ifdef GN_CHAIN_TRACE
+  if (lane == 0 && wave == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u)) gn_chain2_trace_buf[0][GN_CHAIN_MAX_OPS - 1][0] = clock64();
+#endif
+  // Prologue.  The one-thread loop over P.ops[j] that used to build the op table was a chain of 2 n_ops dependent scalar
+  // loads — cache misses — in front of the first instruction of every workgroup (6.8 k cycles at 227 workgroups,
+  // tools/chain2_trace.py), and every later op began with the scalar-cache miss of its own descriptor.  Now: one lane per
+  // op requests the GEMM fields of its descriptor with vector loads; while they are in flight every wave touches each
+  // line of the argument block through the scalar cache (kernarg_warm); the table is written without a barrier of its
+  // own (its first reader is the weight prefetch issued inside the first GEMM op, behind the barrier of the LOAD that
+  // every program starts with); the first GEMM's fragments are requested straight from its descriptor.
+  // (every wave issues the loads — a branch around them makes the compiler wait for the values at its join — wave 0 uses them)
+  const gn_chain_op* __restrict__ const t_o =
+      &((const gn_chain_args*)__builtin_amdgcn_kernarg_segment_ptr())->ops[lane < GN_CHAIN_MAX_OPS ? lane : 0];
+  int t_kind = t_o->kind, t_N = t_o->N, t_K = t_o->K;
+  unsigned long long t_W = (unsigned long long)(uintptr_t)t_o->W;
+  kernarg_warm();
+  // (the loaded values are consumed behind this statement: without it the compiler waits for them in front of the warm-up)
+  asm volatile("" : "+v"(t_kind), "+v"(t_W), "+v"(t_N), "+v"(t_K));
+  if (wave == 0) {
+    const bool is_gemm = lane < P.n_ops && t_kind == GN_OP_GEMM;
+    const unsigned long long gm = __ballot(is_gemm);
+    const int g = __popcll(gm & ((1ull << lane) - 1ull)), ng = __popcll(gm);
+    if (is_gemm) { gemm_W[g] = (const void*)(uintptr_t)t_W; gemm_NK[g] = (t_N << 16) | t_K; }
+    if (lane < 2) { gemm_W[ng + lane] = nullptr; gemm_NK[ng + lane] = 0; }
   }
-  if (HF && tid < 2 * 16 * 5) (&rs[0][0])[tid] = 1.f;
-  __syncthreads();
+#ifdef GN_CHAIN_TRACE
+  if (lane == 0 && wave == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u)) gn_chain2_trace_buf[0][GN_CHAIN_MAX_OPS - 1][1] = clock64();
+#endif
 #ifdef GN_H3_NOSCALE   // diagnosis build only (tools/chain2_trace.py): the cost of the row scales
   const bool scaled = false;
 #else
-  const bool scaled = HF && prog_linear != 0;   // uniform
+  const bool scaled = HF && (meta & 0x100) != 0;   // uniform
 #endif
   float sg[2][HF ? RT : 1];
 #pragma unroll
@@ -101,11 +117,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
 
   // weight fragments of one GEMM op: [k-chunk c][plane p] -> 8 bf16 (A operand rows = this wave's 16 weight rows)
   uint4 bcur[4][NPL];
-  auto wload_op = [&](uint4 (&dst)[4][NPL], int ord) {
+  auto wload = [&](uint4 (&dst)[4][NPL], const void* Wp, const int nk) {
     // packed layout: [col tile][k-chunk][plane (3)][lane][8 bf16]
-    const int nk = __builtin_amdgcn_readfirstlane(gemm_NK[ord]);
     const int N = nk >> 16, kc = ((nk & 0xffff) + 31) >> 5;
-    const uint4* __restrict__ base = reinterpret_cast<const uint4*>(gemm_W[ord]) + ((size_t)wave * kc * SP) * 64 + lane;
+    const uint4* __restrict__ base = reinterpret_cast<const uint4*>(Wp) + ((size_t)wave * kc * SP) * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -114,10 +129,15 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
         if (wave * 16 < N && c < kc) dst[c][p] = base[(c * SP + p) * 64];
       }
   };
+  auto wload_op = [&](uint4 (&dst)[4][NPL], int ord) { wload(dst, gemm_W[ord], __builtin_amdgcn_readfirstlane(gemm_NK[ord])); };
   // One fragment set: the NEXT GEMM's weights are requested right after the current op's MFMA phase (its fragments
   // are dead then) and land under the epilogue + barrier (96 KB per CU arrive in ~2.2 k cycles with every CU asking,
   // profiles/r2_wfetch.txt); a second set held across the MFMA phase pushed the RT = 5 kernel into scratch.
-  wload_op(bcur, 0);
+  {
+    const int fg = meta & 0xff;      // first GEMM op: fragments requested from its descriptor (scalar loads, warm cache)
+    if (fg != 0xff) wload(bcur, P.ops[fg].W, (P.ops[fg].N << 16) | P.ops[fg].K);
+    else wload(bcur, nullptr, 0);
+  }
   int gord = 0;
   // Row tiles of one or two blocks (M <= 8 k rows: the atom-side stacks, 64 workgroups) are latency-bound (4.8 k cycles
   // per op for 0.8 k of MFMA pipe time, tools/chain2_trace.py --small).  Tried for them and dropped, none moved the op
@@ -608,6 +628,13 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P) 
 
 template <int RT, int NPL, bool ADJ, bool HF>
 int launch_chain_split(const gn_chain_args* args, hipStream_t st) {
+  int first = 0xff, linear = 1;
+  for (int i = 0; i < args->n_ops; ++i)
+    if (args->ops[i].kind == GN_OP_GEMM) {
+      if (first == 0xff) first = i;
+      if (args->ops[i].act & 1) linear = 0;
+    }
+  const int meta = first | (linear << 8);
   constexpr int BM = 16 * RT;
   constexpr size_t smem = (size_t)2 * (HF ? 2 : 3) * BM * ROWB + (HF ? (size_t)8 * RT * 1024 : 0);
   static bool configured = false;   // idempotent attribute; a benign race sets it twice
@@ -619,7 +646,7 @@ int launch_chain_split(const gn_chain_args* args, hipStream_t st) {
     }
     configured = true;
   }
-  hipLaunchKernelGGL((chain_split_kernel<RT, NPL, ADJ, HF>), dim3(gn_cdiv(args->M, BM)), dim3(NT), smem, st, *args);
+  hipLaunchKernelGGL((chain_split_kernel<RT, NPL, ADJ, HF>), dim3(gn_cdiv(args->M, BM)), dim3(NT), smem, st, *args, meta);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -132,6 +132,97 @@ __device__ __forceinline__ void g2lds16(const float* gptr, uint32_t lds_base) {
                : "=&s"(keep) : "v"(gptr), "s"(base) : "memory");
 }
 
+// The op descriptors (gn_chain_op, 248 bytes = 4 cache lines each) are read from the kernel-argument segment one op at a
+// time: every op began with a scalar-cache miss (0.6 - 0.9 k cycles between the barrier of one op and the first
+// instruction of the next, tools/chain2_trace.py).  One dword of every 64-byte line of the segment (sizeof(gn_chain_args)
+// = 4968 bytes: 78 lines) is requested here, once, while the first weight fragments are in flight; the descriptors then
+// come from the scalar cache.  One statement with its own wait: the destination register is dead before and after.
+__device__ __forceinline__ void kernarg_warm() {
+  static_assert(sizeof(gn_chain_args) >= 77 * 64 + 4 && sizeof(gn_chain_args) <= 78 * 64, "one load per line of the argument block");
+  uint32_t t;
+  asm volatile(
+    "s_load_dword %0, %1, 0x0\n\t"
+    "s_load_dword %0, %1, 0x40\n\t"
+    "s_load_dword %0, %1, 0x80\n\t"
+    "s_load_dword %0, %1, 0xc0\n\t"
+    "s_load_dword %0, %1, 0x100\n\t"
+    "s_load_dword %0, %1, 0x140\n\t"
+    "s_load_dword %0, %1, 0x180\n\t"
+    "s_load_dword %0, %1, 0x1c0\n\t"
+    "s_load_dword %0, %1, 0x200\n\t"
+    "s_load_dword %0, %1, 0x240\n\t"
+    "s_load_dword %0, %1, 0x280\n\t"
+    "s_load_dword %0, %1, 0x2c0\n\t"
+    "s_load_dword %0, %1, 0x300\n\t"
+    "s_load_dword %0, %1, 0x340\n\t"
+    "s_load_dword %0, %1, 0x380\n\t"
+    "s_load_dword %0, %1, 0x3c0\n\t"
+    "s_load_dword %0, %1, 0x400\n\t"
+    "s_load_dword %0, %1, 0x440\n\t"
+    "s_load_dword %0, %1, 0x480\n\t"
+    "s_load_dword %0, %1, 0x4c0\n\t"
+    "s_load_dword %0, %1, 0x500\n\t"
+    "s_load_dword %0, %1, 0x540\n\t"
+    "s_load_dword %0, %1, 0x580\n\t"
+    "s_load_dword %0, %1, 0x5c0\n\t"
+    "s_load_dword %0, %1, 0x600\n\t"
+    "s_load_dword %0, %1, 0x640\n\t"
+    "s_load_dword %0, %1, 0x680\n\t"
+    "s_load_dword %0, %1, 0x6c0\n\t"
+    "s_load_dword %0, %1, 0x700\n\t"
+    "s_load_dword %0, %1, 0x740\n\t"
+    "s_load_dword %0, %1, 0x780\n\t"
+    "s_load_dword %0, %1, 0x7c0\n\t"
+    "s_load_dword %0, %1, 0x800\n\t"
+    "s_load_dword %0, %1, 0x840\n\t"
+    "s_load_dword %0, %1, 0x880\n\t"
+    "s_load_dword %0, %1, 0x8c0\n\t"
+    "s_load_dword %0, %1, 0x900\n\t"
+    "s_load_dword %0, %1, 0x940\n\t"
+    "s_load_dword %0, %1, 0x980\n\t"
+    "s_load_dword %0, %1, 0x9c0\n\t"
+    "s_load_dword %0, %1, 0xa00\n\t"
+    "s_load_dword %0, %1, 0xa40\n\t"
+    "s_load_dword %0, %1, 0xa80\n\t"
+    "s_load_dword %0, %1, 0xac0\n\t"
+    "s_load_dword %0, %1, 0xb00\n\t"
+    "s_load_dword %0, %1, 0xb40\n\t"
+    "s_load_dword %0, %1, 0xb80\n\t"
+    "s_load_dword %0, %1, 0xbc0\n\t"
+    "s_load_dword %0, %1, 0xc00\n\t"
+    "s_load_dword %0, %1, 0xc40\n\t"
+    "s_load_dword %0, %1, 0xc80\n\t"
+    "s_load_dword %0, %1, 0xcc0\n\t"
+    "s_load_dword %0, %1, 0xd00\n\t"
+    "s_load_dword %0, %1, 0xd40\n\t"
+    "s_load_dword %0, %1, 0xd80\n\t"
+    "s_load_dword %0, %1, 0xdc0\n\t"
+    "s_load_dword %0, %1, 0xe00\n\t"
+    "s_load_dword %0, %1, 0xe40\n\t"
+    "s_load_dword %0, %1, 0xe80\n\t"
+    "s_load_dword %0, %1, 0xec0\n\t"
+    "s_load_dword %0, %1, 0xf00\n\t"
+    "s_load_dword %0, %1, 0xf40\n\t"
+    "s_load_dword %0, %1, 0xf80\n\t"
+    "s_load_dword %0, %1, 0xfc0\n\t"
+    "s_load_dword %0, %1, 0x1000\n\t"
+    "s_load_dword %0, %1, 0x1040\n\t"
+    "s_load_dword %0, %1, 0x1080\n\t"
+    "s_load_dword %0, %1, 0x10c0\n\t"
+    "s_load_dword %0, %1, 0x1100\n\t"
+    "s_load_dword %0, %1, 0x1140\n\t"
+    "s_load_dword %0, %1, 0x1180\n\t"
+    "s_load_dword %0, %1, 0x11c0\n\t"
+    "s_load_dword %0, %1, 0x1200\n\t"
+    "s_load_dword %0, %1, 0x1240\n\t"
+    "s_load_dword %0, %1, 0x1280\n\t"
+    "s_load_dword %0, %1, 0x12c0\n\t"
+    "s_load_dword %0, %1, 0x1300\n\t"
+    "s_load_dword %0, %1, 0x1340\n\t"
+    "s_waitcnt lgkmcnt(0)"
+    : "=&s"(t) : "s"(__builtin_amdgcn_kernarg_segment_ptr()) : "memory");
+}
+
 // s = src_alpha * phis(z) * p * q  (second-order source term, include/gemnet_hip.h); z is only read when mode == 1
 __device__ __forceinline__ float4 src_term(const float4 z, const float4 p, const float4 q, const int mode, const float a) {
   float4 s = make_float4(a * p.x * q.x, a * p.y * q.y, a * p.z * q.z, a * p.w * q.w);

@@ -992,9 +992,19 @@ def bil_reduce_project(Y, x, B, sp, Sm_init=None, B2=None, Sm2=None, want_P=True
                                                      S, C, I, stream()), "gn_bil_reduce_project2_f32")
         return Sm, P
     if is_angle_form(Y, S):   # Y_lm rebuilt in-kernel from (sin, cos) of the two angles
-        check(_lib.load().gn_bil_reduce_project_ang_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
-                                                        ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
-              "gn_bil_reduce_project_ang_f32")
+        lib = _lib.load()
+        # K1 on the fp16 pipe takes x unscaled (fp16 range): only under the fp16-plane Dense arithmetic, whose overflow guard
+        # (model/gemnet.py) covers it — a model on "split6" / "f32" keeps the f32-input MFMA here
+        prev = lib.gn_bil_ang_set_f16(-1) if CHAIN_MODE != "h3" else 0
+        if prev & 1:
+            lib.gn_bil_ang_set_f16(prev & ~1)
+        try:
+            check(lib.gn_bil_reduce_project_ang_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
+                                                    ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
+                  "gn_bil_reduce_project_ang_f32")
+        finally:
+            if prev & 1:
+                lib.gn_bil_ang_set_f16(prev)
         return Sm, P
     check(_lib.load().gn_bil_reduce_project_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
                                                 ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),

@@ -772,8 +772,10 @@ class _FusedBilinear(torch.autograd.Function):
         if ctx.ang and (C, I) != (32, 32):
             raise ValueError("the angle-form tensor basis needs emb_size_quad = emb_size_sbf = 32")
         if not keep_p and not ctx.ang and K.bil_fused_fwd_supported(sph.shape[1], C, I, O):
+            # (K3 on the fp16 pipe keeps P unscaled in fp16 planes: only under the fp16-plane Dense arithmetic and its
+            # overflow guard; the adjoint scales its cotangent rows per edge and has no range limit)
             Sm, out = K.bil_fused_fwd(sph, x, rbf_W1, bilinear_weight(W, True), sp, alpha,   # K1 + K2 + K3, P stays in LDS
-                                      W2T_planes=bilinear_weight_planes(W))
+                                      W2T_planes=bilinear_weight_planes(W) if K.CHAIN_MODE == "h3" else None)
             P = None
         else:
             Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)

@@ -245,7 +245,8 @@ int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_
  * the contraction of gn_bil_dy_multi_ang_f32, bit 2 = gn_bil_expand_ang_f32 with both operands split in registers into two
  * fp16 planes, three v_mfma_f32_16x16x32_f16 products, fp32 accumulation (cotangent blocks under one exact power-of-two
  * scale per edge, lo planes scaled by 2^11 with accumulators of their own); a cleared bit = the f32-input MFMA (same results
- * to fp32 rounding). */
+ * to fp32 rounding).  K1 (bit 0) takes x as it is: fp16 range, |x| < 65 504 — the host clears the bit for models that left the
+ * fp16-plane Dense arithmetic (kernels.bil_reduce_project).  Returns the previous mask; mask < 0 only queries. */
 int gn_bil_ang_set_f16(int mask);
 /* per-quadruplet x-adjoint rows as gn_bil_expand_f32, Y given as angles */
 int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,

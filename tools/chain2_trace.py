@@ -49,6 +49,9 @@ for mode in (MODES[0] if MODES else (("split6",) if QUICK else ("split6", "bf16"
         buf = np.zeros((2, 20, 8), dtype=np.uint64)
         lib.gn_chain2_trace_read(buf.ctypes.data_as(ctypes.c_void_p))
         print(f"[{mode}] M={M} pre/act={pre}: cycles per phase [wait-W, mfma, epilogue, barrier | op total] (wave 0 / wave 7 of block 100)")
+        t = buf[0].astype(np.int64)
+        print(f"   prologue (entry -> op table staged, first barrier): {int(t[19, 1] - t[19, 0])}; entry -> first op {int(t[0, 0] - t[19, 0])}; "
+              f"entry -> end of the last op {int(t[n, 4] - t[19, 0])}")
         for b in range(2):
             t = buf[b].astype(np.int64)
             print(f"   wave{b*7} LOAD: work {int(t[0,3]-t[0,0])} barrier {int(t[0,4]-t[0,3])}")
