@@ -15,6 +15,17 @@ def _seg_offsets_sorted(sorted_idx: torch.Tensor, n_rows: int) -> torch.Tensor:
     return torch.searchsorted(sorted_idx.contiguous(), bounds).to(torch.int32)
 
 
+def _late_wait(obj):
+    """Structures that `GraphPlan.warm(late_stream=...)` builds on a stream of their own carry the event recorded behind
+    their construction: a reader on another stream waits for it first (inside a capture: one more graph edge)."""
+    ev = getattr(obj, "_late", None)
+    if ev is not None:
+        stream, event = ev
+        cur = torch.cuda.current_stream()
+        if cur != stream:
+            cur.wait_event(event)
+
+
 class RowIndex:
     """A row-index array `idx` (T,) into a matrix with `n_rows` rows.
 
@@ -35,6 +46,7 @@ class RowIndex:
 
     @property
     def csr(self):
+        _late_wait(self)
         if self._csr is None:
             if self._csr_builder is not None:
                 self._csr = self._csr_builder()
@@ -121,6 +133,7 @@ class SegmentPlan:
         """(grp_rows, grp_off, grp_kseg, rposT, max_rows) for gn_bil_reduce_t_grouped_f32, or None."""
         if getattr(self, "_row_group", None) is None:
             return None
+        _late_wait(self)
         if self._groups is None:
             key = self._row_group
             rows = torch.argsort(key, stable=True)
@@ -221,17 +234,45 @@ class GraphPlan:
             out += list(self.quad_geom.values()) + [self.q_c, self.q_a, self.q_b, self.q_d]
         return out
 
-    def warm(self):
+    def late_indices(self):
+        """The structures only adjoint kernels read (CSR of the gathers' transposes, the triplet groups of the x-adjoint):
+        the two sorts of T keys among them."""
+        return [self.id_c, self.trip.expand, self.t_c, self.t_a, self.t_b, self.z_rows]
+
+    def warm(self, late_stream=None):
         """Materialise every lazily-built CSR: before a hipGraph capture, and before a forward that forks onto a side
-        stream — a structure first built (sorted) on one stream and read by a kernel of the other is a race."""
+        stream — a structure first built (sorted) on one stream and read by a kernel of the other is a race.
+        `late_stream` (triplets-only plans): the structures of `late_indices` and the triplet groups are built there,
+        beside the forward pass that does not read them; their readers wait for `late_event` (`_late_wait`), and
+        `join_late` orders the calling stream behind the construction (a capture must end with every stream joined)."""
         if not getattr(self, "_warmed", False):
+            late = self.late_indices() if (late_stream is not None and self.triplets_only) else []
             for ri in self.row_indices():
-                ri.csr
-            self.trip.groups
+                if not any(ri is l for l in late):
+                    ri.csr
+            if late:
+                main = torch.cuda.current_stream()
+                late_stream.wait_stream(main)
+                with torch.cuda.stream(late_stream):
+                    for ri in late:
+                        ri.csr
+                    self.trip.groups
+                    ev = torch.cuda.Event()
+                    ev.record(late_stream)
+                for obj in late + [self.trip]:
+                    obj._late = (late_stream, ev)
+                self._late_event = ev
+            else:
+                self.trip.groups
             if not self.triplets_only:
                 self.quad.atom_blocks
             self._warmed = True
         return self
+
+    def join_late(self):
+        ev = getattr(self, "_late_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def to(self, *args, **kwargs):
         """Trainer.dict2device (trainer.py:313-318) calls .to(device) on every dict value."""

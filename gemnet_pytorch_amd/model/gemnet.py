@@ -42,6 +42,7 @@ _H3_GUARD = os.environ.get("GEMNET_H3_GUARD", "1") == "1"     # see GemNet.forwa
 _TRAIN_OVERLAP = os.environ.get("GEMNET_TRAIN_OVERLAP", "1") == "1"  # force training: output blocks on the side stream
 _Q_OVERLAP = os.environ.get("GEMNET_Q_OVERLAP", "1") == "1"          # quadruplet models: output blocks on the side stream
 _RBF_OUT_SIDE = os.environ.get("GEMNET_RBF_OUT_SIDE", "1") == "1"    # output-block radial projection in the forked head
+_PLAN_LATE = os.environ.get("GEMNET_PLAN_LATE", "1") == "1"          # adjoint-only index structures on a stream of their own (in captures)
 
 
 def K_chain_mode():
@@ -398,11 +399,17 @@ class GemNet(torch.nn.Module):
         R = inputs["R"]
         self._check_inputs(R)
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
+        late = None
         if R.is_cuda and self.overlap_output_blocks:
             # the output blocks run on a side stream: every lazily-built index structure they share with the main
             # stream (CSR sorts, triplet groups) must exist before the fork, not be built by whichever stream gets
-            # there first (an un-warmed GemNet-Q batch aborted with a memory fault in one of three runs)
-            plan.warm()
+            # there first (an un-warmed GemNet-Q batch aborted with a memory fault in one of three runs).
+            # A plan that is built INSIDE a capture (padded.py: rebuilt by every replay) puts the structures that only the
+            # adjoint kernels read — two sorts of T keys among them — on a stream of their own, beside the forward pass.
+            if (_PLAN_LATE and self.triplets_only and not self.direct_forces and not getattr(plan, "_warmed", False)
+                    and torch.cuda.is_current_stream_capturing()):
+                late = self._side_stream(R.device, "plan")
+            plan.warm(late_stream=late)
         if not self.direct_forces:
             # The reference flips `inputs["R"].requires_grad` on the caller's tensor (gemnet.py:494,:613).  Here the
             # force is differentiated w.r.t. a FRESH leaf that shares R's storage: autograd keeps a leaf's gradient
@@ -454,6 +461,8 @@ class GemNet(torch.nn.Module):
                     else:
                         F_j = torch.autograd.grad(E_mol, R, grad_outputs=self._cotangent(E_mol, 0),
                                                   create_graph=graph)[0]
+        if late is not None:
+            plan.join_late()
         return E_mol, F_j
 
     def _cotangent(self, E_mol, target):
@@ -472,12 +481,13 @@ class GemNet(torch.nn.Module):
             self._cot[key] = c
         return c
 
-    def _side_stream(self, device):
-        """One side stream per calling stream (several molecule shards may run this module concurrently)."""
+    def _side_stream(self, device, role="out"):
+        """One side stream per calling stream (several molecule shards may run this module concurrently) and role
+        ("out": the output blocks; "plan": the adjoint-only index structures of a plan built inside a capture)."""
         if self._side is None:
             self._side = {}
         cur = torch.cuda.current_stream(device)
-        key = (device.index, cur.cuda_stream)
+        key = (device.index, cur.cuda_stream) if role == "out" else (device.index, cur.cuda_stream, role)
         st = self._side.get(key)
         if st is None:
             st = torch.cuda.Stream(device=device)
@@ -485,8 +495,9 @@ class GemNet(torch.nn.Module):
             # can BE the calling stream (e.g. the capture stream of torch.cuda.graph).  Everything would still be correct
             # (one stream, serial), but the output blocks would then count as same-stream consumers of the gradient sinks
             # and change the summation order — graph replay and eager run would stop being bit-identical.
+            taken = {cur.cuda_stream} | {v.cuda_stream for k, v in self._side.items() if k[:2] == key[:2]}
             for _ in range(4):
-                if st.cuda_stream != cur.cuda_stream:
+                if st.cuda_stream not in taken:
                     break
                 st = torch.cuda.Stream(device=device)
             self._side[key] = st

@@ -253,6 +253,11 @@ class PaddedGraphRunner:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             cap = dict(inputs)                  # a fresh dict: the plan is built inside the capture, from the static buffers
-            self.out = self.model(cap)
+            if getattr(self, "check", False):   # happens-before check of the capture (hbcheck.py); recorder left in self.hb
+                from . import hbcheck
+                with hbcheck.record() as self.hb:
+                    self.out = self.model(cap)
+            else:
+                self.out = self.model(cap)
         self._cap_inputs = cap                  # keeps the plan's tensors (graph memory) referenced
         self.graph = g
