@@ -27,7 +27,10 @@ pmc() {  # mode, bench args...
 pmc T
 pmc train --mode train
 pmc Q --model Q
-echo "== same-box A/B (skipped in round 4)"
+echo "== padded-capacity replay loop (tools/exp/padded_ab.py) + its kernel stats"
+export PYTHONPATH=$R:$R/tests
+timeout 300 python tools/exp/padded_ab.py > $OUT/padded_ab.txt 2>&1; grep "ms" $OUT/padded_ab.txt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_padded -o trace -- python $R/tools/exp/padded_ab.py 30 > $R/$OUT/rocprof_padded.log 2>&1 )
 find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +30M -delete
 echo "== done"
