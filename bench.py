@@ -14,7 +14,8 @@ synthetic batch of 32 molecules x 32 atoms per GPU (BASELINE.json configs[1]), f
 Besides the headline, the same JSON line carries `extra` (never part of `value`):
   extra.train_step                 the full training step (with N > 1 GPUs: including the RCCL gradient all-reduce)
   extra.interaction_block_fwd_bwd  ONE InteractionBlock forward+backward, isolated: step/s and roofline fractions
-  extra.gemnet_q                   BASELINE configs[2]: GemNet-Q forward+force with its own roofline
+  extra.gemnet_q                   BASELINE configs[2]: GemNet-Q forward+force with its own roofline, and extra.gemnet_q.train_step:
+                                   its training step (eager) with the roofline of the dominant library family
   extra.dynamic_shape              a new batch every step: device index build + plan + eager forward+force, and the same
                                    loop padded to fixed capacities and replayed from ONE hipGraph (padded.py)
   extra.train_step_dynamic         the training step on a new batch every step: eager and padded-capacity hipGraph
@@ -474,7 +475,8 @@ def log_families(title, fam):
 
 
 # ------------------------------------------------------------------------------------------------ extra measurements
-def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, warmup=3, want_roofline=True, graph=True):
+def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, warmup=3, want_roofline=True, graph=True,
+                     roof_mode="train"):
     """The full training step (trainer.py:325-360): forward + force + loss + loss.backward() through the
     force + ONE flat-buffer RCCL all-reduce (world > 1) + shared-gradient rescale + global-norm clip + AdamW(amsgrad) + EMA.
     fwd/force/backward are one hipGraph; collective and optimizer launches follow it."""
@@ -512,7 +514,7 @@ def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, w
         out["allreduce_bus_gbs"] = round(2 * (world - 1) / world * nbytes / (el / reps) / 1e9, 2)
     if want_roofline:
         held, ts._graph = getattr(ts, "_graph", None), None
-        roof, fam = family_roofline(lambda: ts(inputs, targets, step_optimizer=False), mode="train")
+        roof, fam = family_roofline(lambda: ts(inputs, targets, step_optimizer=False), mode=roof_mode)
         ts._graph = held
         log_families("training step", fam)
         out["roofline"] = roof
@@ -565,7 +567,7 @@ def extra_interaction_block(model, plan, steps=50, warmup=10):
                 note="forward + backward w.r.t. (h, m, rbf3, rbf_W1, sph, rbf_h), constant weights, one hipGraph replay per step")
 
 
-def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3):
+def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
     """BASELINE.json configs[2]: GemNet-Q (quadruplet interactions on) forward+force on the same batch."""
     from gemnet_pytorch_amd.graph import GraphPlan
     from gemnet_pytorch_amd.model.gemnet import GemNet
@@ -574,7 +576,7 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3):
     torch.manual_seed(1234)
     model = GemNet(**cfg, scale_file=SCALE_FILE).to(dev).eval()
     model.requires_grad_(False)
-    inputs, _ = make_batch(cfg, n_mol, n_atoms, first=rank * n_mol, device=dev)
+    inputs, targets = make_batch(cfg, n_mol, n_atoms, first=rank * n_mol, device=dev)
     plan = GraphPlan.from_inputs(inputs, False).warm()
     sizes = dict(atoms=plan.n_atoms, edges=plan.n_edges, triplets=plan.trip.size, interaction_edges=plan.n_int,
                  intermediate_triplets=plan.n_intm, quadruplets=plan.quad.size)
@@ -585,8 +587,25 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3):
     elapsed = time_steps(graph.replay, steps, warmup)
     roof, fam = family_roofline(step, mode="Q")
     log_families("GemNet-Q forward+force", fam)
-    return dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / elapsed, 1),
-                steps=steps, warmup=warmup, per_gpu=sizes, hipgraph=True, roofline=roof)
+    out = dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / elapsed, 1),
+               steps=steps, warmup=warmup, per_gpu=sizes, hipgraph=True, roofline=roof)
+    del graph, model
+    # The GemNet-Q TRAINING step (trainer.py:325-360 on configs[2]): the Dense stacks, triplet bilinear layers, aggregation and
+    # geometry run as the fused sweeps of ops_train.py; the quadruplet bilinear layer and its tensor basis differentiate
+    # twice through the composite closure (one launch per op) — eager, no hipGraph.
+    if train:
+        try:
+            torch.cuda.empty_cache()
+            ts_out = extra_train_step(cfg, 1234, inputs, targets, 1, n_mol, steps=3, warmup=1, want_roofline=True, graph=False,
+                                      roof_mode="Qtrain")
+            ts_out["peak_memory_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)
+            ts_out["note"] = ("eager; quadruplet bilinear layer + tensor basis on the composite second-order closure, everything else "
+                              "on the fused training sweeps; roofline = dominant LIBRARY launcher family of one step")
+            out["train_step"] = ts_out
+        except Exception as ex:  # noqa: BLE001
+            out["train_step"] = dict(error=f"{type(ex).__name__}: {ex}"[:300])
+            torch.cuda.empty_cache()
+    return out
 
 
 def extra_config4_shard(rank, n_mol=64, n_atoms=64, steps=3, warmup=2):
