@@ -604,7 +604,7 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
             out["train_step"] = ts_out
         except Exception as ex:  # noqa: BLE001
             out["train_step"] = dict(error=f"{type(ex).__name__}: {ex}"[:300])
-            torch.cuda.empty_cache()
+        torch.cuda.empty_cache()      # (41 GiB of cached blocks would make the configs[4] extra skip itself)
     return out
 
 
