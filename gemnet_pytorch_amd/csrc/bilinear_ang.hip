@@ -460,32 +460,47 @@ __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_a
                                                                const int32_t* __restrict__ expand_idx,
                                                                const int32_t* __restrict__ seg_off, float4* __restrict__ g_ang,
                                                                int64_t E) {
-  constexpr int LDD = C + 4;                          // row pitch of a staged dSm block: 16-byte aligned, conflict-free
-  extern __shared__ __attribute__((aligned(16))) float dsm[];   // [nb][S][LDD] then [4 waves][16][LDY]
+  constexpr int LDD = C + 4;                          // row pitch of a staged f32 dSm block: 16-byte aligned, conflict-free
+  // F16: the blocks are staged ALREADY SPLIT — [nb][plane hi | lo][64 rows][32 halves], rows 49..63 zero — so a B fragment
+  // of a tile is two ds_read_b128 and no arithmetic: every 16-quadruplet tile of the edge (~30 of them) reuses the same
+  // nb x 49 x 32 values, and splitting them per tile (16 splits of 8 values per lane) made the VALU the bound of this form.
+  constexpr int PLB = 64 * C * 2;                     // bytes of one plane of one block: 4 KB
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // f32: [nb][S][LDD]; F16: planes; then [4 waves][16][LDY]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, lg = lane >> 4;
   const int64_t e = blockIdx.x;
   const int nb = a.nb;
-  float* __restrict__ dy = dsm + nb * S * LDD + wave * 16 * LDY;
+  unsigned char* const planes = reinterpret_cast<unsigned char*>(dsm);
+  float* __restrict__ dy = (F16 ? reinterpret_cast<float*>(planes + (size_t)nb * 2 * PLB) : dsm + nb * S * LDD) + wave * 16 * LDY;
   __shared__ float wmax[4];
-  float vmax = 0.f;
-  for (int b = 0; b < nb; ++b) {                      // stage dSm_b[e] (49 x 32): 392 float4 per block
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.dS[b] + e * (int64_t)S * C);
-    for (int i = threadIdx.x; i < S * C / 4; i += 256) {
-      const int r = i >> 3, c4i = i & 7;
-      const float4 v = src[i];
-      *reinterpret_cast<float4*>(dsm + (b * S + r) * LDD + 4 * c4i) = v;
-      if (F16) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  float sigma = 1.f, inv_sigma = 1.f;
+  if constexpr (F16) {
+    constexpr int PER = (S * C / 4 + 255) / 256;      // float4 of one block per thread: 2
+    float4 held[4][PER];
+    float vmax = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < nb) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.dS[b] + e * (int64_t)S * C);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          const int i = threadIdx.x + 256 * k;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i < S * C / 4) v = src[i];
+          held[b][k] = v;
+          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+      }
     }
-  }
-  if (F16) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     if (lane == 0) wmax[wave] = vmax;
-  }
-  __syncthreads();
-  float sigma = 1.f, inv_sigma = 1.f;
-  if (F16) {
+    // rows 49..63 of every plane: zero (15 rows x 64 bytes x 2 nb planes)
+    for (int i = threadIdx.x; i < nb * 2 * 15 * 4; i += 256) {
+      const int pl = i / 60, q = i - pl * 60;
+      *reinterpret_cast<uint4*>(planes + (size_t)pl * PLB + S * 64 + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
     const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     const uint32_t ex = __float_as_uint(m) >> 23;                      // m >= 0: biased exponent; m 2^(125 - ex) in [0.25, 0.5)
     const uint32_t ec = ex < 2u ? 2u : (ex > 250u ? 250u : ex);
@@ -493,6 +508,41 @@ __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_a
       sigma = __uint_as_float((252u - ec) << 23);
       inv_sigma = __uint_as_float((2u + ec) << 23);
     }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < nb) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          const int i = threadIdx.x + 256 * k;
+          if (i < S * C / 4) {
+            const int r = i >> 3, c4i = i & 7;
+            const float4 v = held[b][k];
+            const float vs[4] = {v.x * sigma, v.y * sigma, v.z * sigma, v.w * sigma};
+            typedef _Float16 h4_a __attribute__((ext_vector_type(4)));
+            h4_a hh, ll;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const _Float16 h = (_Float16)vs[j];
+              hh[j] = h;
+              ll[j] = (_Float16)((vs[j] - (float)h) * 2048.f);
+            }
+            unsigned char* dst = planes + (size_t)(2 * b) * PLB + r * 64 + c4i * 8;
+            *reinterpret_cast<h4_a*>(dst) = hh;
+            *reinterpret_cast<h4_a*>(dst + PLB) = ll;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  } else {
+    for (int b = 0; b < nb; ++b) {                      // stage dSm_b[e] (49 x 32): 392 float4 per block
+      const float4* __restrict__ src = reinterpret_cast<const float4*>(a.dS[b] + e * (int64_t)S * C);
+      for (int i = threadIdx.x; i < S * C / 4; i += 256) {
+        const int r = i >> 3, c4i = i & 7;
+        *reinterpret_cast<float4*>(dsm + (b * S + r) * LDD + 4 * c4i) = src[i];
+      }
+    }
+    __syncthreads();
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
@@ -518,17 +568,12 @@ __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_a
         }
         h8_a ah, al;
         split8s(xa, ah, al);
-        const float* __restrict__ db = dsm + b * S * LDD;
+        const unsigned char* __restrict__ db = planes + (size_t)(2 * b) * PLB + l15 * 64 + lg * 16;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          // B operand: sigma dSm_b[e][s = 16 nt + l15][c = 8 lg .. 8 lg + 7]; rows >= 49 contribute nothing
-          const int sr = 16 * nt + l15;
-          const float* __restrict__ row = db + min(sr, S - 1) * LDD + 8 * lg;
-          const float4 u0 = *reinterpret_cast<const float4*>(row), u1 = *reinterpret_cast<const float4*>(row + 4);
-          const float sc = sr < S ? sigma : 0.f;
-          const float bv[8] = {u0.x * sc, u0.y * sc, u0.z * sc, u0.w * sc, u1.x * sc, u1.y * sc, u1.z * sc, u1.w * sc};
-          h8_a bh, bl;
-          split8s(bv, bh, bl);
+          // B operand: the staged planes of sigma dSm_b[e][s = 16 nt + l15][c = 8 lg .. 8 lg + 7] (rows >= 49 are zero)
+          const h8_a bh = *reinterpret_cast<const h8_a*>(db + nt * 1024);
+          const h8_a bl = *reinterpret_cast<const h8_a*>(db + nt * 1024 + PLB);
           c4[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c4[nt], 0, 0, 0);
           cx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, cx[nt], 0, 0, 0);
           cx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, cx[nt], 0, 0, 0);
@@ -584,9 +629,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Matrix-pipe arithmetic of the angle-form kernels, a bit mask: 1 = K1 of gn_bil_reduce_project_ang_f32, 2 = the contraction
 // of gn_bil_dy_multi_ang_f32, 4 = gn_bil_expand_ang_f32 on v_mfma_f32_16x16x32_f16 with split fp16 operands; a cleared bit =
-// the f32-input MFMA.  Default 5: measured on MI355X (profiles/r4_q_f16.txt) K1 -25 %, the x-adjoint rows see there, the
-// angle gradient no faster in the exact (scaled-lo) form — its time is the per-quadruplet derivative recurrences, not the MFMAs.
-static int g_ang_f16 = 5;
+// the f32-input MFMA.  Default 7: measured on MI355X (profiles/r4_q_f16.txt) K1 -25 %, the x-adjoint -6 %, the angle gradient
+// -29 % once the edge's dSm blocks are staged ALREADY SPLIT (split per tile it was VALU-bound and no faster than the f32 MFMA).
+static int g_ang_f16 = 7;
 extern "C" int gn_bil_ang_set_f16(int mask) {   // -> the previous mask; mask < 0: query only
   const int prev = g_ang_f16;
   if (mask >= 0) g_ang_f16 = mask & 7;
@@ -658,8 +703,9 @@ extern "C" int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float
     if (b < nb && (!aligned16(a.dS[b]) || !aligned16(a.x[b]))) return (int)hipErrorInvalidValue;
   }
   const size_t smem = ((size_t)nb * S * (C + 4) + 4 * 16 * LDY) * sizeof(float);   // 42 KB at nb = 4
+  const size_t smem16 = (size_t)nb * 2 * 64 * C * 2 + (size_t)4 * 16 * LDY * sizeof(float);   // split planes: 46 KB at nb = 4
   if (g_ang_f16 & 2)
-    hipLaunchKernelGGL(bil_dy_multi_ang_kernel<true>, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream), a,
+    hipLaunchKernelGGL(bil_dy_multi_ang_kernel<true>, dim3((unsigned)E), dim3(256), smem16, static_cast<hipStream_t>(stream), a,
                        reinterpret_cast<const float4*>(ang), expand_idx, seg_off, reinterpret_cast<float4*>(g_ang), E);
   else
     hipLaunchKernelGGL(bil_dy_multi_ang_kernel<false>, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream), a,

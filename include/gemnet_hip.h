@@ -241,7 +241,7 @@ int gn_quad_angles_bwd_ld_f32(const float* g_ang, const float* R, const int32_t*
 /* K1 + K2 of the bilinear layer as gn_bil_reduce_project_f32, Y given as angles */
 int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
                                   const float* B, float* Sm, float* P, int64_t E, int S, int C, int I, void* stream);
-/* Matrix-pipe arithmetic of the angle-form kernels, bit mask (default 5): bit 0 = K1 of gn_bil_reduce_project_ang_f32, bit 1 =
+/* Matrix-pipe arithmetic of the angle-form kernels, bit mask (default 7): bit 0 = K1 of gn_bil_reduce_project_ang_f32, bit 1 =
  * the contraction of gn_bil_dy_multi_ang_f32, bit 2 = gn_bil_expand_ang_f32 with both operands split in registers into two
  * fp16 planes, three v_mfma_f32_16x16x32_f16 products, fp32 accumulation (cotangent blocks under one exact power-of-two
  * scale per edge, lo planes scaled by 2^11 with accumulators of their own); a cleared bit = the f32-input MFMA (same results

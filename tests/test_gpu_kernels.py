@@ -969,14 +969,14 @@ def test_gemm_accumulates_in_place():
     assert out is run and torch.equal(run, ref)
 
 
-@pytest.fixture(params=[5, 7, 0], ids=["f16-K1+expand (default)", "f16-all", "f32-mfma"])
+@pytest.fixture(params=[7, 5, 0], ids=["f16-all (default)", "f16-K1+expand", "f32-mfma"])
 def ang_arithmetic(request):
     """gn_bil_ang_set_f16: which of the angle-form kernels run their products on the fp16 matrix pipe (split operands)."""
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
     lib.gn_bil_ang_set_f16(request.param)
     yield request.param
-    lib.gn_bil_ang_set_f16(5)
+    lib.gn_bil_ang_set_f16(7)
 
 
 @pytest.mark.parametrize("E,J,mk", [(60, 300, 80), (9, 40, 700), (33, 120, 3)])
