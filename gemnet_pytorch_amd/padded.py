@@ -97,7 +97,7 @@ class PaddedGraphRunner:
     A batch that does not fit raises `ValueError` — size the capacities from the first batches with a margin
     (`suggest_capacities`)."""
 
-    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, a_cap=None):
+    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, a_cap=None, index_dtype=torch.int32):
         if not model.triplets_only:
             raise NotImplementedError("padded replay: triplets-only models (forces by autograd or by the direct-force head)")
         self.model = model
@@ -129,13 +129,19 @@ class PaddedGraphRunner:
         self._R_fill = torch.stack([-1.0e3 - 10.0 * fill, torch.full_like(fill, -1.0e3), torch.full_like(fill, -1.0e3)], dim=1)
         self.inputs["R"][:self.a_cap] = self._R_fill
         self.inputs["R"][self.a_cap:] = dummy_positions(self.G, self.inputs["R"])
+        # The edge / triplet arrays live in `index_dtype` (int32: what the kernels read — the plan built inside the replayed
+        # graph then has no conversion launches, and the device index builder hands its int32 arrays over as they are;
+        # batches given as int64 are converted by the copy into the buffers).  Values stay far below 2^31 (checked).
+        if max(self.e_cap, self.t_cap, self.A_tot) >= 2 ** 31:
+            index_dtype = i64
+        self.index_dtype = index_dtype
         for k in PAD_EDGE_KEYS:
-            self.inputs[k] = torch.zeros(self.e_cap, dtype=i64, device=dev)
+            self.inputs[k] = torch.zeros(self.e_cap, dtype=index_dtype, device=dev)
         for k in PAD_TRIP_KEYS:
-            self.inputs[k] = torch.zeros(self.t_cap, dtype=i64, device=dev)
+            self.inputs[k] = torch.zeros(self.t_cap, dtype=index_dtype, device=dev)
         k = torch.arange(self.e_cap, device=dev, dtype=i64)
-        self._pat_src, self._pat_dst = _pad_edges(k, self.a_cap, self.G)
-        self._pat_swap, self._pat_pair = k ^ 1, k // 2
+        self._pat_src, self._pat_dst = (t.to(index_dtype) for t in _pad_edges(k, self.a_cap, self.G))
+        self._pat_swap, self._pat_pair = (k ^ 1).to(index_dtype), (k // 2).to(index_dtype)
         self._arange_t = torch.arange(self.t_cap, device=dev, dtype=i64)
         self.graph = None
         self.out = None
@@ -234,7 +240,7 @@ class PaddedGraphRunner:
         if not positions_ready:
             bs.wait_stream(main)
         with torch.cuda.stream(bs):
-            idx = builder(R)
+            idx = builder(R, dtype=self.index_dtype)
         main.wait_stream(bs)
         for t in idx.values():
             t.record_stream(main)

@@ -103,7 +103,7 @@ class DynamicForceField:
             self._bstream = torch.cuda.Stream(device=R.device)
         self._bstream.wait_stream(main)          # the new positions come from work on the calling stream (the integrator)
         with torch.cuda.stream(self._bstream):
-            idx = self.builder(R)
+            idx = self.builder(R, dtype=torch.int32)     # as built: the padded runner keeps its index buffers in int32
         main.wait_stream(self._bstream)
         for t in idx.values():
             t.record_stream(main)
