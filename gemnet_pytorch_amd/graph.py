@@ -22,7 +22,8 @@ def _late_wait(obj):
     if ev is not None:
         stream, event = ev
         cur = torch.cuda.current_stream()
-        if cur != stream:
+        # (the event belongs to the capture that built the plan; outside of it there is nothing to order against)
+        if cur != stream and torch.cuda.is_current_stream_capturing():
             cur.wait_event(event)
 
 
