@@ -379,8 +379,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, 
           if (grow < M) g2lds16(mul_g + (uint32_t)grow * (uint32_t)N + (uint32_t)n0, stage_lds + t * 1024);
         }
       }
-      // hh | the cross terms hm + mh + hl + lh + mm (summed among themselves first)
-      constexpr int NACC = 2;
+      // hh | the cross terms hm + mh + hl + lh + mm (summed among themselves first).  Format H: hl and lh in registers of their
+      // own — issued back to back into ONE accumulator the second waits for the first (the matrix pipe alone took 2.65 k
+      // cycles per op for 1.92 k of issue time, profiles/r4_chain_mfma_phase.txt)
+      constexpr int NACC = HF ? 3 : 2;
       v4f acc[NACC][RT];
 #pragma unroll
       for (int t = 0; t < RT; ++t)
@@ -439,9 +441,9 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, 
               if constexpr (HF) {
                 const f16x8 ah = __builtin_bit_cast(f16x8, bcur[c][0]), al = __builtin_bit_cast(f16x8, bcur[c][NPL >= 2 ? 1 : 0]);
                 const f16x8 yh = __builtin_bit_cast(f16x8, xf[cur][0]), yl = __builtin_bit_cast(f16x8, xf[cur][1]);
-                GN2_ACC(0) = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh, GN2_ACC(0), 0, 0, 0);
-                GN2_ACC(1) = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, GN2_ACC(1), 0, 0, 0);
-                GN2_ACC(2) = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, GN2_ACC(2), 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, acc[1][t], 0, 0, 0);
+                acc[HF ? 2 : 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, acc[HF ? 2 : 1][t], 0, 0, 0);
                 continue;
               }
               const bf16x8 xh = __builtin_bit_cast(bf16x8, xf[cur][0]);
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, 
       float4 v[RT];            // the three partial sums collapse here: their registers are free for the prefetch below
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        const v4f s = HF ? acc[0][t] + acc[1][t] * H_DOWN : (NPL >= 2 ? acc[0][t] + acc[1][t] : acc[0][t]);
+        const v4f s = HF ? acc[0][t] + (acc[1][t] + acc[HF ? 2 : 1][t]) * H_DOWN : (NPL >= 2 ? acc[0][t] + acc[1][t] : acc[0][t]);
         v[t] = make_float4(s[0], s[1], s[2], s[3]);
       }
       // format H: the products are sigma_a times the true values; what this op leaves in LDS takes the smallest scale

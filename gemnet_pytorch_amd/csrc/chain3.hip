@@ -295,12 +295,13 @@ __global__ __launch_bounds__(NT3, 2) void chain_wide_kernel(const gn_chain_args 
           }
         }
       }
-      // per column tile: hh | the correction terms hl + lh
-      v4f acc[CT][2][RT];
+      // per column tile: hh | hl | lh (the two correction terms in registers of their own, as in chain2.hip: no back-to-back
+      // dependent MFMAs, and the same summation order — the layouts stay bit-identical)
+      v4f acc[CT][3][RT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[ct][0][t] = acc[ct][1][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < RT; ++t) acc[ct][0][t] = acc[ct][1][t] = acc[ct][2][t] = (v4f){0.f, 0.f, 0.f, 0.f};
       if (act0) {
         const unsigned char* xb = smem + a_slot * SLOT + l15 * ROWB;
         const int kc = (K + 31) >> 5;
@@ -331,13 +332,13 @@ __global__ __launch_bounds__(NT3, 2) void chain_wide_kernel(const gn_chain_args 
                 const f16x8 ah = __builtin_bit_cast(f16x8, bcur[0][c][0]), al = __builtin_bit_cast(f16x8, bcur[0][c][1]);
                 acc[0][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh, acc[0][0][t], 0, 0, 0);
                 acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, acc[0][1][t], 0, 0, 0);
-                acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, acc[0][1][t], 0, 0, 0);
+                acc[0][2][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, acc[0][2][t], 0, 0, 0);
               }
               if (act1) {
                 const f16x8 ah = __builtin_bit_cast(f16x8, bcur[1][c][0]), al = __builtin_bit_cast(f16x8, bcur[1][c][1]);
                 acc[1][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yh, acc[1][0][t], 0, 0, 0);
                 acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, yl, acc[1][1][t], 0, 0, 0);
-                acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, acc[1][1][t], 0, 0, 0);
+                acc[1][2][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, yh, acc[1][2][t], 0, 0, 0);
               }
             }
           }
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(NT3, 2) void chain_wide_kernel(const gn_chain_args 
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-          const v4f s = acc[ct][0][t] + acc[ct][1][t] * H_DOWN;
+          const v4f s = acc[ct][0][t] + (acc[ct][1][t] + acc[ct][2][t]) * H_DOWN;
           v[ct][t] = make_float4(s[0], s[1], s[2], s[3]);
         }
       // the products are sigma_a times the true values; what this op leaves in LDS takes the smallest scale among its LDS operands
