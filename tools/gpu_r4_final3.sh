@@ -1,0 +1,4 @@
+#!/bin/bash
+TAG=r4final3; OUT=gpurun_out/$TAG; mkdir -p $OUT
+timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log; cut -c1-200 $OUT/bench_default.json
+timeout 600 python bench.py --mode train --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_T_train.json 2> $OUT/bench_T_train.log; cut -c1-200 $OUT/bench_T_train.json
