@@ -34,16 +34,7 @@ import os
 import sys
 import time
 
-# Hardware queues a replayed hipGraph may use (a switch of the HIP runtime, read when it initialises: before `import torch`).
-# The captured steps have two long branches (main chain | output blocks); on the runtime's default (up to four queues) the
-# branches change queues at forks and pay a cross-queue barrier each time.  Same box, profiles/r4_graph_queues.txt: forward+force
-# 13 678 -> 13 888 molecules/s, training step 10.04 -> 9.87 ms, GemNet-Q unchanged; replays stay bit-identical to the eager run and
-# pass the happens-before checker.  `GEMNET_BENCH_GRAPH_QUEUES=0` (or the variable set by the caller) leaves the runtime's default.
-_GQ = os.environ.get("GEMNET_BENCH_GRAPH_QUEUES", "2")
-if _GQ not in ("", "0"):
-    os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", _GQ)
-
-import torch  # noqa: E402
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -982,7 +973,7 @@ def main():
             "config": {"workload": f"GemNet-{args.model} full (4 blocks, emb 128), batch {args.batch} molecules x "
                                    f"{args.atoms} atoms per GPU, forward+force, fp32 (BASELINE.json configs[{1 if args.model == 'T' else 2}])",
                        "mode": args.mode, "hipgraph": bool(graph), "per_gpu": sizes,
-                       "runtime_env": {"DEBUG_HIP_FORCE_GRAPH_QUEUES": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES")},
+                       "runtime_env": {k: os.environ[k] for k in ("DEBUG_HIP_FORCE_GRAPH_QUEUES",) if k in os.environ},
                        "dense_stack_arithmetic": {"f32": "v_mfma_f32_16x16x4_f32",
                                                   "split6": "fp32 operands as 3 bf16 planes, 6 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (fp32-equivalent: dropped terms < 2^-24)",
                                                   "h3": "fp32 operands as 2 fp16 planes (hi + 2^-11 lo, 22 significand bits), 3 products on v_mfma_f32_16x16x32_f16, fp32 accumulate (operand rounding 2^-22: force MAE 1e-6 eV/A against float64)",
