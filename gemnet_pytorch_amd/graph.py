@@ -240,53 +240,35 @@ class GraphPlan:
         the two sorts of T keys among them."""
         return [self.id_c, self.trip.expand, self.t_c, self.t_a, self.t_b, self.z_rows]
 
-    def warm(self, defer_late=False):
+    def warm(self, late_stream=None):
         """Materialise every lazily-built CSR: before a hipGraph capture, and before a forward that forks onto a side
         stream — a structure first built (sorted) on one stream and read by a kernel of the other is a race.
-        `defer_late` (triplets-only plans): the structures of `late_indices` and the triplet groups are left for
-        `warm_late(stream)`, which builds them beside the forward pass that does not read them; their readers wait for its
-        event (`_late_wait`), and `join_late` orders the calling stream behind the construction (a capture must end with
-        every stream joined)."""
+        `late_stream` (triplets-only plans): the structures of `late_indices` and the triplet groups are built there,
+        beside the forward pass that does not read them; their readers wait for `late_event` (`_late_wait`), and
+        `join_late` orders the calling stream behind the construction (a capture must end with every stream joined)."""
         if not getattr(self, "_warmed", False):
-            late = self.late_indices() if (defer_late and self.triplets_only) else []
+            late = self.late_indices() if (late_stream is not None and self.triplets_only) else []
             for ri in self.row_indices():
                 if not any(ri is l for l in late):
                     ri.csr
             if late:
-                self._late_pending = late
+                main = torch.cuda.current_stream()
+                late_stream.wait_stream(main)
+                with torch.cuda.stream(late_stream):
+                    for ri in late:
+                        ri.csr
+                    self.trip.groups
+                    ev = torch.cuda.Event()
+                    ev.record(late_stream)
+                for obj in late + [self.trip]:
+                    obj._late = (late_stream, ev)
+                self._late_event = ev
             else:
                 self.trip.groups
             if not self.triplets_only:
                 self.quad.atom_blocks
             self._warmed = True
         return self
-
-    @property
-    def late_pending(self):
-        return getattr(self, "_late_pending", None) is not None
-
-    def warm_late(self, stream):
-        """Build the deferred structures on `stream` (ordered behind what the calling stream has issued so far)."""
-        late = getattr(self, "_late_pending", None)
-        if late is None:
-            return
-        self._late_pending = None
-        main = torch.cuda.current_stream()
-        if stream is None or stream == main:
-            for ri in late:
-                ri.csr
-            self.trip.groups
-            return
-        stream.wait_stream(main)
-        with torch.cuda.stream(stream):
-            for ri in late:
-                ri.csr
-            self.trip.groups
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        for obj in late + [self.trip]:
-            obj._late = (stream, ev)
-        self._late_event = ev
 
     def join_late(self):
         ev = getattr(self, "_late_event", None)

@@ -287,10 +287,6 @@ class GemNet(torch.nn.Module):
             # the tensor basis shares cutoff and radial tables with cbf_basis3: reuse rad3
             sbf4 = (rad3, ops.ylm(Phi_cab, Theta_cabd, self.num_spherical))  # ((E,S,R), (Q,S^2))
 
-        if plan.late_pending:
-            # the index structures only adjoint kernels read (plan built inside a capture): on the output blocks' stream,
-            # behind the forked head — that stream idles until the first interaction block is done (no side stream: in line)
-            plan.warm_late(side)
         if h is None:
             h = self.atom_emb(plan.z_rows)
         rbf = ops.accumulate_gradient(rbf)
@@ -412,8 +408,8 @@ class GemNet(torch.nn.Module):
             # adjoint kernels read — two sorts of T keys among them — on a stream of their own, beside the forward pass.
             if (_PLAN_LATE and self.triplets_only and not self.direct_forces and not getattr(plan, "_warmed", False)
                     and torch.cuda.is_current_stream_capturing()):
-                late = True      # built on the output blocks' stream, behind the forked head of the forward (`_energy`)
-            plan.warm(defer_late=bool(late))
+                late = self._side_stream(R.device, "plan")
+            plan.warm(late_stream=late)
         if not self.direct_forces:
             # The reference flips `inputs["R"].requires_grad` on the caller's tensor (gemnet.py:494,:613).  Here the
             # force is differentiated w.r.t. a FRESH leaf that shares R's storage: autograd keeps a leaf's gradient
@@ -465,7 +461,7 @@ class GemNet(torch.nn.Module):
                     else:
                         F_j = torch.autograd.grad(E_mol, R, grad_outputs=self._cotangent(E_mol, 0),
                                                   create_graph=graph)[0]
-        if late:
+        if late is not None:
             plan.join_late()
         return E_mol, F_j
 
