@@ -435,7 +435,6 @@ def capture(step, warm=2):
 
 def time_steps(run, steps, warmup, world=1):
     """`warmup` untimed + exactly `steps` timed calls between barrier + synchronize on both sides; max over ranks."""
-    import gc
     import torch.distributed as dist
     for _ in range(warmup):
         run()
@@ -443,24 +442,14 @@ def time_steps(run, steps, warmup, world=1):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # no cyclic-GC pass inside the timed region (as `timeit` does): this process holds several models and captured graphs,
-    # and a generation-2 collection in the middle of a host-driven loop (index build + padding + replay per step) is
-    # milliseconds that belong to the harness, not to the step
-    gc_was_on = gc.isenabled()
-    gc.collect()
-    gc.disable()
-    try:
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            run()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    finally:
-        if gc_was_on:
-            gc.enable()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
