@@ -172,3 +172,31 @@ def test_multi_target_models_train_on_the_composite_closure(golden_model2):
         grads[train2] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     for n in grads[False]:
         torch.testing.assert_close(grads[True][n], grads[False][n], rtol=1e-10, atol=1e-12)
+
+
+def test_eager_training_steps_do_not_accumulate_sweep_records(golden_model2):
+    """The records shared by the four sweeps hold cotangents whose autograd history leads back — through C++ edges the cyclic
+    garbage collector cannot follow — to the node that owns the record.  Unless the final sweep drops them, every eager
+    training step stays alive for good (activations included): the count of live records must not grow from step to step."""
+    import gc
+    from gemnet_pytorch_amd import ops_train
+    g, tag = golden_model2, "t2s"
+    cfg, params, inputs = load_case(g, tag)
+    with cpu_kernels.emulate():
+        model = build(cfg, params).train()
+        inputs["R"] = inputs["R"].double()
+        Et, Ft = torch.tensor(g[f"{tag}.Et"]).double()[:, None], torch.tensor(g[f"{tag}.Ft"]).double()
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            E, F = model(inputs)
+            GO.training_loss(E[:, :1], F, Et, Ft).backward()
+
+        counts = []
+        for _ in range(5):
+            step()
+            gc.collect()
+            gc.collect()      # (a collected node releases its C++ graph, whose Python side is garbage of the next pass)
+            counts.append(sum(isinstance(o, ops_train._Rec) for o in gc.get_objects()))
+    print("live sweep records after each of five steps:", counts)
+    assert counts[4] <= counts[0] <= 24, counts     # (without the release in the final sweep: 24, 48, 72, 96, 120)
