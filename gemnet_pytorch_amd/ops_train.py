@@ -170,7 +170,9 @@ class _Stack2(torch.autograd.Function):
             Wt = Ws[wi]; wi += 1
             t = _new(M, Wt.shape[0], x)
             _gemm(prog, cache=rec.cache, W=Wt, a_slot=cur, y_slot=-1, out=t)
-            a_in[("t", j)] = y_prev
+            # (an alias, not the returned object: that one gets this node as its grad_fn, and record -> output -> node ->
+            #  record would keep the step's tensors until the cyclic collector's next pass — ~1 GiB per eager step at B = 32)
+            a_in[("t", j)] = y_prev.detach()
             tails.append(t)
         K.chain(prog)
         rec.s1 = dict(z=z, a_in=a_in)

@@ -174,13 +174,16 @@ def test_multi_target_models_train_on_the_composite_closure(golden_model2):
         torch.testing.assert_close(grads[True][n], grads[False][n], rtol=1e-10, atol=1e-12)
 
 
-def test_eager_training_steps_do_not_accumulate_sweep_records(golden_model2):
+@pytest.mark.parametrize("tag", ["t2s", "q2s"])
+def test_eager_training_steps_free_their_records_without_the_cyclic_collector(golden_model2, tag):
     """The records shared by the four sweeps hold cotangents whose autograd history leads back — through C++ edges the cyclic
-    garbage collector cannot follow — to the node that owns the record.  Unless the final sweep drops them, every eager
-    training step stays alive for good (activations included): the count of live records must not grow from step to step."""
+    garbage collector cannot follow — to the node that owns the record; and a stack with tail projections used to record
+    its own output.  Unless the final sweep drops the former and the record holds an alias of the latter, an eager training
+    step's tensors stay alive for good (without the release: 24, 48, 72, ... live records) or until the collector's next
+    pass (~1 GiB per step at B = 32).  With the collector OFF, nothing of a step may survive it."""
     import gc
     from gemnet_pytorch_amd import ops_train
-    g, tag = golden_model2, "t2s"
+    g = golden_model2
     cfg, params, inputs = load_case(g, tag)
     with cpu_kernels.emulate():
         model = build(cfg, params).train()
@@ -192,11 +195,18 @@ def test_eager_training_steps_do_not_accumulate_sweep_records(golden_model2):
             E, F = model(inputs)
             GO.training_loss(E[:, :1], F, Et, Ft).backward()
 
-        counts = []
-        for _ in range(5):
-            step()
-            gc.collect()
-            gc.collect()      # (a collected node releases its C++ graph, whose Python side is garbage of the next pass)
-            counts.append(sum(isinstance(o, ops_train._Rec) for o in gc.get_objects()))
-    print("live sweep records after each of five steps:", counts)
-    assert counts[4] <= counts[0] <= 24, counts     # (without the release in the final sweep: 24, 48, 72, 96, 120)
+        step()
+        gc.collect()
+        gc.collect()
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            for _ in range(3):
+                step()
+            live = sum(isinstance(o, ops_train._Rec) for o in gc.get_objects())
+            garbage = gc.collect()
+        finally:
+            if was_on:
+                gc.enable()
+    assert live == 0, live
+    assert garbage == 0, garbage
