@@ -274,7 +274,7 @@ def _stack_adjoint_(rec, spec, has, want, shapes, g, g_tails, Ws, second, store,
     for j, gt in enumerate(g_tails):
         if gt is not None:
             gt = gt.contiguous()
-            stored[("t", j)] = gt                      # dL/d(tail j) is the pre-activation adjoint of that GEMM
+            stored[("t", j)] = gt.detach()             # dL/d(tail j) is the pre-activation adjoint of that GEMM (values only)
             prog.load(oth, gt)
             _gemm(prog, cache=rec.cache, W=Wof[("t", j)], trans=True, a_slot=oth, y_slot=cur, res=cur, beta=1.0)
     g_skips = [None] * len(layers)
@@ -358,6 +358,11 @@ class _Stack2B(torch.autograd.Function):
         nT = len(spec["tails"])
         g_tails, prev, Ws = rest[:nT], rest[nT + 1], rest[nT + 2:]
         out, st = _stack_adjoint(rec, spec, has, want, shapes, g, g_tails, Ws, second=None, store="mu", prev=prev)
+        # the record keeps ALIASES of stored adjoints that are also returned (a returned tensor gets this node as its grad_fn:
+        # record -> tensor -> node -> record would never be freed when the outer backward does not run)
+        returned = {id(t) for t in out if t is not None}
+        st = {name: {k: (v.detach() if (v is not None and id(v) in returned) else v) for k, v in d.items()}
+              for name, d in st.items()}
         rec.s2 = st
         rec.s3 = None
         ctx.rec, ctx.spec, ctx.has, ctx.shapes, ctx.nT = rec, spec, has, shapes, nT
@@ -614,7 +619,7 @@ class _Head2B(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rec, cfg, g, tok, px, pr, Wa, Wr, Wd):
         out, st = _head_adjoint(rec, cfg, g, (Wa, Wr, Wd), second=None, store="mu", prev=(px, pr))
-        st["g"] = g.contiguous()
+        st["g"] = g.detach().contiguous()     # (values only: with its history the record would own a path back to this node)
         rec.s2, rec.s3 = st, None
         ctx.rec, ctx.cfg = rec, cfg
         ctx.set_materialize_grads(False)
@@ -746,7 +751,7 @@ class _Aggregate2B(torch.autograd.Function):
         acc_r = pr.clone() if pr is not None else None
         g_m, g_rbf = K.rbf_aggregate_bwd(g, s1["m"], s1["rbf"], W.detach().contiguous(), ri.idx32, scale,
                                          want_m=want[0], want_rbf=want[1], acc_m=acc_m, acc_rbf=acc_r)
-        rec.s2, rec.s3 = dict(g=g), None
+        rec.s2, rec.s3 = dict(g=g.detach()), None     # (values only, see _releases_record)
         ctx.rec, ctx.ri, ctx.scale = rec, ri, scale
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(W)
@@ -861,7 +866,7 @@ class _Bilinear2B(torch.autograd.Function):
         mu_P = K.gemm(g, s1["W2"], alpha=alpha).reshape(-1, I, C)
         gB, mu_Sm, gY = K.bil_project_bwd(mu_P, s1["Sm"], s1["B"], s1["x"], sp, want_dY=want[1])
         gx = K.bil_reduce_t(s1["Y"], mu_Sm, sp) if want[2] else None
-        rec.s2, rec.s3 = dict(g=g, mu_P=mu_P, mu_Sm=mu_Sm), None
+        rec.s2, rec.s3 = dict(g=g.detach(), mu_P=mu_P, mu_Sm=mu_Sm), None     # (values only, see _releases_record)
         ctx.rec, ctx.sp, ctx.alpha, ctx.dims = rec, sp, alpha, dims
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(W)

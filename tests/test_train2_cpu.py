@@ -210,3 +210,12 @@ def test_eager_training_steps_free_their_records_without_the_cyclic_collector(go
                 gc.enable()
     assert live == 0, live
     assert garbage == 0, garbage
+    # ... and a train-mode forward whose outputs are dropped WITHOUT a backward (the final sweep never runs) frees them too:
+    # the records keep values, not autograd history (cotangents and returned adjoints are stored as detached aliases)
+    with cpu_kernels.emulate():
+        for _ in range(2):
+            E, F = model(inputs)
+            del E, F
+        gc.collect()
+        gc.collect()
+        assert sum(isinstance(o, ops_train._Rec) for o in gc.get_objects()) == 0
