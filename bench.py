@@ -217,7 +217,7 @@ class LaunchTimer:
                     self.depth -= 1
                 fl, by = self.cost(_name, args, kwargs, out)
                 if _name == "chain":   # the replay runs outside the sweep's arithmetic context (ops_train._sweep_mode)
-                    kwargs = dict(kwargs, mode=kwargs.get("mode") or self.K.CHAIN_MODE)
+                    kwargs = dict(kwargs, mode=kwargs.get("mode") or self.K.DEFAULT_CHAIN_MODE)
                 self.records.append((_name, _fn, args, kwargs, fl, by))
                 return out
 
@@ -337,12 +337,12 @@ def roofline_from(fam, mode="T"):
                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common)
         if bound == "mfma":
             out["mfma_busy_pct"] = mfma_busy(name, mode)
-        if name == "chain" and K.CHAIN_MODE != "f32":
+        if name == "chain" and K.DEFAULT_CHAIN_MODE != "f32":
             # the Dense stacks execute on the bf16 pipe: fraction of THAT pipe's ceiling for this arithmetic
-            nprod = 3 if K.CHAIN_MODE == "h3" else K.CHAIN_MODES[K.CHAIN_MODE]
-            out["executing_pipe"] = (f"{'f16' if K.CHAIN_MODE == 'h3' else 'bf16'} MFMA, {nprod} product(s) per fp32 product"
+            nprod = 3 if K.DEFAULT_CHAIN_MODE == "h3" else K.CHAIN_MODES[K.DEFAULT_CHAIN_MODE]
+            out["executing_pipe"] = (f"{'f16' if K.DEFAULT_CHAIN_MODE == 'h3' else 'bf16'} MFMA, {nprod} product(s) per fp32 product"
                                      + ("; the loss-scaled sweeps S3 / S4 of the training step run 6 bf16 products"
-                                        if K.CHAIN_MODE == "h3" and mode == "train" else ""))
+                                        if K.DEFAULT_CHAIN_MODE == "h3" and mode == "train" else ""))
             out["frac_of_executing_pipe"] = round(ach * nprod / PEAK_BF16_TFLOPS, 4)
             out["peak_executing_pipe_fp32_equiv"] = round(PEAK_BF16_TFLOPS / nprod, 1)
         if bound == "valu":
@@ -560,7 +560,7 @@ def extra_interaction_block(model, plan, steps=50, warmup=10):
     flops = 2 * 2.0 * (E * 281600 + T * 448 + A * 81920)
     byts = 2 * (E * 1612 + T * 36 + A * 1024 + 1.43e6)
     return dict(steps_per_s=round(1.0 / sec, 1), ms_per_step=round(sec * 1e3, 4), steps=steps, warmup=warmup,
-                rows=dict(atoms=A, edges=E, triplets=T), arithmetic=K.CHAIN_MODE,
+                rows=dict(atoms=A, edges=E, triplets=T), arithmetic=K.DEFAULT_CHAIN_MODE,
                 algorithmic_gflop=round(flops / 1e9, 2), algorithmic_mb=round(byts / 1e6, 1),
                 achieved_tflops=round(flops / sec / 1e12, 2), frac_f32_mfma_peak=round(flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 achieved_gbs=round(byts / sec / 1e9, 1), frac_hbm_roofline=round(byts / sec / 1e9 / PEAK_HBM_GBS, 4),
@@ -821,7 +821,7 @@ def main():
                     help="skip the `extra` object (training step, isolated InteractionBlock, GemNet-Q, dynamic shapes)")
     ap.add_argument("--no-config4", action="store_true", help="skip extra.config4_shard (64 x 64-atom GemNet-Q, ~50 GiB, ~20 s)")
     ap.add_argument("--chain-mode", choices=["f32", "split6", "h3", "split3", "bf16"], default=None,
-                    help="arithmetic of the Dense stacks (default: kernels.CHAIN_MODE = h3, fp32 operands as two fp16 planes)")
+                    help="arithmetic of the Dense stacks (default: kernels.DEFAULT_CHAIN_MODE = h3, fp32 operands as two fp16 planes)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: launch the ranks, shard the global batch, run one gloo all-reduce and print the JSON "
                          "skeleton (proves the N-rank launch path on a machine without GPUs; tests/test_bench_cpu.py)")
@@ -872,7 +872,7 @@ def main():
     from gemnet_pytorch_amd.graph import GraphPlan
     from gemnet_pytorch_amd.model.gemnet import GemNet
     if args.chain_mode:
-        K.CHAIN_MODE = args.chain_mode
+        K.DEFAULT_CHAIN_MODE = args.chain_mode
 
     cfg = dict(GEMNET_T)
     if args.model == "Q":
@@ -886,7 +886,7 @@ def main():
     sizes = dict(atoms=plan.n_atoms, edges=plan.n_edges, triplets=plan.trip.size)
     if args.model == "Q":
         sizes.update(interaction_edges=plan.n_int, intermediate_triplets=plan.n_intm, quadruplets=plan.quad.size)
-    log(f"[bench] rank {rank}/{world}: {n_local} molecules, {sizes}, Dense-stack arithmetic {K.CHAIN_MODE}")
+    log(f"[bench] rank {rank}/{world}: {n_local} molecules, {sizes}, Dense-stack arithmetic {K.DEFAULT_CHAIN_MODE}")
 
     extra = {}
     if args.mode == "train":   # explicit request: the training step IS the timed region
@@ -978,7 +978,7 @@ def main():
                                                   "split6": "fp32 operands as 3 bf16 planes, 6 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (fp32-equivalent: dropped terms < 2^-24)",
                                                   "h3": "fp32 operands as 2 fp16 planes (hi + 2^-11 lo, 22 significand bits), 3 products on v_mfma_f32_16x16x32_f16, fp32 accumulate (operand rounding 2^-22: force MAE 1e-6 eV/A against float64)",
                                                   "split3": "3 bf16-plane products, fp32 accumulate",
-                                                  "bf16": "bf16 operands, fp32 accumulate"}[K.CHAIN_MODE],
+                                                  "bf16": "bf16 operands, fp32 accumulate"}[K.DEFAULT_CHAIN_MODE],
                        "parallelism": f"dp{world} (independent molecule shards, no data-path collective"
                                       + ("; the RCCL gradient all-reduce is timed in extra.train_step)" if world > 1 else ")")},
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,

@@ -83,7 +83,8 @@ SIGNATURES = {
     "gn_index_gpu_stage2": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_pm_f32": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i64, _vp],
-    "gn_adamw_ema_step_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp],
+    "gn_adamw_ema_step_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _i, _vp],
+    "gn_nonfinite_flag_f32": [_vp, _i64, _vp, _i, _vp],
     "gn_bil_expand_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bil_dy_multi_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_bmm_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -91,10 +92,10 @@ SIGNATURES = {
     "gn_rbf_aggregate_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "gn_quad_angles_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_quad_angles_bwd_ld_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp],
-    "gn_bil_reduce_project_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
-    "gn_bil_expand_ang_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bil_reduce_project_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
+    "gn_bil_expand_ang_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_expand_atoms_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
-    "gn_bil_dy_multi_ang_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bil_dy_multi_ang_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_gather_mul_f32": [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "gn_dist_fwd_f32": [_vp, _vp, _vp, _vp, _i64, _vp],
@@ -149,18 +150,8 @@ def load():
     lib.gn_abi_version.restype = _i
     lib.gn_chain_wide_tile_rows.restype = _i
     lib.gn_chain_wide_tile_rows.argtypes = [_i]
-    lib.gn_chain_wide_force_tile_rows.restype = _i
-    lib.gn_chain_wide_force_tile_rows.argtypes = [_i]
-    lib.gn_bil_ang_set_f16.restype = _i
-    lib.gn_bil_ang_set_f16.argtypes = [_i]
-    if os.environ.get("GEMNET_ANG_F16"):
-        lib.gn_bil_ang_set_f16(int(os.environ["GEMNET_ANG_F16"]))
-    lib.gn_chain_wide_set_stagger.restype = _i
-    lib.gn_chain_wide_set_stagger.argtypes = [_i]
-    if os.environ.get("GN_CHAIN_STAGGER"):
-        lib.gn_chain_wide_set_stagger(int(os.environ["GN_CHAIN_STAGGER"]))
-    if os.environ.get("GN_CHAIN_TILE_ROWS"):
-        lib.gn_chain_wide_force_tile_rows(int(os.environ["GN_CHAIN_TILE_ROWS"]))
+    # (no setters: since ABI 13 the arithmetic of the angle-form kernels and the tuning of the wide chain layout are arguments
+    #  of each launch — kernels.ANG_F16_MASK / WIDE_TILE_ROWS / WIDE_STAGGER hold the read-only host configuration)
     lib.gn_optim_blocks.restype = _i
     lib.gn_optim_blocks.argtypes = [_i64]
     lib.gn_index_gpu_ws_bytes.restype = _i64

@@ -1409,15 +1409,15 @@ extern "C" int gn_bil_fused_fwd_f32(const float* Y, const float* x, const int32_
   const size_t lds_f = ((size_t)FTE * FLDP + 3 * 4 * 64 * 4) * sizeof(float);
   const size_t lds_h = (size_t)2 * FTE * FPH * 2 + (size_t)3 * 4 * 64 * 4 * sizeof(float);
   const size_t lds = W2T_planes ? lds_h : lds_f;
-  static bool configured = false;   // idempotent attribute; a benign race sets it twice
-  if (!configured) {
+  static std::atomic<bool> configured{false};   // set-once flag of an idempotent attribute (two racing threads both set it)
+  if (!configured.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_fwd_mfma7_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_fwd_mfma7_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
     if (e != hipSuccess) return (int)e;
-    configured = true;
+    configured.store(true, std::memory_order_release);
   }
   if (W2T_planes)
     hipLaunchKernelGGL(bil_fused_fwd_mfma7_kernel<true>, dim3(gn_cdiv(E, FTE)), dim3(1024), lds, static_cast<hipStream_t>(stream),
@@ -1586,15 +1586,15 @@ extern "C" int gn_bil_fused_bwd_f32(const float* g, const float* W2, const void*
   if (!aligned16(g) || !aligned16(W2) || !aligned16(Sm) || !aligned16(B)) return (int)hipErrorInvalidValue;
   if (!aligned16(W2_planes)) return (int)hipErrorInvalidValue;
   constexpr size_t lds = (size_t)16 * (1024 + 4) * sizeof(float);
-  static bool configured = false;   // idempotent attribute; a benign race sets it twice
-  if (!configured) {
+  static std::atomic<bool> configured{false};   // set-once flag of an idempotent attribute (two racing threads both set it)
+  if (!configured.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_bwd_mfma7_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_fused_bwd_mfma7_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    configured = true;
+    configured.store(true, std::memory_order_release);
   }
   if (W2_planes)
     hipLaunchKernelGGL(bil_fused_bwd_mfma7_kernel<true>, dim3((unsigned)gn_cdiv(E, 16)), dim3(1024), lds,

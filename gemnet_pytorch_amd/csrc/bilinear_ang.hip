@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bil_reduce_project_ang_kernel(
 }
 
 // ---- x-adjoint, grouped by reduce edge: dxt[seg(e)] (K4 x C) = Yseg (K4 x S) @ dSm[e] (S x C) -------------------------
-// F16 (bit 2 of gn_bil_ang_set_f16): the product on the fp16 matrix pipe — Y (O(1)) and sigma dSm[e] (one exact power-of-two
+// F16 (arith = GN_ANG_F16): the product on the fp16 matrix pipe — Y (O(1)) and sigma dSm[e] (one exact power-of-two
 // scale per edge: the block is a cotangent of arbitrary magnitude) split into hi + 2^-11 lo planes, the correction products
 // in accumulators of their own (chain2.hip "format H"): 24 MFMAs of 16 cycles per tile of 32 quadruplets instead of 52 of 32.
 template <bool F16>
@@ -627,23 +627,17 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-// Matrix-pipe arithmetic of the angle-form kernels, a bit mask: 1 = K1 of gn_bil_reduce_project_ang_f32, 2 = the contraction
-// of gn_bil_dy_multi_ang_f32, 4 = gn_bil_expand_ang_f32 on v_mfma_f32_16x16x32_f16 with split fp16 operands; a cleared bit =
-// the f32-input MFMA.  Default 7: measured on MI355X (profiles/r4_q_f16.txt) K1 -25 %, the x-adjoint -6 %, the angle gradient
-// -29 % once the edge's dSm blocks are staged ALREADY SPLIT (split per tile it was VALU-bound and no faster than the f32 MFMA).
-static int g_ang_f16 = 7;
-extern "C" int gn_bil_ang_set_f16(int mask) {   // -> the previous mask; mask < 0: query only
-  const int prev = g_ang_f16;
-  if (mask >= 0) g_ang_f16 = mask & 7;
-  return prev;
-}
-
+// Matrix-pipe arithmetic of the angle-form kernels: the `arith` ARGUMENT of every entry point (GN_ANG_F16 = 1: the products on
+// v_mfma_f32_16x16x32_f16 with split fp16 operands; 0: the f32-input MFMA) — per call, no library state (ABI 13; until ABI 12 a
+// process-global mask that the host toggled around single launches, racing with the autograd engine's thread).  Measured on
+// MI355X (profiles/r4_q_f16.txt): K1 -25 %, the x-adjoint -6 %, the angle gradient -29 % once the edge's dSm blocks are staged
+// ALREADY SPLIT (split per tile it was VALU-bound and no faster than the f32 MFMA).
 extern "C" int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx,
                                              const int32_t* seg_off, const float* B, float* Sm, float* P, int64_t E, int S_,
-                                             int C_, int I_, void* stream) {
+                                             int C_, int I_, int arith, void* stream) {
   if (E <= 0) return 0;
-  if (S_ != S || C_ != C || I_ != I || !aligned16(ang)) return (int)hipErrorInvalidValue;
-  if (g_ang_f16 & 1)
+  if (S_ != S || C_ != C || I_ != I || !aligned16(ang) || (arith & ~1)) return (int)hipErrorInvalidValue;
+  if (arith & 1)
     hipLaunchKernelGGL(bil_reduce_project_ang_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const float4*>(ang), x, expand_idx, seg_off, B, Sm, P, E);
   else
@@ -654,10 +648,10 @@ extern "C" int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, c
 }
 
 extern "C" int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S_,
-                                     int C_, void* stream) {
+                                     int C_, int arith, void* stream) {
   if (E <= 0) return 0;
-  if (S_ != S || C_ != C || !aligned16(ang)) return (int)hipErrorInvalidValue;
-  if (g_ang_f16 & 4)
+  if (S_ != S || C_ != C || !aligned16(ang) || (arith & ~1)) return (int)hipErrorInvalidValue;
+  if (arith & 1)
     hipLaunchKernelGGL(bil_expand_ang_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
   else
@@ -676,12 +670,12 @@ extern "C" int gn_bil_expand_atoms_ang_f32(const float* ang, const float* dSm, c
   constexpr int NW = 16, TQ = 16;
   const size_t lds = ((size_t)max_J * C + (size_t)NW * TQ * LDY) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-  static bool configured = false;   // idempotent attribute; a benign race sets it twice
-  if (!configured) {
+  static std::atomic<bool> configured{false};   // set-once flag of an idempotent attribute (two racing threads both set it)
+  if (!configured.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bil_expand_atoms_ang_kernel<NW, TQ>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    configured = true;
+    configured.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((bil_expand_atoms_ang_kernel<NW, TQ>), dim3((unsigned)n_atoms), dim3(NW * 64), lds,
                      static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(ang), dSm, seg_off, expand_idx, a_perm,
@@ -692,9 +686,9 @@ extern "C" int gn_bil_expand_atoms_ang_f32(const float* ang, const float* dSm, c
 
 extern "C" int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float* const* x_list, int nb, const float* ang,
                                        const int32_t* expand_idx, const int32_t* seg_off, float* g_ang, int64_t E, int S_,
-                                       int C_, void* stream) {
+                                       int C_, int arith, void* stream) {
   if (E <= 0 || nb <= 0) return 0;
-  if (nb > 4 || S_ != S || C_ != C || !aligned16(ang) || !aligned16(g_ang)) return (int)hipErrorInvalidValue;
+  if (nb > 4 || S_ != S || C_ != C || !aligned16(ang) || !aligned16(g_ang) || (arith & ~1)) return (int)hipErrorInvalidValue;
   gn_dy_ang_args a;
   a.nb = nb;
   for (int b = 0; b < 4; ++b) {
@@ -704,7 +698,7 @@ extern "C" int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float
   }
   const size_t smem = ((size_t)nb * S * (C + 4) + 4 * 16 * LDY) * sizeof(float);   // 42 KB at nb = 4
   const size_t smem16 = (size_t)nb * 2 * 64 * C * 2 + (size_t)4 * 16 * LDY * sizeof(float);   // split planes: 46 KB at nb = 4
-  if (g_ang_f16 & 2)
+  if (arith & 1)
     hipLaunchKernelGGL(bil_dy_multi_ang_kernel<true>, dim3((unsigned)E), dim3(256), smem16, static_cast<hipStream_t>(stream), a,
                        reinterpret_cast<const float4*>(ang), expand_idx, seg_off, reinterpret_cast<float4*>(g_ang), E);
   else

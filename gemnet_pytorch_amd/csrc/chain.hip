@@ -312,14 +312,14 @@ template <int RT>
 int launch_chain(const gn_chain_args* args, hipStream_t st) {
   constexpr int BM = 16 * RT;
   constexpr size_t smem = (size_t)NSLOT * BM * SLD * sizeof(float);
-  static bool configured = false;   // idempotent attribute; a benign race sets it twice
-  if (!configured) {
+  static std::atomic<bool> configured{false};   // set-once flag of an idempotent attribute (two racing threads both set it)
+  if (!configured.load(std::memory_order_acquire)) {
     if (smem > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<RT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    configured = true;
+    configured.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((chain_kernel<RT>), dim3(gn_cdiv(args->M, BM)), dim3(NT), smem, st, *args);
   GN_LAUNCH_CHECK();

@@ -639,14 +639,14 @@ int launch_chain_split(const gn_chain_args* args, hipStream_t st) {
   const int meta = first | (linear << 8);
   constexpr int BM = 16 * RT;
   constexpr size_t smem = (size_t)2 * (HF ? 2 : 3) * BM * ROWB + (HF ? (size_t)8 * RT * 1024 : 0);
-  static bool configured = false;   // idempotent attribute; a benign race sets it twice
-  if (!configured) {
+  static std::atomic<bool> configured{false};   // set-once flag of an idempotent attribute (two racing threads both set it)
+  if (!configured.load(std::memory_order_acquire)) {
     if (smem > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_split_kernel<RT, NPL, ADJ, HF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    configured = true;
+    configured.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((chain_split_kernel<RT, NPL, ADJ, HF>), dim3(gn_cdiv(args->M, BM)), dim3(NT), smem, st, *args, meta);
   GN_LAUNCH_CHECK();
@@ -771,8 +771,16 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
   if (args->M <= 0 || args->n_ops <= 0) return 0;
   if (args->n_ops > GN_CHAIN_MAX_OPS) return (int)hipErrorInvalidValue;
   if (args->M > (1 << 24)) return (int)hipErrorInvalidValue;
-  const bool wide = nprod == (GN_CHAIN_F16X2 | GN_CHAIN_WIDE);
+  // wide layout: tile height (GN_CHAIN_WIDE_ROWS) and start-up stagger (GN_CHAIN_WIDE_STAGGER) ride in the upper bits of `nprod`
+  // — per call, no library state (ABI 13)
+  const bool wide = (nprod & 0xfff) == (GN_CHAIN_F16X2 | GN_CHAIN_WIDE);
+  const int wide_rows = ((nprod >> 12) & 0xf) * 8, wide_stagger = (nprod >> 16) & 0xffff;
+  if (!wide && (nprod & ~0xfff)) return (int)hipErrorInvalidValue;
+  if (wide && wide_rows > 48) return (int)hipErrorInvalidValue;
   if (nprod != 1 && nprod != 3 && nprod != 6 && nprod != GN_CHAIN_F16X2 && !wide) return (int)hipErrorInvalidValue;
+  // the prologue requests the first GEMM's weights and publishes the op table without a barrier of its own: it relies on the
+  // barrier every LOAD ends with, so a program must start with one (every generated program does)
+  if (args->ops[0].kind != GN_OP_LOAD) return (int)hipErrorInvalidValue;
   for (int i = 0; i < args->n_ops; ++i) {
     const gn_chain_op& o = args->ops[i];
     if (o.kind == GN_OP_GEMM) {
@@ -812,7 +820,7 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
       const gn_chain_op& o = args->ops[i];
       park = park || o.slot == 2 || (o.kind == GN_OP_GEMM && (o.mul_slot == 2 || o.res_slot == 2 || o.res2_slot == 2));
     }
-    if (!park) return gn_chain_wide_dispatch(args, adj, st);
+    if (!park) return gn_chain_wide_dispatch(args, adj, wide_rows, wide_stagger, st);
     nprod = GN_CHAIN_F16X2;
   }
   if (nprod == GN_CHAIN_F16X2) return dispatch_adj<2, true>(args, adj, st);

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT3, 2) void chain_wide_kernel(const gn_chain_args 
   }
   if (tid < 2 * 16 * 3) (&rs[0][0])[tid] = 1.f;
   __syncthreads();
-  // Tuning hook (gn_chain_wide_set_stagger, default 0): the workgroup whose LDS allocation does not start at 0 — the second to
+  // Tuning hook (GN_CHAIN_WIDE_STAGGER bits of `nprod`, default 0): the workgroup whose LDS allocation does not start at 0 — the second to
   // arrive on its CU — starts `stagger` x 64 cycles late, so that one's MFMA phase meets the other's epilogue.  Measured
   // (profiles/r4_chain_layouts.txt): a pair offset by one op finishes exactly that much later — the two workgroups do not
   // disturb each other in phase either; per-wave latency, not contention, sets the time of an op.
@@ -486,23 +486,22 @@ __global__ __launch_bounds__(NT3, 2) void chain_wide_kernel(const gn_chain_args 
   }
 }
 
-int g_stagger = 0;     // start-up offset of the second workgroup of a CU, in units of 64 cycles (gn_chain_wide_set_stagger)
-
+// stagger: start-up offset of the second workgroup of a CU, in units of 64 cycles (GN_CHAIN_WIDE_STAGGER bits of `nprod`)
 template <int RT, bool ADJ>
-int launch_chain_wide(const gn_chain_args* args, int tile_rows, hipStream_t st) {
+int launch_chain_wide(const gn_chain_args* args, int tile_rows, int stagger, hipStream_t st) {
   constexpr int BM = 16 * RT;
   constexpr size_t smem = (size_t)2 * 2 * BM * ROWB + (size_t)4 * CT * RT * 1024;
-  static bool configured = false;   // idempotent attribute; a benign race sets it twice
-  if (!configured) {
+  static std::atomic<bool> configured{false};   // set-once flag of an idempotent attribute (two racing threads both set it)
+  if (!configured.load(std::memory_order_acquire)) {
     if (smem > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_wide_kernel<RT, ADJ>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    configured = true;
+    configured.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((chain_wide_kernel<RT, ADJ>), dim3(gn_cdiv(args->M, tile_rows)), dim3(NT3), smem, st, *args, tile_rows,
-                     g_stagger);
+                     stagger);
   GN_LAUNCH_CHECK();
   return 0;
 }
@@ -511,19 +510,9 @@ int launch_chain_wide(const gn_chain_args* args, int tile_rows, hipStream_t st) 
 
 // Rows per tile of the wide layout: one round of (at most) two workgroups per CU when the rows allow it, else rounds of
 // 48-row tiles balanced over the rounds; the atom-side programs (M <= 4 k rows) keep one 16-row MFMA block per workgroup.
-// gn_chain_wide_force_tile_rows(r) with r a multiple of 8 in 8..48 fixes the height (tuning and tests); 0 = automatic.
-static int g_forced_tile_rows = 0;
-extern "C" int gn_chain_wide_force_tile_rows(int rows) {
-  if (rows != 0 && (rows < 8 || rows > 48 || rows % 8 != 0)) return (int)hipErrorInvalidValue;
-  g_forced_tile_rows = rows;
-  return 0;
-}
-extern "C" int gn_chain_wide_set_stagger(int units_of_64_cycles) {
-  g_stagger = units_of_64_cycles < 0 ? 0 : units_of_64_cycles;
-  return 0;
-}
+// GN_CHAIN_WIDE_ROWS(r) in the `nprod` argument of gn_chain_split_f32, r a multiple of 8 in 8..48, fixes the height for that
+// launch (tuning and tests); 0 = this automatic choice.
 extern "C" int gn_chain_wide_tile_rows(int M) {
-  if (g_forced_tile_rows) return g_forced_tile_rows;
   if (M <= 16 * 256) return 16;
   const int slots = 512;
   int per = gn_cdiv(M, slots);
@@ -536,15 +525,15 @@ extern "C" int gn_chain_wide_tile_rows(int M) {
 }
 
 // called by gn_chain_split_f32 (chain2.hip) for nprod = GN_CHAIN_F16X2 | GN_CHAIN_WIDE, after its argument checks
-int gn_chain_wide_dispatch(const gn_chain_args* args, bool adj, hipStream_t st) {
-  const int tr = gn_chain_wide_tile_rows(args->M);
+int gn_chain_wide_dispatch(const gn_chain_args* args, bool adj, int forced_tile_rows, int stagger, hipStream_t st) {
+  const int tr = forced_tile_rows ? forced_tile_rows : gn_chain_wide_tile_rows(args->M);
   const int rt = gn_cdiv(tr, 16);
   if (adj) {
-    if (rt == 1) return launch_chain_wide<1, true>(args, tr, st);
-    if (rt == 2) return launch_chain_wide<2, true>(args, tr, st);
-    return launch_chain_wide<3, true>(args, tr, st);
+    if (rt == 1) return launch_chain_wide<1, true>(args, tr, stagger, st);
+    if (rt == 2) return launch_chain_wide<2, true>(args, tr, stagger, st);
+    return launch_chain_wide<3, true>(args, tr, stagger, st);
   }
-  if (rt == 1) return launch_chain_wide<1, false>(args, tr, st);
-  if (rt == 2) return launch_chain_wide<2, false>(args, tr, st);
-  return launch_chain_wide<3, false>(args, tr, st);
+  if (rt == 1) return launch_chain_wide<1, false>(args, tr, stagger, st);
+  if (rt == 2) return launch_chain_wide<2, false>(args, tr, stagger, st);
+  return launch_chain_wide<3, false>(args, tr, stagger, st);
 }

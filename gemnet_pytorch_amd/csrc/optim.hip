@@ -37,7 +37,7 @@ __global__ __launch_bounds__(OPT_NT) void adamw_ema_kernel(
     float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ gscale, const float* __restrict__ wd,
     float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax, float* __restrict__ ema, int64_t n,
     const double* __restrict__ partial, int n_partial, float max_norm, float lr, float beta1, float beta2, float eps,
-    float bias1, float bias2_sqrt, float ema_decay, float* __restrict__ norm_out) {
+    float bias1, float bias2_sqrt, float ema_decay, float* __restrict__ norm_out, int32_t* __restrict__ flag, int flag_bit) {
   __shared__ float clip_s;
   if (threadIdx.x == 0) {
     double s = 0.0;
@@ -45,11 +45,15 @@ __global__ __launch_bounds__(OPT_NT) void adamw_ema_kernel(
     const float norm = (float)sqrt(s);
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
     const float coef = max_norm / (norm + 1e-6f);
-    clip_s = coef < 1.0f ? coef : 1.0f;
+    // a non-finite gradient norm with `flag` given: the step is SKIPPED (clip < 0 marks it) and reported
+    const bool bad = flag != nullptr && !(fabsf(norm) <= 3.4028234e38f);
+    clip_s = bad ? -1.0f : (coef < 1.0f ? coef : 1.0f);
     if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+    if (blockIdx.x == 0 && bad) atomicOr(flag, flag_bit);
   }
   __syncthreads();
   const float clip = clip_s;
+  if (clip < 0.0f) return;      // (every block decides from the same partials: all or none)
   const float step = lr / bias1;
   const float omd = 1.0f - ema_decay;
   for (int64_t i = blockIdx.x * (int64_t)OPT_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * OPT_NT) {
@@ -69,7 +73,27 @@ __global__ __launch_bounds__(OPT_NT) void adamw_ema_kernel(
   }
 }
 
+// flag[0] |= bit when x[0 .. n) holds a non-finite value: the range check of a replayed hipGraph (no host read-back inside
+// the graph; the word is sticky until the host clears it)
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, int64_t n, int32_t* __restrict__ flag,
+                                                            int bit) {
+  bool bad = false;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    bad = bad || !(fabsf(x[i]) <= 3.4028234e38f);      // inf and nan both fail the comparison
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, bit);   // (a constant bit: order-independent)
+}
+
 }  // namespace
+
+extern "C" int gn_nonfinite_flag_f32(const float* x, int64_t n, int32_t* flag, int bit, void* stream) {
+  if (n <= 0) return 0;
+  if (!flag || !bit) return (int)hipErrorInvalidValue;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, flag, bit);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int gn_optim_blocks(int64_t n) {
   int64_t b = (n + OPT_NT * 8 - 1) / (OPT_NT * 8);
@@ -79,7 +103,7 @@ extern "C" int gn_optim_blocks(int64_t n) {
 extern "C" int gn_adamw_ema_step_f32(float* p, const float* g, const float* gscale, const float* wd, float* m, float* v,
                                      float* vmax, float* ema, int64_t n, double* partial, float max_norm, float lr,
                                      float beta1, float beta2, float eps, int step, float ema_decay, float* norm_out,
-                                     void* stream) {
+                                     int32_t* flag, int flag_bit, void* stream) {
   if (n <= 0) return 0;
   if (step < 1 || !partial) return (int)hipErrorInvalidValue;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -89,7 +113,7 @@ extern "C" int gn_adamw_ema_step_f32(float* p, const float* g, const float* gsca
   const float bias1 = 1.0f - powf(beta1, (float)step);
   const float bias2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(nb), dim3(OPT_NT), 0, st, p, g, gscale, wd, m, v, vmax, ema, n, partial, nb,
-                     max_norm, lr, beta1, beta2, eps, bias1, bias2_sqrt, ema_decay, norm_out);
+                     max_norm, lr, beta1, beta2, eps, bias1, bias2_sqrt, ema_decay, norm_out, flag, flag_bit);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -80,6 +80,11 @@ def expanded_csr(row_of_edge: RowIndex, seg_off_of_edge: torch.Tensor, n_items: 
     return perm.to(torch.int32).contiguous(), off[seg_e.to(torch.int64)].to(torch.int32).contiguous()
 
 
+def _atom_blocks_on():
+    from . import kernels as _K
+    return _K.USE_ATOM_BLOCKS
+
+
 class SegmentPlan:
     """Triplets (or quadruplets) t with reduce row r(t) (sorted) and expand row g(t)."""
 
@@ -200,7 +205,11 @@ class GraphPlan:
             self.intm_ab = RowIndex(exp_ab, self.n_int, is_sorted=True)
             self.quad = SegmentPlan(inputs["id4_reduce_ca"], inputs["id4_expand_abd"], self.n_edges, self.n_intm)
             # reduce edge c -> a and intermediate triplet a <- b <- d share the target atom a; the latter are sorted by it
-            self.quad.set_atom_blocks(self.id_a, i_a[exp_ab], self.n_atoms)
+            # (only the fused per-atom x-adjoint reads it — kernels.USE_ATOM_BLOCKS, off by default: no gather / bincount /
+            #  host read-back per batch for a structure nobody consumes)
+            from . import kernels as _K
+            if _K.USE_ATOM_BLOCKS:
+                self.quad.set_atom_blocks(self.id_a, i_a[exp_ab], self.n_atoms)
             A = self.n_atoms
             self.quad_geom = {
                 # a - b <- d per intermediate triplet (gemnet.py:385-388)
@@ -265,7 +274,7 @@ class GraphPlan:
                 self._late_event = ev
             else:
                 self.trip.groups
-            if not self.triplets_only:
+            if not self.triplets_only and _atom_blocks_on():
                 self.quad.atom_blocks
             self._warmed = True
         return self

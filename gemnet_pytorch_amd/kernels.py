@@ -5,8 +5,10 @@ missing library raise.  (tests/cpu_kernels.py monkeypatches these launchers with
 restatements to exercise the autograd/model logic on machines without a GPU; that emulation
 lives under tests/ and is never imported by the product.)
 """
+import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -181,6 +183,14 @@ def segsum_multi(terms, n_rows):
     return x
 
 
+def nonfinite_flag(x, flag, bit=1):
+    """flag[0] |= bit when x holds an inf / NaN (gn_nonfinite_flag_f32; no host read-back: runtime.RangeFlag)."""
+    require_device(x, flag)
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and flag.dtype == torch.int32
+    check(_lib.load().gn_nonfinite_flag_f32(ptr(x), x.numel(), ptr(flag), int(bit), stream()), "gn_nonfinite_flag_f32")
+
+
 def rbf_aggregate_supported(m, rbf, W):
     return m.shape[1] == 128 and rbf.shape[1] == 16 and tuple(W.shape) == (128, 16)
 
@@ -276,6 +286,11 @@ def bil_reduce(Y, x, sp):
 # default; GEMNET_ATOM_BLOCKS=1 selects it.
 USE_ATOM_BLOCKS = os.environ.get("GEMNET_ATOM_BLOCKS", "0") == "1"
 ATOM_BLOCK_MAX_ROWS = 848
+# Which angle-form kernels run their products on the fp16 matrix pipe (`arith` = GN_ANG_F16 of the launch): bit 0 = K1 of
+# bil_reduce_project (only under the "h3" Dense arithmetic: x unscaled), bit 1 = the angle gradient bil_dy_multi, bit 2 = the
+# x-adjoint bil_expand (both under an exact per-edge scale: any magnitude).  Read-only configuration (A/B runs, tests).
+GN_ANG_F16 = 1
+ANG_F16_MASK = int(os.environ.get("GEMNET_ANG_F16", "7")) & 7
 
 
 def bil_reduce_t(Y, D, sp):
@@ -295,8 +310,8 @@ def bil_reduce_t(Y, D, sp):
                                                           stream()), "gn_bil_expand_atoms_ang_f32")
             return dx
         dxt = torch.empty((sp.size, C), device=Y.device, dtype=torch.float32)
-        check(_lib.load().gn_bil_expand_ang_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(dxt), sp.n_reduce, S, C, stream()),
-              "gn_bil_expand_ang_f32")
+        check(_lib.load().gn_bil_expand_ang_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(dxt), sp.n_reduce, S, C,
+                                                GN_ANG_F16 if ANG_F16_MASK & 4 else 0, stream()), "gn_bil_expand_ang_f32")
         return segsum(dxt, permT, segT, sp.n_expand)
     if S > 8:
         # tensor basis: per-quadruplet rows grouped by reduce edge (dSm[e] read once per edge), then one CSR sum
@@ -662,7 +677,36 @@ def _sel(x):
 # (three products, csrc/chain2.hip "format H").  "h3" needs its weights packed with SPLIT_FORMAT 1.
 CHAIN_MODES = {"f32": 0, "split6": 6, "split3": 3, "bf16": 1, "h3": 2}
 SPLIT_FORMAT = {"split6": 0, "split3": 0, "bf16": 0, "h3": 1}
-CHAIN_MODE = os.environ.get("GEMNET_CHAIN_MODE", "h3")
+# The process DEFAULT (read once; `bench.py --chain-mode` and tests replace it before any model runs).  The mode a launch runs
+# in is per-call state, never a mutable global: a forward pass selects it for its own thread (`use_mode`, thread-local — the
+# model's `matmul_precision`), every autograd Function records it at forward time (`ctx.mode`) and its backward — which the
+# autograd engine runs on ITS thread, possibly long after the forward's context has closed and after another model with
+# another precision has run — restores it from there (`ops._in_mode`, `ops_train._sweep_mode`).
+DEFAULT_CHAIN_MODE = os.environ.get("GEMNET_CHAIN_MODE", "h3")
+_tls = threading.local()
+
+
+def current_mode():
+    """Arithmetic of the chain / bilinear launches issued by this thread right now."""
+    return getattr(_tls, "mode", None) or DEFAULT_CHAIN_MODE
+
+
+@contextlib.contextmanager
+def use_mode(mode):
+    """Select the arithmetic (CHAIN_MODES) for the launches this THREAD issues inside the block; None keeps the current one."""
+    if mode is None:
+        yield
+        return
+    if mode not in CHAIN_MODES:
+        raise ValueError(f"matmul_precision must be one of {sorted(CHAIN_MODES)}; got {mode!r}")
+    prev = getattr(_tls, "mode", None)
+    _tls.mode = mode
+    try:
+        yield
+    finally:
+        _tls.mode = prev
+
+
 # Kernel layout of the "h3" launches: "tall" = csrc/chain2.hip (one 8-wave workgroup per CU on row tiles of <= 80 rows, a wave
 # owns 16 columns), "wide" = csrc/chain3.hip (workgroups of 4 waves x 32 columns on row tiles of <= 48 rows, two per CU;
 # GN_CHAIN_WIDE).  Same results bit for bit (tests/test_gpu_kernels.py).  Measured on MI355X (profiles/r4_chain_layouts.txt):
@@ -671,6 +715,9 @@ CHAIN_MODE = os.environ.get("GEMNET_CHAIN_MODE", "h3")
 # "tall" stays the default; programs that use the parking slot always take it (the library decides).
 CHAIN_LAYOUT = os.environ.get("GEMNET_CHAIN_LAYOUT", "tall")
 GN_CHAIN_WIDE = 0x100
+# per-launch tuning of the wide layout (GN_CHAIN_WIDE_ROWS / GN_CHAIN_WIDE_STAGGER bits of `nprod`; 0 = automatic / none)
+WIDE_TILE_ROWS = int(os.environ.get("GN_CHAIN_TILE_ROWS", "0"))
+WIDE_STAGGER = int(os.environ.get("GN_CHAIN_STAGGER", "0"))
 # The fp16 planes of "h3" cover the magnitudes the MODEL fixes (activations, first-order adjoints dE/d.): sweeps whose
 # scale follows the caller's loss (S3 / S4 and the energy-only final adjoint of force training, ops_train.py) run in this
 # mode instead when the stack's mode is "h3" — bf16 planes have the fp32 exponent range.
@@ -685,7 +732,7 @@ def linear_mode(mode):
 
 def split_format(mode=None):
     """Packed-weight format (GN_SPLIT_*) of a chain mode; None for the f32 kernel."""
-    return SPLIT_FORMAT.get(mode or CHAIN_MODE)
+    return SPLIT_FORMAT.get(mode or current_mode())
 
 
 def pack_weight_split(W, trans=False, fmt=None):
@@ -831,10 +878,11 @@ def chain(prog, mode=None):
     ops = prog.ops
     if len(ops) > GN_CHAIN_MAX_OPS:
         raise ValueError("chain program too long")
-    nprod = CHAIN_MODES[mode or CHAIN_MODE]
+    mode = mode or current_mode()
+    nprod = CHAIN_MODES[mode]
     if nprod and not chain_split_supported(prog):
         nprod = 0
-    fmt = SPLIT_FORMAT.get(mode or CHAIN_MODE, 0)
+    fmt = SPLIT_FORMAT.get(mode, 0)
     if nprod == CHAIN_MODES["h3"] and h3_hazards(prog):
         raise RuntimeError("chain: this linear program adds a global tensor into an LDS-resident value "
                            f"(ops {h3_hazards(prog)}): not representable in the row-scaled fp16 form 'h3' — "
@@ -859,7 +907,7 @@ def chain(prog, mode=None):
                     Wp = pack_weight_split(W, fmt=fmt)
                 elif getattr(Wp, "_gn_fmt", 0) != fmt:
                     raise RuntimeError(f"chain: weight planes packed in format {getattr(Wp, '_gn_fmt', 0)} handed to a "
-                                       f"launch in mode {mode or CHAIN_MODE!r} (format {fmt})")
+                                       f"launch in mode {mode!r} (format {fmt})")
                 keep.append(Wp)
                 v[F_W] = addr(Wp)
             else:
@@ -959,7 +1007,9 @@ def chain(prog, mode=None):
                            "(CHAIN_MODE f32 / an unsupported shape): use the composite training path")
     cbuf = (ctypes.c_char * args_size).from_buffer(buf)
     if nprod == CHAIN_MODES["h3"] and CHAIN_LAYOUT == "wide":
-        nprod |= GN_CHAIN_WIDE
+        if WIDE_TILE_ROWS and (WIDE_TILE_ROWS % 8 or not 8 <= WIDE_TILE_ROWS <= 48):
+            raise ValueError("GN_CHAIN_TILE_ROWS: a multiple of 8 in 8..48")
+        nprod |= GN_CHAIN_WIDE | ((WIDE_TILE_ROWS // 8) << 12) | ((max(WIDE_STAGGER, 0) & 0xffff) << 16)
     if nprod:
         check(_lib.load().gn_chain_split_f32(ctypes.addressof(cbuf), nprod, stream()), "gn_chain_split_f32")
     else:
@@ -992,19 +1042,13 @@ def bil_reduce_project(Y, x, B, sp, Sm_init=None, B2=None, Sm2=None, want_P=True
                                                      S, C, I, stream()), "gn_bil_reduce_project2_f32")
         return Sm, P
     if is_angle_form(Y, S):   # Y_lm rebuilt in-kernel from (sin, cos) of the two angles
-        lib = _lib.load()
         # K1 on the fp16 pipe takes x unscaled (fp16 range): only under the fp16-plane Dense arithmetic, whose overflow guard
-        # (model/gemnet.py) covers it — a model on "split6" / "f32" keeps the f32-input MFMA here
-        prev = lib.gn_bil_ang_set_f16(-1) if CHAIN_MODE != "h3" else 0
-        if prev & 1:
-            lib.gn_bil_ang_set_f16(prev & ~1)
-        try:
-            check(lib.gn_bil_reduce_project_ang_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
-                                                    ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
-                  "gn_bil_reduce_project_ang_f32")
-        finally:
-            if prev & 1:
-                lib.gn_bil_ang_set_f16(prev)
+        # (model/gemnet.py) covers it — a model on "split6" / "f32" keeps the f32-input MFMA here (`arith` is an argument of
+        # the launch: no library state)
+        arith = GN_ANG_F16 if (ANG_F16_MASK & 1 and current_mode() == "h3") else 0
+        check(_lib.load().gn_bil_reduce_project_ang_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
+                                                        ptr(Sm), ptr(P), sp.n_reduce, S, C, I, arith, stream()),
+              "gn_bil_reduce_project_ang_f32")
         return Sm, P
     check(_lib.load().gn_bil_reduce_project_f32(ptr(Y), ptr(x), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(B),
                                                 ptr(Sm), ptr(P), sp.n_reduce, S, C, I, stream()),
@@ -1086,7 +1130,7 @@ def bil_dy_multi(dSm_list, x_list, sp, ang=None):
         arr = ctypes.c_void_p * nb
         check(_lib.load().gn_bil_dy_multi_ang_f32(arr(*[addr(t) for t in dSm_list]), arr(*[addr(t) for t in x_list]),
                                                   nb, ptr(ang), ptr(sp.expand.idx32), ptr(sp.seg_off), ptr(g_ang), E, S, C,
-                                                  stream()), "gn_bil_dy_multi_ang_f32")
+                                                  GN_ANG_F16 if ANG_F16_MASK & 2 else 0, stream()), "gn_bil_dy_multi_ang_f32")
         return g_ang
     dY = torch.empty((sp.size, S), device=x_list[0].device, dtype=torch.float32)
     arr = ctypes.c_void_p * nb

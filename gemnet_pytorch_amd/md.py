@@ -25,9 +25,12 @@ import torch
 class MoleculeInputs(dict):
     """What `DeviceMolecule.get()` returns: {"R", "Z", "N"} (no index arrays) + the cutoffs that define the graph."""
 
-    def __init__(self, data, cutoff, int_cutoff, triplets_only):
+    def __init__(self, data, cutoff, int_cutoff, triplets_only, layout_key=None):
         super().__init__(data)
         self.cutoff, self.int_cutoff, self.triplets_only = float(cutoff), float(int_cutoff), bool(triplets_only)
+        # (atomic numbers, molecule sizes) as a hashable HOST value — the key of the per-system force field; given by
+        # DeviceMolecule (which holds both on the host), else derived from the tensors once per call (a device read-back)
+        self.layout_key = layout_key
 
 
 class DeviceMolecule:
@@ -43,6 +46,7 @@ class DeviceMolecule:
         self.N = np.array([len(Z)], dtype=np.int32)
         self.device = "cpu"
         self._Z_dev = self._N_dev = None
+        self._key = (np.asarray(Z, dtype=np.int64).tobytes(), (int(len(Z)),))
 
     def update(self, R):
         """New positions (ase_calculator.py:86-97)."""
@@ -61,11 +65,12 @@ class DeviceMolecule:
             self._N_dev = torch.as_tensor(self.N, dtype=torch.int64).to(self.device)
         R = self.R if torch.is_tensor(self.R) else torch.as_tensor(np.asarray(self.R, dtype=np.float32))
         return MoleculeInputs(dict(R=R.to(self.device, dtype=torch.float32), Z=self._Z_dev, N=self._N_dev),
-                              self.cutoff, self.int_cutoff, self.triplets_only)
+                              self.cutoff, self.int_cutoff, self.triplets_only, layout_key=self._key)
 
 
-def predict_molecule(model, inputs):
-    """`GemNet.predict` for `MoleculeInputs`: -> (E, F) on the device, not detached from nothing (inference only)."""
+def predict_molecule(model, inputs, to_host=False):
+    """`GemNet.predict` for `MoleculeInputs`: -> (E, F) on the device (inference only); `to_host`: detached host copies, the
+    replayed step's range flag checked after the copy (what `GemNet.predict` returns)."""
     R, Z, N = inputs["R"], inputs["Z"], inputs["N"]
     if inputs.triplets_only != model.triplets_only:
         raise ValueError("DeviceMolecule(triplets_only=...) does not match the model")
@@ -77,18 +82,22 @@ def predict_molecule(model, inputs):
                                             F=np.zeros((R.shape[0], 3), np.float32)),
                                        inputs.cutoff, inputs.int_cutoff, triplets_only=model.triplets_only)
         b = dc[[0]]
-        return model({k: v for k, v in b.items() if k not in ("E", "F")})
-    key = (tuple(int(z) for z in Z.tolist()) if Z.numel() <= 4096 else id(Z), tuple(int(n) for n in N.tolist()),
-           inputs.cutoff, inputs.int_cutoff, R.device.index)
+        E, F = model({k: v for k, v in b.items() if k not in ("E", "F")})
+        return (E.detach().cpu(), F.detach().cpu()) if to_host else (E, F)
+    lk = inputs.layout_key
+    if lk is None:
+        lk = (Z.detach().cpu().numpy().astype(np.int64).tobytes(), tuple(int(n) for n in N.tolist()))
+    key = (lk, inputs.cutoff, inputs.int_cutoff, R.device.index)
     cache = model.__dict__.setdefault("_md_fields", {})
     ff = cache.get(key)
     was_training = model.training
     if ff is None:
         model.eval()
+        # (the caller's parameters are left as they are — `requires_grad` included: an eval-mode forward with forces by autograd
+        #  treats the weights as constants anyway (ops.constant_weights), and a force field built in the middle of a training
+        #  script must not freeze the model; the reference's predict() does not touch it either, gemnet.py:780-784)
         if model.triplets_only:
             from .runtime import DynamicForceField
-            for p in model.parameters():
-                p.requires_grad_(False)       # a force field: only dE/dR is ever asked for
             ff = DynamicForceField(model, Z, N.cpu().numpy(), inputs.cutoff, inputs.int_cutoff)
         else:
             from .index_device import DeviceGraphBuilder
@@ -102,6 +111,16 @@ def predict_molecule(model, inputs):
         cache[key] = ff
     try:
         model.eval()
-        return ff(R)
+        E, F = ff(R)
+        if to_host:
+            # the MD loop reads its results on the host (ase_calculator.py:166-170): after this copy the replay has completed
+            # and its device-side range check (runtime.RangeFlag) is exact — an overflow of the fp16-plane arithmetic in a
+            # REPLAYED step warns, moves the model to the bf16 planes, captures anew and repeats the step
+            Eh, Fh = E.detach().cpu(), F.detach().cpu()
+            if hasattr(ff, "range_tripped") and ff.range_tripped():
+                E, F = ff.recover(R)
+                Eh, Fh = E.detach().cpu(), F.detach().cpu()
+            return Eh, Fh
+        return E, F
     finally:
         model.train(was_training)

@@ -47,7 +47,7 @@ _PLAN_LATE = os.environ.get("GEMNET_PLAN_LATE", "1") == "1"          # adjoint-o
 
 def K_chain_mode():
     from .. import kernels
-    return kernels.CHAIN_MODE
+    return kernels.current_mode()
 
 
 class GemNet(torch.nn.Module):
@@ -374,14 +374,26 @@ class GemNet(torch.nn.Module):
         value beyond 65 504 becomes inf — fitted scale factors keep activations O(1), a model with
         unfitted ones (the starting state of fit_scaling.py, foreign checkpoints) need not.  A non-finite result of an eager
         forward in that arithmetic switches THIS model to the bf16-plane form ("split6": fp32 exponent range), says so, and
-        repeats the pass.  (One host read-back per eager forward; nothing is checked while a hipGraph is being captured: a
-        capture is preceded by eager warm-up passes of the same batch, which are.)"""
+        repeats the pass.  (One host read-back per eager forward.  A hipGraph cannot read back: a runner hands its
+        `runtime.RangeFlag` in as `inputs["_range_flag"]`, the captured pass ends with the device-side check of the same rows,
+        and the runner polls the flag — PaddedGraphRunner, DynamicForceField, ForceGraphs, TrainStep.)"""
+        with ops.exclusive():
+            return self._forward_guarded(inputs)
+
+    def _forward_guarded(self, inputs):
         out = self._forward(inputs)
         R = inputs["R"]
-        if (_H3_GUARD and R.is_cuda and (self.matmul_precision or K_chain_mode()) == "h3"
-                and not torch.cuda.is_current_stream_capturing()):
-            # (a padded batch — padded.py — names its real rows: the dummy molecule behind them is not the model's concern)
-            rows = inputs.get("_guard_rows")
+        h3 = R.is_cuda and (self.matmul_precision or K_chain_mode()) == "h3"
+        # (a padded batch — padded.py — names its real rows: the dummy molecule behind them is not the model's concern)
+        rows = inputs.get("_guard_rows")
+        flag = inputs.get("_range_flag")
+        if flag is not None and R.is_cuda:
+            # a runner's device-side range check (runtime.RangeFlag): two tiny launches + a copy of one word to pinned host
+            # memory at the end of the pass — what a REPLAYED graph has instead of the read-back below
+            E, F = out
+            flag.watch(E.detach()[:rows[0]] if rows is not None else E.detach(),
+                       F.detach()[:rows[1]] if rows is not None else F.detach())
+        if _H3_GUARD and h3 and not torch.cuda.is_current_stream_capturing():
             seen = out if rows is None else (out[0][:rows[0]], out[1][:rows[1]])
             if not bool(torch.stack([torch.isfinite(t).all() for t in seen]).all()):
                 import warnings
@@ -392,6 +404,9 @@ class GemNet(torch.nn.Module):
                 self._wcache = {}
                 if getattr(self, "_packs", None) is not None:
                     self._packs.clear()
+                if flag is not None:
+                    torch.cuda.current_stream().synchronize()
+                    flag.reset()       # the eager pass reported it itself
                 out = self._forward(inputs)
         return out
 
@@ -550,9 +565,8 @@ class GemNet(torch.nn.Module):
         replayed hipGraph (md.predict_molecule)."""
         from ..md import MoleculeInputs, predict_molecule
         if isinstance(inputs, MoleculeInputs):
-            E, F = predict_molecule(self, inputs)
-        else:
-            E, F = self(inputs)
+            return predict_molecule(self, inputs, to_host=True)
+        E, F = self(inputs)
         return E.detach().cpu(), F.detach().cpu()
 
     def load_weights(self, path):

@@ -19,11 +19,27 @@ computes forces, so no weight-gradient GEMMs are launched for them.
 import contextlib
 
 import os
+import threading
 
 import torch
 
 from . import _lib
 from . import kernels as K
+
+# The switches below (`param_grads`, `fused_first_order`, `weight_cache`, `train2`, `wgrad_queue`, ...) are host-side state of
+# ONE pass that the caller's thread sets and the autograd engine's thread reads — process-wide by necessity (the engine's
+# worker inherits nothing thread-local).  Two Python threads driving two models at once would interleave them, so every
+# section that sets them — GemNet.forward (with the force pass inside it) and the Trainer's / TrainStep's loss.backward() —
+# runs under this one re-entrant lock: passes of different threads serialise on the host (the GPU work they enqueue still
+# overlaps on their streams).  What is NOT under the lock and needs none: the arithmetic mode (thread-local + recorded per
+# autograd node, kernels.use_mode / _in_mode below) and the C ABI itself (no library state, include/gemnet_hip.h).
+_EXCLUSIVE = threading.RLock()
+
+
+def exclusive():
+    """The lock of a pass that sets the process-wide host switches of this module (re-entrant)."""
+    return _EXCLUSIVE
+
 
 _PARAM_GRADS = True
 
@@ -403,21 +419,25 @@ def is_fused():
     return _FUSED
 
 
-@contextlib.contextmanager
 def chain_mode(mode):
-    """Select the arithmetic of the Dense stacks (kernels.CHAIN_MODES) for the enclosed launches; None keeps the
-    current one.  Packed weights are cached per weight and plane format (kernels.SPLIT_FORMAT: the bf16-plane modes share
-    one form, "h3" has its own)."""
-    if mode is None:
-        yield
-        return
-    if mode not in K.CHAIN_MODES:
-        raise ValueError(f"matmul_precision must be one of {sorted(K.CHAIN_MODES)}; got {mode!r}")
-    prev, K.CHAIN_MODE = K.CHAIN_MODE, mode
-    try:
-        yield
-    finally:
-        K.CHAIN_MODE = prev
+    """Select the arithmetic of the Dense stacks (kernels.CHAIN_MODES) for the launches THIS THREAD issues inside the block;
+    None keeps the current one (kernels.use_mode: thread-local, not a process global).  Packed weights are cached per weight
+    and plane format (kernels.SPLIT_FORMAT: the bf16-plane modes share one form, "h3" has its own)."""
+    return K.use_mode(mode)
+
+
+def _in_mode(backward):
+    """Decorator of the `backward` of a Function whose forward recorded `ctx.mode = K.current_mode()`: the backward runs on the
+    autograd engine's thread — inside the forward's `chain_mode` block (inference forces) or long after it closed and another
+    model with another `matmul_precision` ran (direct-force training: loss.backward()) — and issues its launches in the
+    arithmetic of ITS forward, never in whatever a process-global switch happens to hold."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        with K.use_mode(ctx.mode):
+            return backward(ctx, *grads)
+    return wrapped
 
 
 # Derived-weight cache (transposes / contiguous copies of FROZEN weights).  Entries are keyed by the address
@@ -557,7 +577,7 @@ def dense(x, W, act=False, *, mul=None, alpha=1.0, res=None, res_rows=None, beta
                                                                 res_rows, i1, i2))
     if (_TRAIN2 and USE_STACKS and mul is None and alpha == 1.0 and res_rows is None and W.dim() == 2
             and W.shape[0] % 16 == 0 and W.shape[0] <= 128 and W.shape[1] % 4 == 0 and W.shape[1] <= 128
-            and x.dim() == 2 and x.dtype == W.dtype and (x.is_cuda or K.CHAIN_MODE != "f32")):
+            and x.dim() == 2 and x.dtype == W.dtype and (x.is_cuda or K.current_mode() != "f32")):
         # a single Dense as a one-GEMM stack: twice differentiable, one launch per sweep (ops_train.py)
         from . import ops_train
         return ops_train.stack(x, first=dict(W=W, act=act, res=res, beta=beta, res2=res2, beta2=beta2,
@@ -775,7 +795,7 @@ class _FusedBilinear(torch.autograd.Function):
             # (K3 on the fp16 pipe keeps P unscaled in fp16 planes: only under the fp16-plane Dense arithmetic and its
             # overflow guard; the adjoint scales its cotangent rows per edge and has no range limit)
             Sm, out = K.bil_fused_fwd(sph, x, rbf_W1, bilinear_weight(W, True), sp, alpha,   # K1 + K2 + K3, P stays in LDS
-                                      W2T_planes=bilinear_weight_planes(W) if K.CHAIN_MODE == "h3" else None)
+                                      W2T_planes=bilinear_weight_planes(W) if K.current_mode() == "h3" else None)
             P = None
         else:
             Sm, P = K.bil_reduce_project(sph, x, rbf_W1, sp)    # K1 + K2 in one launch: (E,S,C), (E,I,C)
@@ -1074,7 +1094,7 @@ def step_packed(W, trans, cache=None):
     by the four sweeps of that step (ops_train.py); None on the f32 chain kernel / the host emulation.
     `cache`: the store a stack captured in its forward — the S3 / S4 sweeps run inside loss.backward(), after the
     `train2` context of the forward has closed."""
-    if K.CHAIN_MODE == "f32" or not W.is_cuda:
+    if K.current_mode() == "f32" or not W.is_cuda:
         return None
     if cache is None:
         cache = _STEP_PACKED
@@ -1102,7 +1122,7 @@ def packed_weight(W, trans):
     kernel.  Cached with the other derived forms when W is frozen; packed per call when W is trainable (a cache keyed
     by the address of a per-call temporary would hand a later weight the earlier one's planes); None when the chain
     runs on the f32 MFMA or on the host emulation."""
-    if K.CHAIN_MODE == "f32" or not W.is_cuda:
+    if K.current_mode() == "f32" or not W.is_cuda:
         return None
     if not _frozen(W):
         return K.pack_weight_split(W.detach(), trans=trans)
@@ -1136,7 +1156,7 @@ class _Stack(torch.autograd.Function):
         # the backward below is first order and only ever needs ssilu'(z): the split-operand kernel stores that factor
         # (from the sigmoid it evaluates anyway) in place of z, and the adjoint program multiplies instead of evaluating
         # exp + rcp per element again (its epilogues were VALU-bound)
-        deriv = K.CHAIN_MODE != "f32"
+        deriv = K.current_mode() != "f32"
         zs = []
         width = x.shape[1]
         n_out = (layers[-1]["W2"].shape[0] if layers else first["W"].shape[0])
@@ -1175,6 +1195,7 @@ class _Stack(torch.autograd.Function):
             for o in prog.ops:
                 o["pre_deriv"] = False
         ctx.deriv = deriv
+        ctx.mode = K.current_mode()
         K.chain(prog)
         ctx.set_materialize_grads(False)
         ctx.spec = spec
@@ -1191,6 +1212,7 @@ class _Stack(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_in_mode
     def backward(ctx, g, *g_tails):
         spec = ctx.spec
         first, layers, s = spec["first"], spec["layers"], spec["s"]
@@ -1344,11 +1366,13 @@ class _DenseHadamardDown(torch.autograd.Function):
         _gemm(prog, Wd, a_slot=0, y_slot=1, act=act_d, pre_out=z3, out=y)
         K.chain(prog)
         ctx.cfg = cfg
+        ctx.mode = K.current_mode()
         ctx.save_for_backward(z1, r, z3, Wa, Wr, Wd)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_in_mode
     def backward(ctx, g):
         z1, r, z3, Wa, Wr, Wd = ctx.saved_tensors
         act_a, act_d, alpha = ctx.cfg
@@ -1420,12 +1444,14 @@ class _UpPair(torch.autograd.Function):
         _gemm(prog, W_ca, a_slot=0, y_slot=-1, act=act, alpha=alpha, pre_out=z_ca, out=y_ca)
         K.chain(prog)
         ctx.set_materialize_grads(False)
+        ctx.mode = K.current_mode()
         ctx.save_for_backward(z_ac, z_ca, W_ac, W_ca)
         ctx.swap, ctx.act, ctx.alpha, ctx.width = swap, act, alpha, x.shape[1]
         return y_ac, y_ca
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_in_mode
     def backward(ctx, g_ac, g_ca):
         if g_ac is not None:
             raise RuntimeError("up_project_pair: y_ac may only be consumed together with y_ca as a tied residual pair")

@@ -36,7 +36,7 @@ class _Rec:
         self.cache = ops.step_cache()   # packed weights of this training step (shared by all four sweeps)
         # arithmetic of the chain launches: S1 / S2 in the mode of the forward; the loss-scaled sweeps (S3, S4 and an
         # energy-only final adjoint) in kernels.linear_mode of it — the forward's `ops.chain_mode` context has closed by then
-        self.mode = K.CHAIN_MODE
+        self.mode = K.current_mode()
 
 
 def _releases_record(backward):

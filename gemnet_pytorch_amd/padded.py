@@ -145,6 +145,10 @@ class PaddedGraphRunner:
         self._arange_t = torch.arange(self.t_cap, device=dev, dtype=i64)
         self.graph = None
         self.out = None
+        self.flag = None
+        if dev.type == "cuda":
+            from .runtime import RangeFlag
+            self.flag = RangeFlag(dev)      # device-side range check of every replay (fp16-plane arithmetic), polled lazily
 
     @staticmethod
     def _float_dtype(model):
@@ -220,12 +224,27 @@ class PaddedGraphRunner:
         """R (A, 3) float32 on the device, idx: the index dict of this batch, Z: its atomic numbers when they change from
         batch to batch, N: its molecule sizes when those change too (runner built with `a_cap`) -> (E (n_mol, targets),
         F (A, [targets,] 3)); the results live in the graph's static output buffers until the next call."""
+        if self.flag is not None and self.flag.tripped():
+            # an EARLIER replay returned non-finite energies / forces (seen without synchronising: one or two calls late;
+            # a caller that waits for its results anyway checks `flag.tripped()` itself and calls `recover()` — md.py)
+            self.recover()
         self._fill(R, idx, Z, N)
         if self.graph is None:
             self._capture()
         self.graph.replay()
         E, F = self.out
         return E.detach()[:self.n_mol], F.detach()[:self.A]
+
+    def recover(self):
+        """The range flag tripped: move the model off the fp16 planes (runtime.fall_back_to_bf16_planes: warns) and drop the
+        graph — the next call captures anew in the bf16-plane arithmetic."""
+        from .runtime import fall_back_to_bf16_planes
+        torch.cuda.synchronize()
+        self.flag.trips += 1
+        self.flag.reset()
+        if fall_back_to_bf16_planes(self.model, "a replayed padded batch (PaddedGraphRunner)"):
+            self.graph = None
+            self.out = None
 
     def build_and_run(self, builder, R, Z=None, positions_ready=False, N=None):
         """Index build (index_device.DeviceGraphBuilder) + padded replay with the build on a stream of its own: its size
@@ -247,7 +266,9 @@ class PaddedGraphRunner:
         return self(R, idx, Z, N)
 
     def _capture(self):
-        inputs = dict(self.inputs, max_in_degree=self.pad_degree_bound(), _guard_rows=(self.n_mol, self.A))
+        inputs = dict(self.inputs, max_in_degree=self.pad_degree_bound(), _guard_rows=(self.n_mol, self.a_cap))
+        if self.flag is not None:
+            inputs["_range_flag"] = self.flag
         inputs.pop("_plan", None)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -12,7 +12,68 @@ The graphs read the model parameters and the `R` tensors of the sub-batches in p
 copies new coordinates into the captured buffers (MD with a fixed neighbour list); a changed graph
 (new neighbour list) needs a new runner.
 """
+import warnings
+
 import torch
+
+
+class RangeFlag:
+    """The range check of REPLAYED graphs (include/gemnet_hip.h, gn_nonfinite_flag_f32).
+
+    The default Dense arithmetic ("h3") keeps activations in two fp16 planes: beyond 65 504 they become inf, which propagates
+    to the energies and forces; the reference's fp32 (base_layers.py:44-48) has no such cliff.  An eager forward reads its
+    outputs back (GemNet.forward); a captured hipGraph — the MD loop, padded batches, the training step: the paths built for
+    long unattended runs — cannot.  A graph captured with a RangeFlag ends with one tiny launch per output that ORs a bit
+    into ONE device word when the output holds an inf / NaN, and with a copy of that word into pinned host memory; the host
+    reads the pinned copy without synchronising (`tripped()`: what the COMPLETED replays left there — exact right after
+    anything that waited for the replay, e.g. the `.cpu()` of `GemNet.predict`).  The word is sticky until `reset()`.
+    Bits: OUTPUT = non-finite energies / forces of a forward; GRAD = a non-finite gradient norm (the fused optimizer skipped
+    that step, csrc/optim.hip)."""
+    OUTPUT, GRAD = 1, 2
+
+    def __init__(self, device):
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(device).type == "cuda" \
+            else torch.zeros(1, dtype=torch.int32)
+        self.trips = 0
+
+    def watch(self, *tensors, bit=OUTPUT):
+        """Enqueue (or capture) the check of `tensors` (contiguous fp32) and the mirror copy on the current stream."""
+        from . import kernels as K
+        for t in tensors:
+            K.nonfinite_flag(t, self.word, bit)
+        self.mirror()
+
+    def mirror(self):
+        self.host.copy_(self.word, non_blocking=True)
+
+    def tripped(self):
+        return int(self.host[0])
+
+    def reset(self):
+        self.word.zero_()
+        self.host.zero_()
+
+
+def fall_back_to_bf16_planes(model, what):
+    """A replayed graph of `model` produced non-finite values in the fp16-plane arithmetic: warn, move THIS model to the
+    bf16-plane form ("split6": fp32 exponent range) and drop everything derived from its weights in the old format.  The
+    caller captures anew.  False when the model was not on the fp16 planes (the values are non-finite for another reason:
+    nothing to fall back to)."""
+    from . import kernels as K
+    mode = getattr(model, "matmul_precision", None) or K.DEFAULT_CHAIN_MODE
+    if mode != "h3":
+        warnings.warn(f"gemnet_pytorch_amd: non-finite values in {what} (arithmetic {mode!r}: no fp16 range limit involved)",
+                      RuntimeWarning)
+        return False
+    warnings.warn(f"gemnet_pytorch_amd: non-finite values in {what} — the fp16-plane Dense arithmetic ('h3') overflows beyond "
+                  "65504 (are the scale factors fitted?); this model now uses matmul_precision = 'split6' (bf16 planes, fp32 "
+                  "range) and the graph is captured again", RuntimeWarning)
+    model.matmul_precision = "split6"
+    model._wcache = {}
+    if getattr(model, "_packs", None) is not None:
+        model._packs.clear()
+    return True
 
 
 class ForceGraphs:
@@ -34,6 +95,12 @@ class ForceGraphs:
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.batches]
         self.graphs = []
         self.outputs = []
+        self.flag = RangeFlag(dev)
+        self._capture(warmup)
+
+    def _capture(self, warmup=2):
+        model, dev = self.model, self.batches[0]["R"].device
+        self.graphs, self.outputs = [], []
         model.eval()
         cur = torch.cuda.current_stream(dev)
         for inputs, st in zip(self.batches, self.streams):
@@ -46,7 +113,7 @@ class ForceGraphs:
         for inputs, st in zip(self.batches, self.streams):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
-                out = model(inputs)
+                out = model(dict(inputs, _range_flag=self.flag))
             self.graphs.append(g)
             self.outputs.append(out)
         torch.cuda.synchronize(dev)
@@ -55,7 +122,15 @@ class ForceGraphs:
         self.batches[i]["R"].detach().copy_(R)
 
     def replay(self):
-        """Enqueue one step (all sub-batches); the calling stream waits for all of them."""
+        """Enqueue one step (all sub-batches); the calling stream waits for all of them.  A non-finite result of an EARLIER
+        replay (RangeFlag, polled without synchronising) makes the model fall back to the bf16 planes and the graphs are
+        captured again before this step runs."""
+        if self.flag.tripped():
+            self.flag.trips += 1
+            torch.cuda.synchronize()
+            self.flag.reset()
+            if fall_back_to_bf16_planes(self.model, "a replayed forward+force graph (ForceGraphs)"):
+                self._capture()
         cur = torch.cuda.current_stream()
         for g, st in zip(self.graphs, self.streams):
             st.wait_stream(cur)
@@ -124,3 +199,12 @@ class DynamicForceField:
             self.runner = PaddedGraphRunner(self.model, self.Z, self.N, e_cap, t_cap, max_in_degree=self.deg, n_groups=groups)
             self.recaptures += self.runner is not r and r is not None
         return self.runner(R, idx)
+
+    def range_tripped(self):
+        """RangeFlag of the current runner (exact after the caller waited for the last replay)."""
+        return self.runner is not None and self.runner.flag.tripped()
+
+    def recover(self, R):
+        """After `range_tripped()`: fall back to the bf16 planes, capture anew, repeat the step."""
+        self.runner.recover()
+        return self(R)

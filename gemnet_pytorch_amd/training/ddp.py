@@ -107,9 +107,14 @@ class TrainStep:
         self._pinned_counts = None   # ((B_local, A_local), (B_global, A_global)) of the captured static batch
         self._use_pinned = False     # True only inside capture(): the graph replays with the counts it was captured with
         self.wgrad = None
+        self.flag = None
         if self.buf.params[0].is_cuda:
             from .wgrad_queue import WeightGradQueue
             self.wgrad = WeightGradQueue()  # all weight-gradient GEMMs of the final backward as one grouped launch
+            # device-side range check of the step (runtime.RangeFlag): the forward's energies / forces inside the captured
+            # graph, the gradient norm inside the fused optimizer (which skips a non-finite step); polled at the next call
+            from ..runtime import RangeFlag
+            self.flag = RangeFlag(self.buf.params[0].device)
 
     def _counts(self, n_mol, n_atoms, device):
         """(B_global, A_global).  Batches of a real loader vary in atom count and the last one is partial
@@ -142,6 +147,8 @@ class TrainStep:
 
     def _outputs(self, inputs):
         """(E (n_mol, targets), F (n_atoms, 3)) of the batch — a hook for subclasses that run a padded batch."""
+        if self.flag is not None:
+            inputs["_range_flag"] = self.flag
         E, F = self.model(inputs)
         if F.dim() == 3:
             F = F[:, 0]
@@ -152,11 +159,12 @@ class TrainStep:
         loss = self.loss(E, F, targets)
         self.buf.zero()
         # restrict the double backward to the parameters: no gradient w.r.t. the positions
+        from .. import ops
         if self.wgrad is None:
-            torch.autograd.backward(loss, inputs=self.buf.params)
+            with ops.exclusive():
+                torch.autograd.backward(loss, inputs=self.buf.params)
         else:
-            from .. import ops
-            with ops.wgrad_queue(self.wgrad), ops.position_second_order_grads(False):
+            with ops.exclusive(), ops.wgrad_queue(self.wgrad), ops.position_second_order_grads(False):
                 torch.autograd.backward(loss, inputs=self.buf.params)
             self.wgrad.flush()
         return loss.detach()
@@ -191,7 +199,33 @@ class TrainStep:
         finally:
             self._use_pinned = False
         self._graph_key = id(inputs)
+        self._cap_args = (inputs, targets)
         return self
+
+    def _range_check(self):
+        """Poll the range flag (no synchronisation: what completed steps left there).  Tripped: the fused optimizer has
+        skipped the non-finite step(s) on the device; warn, move the model off the fp16 planes and capture the step anew."""
+        if self.flag is None or not self.flag.tripped():
+            return False
+        from ..runtime import fall_back_to_bf16_planes
+        torch.cuda.synchronize()
+        bits = self.flag.tripped()
+        self.flag.trips += 1
+        self.flag.reset()
+        if self.fused is not None and bits & self.flag.GRAD:
+            self.fused.steps = max(0, self.fused.steps - 1)      # (at least one step was skipped on the device)
+        if fall_back_to_bf16_planes(self.model, "a training step (%s)" % ("gradient norm" if bits & self.flag.GRAD else
+                                                                          "energies / forces")):
+            if getattr(self, "_graph", None) is not None:
+                self._recapture()
+            return True
+        return False
+
+    def _recapture(self):
+        inputs, targets = self._cap_args
+        inputs.pop("_plan", None)
+        self._graph = None
+        self.capture(inputs, targets)
 
     def _eager(self, inputs, targets):
         """Eager forward/backward on a private stream: autograd ties every parameter's AccumulateGrad node to the
@@ -212,6 +246,7 @@ class TrainStep:
 
     def __call__(self, inputs, targets, step_optimizer=True):
         self.model.train()
+        self._range_check()
         if getattr(self, "_graph", None) is not None and self._graph_key == id(inputs):
             self._graph.replay()
             loss = self._graph_loss
@@ -220,7 +255,7 @@ class TrainStep:
         self.buf.all_reduce(always=self.always_reduce)
         if self.fused is not None:
             if step_optimizer:
-                self.fused.step()
+                self.fused.step(flag=self.flag)
         else:
             scale_shared_grads(self.model)
             torch.nn.utils.clip_grad_norm_(self.buf.params, max_norm=self.clip)
@@ -260,13 +295,22 @@ class PaddedTrainStep(TrainStep):
     def _local_counts(self, inputs):
         return self.pad.n_mol, self.pad.a_cap
 
+    def _recapture(self):
+        self._captured = False      # (the capture run rebuilds the index plan inside the graph: see _outputs)
+        try:
+            super()._recapture()
+        finally:
+            self._captured = True
+
     def _outputs(self, inputs):
         if not self._captured:
             # the index plan must be built INSIDE the captured region (from the static buffers, so that every replay
             # rebuilds it for the batch just written): no plan cached by an earlier eager call may survive into it.
             # The plan of the capture run itself stays in the dict — its tensors are the graph's memory.
             inputs.pop("_plan", None)
-        inputs["_guard_rows"] = (self.pad.n_mol, self.pad.A)     # range guard of the fp16-plane arithmetic: the real rows
+        # range guard of the fp16-plane arithmetic: the real molecules' rows (up to the atom CAPACITY: a later batch may hold
+        # more atoms than the one the graph is captured on; filler atoms are isolated and finite) — not the dummy molecule's
+        inputs["_guard_rows"] = (self.pad.n_mol, self.pad.a_cap)
         E, F = super()._outputs(inputs)
         return E[:self.pad.n_mol], F[:self.pad.a_cap]
 

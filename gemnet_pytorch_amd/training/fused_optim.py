@@ -59,7 +59,9 @@ class FusedAdamWEMA:
     def zero_grad(self):
         self.flat_g.zero_()
 
-    def step(self, lr=None):
+    def step(self, lr=None, flag=None):
+        """`flag` (runtime.RangeFlag, optional): a non-finite gradient norm then SKIPS the update on the device and sets the
+        flag's GRAD bit (the reference would write NaN into every parameter) — the caller polls it."""
         self.steps += 1
         cache = getattr(self._model, "_wcache", None)
         if cache:
@@ -68,7 +70,10 @@ class FusedAdamWEMA:
             ptr(self.flat_p), ptr(self.flat_g), ptr(self.gscale), ptr(self.wd), ptr(self.m), ptr(self.v),
             ptr(self.vmax), ptr(self.ema), self.n, ptr(self.partial), float(self.clip),
             float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-            int(self.steps), float(self.ema_decay), ptr(self.grad_norm), stream()), "gn_adamw_ema_step_f32")
+            int(self.steps), float(self.ema_decay), ptr(self.grad_norm), ptr(flag.word) if flag is not None else None,
+            flag.GRAD if flag is not None else 0, stream()), "gn_adamw_ema_step_f32")
+        if flag is not None:
+            flag.mirror()
 
     def ema_parameters(self):
         """Views of the averaged weights in parameter order (ExponentialMovingAverage.shadow_params)."""

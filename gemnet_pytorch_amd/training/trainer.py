@@ -258,6 +258,15 @@ class Trainer:
 
     def _train_on_batch_padded(self, ps, inputs, targets, metrics):
         loss = ps.run(inputs, targets)
+        if ps.flag is not None:
+            # the replayed graph cannot read its energies / forces back: its device-side range check (runtime.RangeFlag) is
+            # read here, BEFORE the optimizers see the gradients — an overflow of the fp16-plane arithmetic moves the model to
+            # the bf16 planes (with a warning), the step is captured anew and repeated (all ranks decide together)
+            torch.cuda.current_stream().synchronize()
+            if not self._all_ranks(not ps.flag.tripped()):
+                ps.flag.host.fill_(ps.flag.tripped() | ps.flag.OUTPUT)      # (a rank that did not trip follows the others)
+                if ps._range_check():
+                    loss = ps.run(inputs, targets)
         report = loss.detach().clone()
         if self._world() > 1:
             dist.all_reduce(report)
@@ -297,10 +306,10 @@ class Trainer:
         self._grads.zero()
         # gradients w.r.t. the parameters only: the second-order POSITION terms of the fused geometry ops are not needed
         if self._wgrad is None:
-            with ops.position_second_order_grads(False):
+            with ops.exclusive(), ops.position_second_order_grads(False):
                 torch.autograd.backward(loss, inputs=self._grads.params)
         else:
-            with ops.wgrad_queue(self._wgrad), ops.position_second_order_grads(False):
+            with ops.exclusive(), ops.wgrad_queue(self._wgrad), ops.position_second_order_grads(False):
                 torch.autograd.backward(loss, inputs=self._grads.params)
             self._wgrad.flush()
         self._grads.all_reduce()  # ONE collective (no-op in a single process)

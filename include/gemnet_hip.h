@@ -13,7 +13,9 @@
  *   - caller-owned buffers: no entry point allocates, frees or synchronises.
  *   - every launch goes to the explicit `stream` (a hipStream_t passed as void*).
  *   - return value: 0 on success, otherwise a hipError_t code (gn_error_string()).
- *   - re-entrant, no global mutable state; safe to call from the autograd worker thread.
+ *   - re-entrant, no global mutable state (since ABI 13 every arithmetic / layout switch is an ARGUMENT of the launch it
+ *     applies to; the only statics are set-once std::atomic flags of idempotent kernel attributes); safe to call
+ *     concurrently from the caller's thread and the autograd worker thread(s).
  *   - all floating tensors are fp32, row-major, contiguous unless a leading dimension is given.
  */
 #ifndef GEMNET_HIP_H
@@ -157,12 +159,15 @@ int gn_chain_f32(const gn_chain_args* args, void* stream);
  * waves x 32 output columns over row tiles of gn_chain_wide_tile_rows(M) rows (a multiple of 8, at most 48), two workgroups
  * per CU — one workgroup's epilogue / LOAD / weight wait runs under the other's MFMA phase.  Same results bit for bit. */
 #define GN_CHAIN_WIDE 0x100
+/* Per-launch tuning of the wide layout, OR-ed into `nprod` (ABI 13: until ABI 12 two process-global setters):
+ * GN_CHAIN_WIDE_ROWS(r), r a multiple of 8 in 8..48, fixes the tile height (0 = gn_chain_wide_tile_rows(M));
+ * GN_CHAIN_WIDE_STAGGER(u) starts the second workgroup of a CU u x 64 cycles late (0 = none). */
+#define GN_CHAIN_WIDE_ROWS(r) ((((r) / 8) & 0xf) << 12)
+#define GN_CHAIN_WIDE_STAGGER(u) (((u) & 0xffff) << 16)
+/* A program must start with a GN_OP_LOAD (the kernel's prologue relies on that op's barrier); else hipErrorInvalidValue. */
 int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* stream);
+/* the automatic tile height of the wide layout for M rows (a pure function) */
 int gn_chain_wide_tile_rows(int M);
-/* rows: a multiple of 8 in 8..48 fixes the tile height of the wide layout (tuning, tests); 0 restores the automatic choice */
-int gn_chain_wide_force_tile_rows(int rows);
-/* start-up offset of the second workgroup of a CU in the wide layout, in units of 64 cycles (0 = none; tuning) */
-int gn_chain_wide_set_stagger(int units_of_64_cycles);
 /* W (N,K) fp32 with row pitch ldw — or, trans != 0, the (K,N) matrix whose transpose is the weight — -> three bf16
  * planes in MFMA-fragment order; `out` holds gn_pack_weight_split_bytes(N,K) bytes (16-byte aligned). */
 int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void* out, void* stream);
@@ -238,19 +243,19 @@ int gn_quad_angles_fwd_f32(const float* R, const int32_t* qc, const int32_t* qa,
 int gn_quad_angles_bwd_ld_f32(const float* g_ang, const float* R, const int32_t* qc, const int32_t* qa, const int32_t* qb,
                               const int32_t* qd, float* Gc, int ldc, float* Gb, int ldb, float* Gd, int ldd, int64_t Q,
                               void* stream);
+/* `arith` of the three kernels below: GN_ANG_F16 = both MFMA operands split in registers into two fp16 planes, three
+ * v_mfma_f32_16x16x32_f16 products, fp32 accumulation (cotangent blocks under one exact power-of-two scale per edge, lo planes
+ * scaled by 2^11 with accumulators of their own); 0 = the f32-input MFMA (same results to fp32 rounding).  K1 takes x as it
+ * is: with GN_ANG_F16 |x| must stay below 65 504 — the host passes 0 for models that left the fp16-plane Dense arithmetic and
+ * for operands whose magnitude follows the caller's loss (kernels.bil_reduce_project).  Per call: no library state (ABI 13). */
+#define GN_ANG_F16 1
 /* K1 + K2 of the bilinear layer as gn_bil_reduce_project_f32, Y given as angles */
 int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
-                                  const float* B, float* Sm, float* P, int64_t E, int S, int C, int I, void* stream);
-/* Matrix-pipe arithmetic of the angle-form kernels, bit mask (default 7): bit 0 = K1 of gn_bil_reduce_project_ang_f32, bit 1 =
- * the contraction of gn_bil_dy_multi_ang_f32, bit 2 = gn_bil_expand_ang_f32 with both operands split in registers into two
- * fp16 planes, three v_mfma_f32_16x16x32_f16 products, fp32 accumulation (cotangent blocks under one exact power-of-two
- * scale per edge, lo planes scaled by 2^11 with accumulators of their own); a cleared bit = the f32-input MFMA (same results
- * to fp32 rounding).  K1 (bit 0) takes x as it is: fp16 range, |x| < 65 504 — the host clears the bit for models that left the
- * fp16-plane Dense arithmetic (kernels.bil_reduce_project).  Returns the previous mask; mask < 0 only queries. */
-int gn_bil_ang_set_f16(int mask);
+                                  const float* B, float* Sm, float* P, int64_t E, int S, int C, int I, int arith,
+                                  void* stream);
 /* per-quadruplet x-adjoint rows as gn_bil_expand_f32, Y given as angles */
 int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,
-                          void* stream);
+                          int arith, void* stream);
 /* The same x-adjoint SUMMED over the expand rows, without the per-quadruplet rows in memory: dx[j] = sum_{q: g(q) = j}
  * Y[q] dSm[r(q)].  Needs the quadruplet structure of GemNet (data_container.py:331-397): reduce edge and expand row of a
  * quadruplet end in the same target atom, and the expand rows (intermediate triplets) are sorted by that atom —
@@ -265,7 +270,7 @@ int gn_bil_expand_atoms_ang_f32(const float* ang, const float* dSm, const int32_
 /* gradient w.r.t. the two angles of all nb <= 4 blocks sharing the basis (gn_bil_dy_multi_f32 contracted with dY/d angle) */
 int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float* const* x_list, int nb, const float* ang,
                             const int32_t* expand_idx, const int32_t* seg_off, float* g_ang, int64_t E, int S, int C,
-                            void* stream);
+                            int arith, void* stream);
 
 /* batched small matmul C[b] = opA(A[b]) opB(B[b]), b < batch; row-major (m,k)/(k,n) blocks.
  * Replaces torch.matmul(rbf_W1, sum_k) and its adjoints (efficient.py:177-182). */
@@ -494,11 +499,24 @@ int gn_dact_mul_f32(const float* g, const float* z, int act, const float* mul, f
  * flat fp32 parameter buffer in two launches.  gscale[i]: gradient rescale (1/num_blocks for shared projections);
  * wd[i]: decoupled weight decay of the element's group (0 = plain Adam).  `partial`: caller-owned workspace of
  * gn_optim_blocks(n) doubles.  ema may be NULL.  norm_out (device float, optional) <- pre-clip global gradient norm.
- * step >= 1 is the Adam step count (bias correction computed on the host in fp32 like torch.optim). */
+ * step >= 1 is the Adam step count (bias correction computed on the host in fp32 like torch.optim).
+ * `flag` (device int32, optional; ABI 13): with it a step whose global gradient norm is NOT FINITE leaves p, m, v, vmax and ema
+ * untouched and sets flag[0] |= flag_bit (the reference would write NaN into every parameter, trainer.py:353-358; here the
+ * caller polls the word, warns and — when the fp16-plane arithmetic overflowed — falls back and repeats).  NULL: the
+ * reference's behaviour. */
 int gn_optim_blocks(int64_t n);
 int gn_adamw_ema_step_f32(float* p, const float* g, const float* gscale, const float* wd, float* m, float* v,
                           float* vmax, float* ema, int64_t n, double* partial, float max_norm, float lr, float beta1,
-                          float beta2, float eps, int step, float ema_decay, float* norm_out, void* stream);
+                          float beta2, float eps, int step, float ema_decay, float* norm_out, int32_t* flag, int flag_bit,
+                          void* stream);
+
+/* ---- range check of replayed graphs (ABI 13) -------------------------------------------------------------------------
+ * flag[0] |= bit when x[0 .. n) holds an inf or a NaN.  The default Dense arithmetic keeps activations in two fp16 planes
+ * (GN_CHAIN_F16X2: beyond 65 504 -> inf, which propagates to the energies and forces); the reference's fp32 has no such
+ * cliff (base_layers.py:44-48).  An eager forward reads its outputs back; a captured hipGraph (MD loop, padded batches, the
+ * training step) cannot: it ends with this launch on its energies and forces plus a copy of the word to pinned host memory,
+ * and the host polls that copy without synchronising (runtime.RangeFlag).  The word is sticky until the host clears it. */
+int gn_nonfinite_flag_f32(const float* x, int64_t n, int32_t* flag, int bit, void* stream);
 
 #ifdef __cplusplus
 }

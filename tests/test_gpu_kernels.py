@@ -459,10 +459,8 @@ def test_wide_chain_layout_equals_tall_layout_bitwise(M, width, tile_rows):
     csrc/chain2.hip (8 waves x 16 columns): the same products accumulated in the same order — every output bit for bit, for
     forward stacks (activations, gathered adds, pre-activation / stored-derivative outputs) and first-order adjoint programs
     (row scales, second outputs), ragged last tiles and half-used MFMA row blocks included."""
-    from gemnet_pytorch_amd import _lib
-    lib = _lib.load()
     checked = 0
-    default_layout = K.CHAIN_LAYOUT
+    default_layout, default_rows = K.CHAIN_LAYOUT, K.WIDE_TILE_ROWS
     try:
         import functools
         for maker in (functools.partial(_stack_programs, park=False), functools.partial(_adjoint_programs, park=False),
@@ -475,7 +473,7 @@ def test_wide_chain_layout_equals_tall_layout_bitwise(M, width, tile_rows):
                 if K.h3_hazards(p_dev):
                     break
                 K.CHAIN_LAYOUT = layout
-                assert lib.gn_chain_wide_force_tile_rows(tile_rows if layout == "wide" else 0) == 0
+                K.WIDE_TILE_ROWS = tile_rows if layout == "wide" else 0     # GN_CHAIN_WIDE_ROWS bits of this launch's `nprod`
                 K.chain(p_dev, mode="h3")
                 torch.cuda.synchronize()
                 outs[layout] = o_dev
@@ -484,8 +482,7 @@ def test_wide_chain_layout_equals_tall_layout_bitwise(M, width, tile_rows):
                     assert torch.equal(outs["tall"][k], outs["wide"][k]), (k, tile_rows)
                     checked += 1
     finally:
-        K.CHAIN_LAYOUT = default_layout
-        lib.gn_chain_wide_force_tile_rows(0)
+        K.CHAIN_LAYOUT, K.WIDE_TILE_ROWS = default_layout, default_rows
     assert checked >= 10
 
 
@@ -970,13 +967,11 @@ def test_gemm_accumulates_in_place():
 
 
 @pytest.fixture(params=[7, 5, 0], ids=["f16-all (default)", "f16-K1+expand", "f32-mfma"])
-def ang_arithmetic(request):
-    """gn_bil_ang_set_f16: which of the angle-form kernels run their products on the fp16 matrix pipe (split operands)."""
-    from gemnet_pytorch_amd import _lib
-    lib = _lib.load()
-    lib.gn_bil_ang_set_f16(request.param)
+def ang_arithmetic(request, monkeypatch):
+    """kernels.ANG_F16_MASK: which of the angle-form kernels get `arith = GN_ANG_F16` (products on the fp16 matrix pipe with
+    split operands) — an argument of each launch since ABI 13."""
+    monkeypatch.setattr(K, "ANG_F16_MASK", request.param)
     yield request.param
-    lib.gn_bil_ang_set_f16(7)
 
 
 @pytest.mark.parametrize("E,J,mk", [(60, 300, 80), (9, 40, 700), (33, 120, 3)])
@@ -1027,6 +1022,7 @@ def test_fused_per_atom_x_adjoint_of_the_tensor_basis(n_mol, n_atoms, monkeypatc
     ds = make_dataset(n_mol, n_atoms, config=2)
     b = DataContainer.from_arrays(dict(ds), 5.0, 10.0, triplets_only=False)[list(range(n_mol))]
     inputs = {k: v for k, v in b.items() if k not in ("E", "F")}
+    monkeypatch.setattr(K, "USE_ATOM_BLOCKS", True)      # (the plan only builds the per-atom structure for its one consumer)
     cpu = GraphPlan.from_inputs(dict(inputs), False).quad
     dev_plan = GraphPlan.from_inputs({k: v.to(DEV) for k, v in inputs.items()}, False).warm()
     dev = dev_plan.quad

@@ -104,7 +104,7 @@ def test_matmul_arithmetic_modes(golden_model2, tag, mode, bar, monkeypatch):
     from gemnet_pytorch_amd import kernels as K
     g = golden_model2
     cfg, params, inputs = load_case(g, tag)
-    monkeypatch.setattr(K, "CHAIN_MODE", mode)
+    monkeypatch.setattr(K, "DEFAULT_CHAIN_MODE", mode)
     model = build(cfg, params).eval()
     E, F = model(to_dev(inputs))
     f_mae = float(np.abs(F.detach().cpu().numpy() - g[f"{tag}.F"]).mean())
@@ -123,7 +123,7 @@ def test_fp16_plane_overflow_falls_back_to_bf16_planes(golden_model2, train, mon
     bf16 planes hold without trouble — must not return inf / nan silently: the eager forward notices, switches this model to "split6", warns, and returns what a split6 model returns."""
     from gemnet_pytorch_amd import kernels as K
     cfg, params, inputs = load_case(golden_model2, "t4s")
-    monkeypatch.setattr(K, "CHAIN_MODE", "h3")
+    monkeypatch.setattr(K, "DEFAULT_CHAIN_MODE", "h3")
 
     def blown(model):
         blk = model.int_blocks[1]
@@ -255,7 +255,7 @@ def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch, mode, e_ba
     energy of this unscaled fixture, |E| = 0.87, moves by 2.3e-5 — the force bar is the same for both)."""
     from gemnet_pytorch_amd import kernels as K
     from gemnet_pytorch_amd import ops
-    monkeypatch.setattr(K, "CHAIN_MODE", mode)
+    monkeypatch.setattr(K, "DEFAULT_CHAIN_MODE", mode)
     cfg, params, inputs = load_case(golden_model, "t2")
     model = build(cfg, params).eval()
     dev = to_dev(inputs)

@@ -42,11 +42,9 @@ for sig, ps in groups.items():
     t = {}
     for label, mode, layout, rows in COLS:
         K.CHAIN_LAYOUT = layout
-        lib.gn_chain_wide_force_tile_rows(max(rows, 0))
-        lib.gn_chain_wide_set_stagger(max(-rows, 0))
+        K.WIDE_TILE_ROWS, K.WIDE_STAGGER = max(rows, 0), max(-rows, 0)      # bits of this launch's `nprod` (ABI 13)
         t[label] = timeit(lambda: orig(ps[0], mode), iters=100)
         tot[label] += t[label] * len(ps)
     print(f"{sig[0]:6d} {len(ps):3d} " + " ".join(f"{t[c[0]]:9.1f}" for c in COLS) + f"  {'P' if uses_park(ps[0]) else '-':>4s}  {sig[1]}")
-lib.gn_chain_wide_force_tile_rows(0)
-lib.gn_chain_wide_set_stagger(0)
+K.WIDE_TILE_ROWS = K.WIDE_STAGGER = 0
 print("total per step:", {k: round(v, 1) for k, v in tot.items()}, "us;", len(progs), "launches")

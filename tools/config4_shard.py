@@ -56,7 +56,7 @@ for mode in (None, "bf16"):
         E, F = model(inputs)
     torch.cuda.synchronize()
     res[mode or "default"] = dict(ms_per_step=(time.perf_counter() - t1) / steps * 1e3, E=E.detach().clone(), F=F.detach().clone())
-    print(f"[config4] {mode or K.CHAIN_MODE + ' (default)'}: {res[mode or 'default']['ms_per_step']:.1f} ms/step (eager), "
+    print(f"[config4] {mode or K.DEFAULT_CHAIN_MODE + ' (default)'}: {res[mode or 'default']['ms_per_step']:.1f} ms/step (eager), "
           f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 ref, b = res["default"], res["bf16"]
 out = dict(config="GemNet-Q, %d molecules x %d atoms, forward+force, 1 GPU (shard of BASELINE configs[4])" % (n_mol, n_atoms),
@@ -68,6 +68,6 @@ out = dict(config="GemNet-Q, %d molecules x %d atoms, forward+force, 1 GPU (shar
                                 energy_max_abs=float((b["E"] - ref["E"]).abs().max()),
                                 max_abs_energy=float(ref["E"].abs().max())),
            peak_memory_gib=round(torch.cuda.max_memory_allocated() / 2**30, 1),
-           note="bf16 = Dense stacks with bf16 MFMA operands, fp32 accumulate; default = kernels.CHAIN_MODE (two fp16 planes, three products). "
+           note="bf16 = Dense stacks with bf16 MFMA operands, fp32 accumulate; default = kernels.DEFAULT_CHAIN_MODE (two fp16 planes, three products). "
                 "The default run itself is covered by the golden / property tests; forces scaled to mean|F| = 1 eV/A.")
 print(json.dumps(out))
