@@ -26,6 +26,10 @@ from test_gpu_fullsize import FULL
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# replays per configuration of the bitwise "replay == eager" checks: the packed-FP32 finding of round 4 showed up in 40-90 % of
+# the replays of the configurations below, so 200 clean replays each are the standing evidence that no kernel family of the
+# library is a victim of the co-run hazard (build policy: __graft_entry__.PACKED_OK)
+REPLAYS = 200
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -69,7 +73,7 @@ def test_captured_forward_force_has_no_unordered_conflict_and_replays_bitwise(ki
         with hbcheck.record() as rec:
             Eg, Fg = model(inputs)
     assert_clean(rec, min_streams=2)        # the side stream is really in use (quadruplet models included)
-    for _ in range(10):
+    for _ in range(REPLAYS):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(Eg, E0) and torch.equal(Fg, F0)
@@ -88,7 +92,7 @@ def test_captured_training_step_has_no_unordered_conflict_and_replays_bitwise():
     ref = ts.buf.flat.clone()
     ts.capture(inputs, targets, check=True)
     assert_clean(ts.hb, min_streams=2)      # output blocks of the training step on the side stream again
-    for _ in range(6):
+    for _ in range(REPLAYS):
         ts(inputs, targets, step_optimizer=False)
         torch.cuda.synchronize()
         assert torch.equal(ts.buf.flat, ref)
@@ -96,9 +100,9 @@ def test_captured_training_step_has_no_unordered_conflict_and_replays_bitwise():
 
 def test_aggregation_kernels_stay_exact_next_to_chain_kernels_of_another_graph_branch():
     for mode in ("h3", "split6"):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp", "graph_corun.py"), mode, "40"],
-                             capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp", "graph_corun.py"), mode, str(REPLAYS)],
+                             capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
         print(out.stdout)
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [ln for ln in out.stdout.splitlines() if "branch" in ln]
-        assert len(lines) == 2 and all("differ in 0/40 replays, aggregation outputs in 0/40" in ln for ln in lines), lines
+        assert len(lines) == 2 and all(f"differ in 0/{REPLAYS} replays, aggregation outputs in 0/{REPLAYS}" in ln for ln in lines), lines
