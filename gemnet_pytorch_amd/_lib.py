@@ -96,6 +96,9 @@ SIGNATURES = {
     "gn_bil_expand_ang_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_expand_atoms_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_dy_multi_ang_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "gn_quad_angles_jvp_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "gn_bil_reduce_project_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "gn_bil_expand_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_gather_mul_f32": [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "gn_dist_fwd_f32": [_vp, _vp, _vp, _vp, _i64, _vp],

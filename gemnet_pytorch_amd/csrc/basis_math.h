@@ -301,8 +301,9 @@ GN_HD double ylm_dot(double theta, double ph, int S, int kt, int kp, const float
 // 10 k cycles per 64 quadruplets on gfx950.  The bilinear kernels that rebuild the tensor basis on the fly
 // (csrc/bilinear_ang.hip) evaluate a row per quadruplet per pass, so they use these fully unrolled forms in f32:
 // ~200 FMAs per row; deviation from the f64 row <= 2e-6 of the largest component (tests/test_host_math.py).
-template <typename T>
-GN_HD void ylm7_row_T(T sn, T cs, T s1, T c1, float* o) {
+// emit(slot, value of type T) for the 49 harmonics in the reference order
+template <typename T, typename F>
+GN_HD void ylm7_visit_T(T sn, T cs, T s1, T c1, F emit) {
   constexpr int L = 7;
   T cm[L], sm[L];
   cm[0] = T(1); sm[0] = T(0);
@@ -325,13 +326,43 @@ GN_HD void ylm7_row_T(T sn, T cs, T s1, T c1, float* o) {
       if (l > m) { qb = qa; qa = ql; }
       const T tv = ql * T((m == 0 ? 1.0 : 1.4142135623730951) * ylm_prefactor_tab(l, m));
       if (m == 0) {
-        o[l * l] = (float)tv;
+        emit(l * l, tv);
       } else {
-        o[l * l + m] = (float)(tv * cm[m]);
-        o[l * l + 2 * l + 1 - m] = (float)(tv * sm[m]);
+        emit(l * l + m, tv * cm[m]);
+        emit(l * l + 2 * l + 1 - m, tv * sm[m]);
       }
     }
   }
+}
+
+template <typename T>
+GN_HD void ylm7_row_T(T sn, T cs, T s1, T c1, float* o) {
+  ylm7_visit_T<T>(sn, cs, s1, c1, [o](int slot, T v) { o[slot] = (float)v; });
+}
+
+// First-order dual number in f32: value + one directional derivative.  ylm7_visit_T<DualF> with
+//   sn = (sin th, cos th * dth), cs = (cos th, -sin th * dth), s1 = (sin ph, cos ph * dph), c1 = (cos ph, -sin ph * dph)
+// yields every Y_j together with its TANGENT  dY_j = dY_j/dth * dth + dY_j/dph * dph  — the rows the second-order sweeps of
+// force training contract with (trainer.py:346 through basis_layers.py:239-295: the tangent of the tensor basis along the
+// position tangent u = dL/dF), at about twice the cost of the plain row and without a hand-derived derivative table.
+struct DualF {
+  float v, d;
+  GN_HD DualF() : v(0.f), d(0.f) {}
+  GN_HD DualF(float v_, float d_) : v(v_), d(d_) {}
+  GN_HD explicit DualF(double c) : v((float)c), d(0.f) {}
+  GN_HD explicit DualF(int c) : v((float)c), d(0.f) {}
+};
+GN_HD DualF operator+(DualF a, DualF b) { return DualF(a.v + b.v, a.d + b.d); }
+GN_HD DualF operator-(DualF a, DualF b) { return DualF(a.v - b.v, a.d - b.d); }
+GN_HD DualF operator*(DualF a, DualF b) { return DualF(a.v * b.v, a.d * b.v + a.v * b.d); }
+
+// o_val[j] = Y_j, o_tan[j] = dY_j (either may be null) for the tangent (dth, dph) of the two angles
+GN_HD void ylm7_row_tangent(float sn, float cs, float s1, float c1, float dth, float dph, float* o_val, float* o_tan) {
+  ylm7_visit_T<DualF>(DualF(sn, cs * dth), DualF(cs, -sn * dth), DualF(s1, c1 * dph), DualF(c1, -s1 * dph),
+                      [o_val, o_tan](int slot, DualF y) {
+                        if (o_val) o_val[slot] = y.v;
+                        if (o_tan) o_tan[slot] = y.d;
+                      });
 }
 
 // g_theta = sum_j g[j] dY_j/dtheta, g_phi = sum_j g[j] dY_j/dphi for the 49 harmonics of S = 7 (ylm_dot_grad_sc in T)

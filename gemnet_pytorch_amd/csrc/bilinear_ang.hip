@@ -623,6 +623,207 @@ __global__ __launch_bounds__(256) void bil_dy_multi_ang_kernel(const gn_dy_ang_a
   }
 }
 
+// ---- second-order sweeps of GemNet-Q force training: TANGENT rows ------------------------------------------------------
+// `loss.backward()` through the force (trainer.py:338-346) differentiates the first adjoint of the quadruplet bilinear layer
+// (interaction_block.py:517-566, efficient.py:159-189) once more.  With the basis in angle form the tangent of Y along the
+// position tangent u = dL/dF is  dY[q] = Y_theta[q] dtheta[q] + Y_phi[q] dphi[q]  — rebuilt per quadruplet with dual numbers
+// through the same unrolled recurrences (basis_math.h: ylm7_row_tangent), 32 B per quadruplet (angles + their tangents)
+// instead of two (Q, 49) arrays.  Both kernels run the f32-input MFMA: tangents carry the scale of the caller's loss (no
+// fp16 range), and they are 2 of the ~11 quadruplet passes of a training step.
+//   S3   Smd[e] = sum_{q in seg(e)} ( dY[q] (x) x[g(q)] + Y[q] (x) tx[g(q)] );   Pd[e] = B[e]^T Smd[e] + tB[e]^T Sm[e]
+//   S4   dxt[q] = Y[q] D1[e] + dY[q] D2[e]          (x-adjoint rows: D1 = the second adjoint of Sm, D2 = mu_Sm of the first)
+template <bool HAS_T, bool HAS_TX>
+__global__ __launch_bounds__(256) void bil_reduce_project_ang_tan_kernel(
+    const float4* __restrict__ ang, const float4* __restrict__ tang, const float* __restrict__ x, const float* __restrict__ tx,
+    const int32_t* __restrict__ expand_idx, const int32_t* __restrict__ seg_off, const float* __restrict__ B,
+    const float* __restrict__ tB, const float* __restrict__ Sm, float* __restrict__ Smd, float* __restrict__ Pd, int64_t E) {
+  constexpr int TQ = 32, LD = C + 4;
+  constexpr int YSZ = (TQ * LDY > 52 * LD) ? TQ * LDY : 52 * LD;
+  __shared__ __attribute__((aligned(16))) float ysm[4][YSZ];   // Y rows of one tile; later Smd[52][LD] of the edge
+  __shared__ __attribute__((aligned(16))) float ytm[4][HAS_T ? TQ * LDY : 1];   // dY rows of the tile
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  float* __restrict__ ys = ysm[wave];
+  float* __restrict__ yt = ytm[wave];
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  v4f_a acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+  for (int tb = t0; tb < t1; tb += TQ) {
+    const int nq = min(TQ, t1 - tb);
+    int gq = 0;
+    if (lane < nq) {
+      gq = expand_idx[tb + lane];
+      const float4 a4 = ang[tb + lane];
+      if constexpr (HAS_T) {
+        const float4 t4 = tang[tb + lane];
+        ylm7_row_tangent(a4.x, a4.y, a4.z, a4.w, t4.x, t4.y, HAS_TX ? ys + lane * LDY : nullptr, yt + lane * LDY);
+      } else {
+        ylm7_row_T<float>(a4.x, a4.y, a4.z, a4.w, ys + lane * LDY);
+      }
+    }
+    wave_lds_sync();
+    for (int k = 0; k < nq; k += 4) {       // K-steps of 4 quadruplets: lane (l15, lg) supplies row q = k + lg
+      const int q = k + lg;
+      const bool ok = q < nq;
+      const int64_t row = (int64_t)__shfl(gq, min(q, nq - 1), 64) * C + l15;
+      float b[2] = {0.f, 0.f}, bt[2] = {0.f, 0.f};
+      if constexpr (HAS_T) { const float v0 = x[row], v1 = x[row + 16]; b[0] = ok ? v0 : 0.f; b[1] = ok ? v1 : 0.f; }
+      if constexpr (HAS_TX) { const float v0 = tx[row], v1 = tx[row + 16]; bt[0] = ok ? v0 : 0.f; bt[1] = ok ? v1 : 0.f; }
+      const int qr = min(q, nq - 1) * LDY;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int sc = mt < 3 ? 16 * mt + l15 : 48;
+        if constexpr (HAS_T) {
+          const float a = ok ? yt[qr + sc] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if constexpr (HAS_TX) {
+          const float a = ok ? ys[qr + sc] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bt[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+  // D layout: col = l15 (c within tile), row = 4 lg + r (s within tile).  Tile mt = 3 was fed s = 48 in EVERY row: only its
+  // row 0 (s = 48) is meaningful
+  float* __restrict__ so = Smd + e * (int64_t)S * C;
+  float (*sml)[LD] = reinterpret_cast<float (*)[LD]>(ys);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int srow = 16 * mt + 4 * lg + r;
+        const float v = acc[mt][nt][r];
+        if (srow < S) so[srow * C + 16 * nt + l15] = v;
+        if (srow < 52) sml[srow][16 * nt + l15] = srow < S ? v : 0.f;
+      }
+  wave_lds_sync();
+  if (!Pd) return;
+  // K2: Pd[i, c] = sum_s B[e, s, i] Smd[s, c] + sum_s tB[e, s, i] Sm[e, s, c]
+  v4f_a pacc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) pacc[mt][nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ be = B + e * (int64_t)S * I;
+#pragma unroll
+  for (int kk = 0; kk < 13; ++kk) {
+    const int sk = 4 * kk + lg;
+    const bool ok = sk < S;
+    const float a_0 = ok ? be[min(sk, S - 1) * I + l15] : 0.f;
+    const float a_1 = ok ? be[min(sk, S - 1) * I + 16 + l15] : 0.f;
+    const float b_0 = sml[sk][l15];
+    const float b_1 = sml[sk][16 + l15];
+    pacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_0, pacc[0][0], 0, 0, 0);
+    pacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_1, pacc[0][1], 0, 0, 0);
+    pacc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_0, pacc[1][0], 0, 0, 0);
+    pacc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_1, pacc[1][1], 0, 0, 0);
+  }
+  if (tB) {
+    const float* __restrict__ tbe = tB + e * (int64_t)S * I;
+    const float* __restrict__ sme = Sm + e * (int64_t)S * C;
+#pragma unroll
+    for (int kk = 0; kk < 13; ++kk) {
+      const int sk = 4 * kk + lg;
+      const bool ok = sk < S;
+      const int sr = min(sk, S - 1);
+      const float a_0 = ok ? tbe[sr * I + l15] : 0.f;
+      const float a_1 = ok ? tbe[sr * I + 16 + l15] : 0.f;
+      const float b_0 = ok ? sme[sr * C + l15] : 0.f;
+      const float b_1 = ok ? sme[sr * C + 16 + l15] : 0.f;
+      pacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_0, pacc[0][0], 0, 0, 0);
+      pacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, b_1, pacc[0][1], 0, 0, 0);
+      pacc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_0, pacc[1][0], 0, 0, 0);
+      pacc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_1, b_1, pacc[1][1], 0, 0, 0);
+    }
+  }
+  float* __restrict__ po = Pd + e * (int64_t)I * C;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) po[(16 * mt + 4 * lg + r) * C + 16 * nt + l15] = pacc[mt][nt][r];
+}
+
+template <bool HAS_D1>
+__global__ __launch_bounds__(256) void bil_expand_ang_tan_kernel(const float4* __restrict__ ang, const float4* __restrict__ tang,
+                                                                 const float* __restrict__ D1, const float* __restrict__ D2,
+                                                                 const int32_t* __restrict__ seg_off, float* __restrict__ dxt,
+                                                                 int64_t E) {
+  constexpr int TQ = 32;
+  __shared__ float ysm[4][HAS_D1 ? TQ * LDY : 1];
+  __shared__ float ytm[4][TQ * LDY];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  float* __restrict__ ys = ysm[wave];
+  float* __restrict__ yt = ytm[wave];
+  const int t0 = seg_off[e], t1 = seg_off[e + 1];
+  float b1[13][2], b2[13][2];   // D1 / D2 [e][4 kk + lg][16 nt + l15]
+#pragma unroll
+  for (int kk = 0; kk < 13; ++kk) {
+    const int sr = 4 * kk + lg;
+    const int64_t off = e * (int64_t)S * C + min(sr, S - 1) * C + l15;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float v2 = D2[off + 16 * nt];
+      b2[kk][nt] = sr < S ? v2 : 0.f;
+      if constexpr (HAS_D1) {
+        const float v1 = D1[off + 16 * nt];
+        b1[kk][nt] = sr < S ? v1 : 0.f;
+      }
+    }
+  }
+  for (int tb = t0; tb < t1; tb += TQ) {
+    const int nq = min(TQ, t1 - tb);
+    if (lane < nq) {
+      const float4 a4 = ang[tb + lane], t4 = tang[tb + lane];
+      ylm7_row_tangent(a4.x, a4.y, a4.z, a4.w, t4.x, t4.y, HAS_D1 ? ys + lane * LDY : nullptr, yt + lane * LDY);
+    }
+    wave_lds_sync();
+    for (int sub = 0; sub < nq; sub += 16) {   // row tiles of 16 quadruplets: lane (l15, lg) <- rows [sub + l15][4 kk + lg]
+      const int qr = min(sub + l15, nq - 1) * LDY + lg;
+      v4f_a c0 = (v4f_a){0.f, 0.f, 0.f, 0.f}, c1 = (v4f_a){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 13; ++kk) {
+        const bool s_ok = kk < 12 || lg == 0;
+        const float tv = yt[qr + (kk < 12 ? 4 * kk : 48 - lg)];     // (kk = 12: only s = 48 exists; lanes lg > 0 feed zero)
+        const float at = s_ok ? tv : 0.f;
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at, b2[kk][0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(at, b2[kk][1], c1, 0, 0, 0);
+        if constexpr (HAS_D1) {
+          const float yv = ys[qr + (kk < 12 ? 4 * kk : 48 - lg)];
+          const float a = s_ok ? yv : 0.f;
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[kk][0], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[kk][1], c1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = sub + 4 * lg + r;
+        if (q < nq) {
+          float* __restrict__ o = dxt + (int64_t)(tb + q) * C + l15;
+          o[0] = c0[r];
+          o[16] = c1[r];
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -704,6 +905,46 @@ extern "C" int gn_bil_dy_multi_ang_f32(const float* const* dSm_list, const float
   else
     hipLaunchKernelGGL(bil_dy_multi_ang_kernel<false>, dim3((unsigned)E), dim3(256), smem, static_cast<hipStream_t>(stream), a,
                        reinterpret_cast<const float4*>(ang), expand_idx, seg_off, reinterpret_cast<float4*>(g_ang), E);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_reduce_project_ang_tan_f32(const float* ang, const float* tang, const float* x, const float* tx,
+                                                 const int32_t* expand_idx, const int32_t* seg_off, const float* B,
+                                                 const float* tB, const float* Sm, float* Smd, float* Pd, int64_t E, int S_,
+                                                 int C_, int I_, void* stream) {
+  if (E <= 0) return 0;
+  if (S_ != S || C_ != C || I_ != I || !aligned16(ang) || (tang && !aligned16(tang))) return (int)hipErrorInvalidValue;
+  if ((!tang && !tx) || (tang && !x) || !Smd || (tB && !Sm)) return (int)hipErrorInvalidValue;
+  const dim3 grid(gn_cdiv(E, 4)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float4* a4 = reinterpret_cast<const float4*>(ang);
+  const float4* t4 = reinterpret_cast<const float4*>(tang);
+  if (tang && tx)
+    hipLaunchKernelGGL((bil_reduce_project_ang_tan_kernel<true, true>), grid, block, 0, st, a4, t4, x, tx, expand_idx, seg_off, B,
+                       tB, Sm, Smd, Pd, E);
+  else if (tang)
+    hipLaunchKernelGGL((bil_reduce_project_ang_tan_kernel<true, false>), grid, block, 0, st, a4, t4, x, tx, expand_idx, seg_off,
+                       B, tB, Sm, Smd, Pd, E);
+  else
+    hipLaunchKernelGGL((bil_reduce_project_ang_tan_kernel<false, true>), grid, block, 0, st, a4, t4, x, tx, expand_idx, seg_off,
+                       B, tB, Sm, Smd, Pd, E);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_expand_ang_tan_f32(const float* ang, const float* tang, const float* D1, const float* D2,
+                                         const int32_t* seg_off, float* dxt, int64_t E, int S_, int C_, void* stream) {
+  if (E <= 0) return 0;
+  if (S_ != S || C_ != C || !aligned16(ang) || !tang || !aligned16(tang) || !D2) return (int)hipErrorInvalidValue;
+  const dim3 grid(gn_cdiv(E, 4)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (D1)
+    hipLaunchKernelGGL(bil_expand_ang_tan_kernel<true>, grid, block, 0, st, reinterpret_cast<const float4*>(ang),
+                       reinterpret_cast<const float4*>(tang), D1, D2, seg_off, dxt, E);
+  else
+    hipLaunchKernelGGL(bil_expand_ang_tan_kernel<false>, grid, block, 0, st, reinterpret_cast<const float4*>(ang),
+                       reinterpret_cast<const float4*>(tang), D1, D2, seg_off, dxt, E);
   GN_LAUNCH_CHECK();
   return 0;
 }

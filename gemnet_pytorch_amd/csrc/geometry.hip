@@ -306,6 +306,33 @@ __global__ __launch_bounds__(256) void quad_angles_bwd_kernel(const float4* __re
   }
 }
 
+// Tangent pass of the angle form (the double backward of quad_angles_bwd_kernel under trainer.py:346): for a position tangent
+// tR (A,3) — the cotangent dL/dF of the force — tang[q] = (dPhi_cab . tR, dTheta_cabd . tR, 0, 0): the directional derivatives
+// of the two angles, i.e. the gradient of  sum_q <G(q), tR>  w.r.t. the incoming g_ang.  Formed from the SAME closed-form
+// adjoints as the first-order kernel (unit cotangents), so first adjoint and tangent agree to rounding.
+__global__ __launch_bounds__(256) void quad_angles_jvp_kernel(const float* __restrict__ R, const float* __restrict__ tR,
+                                                              const int32_t* __restrict__ qc, const int32_t* __restrict__ qa,
+                                                              const int32_t* __restrict__ qb, const int32_t* __restrict__ qd,
+                                                              float4* __restrict__ tang, int64_t Q) {
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < Q; q += (int64_t)gridDim.x * 256) {
+    const int64_t ia = qa[q], ib = qb[q], ic = qc[q], id = qd[q];
+    const V3 Ra = v3(R + 3 * ia), Rb = v3(R + 3 * ib);
+    const V3 uac = v3(R + 3 * ic) - Ra, uab = Rb - Ra, ubd = v3(R + 3 * id) - Rb;
+    const V3 uba = (-1.0f) * uab;
+    const V3 ta = v3(tR + 3 * ia), tb = v3(tR + 3 * ib);
+    const V3 dac = v3(tR + 3 * ic) - ta, dab = tb - ta, dbd = v3(tR + 3 * id) - tb;
+    const V3 p1 = reject(uac, uab), p2 = reject(ubd, uba);
+    V3 g_ab, g_ac, gp1, gp2, t1, t2, g_bd, g_ba;
+    angle_uv_bwd(uab, uac, 1.0f, g_ab, g_ac);
+    const float dphi = dot(g_ab, dab) + dot(g_ac, dac);
+    angle_uv_bwd(p1, p2, 1.0f, gp1, gp2);
+    reject_bwd(uac, uab, gp1, t1, t2);      // d p1 / d(uac, uab)
+    reject_bwd(ubd, uba, gp2, g_bd, g_ba);  // d p2 / d(ubd, uba);  d uba = -d uab
+    const float dth = dot(t1, dac) + dot(t2, dab) + dot(g_bd, dbd) - dot(g_ba, dab);
+    tang[q] = make_float4(dphi, dth, 0.f, 0.f);
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -401,6 +428,16 @@ extern "C" int gn_quad_angles_bwd_ld_f32(const float* g_ang, const float* R, con
   if (ldc < 3 || ldb < 3 || ldd < 3) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(quad_angles_bwd_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4*>(g_ang), R, qc, qa, qb, qd, Gc, Gb, Gd, Q, ldc, ldb, ldd);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_quad_angles_jvp_f32(const float* R, const float* tR, const int32_t* qc, const int32_t* qa, const int32_t* qb,
+                                      const int32_t* qd, float* tang, int64_t Q, void* stream) {
+  if (Q <= 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(tang) & 15u) != 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(quad_angles_jvp_kernel, dim3(grid_for(Q)), dim3(256), 0, static_cast<hipStream_t>(stream), R, tR, qc, qa,
+                     qb, qd, reinterpret_cast<float4*>(tang), Q);
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -1116,6 +1116,57 @@ def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
     return Gc, Gb, Gd
 
 
+def quad_angles_jvp(R, tR, qc, qa, qb, qd):
+    """tang (Q,4) = (dPhi_cab . tR, dTheta_cabd . tR, 0, 0): the tangents of the two quadruplet angles along the position
+    tangent tR (A,3) — the double backward of `quad_angles_bwd` (gn_quad_angles_jvp_f32)."""
+    require_device(R, tR, qc, qa, qb, qd)
+    R, tR = _f32c(R), _f32c(tR)
+    Q = qc.shape[0]
+    tang = torch.empty((Q, 4), device=R.device, dtype=torch.float32)
+    check(_lib.load().gn_quad_angles_jvp_f32(ptr(R), ptr(tR), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(tang), Q, stream()),
+          "gn_quad_angles_jvp_f32")
+    return tang
+
+
+def bil_reduce_project_tan(ang, tang, x, tx, B, tB, Sm, sp, want_P=True):
+    """Tangent sweep S3 of the quadruplet bilinear layer in ONE launch (gn_bil_reduce_project_ang_tan_f32):
+    Smd[e] = sum_q (dY[q] (x) x[g(q)] + Y[q] (x) tx[g(q)]),  Pd[e] = B[e]^T Smd[e] + tB[e]^T Sm[e];  dY from the angle tangents
+    `tang` (Q,4).  tang / tx / tB may be None (at least one of tang, tx) -> (Smd (E,S,C), Pd (E,I,C) | None)."""
+    require_device(ang, x, B)
+    assert tang is not None or tx is not None
+    ang, x, B = _f32c(ang), _f32c(x), _f32c(B)
+    tang, tx, tB, Sm = (None if t is None else _f32c(t) for t in (tang, tx, tB, Sm))
+    S, C, I = B.shape[1], x.shape[1], B.shape[2]
+    assert is_angle_form(ang, S) and (tang is None or tang.shape == ang.shape) and (tx is None or tx.shape == x.shape)
+    assert tB is None or (tB.shape == B.shape and Sm is not None and Sm.shape == (sp.n_reduce, S, C))
+    Smd = torch.empty((sp.n_reduce, S, C), device=x.device, dtype=torch.float32)
+    Pd = torch.empty((sp.n_reduce, I, C), device=x.device, dtype=torch.float32) if want_P else None
+    check(_lib.load().gn_bil_reduce_project_ang_tan_f32(ptr(ang), ptr(tang), ptr(x), ptr(tx), ptr(sp.expand.idx32),
+                                                        ptr(sp.seg_off), ptr(B), ptr(tB), ptr(Sm), ptr(Smd), ptr(Pd),
+                                                        sp.n_reduce, S, C, I, stream()), "gn_bil_reduce_project_ang_tan_f32")
+    return Smd, Pd
+
+
+def bil_reduce_t_tan(ang, tang, D1, D2, sp):
+    """x-adjoint of the second adjoint S4 of the quadruplet bilinear layer: dx[j] = sum_{q: g(q) = j} (Y[q] D1[r(q)] + dY[q]
+    D2[r(q)]) — per-quadruplet rows by gn_bil_expand_ang_tan_f32, then the CSR sum over the expand rows.  D1 may be None."""
+    require_device(ang, tang, D2)
+    ang, tang, D2 = _f32c(ang), _f32c(tang), _f32c(D2)
+    D1 = None if D1 is None else _f32c(D1)
+    S, C = D2.shape[1], D2.shape[2]
+    assert is_angle_form(ang, S) and tang.shape == ang.shape and (D1 is None or D1.shape == D2.shape)
+    dxt = torch.empty((sp.size, C), device=ang.device, dtype=torch.float32)
+    check(_lib.load().gn_bil_expand_ang_tan_f32(ptr(ang), ptr(tang), ptr(D1), ptr(D2), ptr(sp.seg_off), ptr(dxt), sp.n_reduce,
+                                                S, C, stream()), "gn_bil_expand_ang_tan_f32")
+    permT, segT = sp.expand.csr
+    return segsum(dxt, permT, segT, sp.n_expand)
+
+
+def bil_ang_train_supported(S, C, I):
+    """Shapes of the fused twice-differentiable quadruplet bilinear layer in angle form (ops_train._BilinearAng2)."""
+    return (S, C, I) == (49, 32, 32)
+
+
 def bil_dy_multi(dSm_list, x_list, sp, ang=None):
     """dY (T,S) = sum_b sum_c x_b[g(t),c] dSm_b[r(t),s,c] for the blocks b that share one tensor basis (one pass).
     With `ang` (the basis in angle form): the gradient w.r.t. the two angles, (T,4), instead."""

@@ -277,15 +277,29 @@ class GemNet(torch.nn.Module):
             sbf4 = (rad3, ops.share_gradient(ops.quad_basis(R, plan.q_c, plan.q_a, plan.q_b, plan.q_d, S, plan=plan,
                                                             angle_form=ang)))
         elif not T:
-            if ops.train2_enabled() and not self.direct_forces:
+            qi = self.int_blocks[0].quad_interaction.mlp_sbf.weight
+            if (ops.train2_enabled() and not self.direct_forces and self.num_spherical == 7
+                    and ops.quad_train2_enabled(qi.shape[0], qi.shape[1], self.num_spherical ** 2)):
+                # force training of the quadruplet interaction on fused kernels: the a - b <- d angles and the two quadruplet
+                # angles as twice-differentiable kernels, the tensor basis in ANGLE form (16 B per quadruplet; the bilinear
+                # twins rebuild Y_lm and its tangent in-kernel, ops_train._BilinearAng2) — no (Q, 49) array in any of the four
+                # sweeps, no ATen launch over (Q, 3) temporaries
                 from .. import ops_train
+                qg = plan.quad_geom
                 D_ab = ops_train.distances(R, plan.int_b, plan.int_a)
+                Phi_abd = ops_train.triplet_angles(R, qg["a_of_exp"], qg["b_of_exp"], qg["d_of_exp"])
+                cbf4 = self.cbf_basis(D_ab, Phi_abd, plan.intm_ab)
+                sbf4 = (rad3, ops_train.quad_angles(R, plan.q_c, plan.q_a, plan.q_b, plan.q_d, plan))
             else:
-                D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
-            Phi_cab, Phi_abd, Theta_cabd = self.calculate_angles(R, plan)
-            cbf4 = self.cbf_basis(D_ab, Phi_abd, plan.intm_ab)           # (I, S*R)
-            # the tensor basis shares cutoff and radial tables with cbf_basis3: reuse rad3
-            sbf4 = (rad3, ops.ylm(Phi_cab, Theta_cabd, self.num_spherical))  # ((E,S,R), (Q,S^2))
+                if ops.train2_enabled() and not self.direct_forces:
+                    from .. import ops_train
+                    D_ab = ops_train.distances(R, plan.int_b, plan.int_a)
+                else:
+                    D_ab, _ = self.calculate_interatomic_vectors(R, plan.int_b, plan.int_a)
+                Phi_cab, Phi_abd, Theta_cabd = self.calculate_angles(R, plan)
+                cbf4 = self.cbf_basis(D_ab, Phi_abd, plan.intm_ab)           # (I, S*R)
+                # the tensor basis shares cutoff and radial tables with cbf_basis3: reuse rad3
+                sbf4 = (rad3, ops.ylm(Phi_cab, Theta_cabd, self.num_spherical))  # ((E,S,R), (Q,S^2))
 
         if h is None:
             h = self.atom_emb(plan.z_rows)
@@ -415,6 +429,7 @@ class GemNet(torch.nn.Module):
         self._check_inputs(R)
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
         late = None
+        pos_graph = False
         if R.is_cuda and self.overlap_output_blocks:
             # the output blocks run on a side stream: every lazily-built index structure they share with the main
             # stream (CSR sorts, triplet groups) must exist before the fork, not be built by whichever stream gets
@@ -434,7 +449,7 @@ class GemNet(torch.nn.Module):
             # A caller whose R already takes part in an autograd graph (a non-leaf, or a leaf that requires grad:
             # Hessians, position-dependent losses) keeps its tensor, as in the reference.
             if R.requires_grad:
-                pass
+                pos_graph = True      # the caller may differentiate through the force w.r.t. its positions (ops.position_graph)
             else:
                 R = R.detach().requires_grad_(True)
         # second-order graph only when it can be used (see module docstring)
@@ -456,7 +471,8 @@ class GemNet(torch.nn.Module):
         t2 = bool(graph) and ops.USE_TRAIN2 and not AutomaticFit.fitting_mode and mode != "f32" and self.num_targets == 1
         with ops.weight_cache(self._wcache), ops.fused_first_order(fused), ops.param_grads(not const_w), \
                 ops.train2(t2, self._packs if (t2 and R.is_cuda) else None), \
-                ops.chain_mode(self.matmul_precision), torch.enable_grad() if not self.direct_forces else _nullcontext():
+                ops.chain_mode(self.matmul_precision), ops.position_graph(pos_graph), \
+                torch.enable_grad() if not self.direct_forces else _nullcontext():
             E_mol, F_ca, V_ca = self._energy(R, plan)
 
             if self.direct_forces:

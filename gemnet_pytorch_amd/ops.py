@@ -895,6 +895,10 @@ def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
     if _FUSED:
         return _FusedBilinear.apply(rbf_W1, sph, x, W, sp, float(alpha))
     C, I, O = W.shape
+    if _TRAIN2 and USE_TRAIN2_BILINEAR and K.is_angle_form(sph, rbf_W1.shape[1]):
+        # the tensor basis in angle form (GemNet.forward chose it: quad_train2_enabled): fused twins on the *_ang kernels
+        from . import ops_train
+        return ops_train.bilinear_ang(rbf_W1, sph, x, W, sp, alpha)
     if _TRAIN2 and USE_TRAIN2_BILINEAR and K.bil_train_supported(sph.shape[1], C, I):
         from . import ops_train
         return ops_train.bilinear(rbf_W1, sph, x, W, sp, alpha)
@@ -1082,6 +1086,33 @@ def position_second_order_grads(enabled: bool):
 
 def position_second_order():
     return _POSITION_2ND
+
+
+# Does the CALLER of this pass differentiate w.r.t. positions a second time?  GemNet.forward knows: it differentiates the energy
+# w.r.t. a fresh leaf of its own unless the caller's R already takes part in an autograd graph (model/gemnet.py) — only then can
+# anybody ask for d(loss)/dR through the force.  The fused twins provide the second-order POSITION terms of distances and
+# triplet angles (dual numbers, csrc/geometry2.hip) but not those of the quadruplet geometry / tensor basis (the Hessian of the
+# two angles and the second derivatives of the 49 harmonics): with a position graph requested the quadruplet path stays on the
+# composite closure, which is closed under differentiation to any order.
+_POSITION_GRAPH = False
+USE_TRAIN2_QUAD = os.environ.get("GEMNET_TRAIN2_QUAD", "1") == "1"
+
+
+@contextlib.contextmanager
+def position_graph(enabled: bool):
+    global _POSITION_GRAPH
+    old = _POSITION_GRAPH
+    _POSITION_GRAPH = bool(enabled)
+    try:
+        yield
+    finally:
+        _POSITION_GRAPH = old
+
+
+def quad_train2_enabled(C=32, I=32, S=49):
+    """Force training of the quadruplet interaction on the fused angle-form twins (ops_train._QuadAngles2 / _BilinearAng2)?"""
+    return (_TRAIN2 and USE_TRAIN2_QUAD and USE_TRAIN2_BILINEAR and USE_QUAD_ANGLES and not _POSITION_GRAPH
+            and K.bil_ang_train_supported(S, C, I))
 
 
 def step_cache():
@@ -1520,34 +1551,43 @@ class _QuadBasis(torch.autograd.Function):
         ri_c, ri_a, ri_b, ri_d, S, plan = ctx.cfg
         if not ctx.needs_input_grad[0]:
             return (None,) * 8
-        idx = (ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32)
-        if plan is None:
-            if ctx.angle_form:
-                Gc, Gb, Gd = K.quad_angles_bwd(gY, R, *idx)
-            else:
-                Gc, Gb, Gd = K.quad_basis_bwd(gY, R, *idx, S)
-            gR = (K.segsum(Gc, *ri_c.csr, ri_c.n_rows) + K.segsum(Gb, *ri_b.csr, ri_b.n_rows)
-                  + K.segsum(Gd, *ri_d.csr, ri_d.n_rows) - K.segsum(Gc + Gb + Gd, *ri_a.csr, ri_a.n_rows))
+        return (_quad_adjoint(gY, R, ri_c, ri_a, ri_b, ri_d, plan, S, ctx.angle_form),) + (None,) * 7
+
+
+def _quad_adjoint(gY, R, ri_c, ri_a, ri_b, ri_d, plan, S, angle_form):
+    """dE/dR (A,3) from the gradient w.r.t. the quadruplet basis — gY (Q,S^2), or in angle form g_ang (Q,4) = (dE/dPhi_cab,
+    dE/dTheta_cabd, 0, 0): the per-quadruplet position terms of atoms c, b, d (a: minus their sum) reduced onto the atoms."""
+    idx = (ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32)
+    if plan is None:
+        if angle_form:
+            Gc, Gb, Gd = K.quad_angles_bwd(gY, R, *idx)
         else:
-            # two-level sums: the quadruplets of one reduce edge (c -> a) are contiguous and share c and a, so their
-            # contributions are first summed per edge with coalesced reads (9 M x 12 B gathered through a
-            # permutation by atom ran at 180 GB/s), then the 18 k edge rows go to the atoms
-            # b and d are shared by the quadruplets of one intermediate triplet (a, b, d): [Gb | Gd] rows of 32 B
-            # are summed per intermediate triplet in one float4 pass, then the 0.6 M rows go to the atoms
-            if ctx.angle_form:
-                Gc, Gbd = K.quad_angles_bwd(gY, R, *idx, packed=True)
-            else:
-                Gc, Gbd = K.quad_basis_bwd_packed(gY, R, *idx, S)
-            seg, E = plan.quad.seg_off, plan.n_edges
-            Ec = K.segsum(Gc, None, seg, E)
-            Ebd = K.segsum(Gbd, None, seg, E)
-            Ea = Ec + Ebd[:, 0:3] + Ebd[:, 4:7]
-            Ibd = K.segsum(Gbd, *plan.quad.expand.csr, plan.quad.n_expand)
-            rb, rd = plan.quad_geom["b_of_exp"], plan.quad_geom["d_of_exp"]
-            gR = (K.segsum(Ec, *plan.id_c.csr, plan.id_c.n_rows) - K.segsum(Ea, *plan.id_a.csr, plan.id_a.n_rows)
-                  + K.segsum(Ibd[:, 0:3].contiguous(), *rb.csr, rb.n_rows)
-                  + K.segsum(Ibd[:, 4:7].contiguous(), *rd.csr, rd.n_rows))
-        return (gR,) + (None,) * 7
+            Gc, Gb, Gd = K.quad_basis_bwd(gY, R, *idx, S)
+        return (K.segsum(Gc, *ri_c.csr, ri_c.n_rows) + K.segsum(Gb, *ri_b.csr, ri_b.n_rows)
+                + K.segsum(Gd, *ri_d.csr, ri_d.n_rows) - K.segsum(Gc + Gb + Gd, *ri_a.csr, ri_a.n_rows))
+    # two-level sums: the quadruplets of one reduce edge (c -> a) are contiguous and share c and a, so their
+    # contributions are first summed per edge with coalesced reads (9 M x 12 B gathered through a
+    # permutation by atom ran at 180 GB/s), then the 18 k edge rows go to the atoms
+    # b and d are shared by the quadruplets of one intermediate triplet (a, b, d): [Gb | Gd] rows of 32 B
+    # are summed per intermediate triplet in one float4 pass, then the 0.6 M rows go to the atoms
+    if angle_form:
+        Gc, Gbd = K.quad_angles_bwd(gY, R, *idx, packed=True)
+    else:
+        Gc, Gbd = K.quad_basis_bwd_packed(gY, R, *idx, S)
+    seg, E = plan.quad.seg_off, plan.n_edges
+    Ec = K.segsum(Gc, None, seg, E)
+    Ebd = K.segsum(Gbd, None, seg, E)
+    Ea = Ec + Ebd[:, 0:3] + Ebd[:, 4:7]
+    Ibd = K.segsum(Gbd, *plan.quad.expand.csr, plan.quad.n_expand)
+    rb, rd = plan.quad_geom["b_of_exp"], plan.quad_geom["d_of_exp"]
+    return (K.segsum(Ec, *plan.id_c.csr, plan.id_c.n_rows) - K.segsum(Ea, *plan.id_a.csr, plan.id_a.n_rows)
+            + K.segsum(Ibd[:, 0:3].contiguous(), *rb.csr, rb.n_rows)
+            + K.segsum(Ibd[:, 4:7].contiguous(), *rd.csr, rd.n_rows))
+
+
+def quad_angles_adjoint(g_ang, R, ri_c, ri_a, ri_b, ri_d, plan=None):
+    """First adjoint of the angle form (ops_train._QuadAngles2)."""
+    return _quad_adjoint(g_ang, R, ri_c, ri_a, ri_b, ri_d, plan, 7, True)
 
 
 # The tensor basis of GemNet-Q in angle form (16 B per quadruplet instead of the 196-B harmonics row, rebuilt inside the

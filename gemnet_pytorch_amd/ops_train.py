@@ -909,6 +909,128 @@ def bilinear(rbf_W1, sph, x, W, sp, alpha=1.0):
     return out
 
 
+# ============================================================== quadruplet bilinear layer, tensor basis in ANGLE form
+class _BilinearAng2(torch.autograd.Function):
+    """The quadruplet bilinear layer (interaction_block.py:517-566, efficient.py:159-189; S = 49, C = I = 32) with the tensor
+    basis given as `ang` (Q,4) = (sin, cos) of (Phi_cab, Theta_cabd) instead of the (Q,49) harmonics (basis_layers.py:239-295),
+    trainable W, twice differentiable on the fused angle-form kernels (csrc/bilinear_ang.hip).  Same algebra as _Bilinear2
+    with Y a FUNCTION of the two angles: the gradient slot of `ang` carries g_ang (Q,4) = (dE/dPhi, dE/dTheta, 0, 0) (the
+    convention of ops._QuadBasis), its tangent is t_ang (Q,4) = (dPhi, dTheta, 0, 0) along u = dL/dF, and
+        dY[q] = Y_theta[q] dPhi[q] + Y_phi[q] dTheta[q]
+    is rebuilt in-kernel by dual numbers next to Y[q] (no (Q,49) array in any sweep):
+        S1   Sm, P = K1K2(ang, x, B);  out = alpha P W2
+        S2   mu_P = alpha g W2^T;  gB = Sm mu_P^T;  mu_Sm = B mu_P;  gx = K1^T(Y, mu_Sm);  g_ang = <mu_Sm . x, dY/d angle>
+        S3   Smd = K1(dY, x) + K1(Y, tx);  Pd = B^T Smd + tB^T Sm          (ONE launch: gn_bil_reduce_project_ang_tan_f32)
+             d g = alpha Pd W2
+        S4   Pb = alpha ob W2^T;  gB = Sm Pb^T + Smd mu_P^T;  Smb = B Pb + tB mu_P;
+             gx = K1^T(Y, Smb) + K1^T(dY, mu_Sm)                           (ONE launch + the CSR sum: gn_bil_expand_ang_tan_f32)
+        dW2  = alpha (P^T ob + Pd^T g)
+    The angles depend on the positions only, so S4 owes them a gradient only when the CALLER differentiates w.r.t. positions a
+    second time (ops.position_graph): that case needs the second derivatives of the 49 harmonics and stays on the composite
+    closure (ops.bilinear routes it there); here the angle slot of S4 is left empty."""
+
+    @staticmethod
+    def forward(ctx, B, ang, x, W, sp, alpha):
+        C, I, O = W.shape
+        B, ang, x = B.contiguous(), ang.contiguous(), x.contiguous()
+        W2 = W.detach().permute(1, 0, 2).reshape(I * C, O).contiguous()
+        W2T = W2.t().contiguous()
+        Sm, P = K.bil_reduce_project(ang, x, B, sp)
+        out = K.gemm(P.reshape(-1, I * C), W2T, alpha=alpha)
+        rec = _Rec()
+        rec.s1 = dict(B=B, ang=ang, x=x, W2=W2, W2T=W2T, Sm=Sm, P=P)
+        tok = x.new_empty(0)
+        ctx.rec, ctx.sp, ctx.alpha, ctx.dims = rec, sp, alpha, (C, I, O)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(tok, W)
+        return out, tok
+
+    @staticmethod
+    @_releases_record
+    def backward(ctx, g, g_tok):
+        tok, W = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (B, ang, x, W, sp, alpha)
+        if g is None:
+            return (None,) * 6
+        rec, sp, alpha = ctx.rec, ctx.sp, ctx.alpha
+        C, I, O = ctx.dims
+        if torch.is_grad_enabled():
+            gB, g_ang, gx = _BilinearAng2B.apply(rec, sp, alpha, ctx.dims, tuple(need[:3]), g, tok, W)
+            return gB, g_ang, gx, None, None, None
+        s1, s2, s3 = rec.s1, rec.s2, rec.s3
+        rec.s3 = None
+        g = g.contiguous()
+        with ops.chain_mode(rec.mode):
+            Pb = K.gemm(g, s1["W2"], alpha=alpha).reshape(-1, I, C)
+            gB, Smb, _ = K.bil_project_bwd(Pb, s1["Sm"], s1["B"], s1["x"], sp, want_dY=False)
+            t_ang = None
+            if s3 is not None and s2 is not None:
+                Smd, tB, t_ang = s3["Smd"], s3["tB"], s3["t_ang"]
+                if Smd is not None or tB is not None:
+                    zS = Smd if Smd is not None else torch.zeros_like(s1["Sm"])
+                    zB = tB if tB is not None else torch.zeros_like(s1["B"])
+                    gB, Smb2, _ = K.bil_project_bwd(s2["mu_P"], zS, zB, s1["x"], sp, want_dY=False, gB_accum=gB)
+                    if tB is not None:
+                        Smb = Smb.add_(Smb2)
+            gx = None
+            if need[2]:
+                if t_ang is not None and s2 is not None:
+                    gx = K.bil_reduce_t_tan(s1["ang"], t_ang, Smb, s2["mu_Sm"], sp)
+                else:
+                    gx = K.bil_reduce_t(s1["ang"], Smb, sp)
+        gW = None
+        if need[3] and ops._PARAM_GRADS:
+            gW = _wgrad_bilinear(W, s1["P"], g, alpha)
+        return (gB if need[0] else None), None, gx, gW, None, None
+
+
+class _BilinearAng2B(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rec, sp, alpha, dims, want, g, tok, W):
+        C, I, O = dims
+        s1 = rec.s1
+        g = g.contiguous()
+        with ops.chain_mode(rec.mode):
+            mu_P = K.gemm(g, s1["W2"], alpha=alpha).reshape(-1, I, C)
+            gB, mu_Sm, _ = K.bil_project_bwd(mu_P, s1["Sm"], s1["B"], s1["x"], sp, want_dY=False)
+            g_ang = K.bil_dy_multi([mu_Sm], [s1["x"]], sp, ang=s1["ang"]) if want[1] else None
+            gx = K.bil_reduce_t(s1["ang"], mu_Sm, sp) if want[2] else None
+        rec.s2, rec.s3 = dict(g=g.detach(), mu_P=mu_P, mu_Sm=mu_Sm), None     # (values only, see _releases_record)
+        ctx.rec, ctx.sp, ctx.alpha, ctx.dims = rec, sp, alpha, dims
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(W)
+        return (gB if want[0] else None), g_ang, gx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, tB, t_ang, tx):
+        (W,) = ctx.saved_tensors
+        need = ctx.needs_input_grad      # (rec, sp, alpha, dims, want, g, tok, W)
+        if tB is None and t_ang is None and tx is None:
+            return (None,) * 8
+        rec, sp, alpha = ctx.rec, ctx.sp, ctx.alpha
+        C, I, O = ctx.dims
+        s1, s2 = rec.s1, rec.s2
+        tB = None if tB is None else tB.contiguous()
+        t_ang = None if t_ang is None else t_ang.contiguous()
+        tx = None if tx is None else tx.contiguous()
+        if t_ang is None and tx is None:
+            Smd, Pd = None, K.bmm(tB, s1["Sm"], True, False)
+        else:
+            Smd, Pd = K.bil_reduce_project_tan(s1["ang"], t_ang, s1["x"], tx, s1["B"], tB, s1["Sm"], sp)
+        gd = K.gemm(Pd.reshape(-1, I * C), s1["W2T"], alpha=alpha) if need[5] else None
+        rec.s3 = dict(Smd=Smd, tB=tB, t_ang=t_ang, tx=tx)
+        gW = None
+        if need[7] and ops._PARAM_GRADS:
+            gW = _wgrad_bilinear(W, Pd, s2["g"], alpha)
+        return None, None, None, None, None, gd, None, gW
+
+
+def bilinear_ang(rbf_W1, ang, x, W, sp, alpha=1.0):
+    out, _ = _BilinearAng2.apply(rbf_W1, ang, x, W, sp, float(alpha))
+    return out
+
+
 # =================================================================================== distances and triplet angles from R
 class _Dist2(torch.autograd.Function):
     """D[e] = |R[a(e)] - R[c(e)]| (gemnet.py:261-286), twice differentiable on three kernels (csrc/geometry2.hip) — the
@@ -1011,3 +1133,51 @@ class _Angle2B(torch.autograd.Function):
 
 def triplet_angles(R, ri_c, ri_a, ri_b):
     return _Angle2.apply(R, ri_c, ri_a, ri_b)
+
+
+# ==================================================================== the two quadruplet angles from R, in angle form
+class _QuadAngles2(torch.autograd.Function):
+    """ang (Q,4) = (sin, cos) of Phi_cab and Theta_cabd from the four atoms of every quadruplet (gemnet.py:334-418:
+    calculate_angles — two neighbour angles, two vector rejections, the dihedral), twice differentiable on three kernels
+    (csrc/geometry.hip: value, first adjoint, tangent) — the composite closure spends ~25 ATen launches over (Q,3) arrays
+    (9 M rows at B = 32) per pass on the same arithmetic.  Gradient convention of the angle form: the slot of `ang` carries
+    g_ang (Q,4) = (dE/dPhi, dE/dTheta, 0, 0).  Second-order POSITION terms (the Hessian of the two angles) are not provided:
+    the fused quadruplet path is only taken when the caller does not differentiate w.r.t. positions again
+    (ops.position_graph)."""
+
+    @staticmethod
+    def forward(ctx, R, ri_c, ri_a, ri_b, ri_d, plan):
+        ctx.save_for_backward(R)
+        ctx.cfg = (ri_c, ri_a, ri_b, ri_d, plan)
+        return K.quad_angles_fwd(R, ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32)
+
+    @staticmethod
+    def backward(ctx, g_ang):
+        (R,) = ctx.saved_tensors
+        if g_ang is None or not ctx.needs_input_grad[0]:
+            return (None,) * 6
+        if torch.is_grad_enabled():
+            return (_QuadAngles2B.apply(g_ang, R, *ctx.cfg),) + (None,) * 5
+        return (ops.quad_angles_adjoint(g_ang.contiguous(), R, *ctx.cfg),) + (None,) * 5
+
+
+class _QuadAngles2B(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_ang, R, ri_c, ri_a, ri_b, ri_d, plan):
+        ctx.save_for_backward(R)
+        ctx.cfg = (ri_c, ri_a, ri_b, ri_d)
+        return ops.quad_angles_adjoint(g_ang.contiguous(), R, ri_c, ri_a, ri_b, ri_d, plan)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, tR):
+        (R,) = ctx.saved_tensors
+        if tR is None or not ctx.needs_input_grad[0]:
+            return (None,) * 7
+        ri_c, ri_a, ri_b, ri_d = ctx.cfg
+        t_ang = K.quad_angles_jvp(R, tR.contiguous(), ri_c.idx32, ri_a.idx32, ri_b.idx32, ri_d.idx32)
+        return (t_ang,) + (None,) * 6
+
+
+def quad_angles(R, ri_c, ri_a, ri_b, ri_d, plan=None):
+    return _QuadAngles2.apply(R, ri_c, ri_a, ri_b, ri_d, plan)

@@ -256,6 +256,23 @@ int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_
 /* per-quadruplet x-adjoint rows as gn_bil_expand_f32, Y given as angles */
 int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,
                           int arith, void* stream);
+/* Second-order sweeps of GemNet-Q force training (trainer.py:338-346: loss.backward() through dE/dR) in angle form (ABI 13).
+ * tang (Q,4) = (dPhi_cab, dTheta_cabd, 0, 0): the tangents of the two angles along the position tangent u = dL/dF
+ * (gn_quad_angles_jvp_f32: the double backward of gn_quad_angles_bwd_ld_f32); the kernels rebuild
+ * dY[q] = Y_theta dPhi + Y_phi dTheta with dual numbers next to Y[q].  f32-input MFMA (tangents carry the scale of the loss).
+ *   gn_bil_reduce_project_ang_tan_f32   Smd[e] = sum_{q in seg(e)} ( dY[q] (x) x[g(q)] + Y[q] (x) tx[g(q)] )
+ *                                        Pd[e]  = B[e]^T Smd[e] + tB[e]^T Sm[e]
+ *       (tang / x NULL: no first term; tx NULL: no second; at least one; tB NULL: no tB^T Sm term; Pd NULL: K2 skipped) — the
+ *       tangent sweep S3 of the quadruplet bilinear layer (interaction_block.py:517-566, efficient.py:159-189) in ONE launch
+ *   gn_bil_expand_ang_tan_f32           dxt[q] = Y[q] D1[e] + dY[q] D2[e]    (D1 NULL: the second term only) — the per-quadruplet
+ *       x-adjoint rows of the second adjoint S4 (summed over the expand rows by gn_segsum_rows_f32) */
+int gn_quad_angles_jvp_f32(const float* R, const float* tR, const int32_t* qc, const int32_t* qa, const int32_t* qb,
+                           const int32_t* qd, float* tang, int64_t Q, void* stream);
+int gn_bil_reduce_project_ang_tan_f32(const float* ang, const float* tang, const float* x, const float* tx,
+                                      const int32_t* expand_idx, const int32_t* seg_off, const float* B, const float* tB,
+                                      const float* Sm, float* Smd, float* Pd, int64_t E, int S, int C, int I, void* stream);
+int gn_bil_expand_ang_tan_f32(const float* ang, const float* tang, const float* D1, const float* D2, const int32_t* seg_off,
+                              float* dxt, int64_t E, int S, int C, void* stream);
 /* The same x-adjoint SUMMED over the expand rows, without the per-quadruplet rows in memory: dx[j] = sum_{q: g(q) = j}
  * Y[q] dSm[r(q)].  Needs the quadruplet structure of GemNet (data_container.py:331-397): reduce edge and expand row of a
  * quadruplet end in the same target atom, and the expand rows (intermediate triplets) are sorted by that atom —

@@ -398,6 +398,50 @@ def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
     return Gc, Gbd
 
 
+def _ang_to_dY(ang, tang):
+    """The tangent rows dY = Y_theta dtheta + Y_phi dphi (forward-mode through the oracle's harmonics)."""
+    th = torch.atan2(ang[:, 0], ang[:, 1]).detach()
+    ph = torch.atan2(ang[:, 2], ang[:, 3]).detach()
+    _, dY = torch.func.jvp(lambda a, b: B.real_sph_harm_full(7, a, b), (th, ph), (tang[:, 0].detach(), tang[:, 1].detach()))
+    return dY
+
+
+def quad_angles_jvp(R, tR, qc, qa, qb, qd):
+    idx = [i.long() for i in (qc, qa, qb, qd)]
+
+    def f(Rx):
+        return torch.stack(_quad_angles(Rx[idx[0]], Rx[idx[1]], Rx[idx[2]], Rx[idx[3]]), dim=1)
+    _, t = torch.func.jvp(f, (R.detach(),), (tR.detach(),))
+    out = torch.zeros((t.shape[0], 4), dtype=R.dtype)
+    out[:, 0:2] = t
+    return out
+
+
+def bil_reduce_project_tan(ang, tang, x, tx, Bm, tB, Sm, sp, want_P=True):
+    Smd = torch.zeros((sp.n_reduce, Bm.shape[1], x.shape[1]), dtype=x.dtype)
+    if tang is not None:
+        Smd = Smd + bil_reduce(_ang_to_dY(ang, tang), x, sp)
+    if tx is not None:
+        Smd = Smd + bil_reduce(_ang_to_Y(ang), tx, sp)
+    if not want_P:
+        return Smd, None
+    Pd = torch.bmm(Bm.transpose(1, 2), Smd)
+    if tB is not None:
+        Pd = Pd + torch.bmm(tB.transpose(1, 2), Sm)
+    return Smd, Pd
+
+
+def bil_reduce_t_tan(ang, tang, D1, D2, sp):
+    dx = bil_reduce_t(_ang_to_dY(ang, tang), D2, sp)
+    if D1 is not None:
+        dx = dx + bil_reduce_t(_ang_to_Y(ang), D1, sp)
+    return dx
+
+
+def bil_ang_train_supported(S, C, I):
+    return S == 49       # the emulation takes any channel widths (the test models are small)
+
+
 def bil_project_bwd(dP, Sm, Bm, x, sp, dY_accum=None, want_dY=True, gB_accum=None, dSm_accum=None):
     gB = torch.bmm(Sm, dP.transpose(1, 2))
     if gB_accum is not None:
@@ -542,7 +586,7 @@ def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=Tru
     return g_m, g_rbf
 
 
-_NAMES = ["dist_fwd", "dist_bwd", "dist_jvp", "angle_fwd", "angle_bwd", "angle_jvp", "bil_train_supported", "gather_mul", "bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+_NAMES = ["quad_angles_jvp", "bil_reduce_project_tan", "bil_reduce_t_tan", "bil_ang_train_supported", "dist_fwd", "dist_bwd", "dist_jvp", "angle_fwd", "angle_bwd", "angle_jvp", "bil_train_supported", "gather_mul", "bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

@@ -21,6 +21,11 @@ void shim_ylm7_row_f32(const double* th, const double* ph, float* out, int n) {
   for (int i = 0; i < n; ++i)
     ylm7_row_T<float>((float)sin(th[i]), (float)cos(th[i]), (float)sin(ph[i]), (float)cos(ph[i]), out + i * 49);
 }
+void shim_ylm7_row_tangent(const double* th, const double* ph, const float* dth, const float* dph, float* val, float* tan, int n) {
+  for (int i = 0; i < n; ++i)
+    ylm7_row_tangent((float)sin(th[i]), (float)cos(th[i]), (float)sin(ph[i]), (float)cos(ph[i]), dth[i], dph[i], val + i * 49,
+                     tan + i * 49);
+}
 void shim_ylm_row_f64(const double* th, const double* ph, float* out, int n) {
   for (int i = 0; i < n; ++i) ylm_row_sc(sin(th[i]), cos(th[i]), sin(ph[i]), cos(ph[i]), 7, out + i * 49);
 }

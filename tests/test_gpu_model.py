@@ -198,7 +198,7 @@ def test_repeatable_bitwise(golden_model):
 def test_native_library_loaded():
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
-    assert lib.gn_abi_version() == 12
+    assert lib.gn_abi_version() == 13
     with open("/proc/self/maps") as f:
         assert "libgemnet_hip.so" in f.read()
 
@@ -265,7 +265,14 @@ def test_layer_stacks_match_per_layer_path(golden_model, monkeypatch, mode, e_ba
     E1, F1 = model(dev)
     fs = max(1.0, float(F0.abs().mean()))
     assert float((F1 - F0).abs().mean()) <= 1e-5 * fs
-    assert float((E1 - E0).abs().max()) <= e_bar * max(1.0, float(E0.abs().max()))
+    # energies: each path against the float64 REFERENCE (the unscaled fixture sums cancelling terms: the two fp32 paths sit on
+    # either side of it), and against each other within the sum of the two bars
+    E_ref = torch.tensor(golden_model["t2.E"], device=E0.device, dtype=torch.float32).reshape(E0.shape)
+    es = max(1.0, float(E_ref.abs().max()))
+    err0, err1 = float((E0 - E_ref).abs().max()), float((E1 - E_ref).abs().max())
+    print(f"[{mode}] |E - E_ref|: per-layer {err0:.2e}, stacks {err1:.2e}; |E_stacks - E_per_layer| {float((E1 - E0).abs().max()):.2e}")
+    assert err0 <= 2e-5 * es and err1 <= e_bar * es
+    assert float((E1 - E0).abs().max()) <= (2e-5 + e_bar) * es
 
 
 def test_fused_trainer_step_matches_torch_optimizers(golden_model):

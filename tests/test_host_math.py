@@ -154,3 +154,26 @@ def test_fixed_size_f32_rows_match_the_f64_visitors(shim):
     shim.shim_ylm7_dot_grad(_p(th), _p(ph), _p(g), _p(o64), n, 0)
     scale = np.abs(o64).max()
     assert np.abs(o32 - o64).max() <= 2e-5 * scale, (np.abs(o32 - o64).max(), scale)
+
+
+def test_tangent_rows_by_dual_numbers_match_the_derivative_rows(shim):
+    """ylm7_row_tangent (csrc/basis_math.h: DualF through the unrolled f32 recurrences) — the rows dY = Y_theta dtheta +
+    Y_phi dphi that the second-order sweeps of GemNet-Q force training rebuild per quadruplet (csrc/bilinear_ang.hip, *_tan
+    kernels) — against the f64 derivative visitors (ylm_row with kt / kp = 1), for tangents of any magnitude."""
+    rs = np.random.RandomState(1)
+    n = 3000
+    th = np.concatenate([rs.uniform(0.01, np.pi - 0.01, n - 4), [1e-3, np.pi - 1e-3, 0.5 * np.pi, 1.0]])
+    ph = np.concatenate([rs.uniform(0, np.pi, n - 4), [0.3, 2.0, 1e-5, np.pi - 1e-6]])
+    scale = 10.0 ** rs.uniform(-6, 3, n)
+    dth = (rs.standard_normal(n) * scale).astype(np.float32)
+    dph = (rs.standard_normal(n) * scale).astype(np.float32)
+    val, tan = np.zeros((n, 49), np.float32), np.zeros((n, 49), np.float32)
+    shim.shim_ylm7_row_tangent(_p(th), _p(ph), _p(dth), _p(dph), _p(val), _p(tan), n)
+    y, yt, yp = (np.zeros((n, 49), np.float32) for _ in range(3))
+    shim.shim_ylm(_p(th), _p(ph), _p(y), n, 7, 0, 0)
+    shim.shim_ylm(_p(th), _p(ph), _p(yt), n, 7, 1, 0)
+    shim.shim_ylm(_p(th), _p(ph), _p(yp), n, 7, 0, 1)
+    assert np.abs(val - y).max() <= 2e-6 * np.abs(y).max()
+    ref = yt.astype(np.float64) * dth[:, None] + yp.astype(np.float64) * dph[:, None]
+    row = np.abs(ref).max(axis=1, keepdims=True) + 1e-30
+    assert (np.abs(tan - ref) / row).max() <= 2e-5, (np.abs(tan - ref) / row).max()
