@@ -144,6 +144,23 @@ class LaunchTimer:
             fl = 2.0 * nb * sp.size * S * C + (2.0 * 600 * sp.size if ang else 0.0)   # + Y_lm and both angle derivatives
             by = nb * (sp.n_reduce * S * C + sp.n_expand * C) * f32 + sp.size * ((32 if ang else S * f32) + 4)
             return fl, by
+        if name == "bil_reduce_project_tan":      # S3 of the quadruplet layer: (ang, tang, x, tx, B, tB, Sm, sp)
+            ang, tang, x, tx, B, tB, Sm, sp = args[:8]
+            E, S, I = sp.n_reduce, B.shape[1], B.shape[2]
+            C = x.shape[1]
+            nt = (tang is not None) + (tx is not None)
+            fl = 2.0 * nt * sp.size * S * C + 2.0 * E * S * I * C * (2 if tB is not None else 1) + 2.0 * 400 * sp.size
+            by = sp.size * (32 + 8) + nt * sp.n_expand * C * f32 + E * (S * C + S * I + I * C) * f32
+            if tB is not None:
+                by += E * (S * I + S * C) * f32
+            return fl, by
+        if name == "bil_reduce_t_tan":            # x-adjoint of S4: (ang, tang, D1, D2, sp)
+            ang, tang, D1, D2, sp = args[:5]
+            E, S, C = D2.shape
+            nd = 2 if D1 is not None else 1
+            fl = 2.0 * nd * sp.size * S * C + 2.0 * 400 * sp.size
+            by = sp.size * (32 + 8) + nd * E * S * C * f32 + sp.n_expand * C * f32
+            return fl, by
         if name == "bil_fused_fwd":
             Y, x, B, W2T, sp = args[:5]
             S, C, I, O = Y.shape[1], x.shape[1], B.shape[2], W2T.shape[0]
@@ -199,7 +216,8 @@ class LaunchTimer:
                 "bil_reduce_t", "bil_dot", "bil_reduce_project", "bil_fused_fwd", "bil_fused_bwd", "bil_project_bwd", "bil_dy_multi", "segsum_multi",
                 "bessel_rbf", "sph_radial", "ylm0",
                 "ylm", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "quad_basis_fwd",
-                "quad_basis_bwd"]
+                "quad_basis_bwd", "quad_angles_fwd", "quad_angles_bwd", "quad_angles_jvp", "bil_reduce_project_tan",
+                "bil_reduce_t_tan"]
 
     def __enter__(self):
         self.depth = 0
@@ -316,7 +334,8 @@ def family_bound(name, calls_ang):
     rebuild Y_lm per quadruplet: DESIGN.md section 8.4), or HBM."""
     if name in MFMA_FAMILIES:
         return "mfma"
-    if calls_ang and name in ("bil_reduce_project", "bil_reduce_t", "bil_dy_multi"):
+    if (calls_ang and name in ("bil_reduce_project", "bil_reduce_t", "bil_dy_multi")) or name in ("bil_reduce_project_tan",
+                                                                                                   "bil_reduce_t_tan"):
         return "valu"
     return "hbm"
 
@@ -590,17 +609,20 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
     out = dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / elapsed, 1),
                steps=steps, warmup=warmup, per_gpu=sizes, hipgraph=True, roofline=roof)
     del graph, model
-    # The GemNet-Q TRAINING step (trainer.py:325-360 on configs[2]): the Dense stacks, triplet bilinear layers, aggregation and
-    # geometry run as the fused sweeps of ops_train.py; the quadruplet bilinear layer and its tensor basis differentiate
-    # twice through the composite closure (one launch per op) — eager, no hipGraph.
+    # The GemNet-Q TRAINING step (trainer.py:325-360 on configs[2]): every layer on the fused sweeps of ops_train.py — since
+    # round 5 also the quadruplet geometry and the quadruplet bilinear layer with its tensor basis in ANGLE form
+    # (ops_train._QuadAngles2 / _BilinearAng2: tangent rows rebuilt in-kernel by dual numbers, no (Q, 49) array in any of the
+    # four sweeps) — captured in ONE hipGraph like the GemNet-T step.
     if train:
         try:
             torch.cuda.empty_cache()
-            ts_out = extra_train_step(cfg, 1234, inputs, targets, 1, n_mol, steps=3, warmup=1, want_roofline=True, graph=False,
+            torch.cuda.reset_peak_memory_stats(dev)
+            ts_out = extra_train_step(cfg, 1234, inputs, targets, 1, n_mol, steps=5, warmup=2, want_roofline=True, graph=True,
                                       roof_mode="Qtrain")
             ts_out["peak_memory_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)
-            ts_out["note"] = ("eager; quadruplet bilinear layer + tensor basis on the composite second-order closure, everything else "
-                              "on the fused training sweeps; roofline = dominant LIBRARY launcher family of one step")
+            ts_out["note"] = ("forward + force + loss.backward() through the force + fused optimizer; quadruplet interaction on the "
+                              "fused angle-form twins (round 4: composite closure over the (Q, 49) harmonics, eager, 112-150 ms); "
+                              "roofline = dominant LIBRARY launcher family of one step")
             out["train_step"] = ts_out
         except Exception as ex:  # noqa: BLE001
             out["train_step"] = dict(error=f"{type(ex).__name__}: {ex}"[:300])

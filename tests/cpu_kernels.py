@@ -398,20 +398,28 @@ def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
     return Gc, Gbd
 
 
+def _jvp(f, x, t):
+    """J t by the double-backward trick (plain autograd: `torch.func.jvp` leaves cyclic garbage behind, and the leak test of
+    the training records counts what the cyclic collector finds)."""
+    with torch.enable_grad():
+        x = x.detach().clone().requires_grad_(True)
+        y = f(x)
+        v = torch.zeros_like(y, requires_grad=True)
+        (g,) = torch.autograd.grad(y, x, v, create_graph=True)
+        (jt,) = torch.autograd.grad(g, v, t.detach())
+    return jt.detach()
+
+
 def _ang_to_dY(ang, tang):
     """The tangent rows dY = Y_theta dtheta + Y_phi dphi (forward-mode through the oracle's harmonics)."""
     th = torch.atan2(ang[:, 0], ang[:, 1]).detach()
     ph = torch.atan2(ang[:, 2], ang[:, 3]).detach()
-    _, dY = torch.func.jvp(lambda a, b: B.real_sph_harm_full(7, a, b), (th, ph), (tang[:, 0].detach(), tang[:, 1].detach()))
-    return dY
+    return _jvp(lambda a: B.real_sph_harm_full(7, a[:, 0], a[:, 1]), torch.stack([th, ph], 1), tang[:, 0:2])
 
 
 def quad_angles_jvp(R, tR, qc, qa, qb, qd):
     idx = [i.long() for i in (qc, qa, qb, qd)]
-
-    def f(Rx):
-        return torch.stack(_quad_angles(Rx[idx[0]], Rx[idx[1]], Rx[idx[2]], Rx[idx[3]]), dim=1)
-    _, t = torch.func.jvp(f, (R.detach(),), (tR.detach(),))
+    t = _jvp(lambda Rx: torch.stack(_quad_angles(Rx[idx[0]], Rx[idx[1]], Rx[idx[2]], Rx[idx[3]]), dim=1), R, tR)
     out = torch.zeros((t.shape[0], 4), dtype=R.dtype)
     out[:, 0:2] = t
     return out

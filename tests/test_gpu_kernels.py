@@ -1010,6 +1010,69 @@ def test_tensor_basis_angle_form_kernels(E, J, mk, ang_arithmetic):
             close(got_s, ref_s, atol=3e-5 * float(ref_s.abs().max()), rtol=0)
 
 
+@pytest.mark.parametrize("E,J,mk", [(60, 300, 80), (9, 40, 700), (33, 120, 3)])
+def test_tensor_basis_tangent_kernels_of_force_training(E, J, mk):
+    """gn_bil_reduce_project_ang_tan_f32 / gn_bil_expand_ang_tan_f32 — the S3 / S4 sweeps of GemNet-Q force training with the
+    tangent rows dY = Y_theta dPhi + Y_phi dTheta rebuilt in-kernel by dual numbers — against the float64 restatements that
+    differentiate the oracle's (Q,49) harmonics, for every combination of optional operands and tangents of any magnitude
+    (they carry the scale of the caller's loss)."""
+    g = torch.Generator().manual_seed(E * mk + 1)
+    S, C, I = 49, 32, 32
+    cpu, dev = _segplan(g, E, J, mk)
+    Q = cpu.size
+    th, ph = torch.rand(Q, generator=g, dtype=torch.float64) * 3.0 + 0.05, torch.rand(Q, generator=g, dtype=torch.float64) * 3.1
+    ang = torch.stack([torch.sin(th), torch.cos(th), torch.sin(ph), torch.cos(ph)], 1)
+    x, tx, B_, tB, Sm = rnd(g, J, C), rnd(g, J, C), rnd(g, E, S, I), rnd(g, E, S, I), rnd(g, E, S, C)
+    D1, D2 = rnd(g, E, S, C), rnd(g, E, S, C)
+    for scale in (1.0, 3e-6, 1e4):
+        tang = torch.zeros(Q, 4, dtype=torch.float64)
+        tang[:, 0:2] = rnd(g, Q, 2) * scale
+        for use_t, use_tx, use_tB in ((True, True, True), (True, False, False), (False, True, True), (True, True, False)):
+            a = (tang if use_t else None, x, tx * scale if use_tx else None, B_, tB * scale if use_tB else None, Sm)
+            Smd_ref, Pd_ref = CK.bil_reduce_project_tan(ang, a[0], a[1], a[2], a[3], a[4], a[5], cpu)
+            Smd, Pd = K.bil_reduce_project_tan(f32(ang), None if a[0] is None else f32(a[0]), f32(a[1]),
+                                               None if a[2] is None else f32(a[2]), f32(a[3]),
+                                               None if a[4] is None else f32(a[4]), f32(a[5]), dev)
+            close(Smd, Smd_ref, atol=3e-5 * max(1e-30, float(Smd_ref.abs().max())), rtol=0)
+            close(Pd, Pd_ref, atol=3e-5 * max(1e-30, float(Pd_ref.abs().max())), rtol=0)
+        Smd_only, none = K.bil_reduce_project_tan(f32(ang), f32(tang), f32(x), None, f32(B_), None, None, dev, want_P=False)
+        assert none is None
+        ref_only = CK.bil_reduce_project_tan(ang, tang, x, None, B_, None, None, cpu, want_P=False)[0]
+        close(Smd_only, ref_only, atol=3e-5 * float(ref_only.abs().max()), rtol=0)
+        for use_D1 in (True, False):
+            ref = CK.bil_reduce_t_tan(ang, tang, D1 * scale if use_D1 else None, D2, cpu)
+            got = K.bil_reduce_t_tan(f32(ang), f32(tang), f32(D1 * scale) if use_D1 else None, f32(D2), dev)
+            close(got, ref, atol=3e-5 * float(ref.abs().max()), rtol=0)
+
+
+def test_quad_angles_tangent_kernel():
+    """gn_quad_angles_jvp_f32: (dPhi_cab, dTheta_cabd) along a position tangent — the double backward of gn_quad_angles_bwd —
+    against forward-mode differentiation of the float64 geometry (gemnet.py:334-418), and consistent with the first adjoint:
+    <tang, g_ang> == <tR, G(g_ang)> for random g_ang (the two kernels are transposes of one Jacobian)."""
+    g = torch.Generator().manual_seed(5)
+    A, Q = 40, 3000
+    R = rnd(g, A, 3) * 2.0
+    tR = rnd(g, A, 3)
+    idx = [torch.randint(0, A, (Q,), generator=g) for _ in range(4)]
+    keep = (idx[0] != idx[1]) & (idx[1] != idx[2]) & (idx[2] != idx[3]) & (idx[0] != idx[2]) & (idx[1] != idx[3])
+    qc, qa, qb, qd = (i[keep].to(torch.int32) for i in idx)
+    dev_idx = [t.to(DEV) for t in (qc, qa, qb, qd)]
+    ref = CK.quad_angles_jvp(R, tR, qc, qa, qb, qd)
+    got = K.quad_angles_jvp(f32(R), f32(tR), *dev_idx)
+    assert bool((got[:, 2:] == 0).all())
+    ok = ref.abs().max(dim=1).values < 50          # (nearly collinear quadruplets: derivatives of order 1 / sin)
+    close(got[ok.to(DEV)], ref[ok], atol=2e-4 * float(ref[ok].abs().max()), rtol=2e-3)
+    g_ang = torch.zeros(qc.shape[0], 4, dtype=torch.float64)
+    g_ang[:, 0:2] = rnd(g, qc.shape[0], 2)
+    g_ang[~ok] = 0
+    Gc, Gb, Gd = K.quad_angles_bwd(f32(g_ang), f32(R), *dev_idx)
+    Gc, Gb, Gd = (t.double().cpu() for t in (Gc, Gb, Gd))
+    lhs = float((got.double().cpu() * g_ang).sum())
+    rhs = float((Gc * tR[qc.long()]).sum() + (Gb * tR[qb.long()]).sum() + (Gd * tR[qd.long()]).sum()
+                - ((Gc + Gb + Gd) * tR[qa.long()]).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
 @pytest.mark.parametrize("n_mol,n_atoms", [(3, 12), (2, 32)])
 def test_fused_per_atom_x_adjoint_of_the_tensor_basis(n_mol, n_atoms, monkeypatch):
     """gn_bil_expand_atoms_ang_f32 — one workgroup per target atom, the atom's expand rows summed in LDS edge by edge, no
