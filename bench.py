@@ -234,8 +234,9 @@ class LaunchTimer:
                 finally:
                     self.depth -= 1
                 fl, by = self.cost(_name, args, kwargs, out)
-                if _name == "chain":   # the replay runs outside the sweep's arithmetic context (ops_train._sweep_mode)
-                    kwargs = dict(kwargs, mode=kwargs.get("mode") or self.K.DEFAULT_CHAIN_MODE)
+                if _name == "chain":   # the replay runs outside the sweep's arithmetic context (ops_train._sweep_mode: thread-
+                    # local, and this wrapper runs on the launching thread — the autograd engine's for the backward sweeps)
+                    kwargs = dict(kwargs, mode=kwargs.get("mode") or self.K.current_mode())
                 self.records.append((_name, _fn, args, kwargs, fl, by))
                 return out
 

@@ -241,7 +241,10 @@ class GraphPlan:
                self.t_c, self.t_a, self.t_b, self.z_rows]
         if not self.triplets_only:
             out += [self.int_a, self.int_b, self.intm_db, self.intm_ab, self.quad.reduce, self.quad.expand]
-            out += list(self.quad_geom.values()) + [self.q_c, self.q_a, self.q_b, self.q_d]
+            # (the CSRs of the four atoms of every quadruplet — q_c, q_a, q_b, q_d: four sorts of Q keys, 9 M at B = 32 — are NOT
+            #  built here: the force assembly sums per reduce edge / intermediate triplet first (ops._quad_adjoint with the
+            #  plan: the only form the model calls); without a plan they are built on first use)
+            out += list(self.quad_geom.values())
         return out
 
     def late_indices(self):

@@ -16,8 +16,8 @@ is used unchanged:
     from gemnet_pytorch_amd.md import DeviceMolecule as Molecule          # the only edited line of an MD script
     calc = GNNCalculator(Molecule(R, Z, cutoff, int_cutoff, triplets_only), model=model, atoms=atoms)
 
-Models the padded replay does not cover (quadruplet interactions) are served by the device index builder
-+ the eager forward — still without the host-side index construction."""
+Triplets-only and quadruplet models alike (GemNet-Q — the model of the reference's MD example — since round 5: the padding
+scheme covers interaction edges, intermediate triplets and quadruplets, padded.py)."""
 import numpy as np
 import torch
 
@@ -96,16 +96,8 @@ def predict_molecule(model, inputs, to_host=False):
         # (the caller's parameters are left as they are — `requires_grad` included: an eval-mode forward with forces by autograd
         #  treats the weights as constants anyway (ops.constant_weights), and a force field built in the middle of a training
         #  script must not freeze the model; the reference's predict() does not touch it either, gemnet.py:780-784)
-        if model.triplets_only:
-            from .runtime import DynamicForceField
-            ff = DynamicForceField(model, Z, N.cpu().numpy(), inputs.cutoff, inputs.int_cutoff)
-        else:
-            from .index_device import DeviceGraphBuilder
-            builder = DeviceGraphBuilder(N.cpu().numpy(), inputs.cutoff, inputs.int_cutoff, model.triplets_only, device=R.device)
-
-            def ff(R_, builder=builder):
-                idx = builder(R_)
-                return model(dict(R=R_, Z=Z, N=N, **idx))
+        from .runtime import DynamicForceField
+        ff = DynamicForceField(model, Z, N.cpu().numpy(), inputs.cutoff, inputs.int_cutoff)
         if len(cache) >= 8:
             cache.pop(next(iter(cache)))
         cache[key] = ff

@@ -19,8 +19,16 @@ those capacities is replayed:
 Molecules are independent (block-diagonal index arrays), every kernel of the path treats a row on its own and sums a
 segment in index order: the real molecules' energies and forces are those of the unpadded batch, bit for bit
 (tests/test_gpu_padded.py).  With an atom capacity (`a_cap`) the molecules may differ in size from call to call as well: the
-atoms between the batch and the capacity are isolated filler atoms of the dummy molecule.  Triplets-only models with forces
-by autograd.  Callers: `runtime.DynamicForceField` (the MD loop), `training.ddp.PaddedTrainStep` and
+atoms between the batch and the capacity are isolated filler atoms of the dummy molecule.
+
+Quadruplet models (GemNet-Q; round 5) — the model of the reference's only recorded run, the MD of ase_example.ipynb through
+ase_calculator.py:148-170 — pad the same way with groups of FOUR dummy atoms (a, b, c, d: 1 A bonds a-b, a-c, b-d, all angles
+and the dihedral c-a-b-d 90 degrees), pad edges cycling b->a, c->a, d->b (+ reverses) in UNITS of six, and three more
+capacities: interaction edges (pad: b->a / a->b of a group), intermediate triplets (pad: (edge d->b, interaction edge b->a),
+sorted by interaction edge like the real ones) and quadruplets (pad: reduce edge c->a of a unit, sorted; expand row = a pad
+intermediate triplet).  A pad row only needs valid indices and a non-degenerate geometry — the real molecules never see it.
+
+Callers: `runtime.DynamicForceField` (the MD loop), `training.ddp.PaddedTrainStep` and
 `Trainer.enable_padded_graph` (the training step in the same form), `bench.py` (`extra.dynamic_shape`,
 `extra.train_step_dynamic`).
 """
@@ -29,60 +37,136 @@ import torch
 
 PAD_EDGE_KEYS = ("id_c", "id_a", "id_swap", "id_undir")
 PAD_TRIP_KEYS = ("id3_reduce_ca", "id3_expand_ba")
+PAD_INT_KEYS = ("id4_int_a", "id4_int_b")
+PAD_INTM_KEYS = ("id4_reduce_intm_ca", "id4_reduce_intm_ab", "id4_expand_intm_db", "id4_expand_intm_ab")
+PAD_QUAD_KEYS = ("id4_reduce_ca", "id4_expand_db", "id4_reduce_cab", "id4_expand_abd")
 
 
-def _pad_edges(k, n_atoms, n_groups):
+def _pad_edges(k, n_atoms, n_groups, quad=False):
     """Pad edge number k (0-based behind the real edges) -> (source atom, target atom).  Pairs (edge, reverse); the pairs
-    alternate b->a | c->a and cycle over the groups of three dummy atoms."""
+    alternate b->a | c->a and cycle over the groups of three dummy atoms.  `quad`: groups of FOUR atoms (a, b, c, d) and
+    three kinds of pairs b->a | c->a | d->b — a UNIT of six pad edges per visit of a group."""
     pair, rev = k // 2, k % 2
-    typ, grp = pair % 2, (pair // 2) % max(n_groups, 1)
-    a = n_atoms + 3 * grp
-    other = a + 1 + typ                           # b or c
-    return torch.where(rev == 0, other, a), torch.where(rev == 0, a, other)
+    G = max(n_groups, 1)
+    if not quad:
+        typ, grp = pair % 2, (pair // 2) % G
+        a = n_atoms + 3 * grp
+        other = a + 1 + typ                           # b or c
+        return torch.where(rev == 0, other, a), torch.where(rev == 0, a, other)
+    typ, grp = pair % 3, (pair // 3) % G
+    a = n_atoms + 4 * grp
+    src = torch.where(typ == 2, a + 3, a + 1 + typ)   # b, c or d
+    dst = torch.where(typ == 2, a + 1, a)             # a, a or b
+    return torch.where(rev == 0, src, dst), torch.where(rev == 0, dst, src)
 
 
-def _pad_triplets(j, E, ep, tp):
+def _pad_triplets(j, E, ep, tp, quad=False):
     """Pad triplet number j of tp -> (reduce edge, expand edge): the forward edges (even k) of the complete quads, spread
     evenly and ALREADY sorted by reduce edge (f grows with j); the expand edge is the other forward edge of the quad —
-    same target atom a, the other source."""
-    n_fwd = 2 * (ep // 4)
-    f = (j * n_fwd) // max(tp, 1)
-    return E + 2 * f, E + 2 * (f ^ 1)
+    same target atom a, the other source.  `quad`: the forward edges b->a, c->a (offsets 0 and 2) of the complete units."""
+    if not quad:
+        n_fwd = 2 * (ep // 4)
+        f = (j * n_fwd) // max(tp, 1)
+        return E + 2 * f, E + 2 * (f ^ 1)
+    s = (j * (2 * (ep // 6))) // max(tp, 1)
+    u, w = s // 2, s % 2
+    return E + 6 * u + 2 * w, E + 6 * u + 2 * (1 - w)
 
 
-def pad_indices(idx, n_atoms, e_cap, t_cap, n_groups, dtype=torch.int64):
+def _pad_int_edges(k, n_atoms, n_groups):
+    """Pad interaction edge k -> (id4_int_b = source, id4_int_a = target): pairs b->a, a->b cycling over the groups."""
+    p, rev = k // 2, k % 2
+    a = n_atoms + 4 * (p % max(n_groups, 1))
+    return torch.where(rev == 0, a + 1, a), torch.where(rev == 0, a, a + 1)
+
+
+def _pad_intm(i, E, Eint, ep, eintp, ip, n_groups):
+    """Pad intermediate triplet i of ip -> (embedding edge c->a, embedding edge d->b, interaction edge b->a): interaction edges
+    spread evenly and sorted (id4_expand_intm_ab is a sorted list), the embedding edges those of a unit of the same group
+    when one exists."""
+    n_ab, n_units, G = (eintp + 1) // 2, max(ep // 6, 1), max(n_groups, 1)
+    p = (i * n_ab) // max(ip, 1)
+    g = p % G
+    u = torch.where(g < n_units, g, p % n_units)
+    return E + 6 * u + 2, E + 6 * u + 4, Eint + 2 * p
+
+
+def _pad_quads(q, E, I, ep, ip, qp):
+    """Pad quadruplet q of qp -> (reduce edge c->a, index of a pad intermediate triplet): reduce edges spread evenly over the
+    units and sorted; the expand rows cycle over the pad intermediate triplets."""
+    u = (q * max(ep // 6, 1)) // max(qp, 1)
+    return E + 6 * u + 2, I + q % max(ip, 1)
+
+
+def _check_quad_padding(ep, tp, eintp, ip, qp):
+    if (tp or ip or qp) and ep < 6:
+        raise ValueError("pad triplets / intermediate triplets / quadruplets need a complete unit of six pad edges")
+    if ip and eintp < 1:
+        raise ValueError("pad intermediate triplets need a pad interaction edge")
+    if qp and ip < 1:
+        raise ValueError("pad quadruplets need a pad intermediate triplet")
+
+
+def pad_indices(idx, n_atoms, e_cap, t_cap, n_groups, dtype=torch.int64, quad_caps=None):
     """idx: the index dict of one batch (id_c, id_a, id_swap, id_undir, id3_reduce_ca, id3_expand_ba; any int dtype)
     -> dict of the same keys padded to (e_cap, t_cap) as described in the module docstring.  Pure index arithmetic
-    (runs on any device, no host sync besides the shapes)."""
+    (runs on any device, no host sync besides the shapes).  `quad_caps` = (eint_cap, i_cap, q_cap): a quadruplet batch (idx
+    then also holds the eleven id4_* arrays) padded with groups of four dummy atoms."""
+    quad = quad_caps is not None
     E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
     ep, tp = e_cap - E, t_cap - T
     if ep < 0 or tp < 0:
         raise ValueError(f"batch ({E} edges, {T} triplets) exceeds the capacities ({e_cap}, {t_cap})")
     if ep % 2 or E % 2 or tp % 2:
         raise ValueError("edge and triplet padding must be even (edges and triplets come in pairs)")
-    if tp and ep < 4:
-        raise ValueError("pad triplets need a complete quad of pad edges")
+    if tp and ep < (6 if quad else 4):
+        raise ValueError("pad triplets need a complete quad of pad edges (a unit of six for quadruplet batches)")
     dev = idx["id_c"].device
     k = torch.arange(ep, device=dev, dtype=torch.int64)
-    src, dst = _pad_edges(k, n_atoms, n_groups)
+    src, dst = _pad_edges(k, n_atoms, n_groups, quad)
     out = {
         "id_c": torch.cat([idx["id_c"].to(dtype), src.to(dtype)]),
         "id_a": torch.cat([idx["id_a"].to(dtype), dst.to(dtype)]),
         "id_swap": torch.cat([idx["id_swap"].to(dtype), (E + (k ^ 1)).to(dtype)]),
         "id_undir": torch.cat([idx["id_undir"].to(dtype), (E // 2 + k // 2).to(dtype)]),
     }
-    red, exp = _pad_triplets(torch.arange(tp, device=dev, dtype=torch.int64), E, ep, tp)
+    red, exp = _pad_triplets(torch.arange(tp, device=dev, dtype=torch.int64), E, ep, tp, quad)
     out["id3_reduce_ca"] = torch.cat([idx["id3_reduce_ca"].to(dtype), red.to(dtype)])
     out["id3_expand_ba"] = torch.cat([idx["id3_expand_ba"].to(dtype), exp.to(dtype)])
+    if quad:
+        eint_cap, i_cap, q_cap = quad_caps
+        Eint, I, Q = int(idx["id4_int_a"].shape[0]), int(idx["id4_expand_intm_db"].shape[0]), int(idx["id4_reduce_ca"].shape[0])
+        if int(idx["id4_reduce_intm_ca"].shape[0]) != I:
+            raise ValueError("the two intermediate-triplet lists differ in length")
+        eintp, ip, qp = eint_cap - Eint, i_cap - I, q_cap - Q
+        if min(eintp, ip, qp) < 0:
+            raise ValueError(f"batch ({Eint} interaction edges, {I} intermediate triplets, {Q} quadruplets) exceeds the "
+                             f"capacities {tuple(quad_caps)}")
+        _check_quad_padding(ep, tp, eintp, ip, qp)
+        ar = lambda n: torch.arange(n, device=dev, dtype=torch.int64)      # noqa: E731
+        ib, ia = _pad_int_edges(ar(eintp), n_atoms, n_groups)
+        out["id4_int_b"] = torch.cat([idx["id4_int_b"].to(dtype), ib.to(dtype)])
+        out["id4_int_a"] = torch.cat([idx["id4_int_a"].to(dtype), ia.to(dtype)])
+        ca, db, ab = _pad_intm(ar(ip), E, Eint, ep, eintp, ip, n_groups)
+        for key, v in (("id4_reduce_intm_ca", ca), ("id4_reduce_intm_ab", ab), ("id4_expand_intm_db", db),
+                       ("id4_expand_intm_ab", ab)):
+            out[key] = torch.cat([idx[key].to(dtype), v.to(dtype)])
+        rq, im = _pad_quads(ar(qp), E, I, ep, ip, qp)
+        out["id4_reduce_ca"] = torch.cat([idx["id4_reduce_ca"].to(dtype), rq.to(dtype)])
+        out["id4_expand_abd"] = torch.cat([idx["id4_expand_abd"].to(dtype), im.to(dtype)])
+        out["id4_reduce_cab"] = torch.cat([idx["id4_reduce_cab"].to(dtype), im.to(dtype)])
+        out["id4_expand_db"] = torch.cat([idx["id4_expand_db"].to(dtype), db[im - I].to(dtype) if qp else db[:0].to(dtype)])
     return out
 
 
-def dummy_positions(n_groups, like, offset=1.0e3):
+def dummy_positions(n_groups, like, offset=1.0e3, quad=False):
     """(3 G, 3) positions: group g = atoms a, b, c with |ab| = |ac| = 1 A and a right angle, 10 A between groups, `offset`
-    away from the origin (real molecules of a batch sit near it)."""
+    away from the origin (real molecules of a batch sit near it).  `quad`: (4 G, 3) — a fourth atom d bonded to b, out of the
+    plane: the angles c-a-b, a-b-d and the dihedral c-a-b-d are all 90 degrees."""
     g = torch.arange(n_groups, device=like.device, dtype=like.dtype)
     base = torch.stack([offset + 10.0 * g, torch.full_like(g, offset), torch.full_like(g, offset)], dim=1)
-    d = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], device=like.device, dtype=like.dtype)
+    rows = [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]] + ([[1.0, 0.0, 1.0]] if quad else [])
+    d = torch.tensor(rows, device=like.device, dtype=like.dtype)
     return (base[:, None, :] + d[None, :, :]).reshape(-1, 3)
 
 
@@ -97,9 +181,14 @@ class PaddedGraphRunner:
     A batch that does not fit raises `ValueError` — size the capacities from the first batches with a margin
     (`suggest_capacities`)."""
 
-    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, a_cap=None, index_dtype=torch.int32):
-        if not model.triplets_only:
-            raise NotImplementedError("padded replay: triplets-only models (forces by autograd or by the direct-force head)")
+    def __init__(self, model, Z, N, e_cap, t_cap, max_in_degree=None, n_groups=None, a_cap=None, index_dtype=torch.int32,
+                 quad_caps=None):
+        """`quad_caps` = (eint_cap, i_cap, q_cap): capacities of interaction edges, intermediate triplets and quadruplets —
+        required for quadruplet models (`suggest_capacities` sizes all five from a few batches)."""
+        self.quad = not model.triplets_only
+        if self.quad and quad_caps is None:
+            raise ValueError("quadruplet models need quad_caps = (eint_cap, i_cap, q_cap)")
+        self.GS = 4 if self.quad else 3              # atoms per dummy group
         self.model = model
         dev = Z.device
         self.A, self.n_mol = int(Z.shape[0]), int(N.shape[0])          # A: atoms of the CURRENT batch
@@ -111,7 +200,7 @@ class PaddedGraphRunner:
         self.deg = int(max_in_degree) if max_in_degree is not None else int(N.max().item()) - 1
         # every group's atom a takes pad edges of both kinds: at most 2 * ceil(pad quads / G) incoming
         self.G = int(n_groups) if n_groups is not None else max(1, -(-self.e_cap // (16 * max(self.deg, 2))))
-        Ap = 3 * self.G
+        Ap = self.GS * self.G
         self.A_tot = self.a_cap + Ap
         i64 = torch.int64
         n_fill = self.a_cap - self.A
@@ -128,19 +217,29 @@ class PaddedGraphRunner:
         fill = torch.arange(self.a_cap, device=dev, dtype=self.inputs["R"].dtype)
         self._R_fill = torch.stack([-1.0e3 - 10.0 * fill, torch.full_like(fill, -1.0e3), torch.full_like(fill, -1.0e3)], dim=1)
         self.inputs["R"][:self.a_cap] = self._R_fill
-        self.inputs["R"][self.a_cap:] = dummy_positions(self.G, self.inputs["R"])
+        self.inputs["R"][self.a_cap:] = dummy_positions(self.G, self.inputs["R"], quad=self.quad)
         # The edge / triplet arrays live in `index_dtype` (int32: what the kernels read — the plan built inside the replayed
         # graph then has no conversion launches, and the device index builder hands its int32 arrays over as they are;
         # batches given as int64 are converted by the copy into the buffers).  Values stay far below 2^31 (checked).
-        if max(self.e_cap, self.t_cap, self.A_tot) >= 2 ** 31:
+        self.quad_caps = tuple(int(c) for c in quad_caps) if self.quad else None
+        if max((self.e_cap, self.t_cap, self.A_tot) + (self.quad_caps or ())) >= 2 ** 31:
             index_dtype = i64
         self.index_dtype = index_dtype
         for k in PAD_EDGE_KEYS:
             self.inputs[k] = torch.zeros(self.e_cap, dtype=index_dtype, device=dev)
         for k in PAD_TRIP_KEYS:
             self.inputs[k] = torch.zeros(self.t_cap, dtype=index_dtype, device=dev)
+        if self.quad:
+            eint_cap, i_cap, q_cap = self.quad_caps
+            for k in PAD_INT_KEYS:
+                self.inputs[k] = torch.zeros(eint_cap, dtype=index_dtype, device=dev)
+            for k in PAD_INTM_KEYS:
+                self.inputs[k] = torch.zeros(i_cap, dtype=index_dtype, device=dev)
+            for k in PAD_QUAD_KEYS:
+                self.inputs[k] = torch.zeros(q_cap, dtype=index_dtype, device=dev)
+            self._arange_q = torch.arange(max(eint_cap, i_cap, q_cap), device=dev, dtype=i64)
         k = torch.arange(self.e_cap, device=dev, dtype=i64)
-        self._pat_src, self._pat_dst = (t.to(index_dtype) for t in _pad_edges(k, self.a_cap, self.G))
+        self._pat_src, self._pat_dst = (t.to(index_dtype) for t in _pad_edges(k, self.a_cap, self.G, self.quad))
         self._pat_swap, self._pat_pair = (k ^ 1).to(index_dtype), (k // 2).to(index_dtype)
         self._arange_t = torch.arange(self.t_cap, device=dev, dtype=i64)
         self.graph = None
@@ -166,10 +265,33 @@ class PaddedGraphRunner:
     def suggest_capacities(sizes, margin=0.06):
         """sizes: [(E, T), ...] of a few batches -> (e_cap, t_cap).  Triplets get `margin` head room, edges a little more:
         every pad triplet needs a pad edge to reduce into, and a pad edge with hundreds of triplets is a long tail for the
-        one wave that owns it (a real edge has ~18)."""
+        one wave that owns it (a real edge has ~18).  Quadruplet batches: sizes [(E, T, Eint, I, Q), ...] ->
+        (e_cap, t_cap, (eint_cap, i_cap, q_cap))."""
         e = max(s[0] for s in sizes)
         t = max(s[1] for s in sizes)
-        return int(e * (1 + 1.5 * margin)) // 4 * 4 + 8, int(t * (1 + margin)) // 2 * 2 + 2
+        if len(sizes[0]) == 2:
+            return int(e * (1 + 1.5 * margin)) // 4 * 4 + 8, int(t * (1 + margin)) // 2 * 2 + 2
+        ei, im, q = (max(s[k] for s in sizes) for k in (2, 3, 4))
+        return (int(e * (1 + 1.5 * margin)) // 12 * 12 + 24, int(t * (1 + margin)) // 2 * 2 + 2,
+                (int(ei * (1 + 1.5 * margin)) + 4, int(im * (1 + margin)) + 4, int(q * (1 + margin)) + 4))
+
+    @staticmethod
+    def sizes_of(idx):
+        """(E, T[, Eint, I, Q]) of an index dict."""
+        s = (int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0]))
+        if "id4_reduce_ca" in idx:
+            s += (int(idx["id4_int_a"].shape[0]), int(idx["id4_expand_intm_db"].shape[0]), int(idx["id4_reduce_ca"].shape[0]))
+        return s
+
+    def fits(self, sizes):
+        """Does a batch of these sizes (sizes_of) fit the capacities with valid padding?"""
+        E, T = sizes[:2]
+        ep, tp = self.e_cap - E, self.t_cap - T
+        ok = ep >= 0 and tp >= 0 and not (tp and ep < (6 if self.quad else 4)) and -(-(ep // 2) // self.G) <= self.pad_degree_bound()
+        if ok and self.quad:
+            eintp, ip, qp = (c - n for c, n in zip(self.quad_caps, sizes[2:5]))
+            ok = min(eintp, ip, qp) >= 0 and not ((ip or qp) and ep < 6) and not (ip and eintp < 1) and not (qp and ip < 1)
+        return ok
 
     def _fill(self, R, idx, Z=None, N=None):
         """Write one batch into the static buffers: the real rows as they are, the pad rows from the patterns computed
@@ -198,8 +320,9 @@ class PaddedGraphRunner:
         ep, tp = self.e_cap - E, self.t_cap - T
         if ep < 0 or tp < 0:
             raise ValueError(f"batch ({E} edges, {T} triplets) exceeds the capacities ({self.e_cap}, {self.t_cap})")
-        if ep % 2 or tp % 2 or (tp and ep < 4):
-            raise ValueError("edge and triplet padding must be even, and pad triplets need a complete quad of pad edges")
+        if ep % 2 or tp % 2 or (tp and ep < (6 if self.quad else 4)):
+            raise ValueError("edge and triplet padding must be even, and pad triplets need a complete quad of pad edges "
+                             "(a unit of six for quadruplet models)")
         # in-degree of a group's atom a: both kinds of pairs land on it
         if -(-(ep // 2) // self.G) > self.pad_degree_bound():
             raise ValueError(f"{ep} pad edges over {self.G} dummy groups exceed the in-degree bound {self.pad_degree_bound()}")
@@ -212,10 +335,44 @@ class PaddedGraphRunner:
             torch.add(self._pat_swap[:ep], E, out=buf["id_swap"][E:])
             torch.add(self._pat_pair[:ep], E // 2, out=buf["id_undir"][E:])
         if tp:
-            red, exp = _pad_triplets(self._arange_t[:tp], E, ep, tp)
+            red, exp = _pad_triplets(self._arange_t[:tp], E, ep, tp, self.quad)
             buf["id3_reduce_ca"][T:].copy_(red)
             buf["id3_expand_ba"][T:].copy_(exp)
+        if self.quad:
+            self._fill_quad(idx, E, ep, tp)
         buf["R"][:self.A].copy_(R)
+
+    def _fill_quad(self, idx, E, ep, tp):
+        """Interaction edges, intermediate triplets and quadruplets of one batch + their pad rows (module docstring)."""
+        buf = self.inputs
+        Eint, I, Q = int(idx["id4_int_a"].shape[0]), int(idx["id4_expand_intm_db"].shape[0]), int(idx["id4_reduce_ca"].shape[0])
+        if int(idx["id4_reduce_intm_ca"].shape[0]) != I:
+            raise ValueError("the two intermediate-triplet lists differ in length")
+        eint_cap, i_cap, q_cap = self.quad_caps
+        eintp, ip, qp = eint_cap - Eint, i_cap - I, q_cap - Q
+        if min(eintp, ip, qp) < 0:
+            raise ValueError(f"batch ({Eint} interaction edges, {I} intermediate triplets, {Q} quadruplets) exceeds the "
+                             f"capacities {self.quad_caps}")
+        _check_quad_padding(ep, tp, eintp, ip, qp)
+        for k in PAD_INT_KEYS + PAD_INTM_KEYS + PAD_QUAD_KEYS:
+            buf[k][:idx[k].shape[0]].copy_(idx[k])
+        ar = self._arange_q
+        if eintp:
+            ib, ia = _pad_int_edges(ar[:eintp], self.a_cap, self.G)
+            buf["id4_int_b"][Eint:].copy_(ib)
+            buf["id4_int_a"][Eint:].copy_(ia)
+        if ip:
+            ca, db, ab = _pad_intm(ar[:ip], E, Eint, ep, eintp, ip, self.G)
+            buf["id4_reduce_intm_ca"][I:].copy_(ca)
+            buf["id4_expand_intm_db"][I:].copy_(db)
+            buf["id4_reduce_intm_ab"][I:].copy_(ab)
+            buf["id4_expand_intm_ab"][I:].copy_(ab)
+        if qp:
+            rq, im = _pad_quads(ar[:qp], E, I, ep, ip, qp)
+            buf["id4_reduce_ca"][Q:].copy_(rq)
+            buf["id4_expand_abd"][Q:].copy_(im)
+            buf["id4_reduce_cab"][Q:].copy_(im)
+            buf["id4_expand_db"][Q:].copy_(db[im - I])
 
     def pad_degree_bound(self):
         return max(self.deg, 2)

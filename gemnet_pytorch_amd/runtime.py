@@ -157,7 +157,9 @@ class DynamicForceField:
     Every call builds the index arrays on the device (index_device.DeviceGraphBuilder, on a stream of its own), pads them to
     the current capacities and replays the one captured graph (padded.PaddedGraphRunner: bit-identical to the eager run
     on the unpadded arrays).  The capacities start `margin` above the first call's sizes; a call that outgrows them
-    captures a new graph with `margin` head room again (counted in `recaptures`).  Triplets-only models."""
+    captures a new graph with `margin` head room again (counted in `recaptures`).  Triplets-only AND quadruplet models (the
+    latter since round 5: padded.py pads interaction edges, intermediate triplets and quadruplets as well — GemNet-Q is the
+    model of the reference's MD example, ase_example.ipynb cell 13)."""
 
     def __init__(self, model, Z, N_host, cutoff, int_cutoff, margin=0.08, max_in_degree=None):
         from .index_device import DeviceGraphBuilder
@@ -187,16 +189,22 @@ class DynamicForceField:
     def __call__(self, R):
         from .padded import PaddedGraphRunner
         idx = self._build(R)
-        E, T = int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0])
+        sizes = PaddedGraphRunner.sizes_of(idx)
         r = self.runner
-        # pad triplets need a complete quad of pad edges; the pad edges must fit the dummy groups' in-degree bound
-        fits = r is not None and E + 4 <= r.e_cap and T <= r.t_cap and -(-((r.e_cap - E) // 2) // r.G) <= r.pad_degree_bound()
-        if not fits:
-            e_cap = int(E * (1 + 1.5 * self.margin)) // 2 * 2 + 8
-            t_cap = int(T * (1 + self.margin)) // 2 * 2 + 2
+        # pad triplets need a complete quad (unit) of pad edges; the pad edges must fit the dummy groups' in-degree bound
+        if r is None or not r.fits(sizes):
+            E, T = sizes[:2]
+            m = self.margin
+            e_cap = int(E * (1 + 1.5 * m)) // 12 * 12 + 24
+            t_cap = int(T * (1 + m)) // 2 * 2 + 2
             # dummy groups for the largest padding this runner may see (a later call with fewer edges pads more)
-            groups = max(1, -(-int(e_cap * min(1.0, 4 * self.margin)) // (2 * max(self.deg, 2))))
-            self.runner = PaddedGraphRunner(self.model, self.Z, self.N, e_cap, t_cap, max_in_degree=self.deg, n_groups=groups)
+            groups = max(1, -(-int(e_cap * min(1.0, 4 * m)) // (2 * max(self.deg, 2))))
+            quad_caps = None
+            if not self.model.triplets_only:
+                Eint, I, Q = sizes[2:5]
+                quad_caps = (int(Eint * (1 + 1.5 * m)) + 4, int(I * (1 + m)) + 4, int(Q * (1 + m)) + 4)
+            self.runner = PaddedGraphRunner(self.model, self.Z, self.N, e_cap, t_cap, max_in_degree=self.deg, n_groups=groups,
+                                            quad_caps=quad_caps)
             self.recaptures += self.runner is not r and r is not None
         return self.runner(R, idx)
 
