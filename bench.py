@@ -609,6 +609,12 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
     log_families("GemNet-Q forward+force", fam)
     out = dict(ms_per_step=round(elapsed / steps * 1e3, 3), molecules_per_s=round(n_mol * steps / elapsed, 1),
                steps=steps, warmup=warmup, per_gpu=sizes, hipgraph=True, roofline=roof)
+    # a NEW GemNet-Q batch every step: eager against the padded replay (padded.py pads interaction edges, intermediate triplets
+    # and quadruplets too since round 5) — the MD loop of the reference's example runs exactly this model
+    try:
+        out["dynamic_shape"] = extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=3, steps=6, warmup=2)
+    except Exception as ex:  # noqa: BLE001
+        out["dynamic_shape"] = dict(error=f"{type(ex).__name__}: {ex}"[:300])
     del graph, model
     # The GemNet-Q TRAINING step (trainer.py:325-360 on configs[2]): every layer on the fused sweeps of ops_train.py — since
     # round 5 also the quadruplet geometry and the quadruplet bilinear layer with its tensor basis in ANGLE form
@@ -722,13 +728,14 @@ def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12,
                     "positions / Z / N resident in HBM")
     # the same loop with every batch padded to fixed capacities and ONE captured hipGraph replayed (padded.py): the index
     # plan is rebuilt on the device inside the graph, the host launches the index build, a dozen small padding ops, the replay
-    if cfg["triplets_only"]:
+    if True:       # (triplets-only models since round 3, quadruplet models since round 5)
         try:
             from gemnet_pytorch_amd.padded import PaddedGraphRunner
             idxs = [builders[b](data[b]["R"]) for b in range(n_batches)]
-            sizes = [(int(i["id_c"].shape[0]), int(i["id3_reduce_ca"].shape[0])) for i in idxs]
-            e_cap, t_cap = PaddedGraphRunner.suggest_capacities(sizes)
-            runner = PaddedGraphRunner(model, data[0]["Z"], data[0]["N"], e_cap, t_cap)
+            sizes = [PaddedGraphRunner.sizes_of(i) for i in idxs]
+            caps = PaddedGraphRunner.suggest_capacities(sizes)
+            runner = PaddedGraphRunner(model, data[0]["Z"], data[0]["N"], caps[0], caps[1],
+                                       quad_caps=caps[2] if len(caps) > 2 else None)
             state["i"] = 0
 
             def pstep():
@@ -744,7 +751,9 @@ def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12,
             E1, F1 = runner(data[0]["R"], idxs[0], Z=data[0]["Z"])
             out["padded_graph"] = dict(ms_per_step=round(el / psteps * 1e3, 3), molecules_per_s=round(n_mol * psteps / el, 1),
                                        steps=psteps,
-                                       capacities=dict(edges=runner.e_cap, triplets=runner.t_cap, dummy_atoms=3 * runner.G),
+                                       capacities=dict(edges=runner.e_cap, triplets=runner.t_cap, dummy_atoms=runner.GS * runner.G,
+                                                       **(dict(zip(("interaction_edges", "intermediate_triplets", "quadruplets"),
+                                                                   runner.quad_caps)) if runner.quad_caps else {})),
                                        batch_sizes=sizes, max_abs_force_deviation_vs_eager=float((F1 - F0).abs().max()),
                                        note="every batch padded with a dummy molecule to fixed capacities, one captured "
                                             "hipGraph replayed; index build (with its size read-back) per step, on its own stream "
