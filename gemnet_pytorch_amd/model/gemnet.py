@@ -93,9 +93,11 @@ class GemNet(torch.nn.Module):
         self.triplets_only = triplets_only
         self.num_spherical = num_spherical
         self.force_graph = None  # None: auto (training & grad enabled); True/False: forced
-        # arithmetic of the LDS-resident Dense stacks (kernels.CHAIN_MODES): None = the package default ("split6":
-        # fp32-equivalent split-bf16 products); "bf16" = plain bf16 MFMA operands with fp32 accumulation, fp32
-        # everywhere else (BASELINE configs[4]); "f32" = the f32-input MFMA
+        # arithmetic of the LDS-resident Dense stacks: None = the package default ("h3": fp32 operands as two fp16 planes,
+        # three products), "split6" = three bf16 planes / six products (fp32 exponent range), "f32" = the f32-input MFMA — all
+        # three at fp32 accuracy (force MAE 1e-6 .. 4e-6 eV/A against float64).  Single-plane bf16 / three-product modes exist
+        # in the chain KERNEL (kernels.CHAIN_MODES, tests) but are not a model option: measured on the configs[4] shard they are
+        # slower than the default (116 vs 109 ms) at 4e-2 eV/A
         self.matmul_precision = None
         self.overlap_output_blocks = True
         self._side = None
@@ -424,9 +426,15 @@ class GemNet(torch.nn.Module):
                 out = self._forward(inputs)
         return out
 
+    PRECISIONS = (None, "h3", "split6", "f32")
+
     def _forward(self, inputs):
         R = inputs["R"]
         self._check_inputs(R)
+        if self.matmul_precision not in self.PRECISIONS and not getattr(self, "_experimental_precision", False):
+            raise ValueError(f"matmul_precision must be one of {self.PRECISIONS}; got {self.matmul_precision!r} (reduced-precision "
+                             "operand modes are kernel-level experiments, not a model option: slower AND 4e-2 eV/A off on "
+                             "BASELINE configs[4], DESIGN.md section 14)")
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
         late = None
         pos_graph = False

@@ -287,7 +287,7 @@ class PaddedGraphRunner:
         """Does a batch of these sizes (sizes_of) fit the capacities with valid padding?"""
         E, T = sizes[:2]
         ep, tp = self.e_cap - E, self.t_cap - T
-        ok = ep >= 0 and tp >= 0 and not (tp and ep < (6 if self.quad else 4)) and -(-(ep // 2) // self.G) <= self.pad_degree_bound()
+        ok = ep >= 0 and tp >= 0 and not (tp and ep < (6 if self.quad else 4)) and self.pad_in_degree(ep) <= self.pad_degree_bound()
         if ok and self.quad:
             eintp, ip, qp = (c - n for c, n in zip(self.quad_caps, sizes[2:5]))
             ok = min(eintp, ip, qp) >= 0 and not ((ip or qp) and ep < 6) and not (ip and eintp < 1) and not (qp and ip < 1)
@@ -323,8 +323,7 @@ class PaddedGraphRunner:
         if ep % 2 or tp % 2 or (tp and ep < (6 if self.quad else 4)):
             raise ValueError("edge and triplet padding must be even, and pad triplets need a complete quad of pad edges "
                              "(a unit of six for quadruplet models)")
-        # in-degree of a group's atom a: both kinds of pairs land on it
-        if -(-(ep // 2) // self.G) > self.pad_degree_bound():
+        if self.pad_in_degree(ep) > self.pad_degree_bound():
             raise ValueError(f"{ep} pad edges over {self.G} dummy groups exceed the in-degree bound {self.pad_degree_bound()}")
         buf = self.inputs
         for k in PAD_EDGE_KEYS + PAD_TRIP_KEYS:
@@ -376,6 +375,14 @@ class PaddedGraphRunner:
 
     def pad_degree_bound(self):
         return max(self.deg, 2)
+
+    def pad_in_degree(self, ep):
+        """Largest in-degree of a dummy atom with `ep` pad edges.  Triplet layout: both kinds of pairs (b->a, c->a) land on a
+        group's atom a: the pairs of the group.  Quadruplet layout: a unit of six pad edges puts two on a (b->a, c->a) and two
+        on b (a->b, d->b): twice the units of the group."""
+        if self.quad:
+            return 2 * -(-(-(-ep // 6)) // self.G)
+        return -(-(ep // 2) // self.G)
 
     def __call__(self, R, idx, Z=None, N=None):
         """R (A, 3) float32 on the device, idx: the index dict of this batch, Z: its atomic numbers when they change from

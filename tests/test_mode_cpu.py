@@ -53,6 +53,7 @@ def test_two_models_two_precisions_backward_on_another_thread(golden_model, monk
             cfg, params, inputs = load_case(g, "t2")
             m = build(cfg, params)
             m.matmul_precision = prec
+            m._experimental_precision = True     # (the single-plane kernel mode: its loss-scaled sweeps differ from h3's)
             m.train()
             inputs["R"] = inputs["R"].double()
             log.clear()

@@ -45,6 +45,7 @@ with torch.no_grad():
         ob.out_energy.weight.mul_(s)
 model._wcache.clear()
 res = {}
+model._experimental_precision = True    # kernel-level experiment (not a model option since round 5)
 for mode in (None, "bf16"):
     model.matmul_precision = mode
     for _ in range(2):
