@@ -503,6 +503,7 @@ def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, w
     from gemnet_pytorch_amd.model.gemnet import GemNet
     from gemnet_pytorch_amd.training.ddp import TrainStep
     torch.manual_seed(model_seed)
+    torch.cuda.reset_peak_memory_stats(inputs["R"].device)
     model = GemNet(**cfg, scale_file=SCALE_FILE).to(inputs["R"].device)
     ts = TrainStep(model, world_size=world, fused_optimizer=True)
     inputs = {k: v for k, v in inputs.items() if k != "_plan"}
@@ -519,7 +520,10 @@ def extra_train_step(cfg, model_seed, inputs, targets, world, batch, steps=10, w
                collective=("all_reduce(sum) of one flat %.1f MB fp32 gradient buffer per step over RCCL"
                            % (ts.buf.flat.numel() * 4 / 1e6)) if world > 1 else "none (single process)",
                optimizer="fused rescale + clip + AdamW(amsgrad) + EMA, 2 launches (csrc/optim.hip)",
-               loss=float(ts.last_loss))
+               loss=float(ts.last_loss),
+               # peak of the timed steps (capture + replays); the instrumented pass below holds every intermediate of a step
+               # alive through its launch records and is not part of it
+               peak_memory_gib=round(torch.cuda.max_memory_allocated(inputs["R"].device) / 2**30, 1))
     if world > 1:
         # the collective alone: the flat gradient buffer through RCCL, back to back between two syncs (max over ranks)
         import torch.distributed as dist
@@ -626,7 +630,6 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
             torch.cuda.reset_peak_memory_stats(dev)
             ts_out = extra_train_step(cfg, 1234, inputs, targets, 1, n_mol, steps=5, warmup=2, want_roofline=True, graph=True,
                                       roof_mode="Qtrain")
-            ts_out["peak_memory_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)
             ts_out["note"] = ("forward + force + loss.backward() through the force + fused optimizer; quadruplet interaction on the "
                               "fused angle-form twins (round 4: composite closure over the (Q, 49) harmonics, eager, 112-150 ms); "
                               "roofline = dominant LIBRARY launcher family of one step")

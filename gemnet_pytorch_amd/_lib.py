@@ -99,6 +99,8 @@ SIGNATURES = {
     "gn_quad_angles_jvp_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_bil_reduce_project_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_expand_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_csr_build_i32": [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp],
+    "gn_seg_offsets_i32": [_vp, _i64, _i64, _vp, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "gn_gather_mul_f32": [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "gn_dist_fwd_f32": [_vp, _vp, _vp, _vp, _i64, _vp],
@@ -157,6 +159,8 @@ def load():
     #  of each launch — kernels.ANG_F16_MASK / WIDE_TILE_ROWS / WIDE_STAGGER hold the read-only host configuration)
     lib.gn_optim_blocks.restype = _i
     lib.gn_optim_blocks.argtypes = [_i64]
+    lib.gn_csr_ws_bytes.restype = _i64
+    lib.gn_csr_ws_bytes.argtypes = [_i64, _i64]
     lib.gn_index_gpu_ws_bytes.restype = _i64
     lib.gn_index_gpu_ws_bytes.argtypes = [_i, _i64, _i]
     lib.gn_pack_weight_split_bytes.restype = _i64

@@ -51,6 +51,13 @@ class RowIndex:
         if self._csr is None:
             if self._csr_builder is not None:
                 self._csr = self._csr_builder()
+            elif self.idx32.is_cuda and _native_csr():
+                # one native launch pair per grouping (csrc/csr.hip: radix sort over the significant key bits, int32 throughout)
+                from . import kernels as _K
+                if self.is_sorted:
+                    self._csr = (None, _K.seg_offsets(self.idx32, self.n_rows))
+                else:
+                    self._csr = _K.csr_build(self.idx32, self.n_rows)
             elif self.is_sorted:
                 self._csr = (None, _seg_offsets_sorted(self.idx64, self.n_rows))
             else:
@@ -78,6 +85,11 @@ def expanded_csr(row_of_edge: RowIndex, seg_off_of_edge: torch.Tensor, n_items: 
     k = torch.searchsorted(off[1:].contiguous(), j, right=True)      # slot of the edge that owns item j
     perm = so[order[k]] + (j - off[k])
     return perm.to(torch.int32).contiguous(), off[seg_e.to(torch.int64)].to(torch.int32).contiguous()
+
+
+def _native_csr():
+    from . import kernels as _K
+    return _K.USE_NATIVE_CSR
 
 
 def _atom_blocks_on():
@@ -142,8 +154,13 @@ class SegmentPlan:
         _late_wait(self)
         if self._groups is None:
             key = self._row_group
-            rows = torch.argsort(key, stable=True)
-            off = _seg_offsets_sorted(key[rows], self._n_groups)
+            if key.is_cuda and _native_csr():
+                from . import kernels as _K
+                rows32, off = _K.csr_build(key.to(torch.int32), self._n_groups)
+                rows = rows32.to(torch.int64)
+            else:
+                rows = torch.argsort(key, stable=True)
+                off = _seg_offsets_sorted(key[rows], self._n_groups)
             rank = torch.empty_like(rows)
             rank[rows] = torch.arange(rows.shape[0], device=rows.device) - off.to(torch.int64)[key[rows]]
             permT, segT = self.expand.csr

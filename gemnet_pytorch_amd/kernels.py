@@ -183,6 +183,36 @@ def segsum_multi(terms, n_rows):
     return x
 
 
+USE_NATIVE_CSR = os.environ.get("GEMNET_NATIVE_CSR", "1") == "1"
+
+
+def csr_build(idx32, n_rows):
+    """(perm int32, seg_off int32 (n_rows + 1)) of the int32 keys `idx32` by row, stable (gn_csr_build_i32: one radix sort over
+    the significant key bits + one lower-bound launch; the torch form was argsort + gather + arange + searchsorted + casts)."""
+    require_device(idx32)
+    assert idx32.dtype == torch.int32 and idx32.dim() == 1
+    idx32 = idx32.contiguous()
+    n = int(idx32.shape[0])
+    lib = _lib.load()
+    nbytes = int(lib.gn_csr_ws_bytes(n, int(n_rows)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=idx32.device)
+    perm = torch.empty(n, dtype=torch.int32, device=idx32.device)
+    seg = torch.empty(int(n_rows) + 1, dtype=torch.int32, device=idx32.device)
+    check(lib.gn_csr_build_i32(ptr(idx32), n, int(n_rows), ptr(perm), ptr(seg), ptr(ws), nbytes, stream()), "gn_csr_build_i32")
+    return perm, seg
+
+
+def seg_offsets(sorted_idx32, n_rows):
+    """seg_off int32 (n_rows + 1) of SORTED int32 keys (gn_seg_offsets_i32)."""
+    require_device(sorted_idx32)
+    assert sorted_idx32.dtype == torch.int32
+    sorted_idx32 = sorted_idx32.contiguous()
+    seg = torch.empty(int(n_rows) + 1, dtype=torch.int32, device=sorted_idx32.device)
+    check(_lib.load().gn_seg_offsets_i32(ptr(sorted_idx32), int(sorted_idx32.shape[0]), int(n_rows), ptr(seg), stream()),
+          "gn_seg_offsets_i32")
+    return seg
+
+
 def nonfinite_flag(x, flag, bit=1):
     """flag[0] |= bit when x holds an inf / NaN (gn_nonfinite_flag_f32; no host read-back: runtime.RangeFlag)."""
     require_device(x, flag)

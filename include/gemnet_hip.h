@@ -339,6 +339,18 @@ int gn_segsum_rows_f32(const float* y, const int32_t* perm, const int32_t* seg_o
 int gn_segsum_multi_f32(int n_terms, const float* const* y, const int32_t* const* perm, const int32_t* const* seg_off,
                         const float* sign, float* x, int64_t N, int C, void* stream);
 
+/* ---- CSR groupings of the index plans (csrc/csr.hip; ABI 13) ------------------------------------------------------------
+ * The transposed grouping of a gather `y = x[idx]` (interaction_block.py:543,548,562,678,693; embedding_block.py:70-71;
+ * atom_update_block.py:67): perm[k] = position of the k-th entry in row order (STABLE: entries of a row keep their input order,
+ * the permutation of a stable argsort), seg_off[r] = number of entries with a key below r (n_rows + 1 values).  One rocPRIM
+ * radix sort of (key, position) pairs over the significant key bits + one lower-bound launch; `ws`: caller-owned workspace of
+ * gn_csr_ws_bytes(n, n_rows) bytes (256-byte aligned); no allocation, no synchronisation (capturable).  Keys int32 in
+ * [0, n_rows), n < 2^31.  gn_seg_offsets_i32: the offsets alone for keys that are already sorted. */
+int64_t gn_csr_ws_bytes(int64_t n, int64_t n_rows);
+int gn_csr_build_i32(const int32_t* keys, int64_t n, int64_t n_rows, int32_t* perm, int32_t* seg_off, void* ws,
+                     int64_t ws_bytes, void* stream);
+int gn_seg_offsets_i32(const int32_t* sorted_keys, int64_t n, int64_t n_rows, int32_t* seg_off, void* stream);
+
 /* ---- bilinear aggregation, CSR-segmented (P4: efficient.py:159-189 without the zero-padded
  *      (E,Kmax,C) tensors; SURVEY.md Appendix D kernels K1 and its two adjoints) -----------
  * r(t) = reduce edge of triplet/quadruplet t (sorted ascending, seg_off[e]..seg_off[e+1]),

@@ -79,3 +79,26 @@ def test_model_forward_on_device_built_graph(golden_model):
         Fref = g[f"{tag}.F"]
         assert float(np.abs(F.detach().cpu().numpy() - Fref).mean()) <= 1e-5 * max(1.0, float(np.abs(Fref).mean()))
         assert float(np.abs(E.detach().cpu().numpy() - g[f"{tag}.E"]).max()) <= 2e-5 * max(1.0, float(np.abs(g[f"{tag}.E"]).max()))
+
+
+@pytest.mark.parametrize("n,n_rows", [(0, 5), (1, 1), (1000, 7), (18122, 1024), (332072, 18122), (2_000_003, 600_001), (4096, 2 ** 20)])
+def test_native_csr_build_equals_the_stable_sort(n, n_rows):
+    """gn_csr_build_i32 (csrc/csr.hip: rocPRIM radix sort of (key, position) pairs over the significant key bits + a lower-bound
+    launch) against the torch construction it replaces in graph.RowIndex.csr: the permutation of the STABLE argsort and the
+    row offsets, bit for bit — also for rows without entries, a single row, and keys that use the top bit of their range."""
+    import torch
+    from gemnet_pytorch_amd import kernels as K
+    g = torch.Generator().manual_seed(n + n_rows)
+    keys = torch.randint(0, n_rows, (n,), generator=g, dtype=torch.int64)
+    if n > 10:
+        keys[::3] = n_rows - 1                                  # heavy duplicates: stability matters
+        keys[1::7] = torch.randint(0, max(n_rows // 100, 1), (len(keys[1::7]),), generator=g)
+    dev = keys.to("cuda")
+    perm, seg = K.csr_build(dev.to(torch.int32), n_rows)
+    ref_perm = torch.argsort(dev, stable=True)
+    bounds = torch.arange(n_rows + 1, device="cuda")
+    ref_seg = torch.searchsorted(dev[ref_perm].contiguous(), bounds)
+    assert perm.dtype == torch.int32 and seg.dtype == torch.int32 and seg.shape[0] == n_rows + 1
+    assert torch.equal(perm.long(), ref_perm) and torch.equal(seg.long(), ref_seg)
+    srt = dev[ref_perm].to(torch.int32)
+    assert torch.equal(K.seg_offsets(srt, n_rows).long(), ref_seg)
