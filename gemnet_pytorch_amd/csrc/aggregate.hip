@@ -227,6 +227,89 @@ __global__ __launch_bounds__(256) GN_AGG_ATTR void rbf_aggregate_bwd_kernel(cons
   }
 }
 
+// Adjoint, second form (round 5): the same arithmetic in the same order (bit-identical results), restructured around what the
+// first form spends its time on — a chain of dependent loads per edge (id_a[e] -> g_out row) issued through the VECTOR memory
+// pipe by 8 192 short-lived waves that each fetch the 8 KB weight matrix into registers for ~2 edges of work:
+//   * the wave index is made provably uniform (readfirstlane), so the edge id, id_a[e] and the 64-byte rbf row of the edge
+//     are SCALAR loads (scalar cache, SGPR operands of the FMAs: no VGPRs, no vector-memory slots);
+//   * W goes through LDS once per workgroup (two coalesced float4 loads per thread) instead of 40 loads per lane;
+//   * one resident round of waves (grid = 4 waves x 4 workgroups per CU), each walking ~4-5 edges with the NEXT edge's
+//     operands requested before the current edge is computed.
+__global__ __launch_bounds__(256) GN_AGG_ATTR void rbf_aggregate_bwd_kernel_v2(const float* __restrict__ g_out, const float* __restrict__ m,
+                                                                   const float* __restrict__ rbf, const float* __restrict__ W,
+                                                                   const int32_t* __restrict__ id_a, float* g_m, float* g_rbf,
+                                                                   int64_t E, float scale, int accum) {
+  constexpr int WP = R + 1;                                   // LDS row pitch of W: conflict-free column reads
+  __shared__ float Wl[C * WP];
+  __shared__ __attribute__((aligned(16))) float tsm[4][C];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kq = lane & 15, part = lane >> 4;
+  for (int i = threadIdx.x; i < C * R / 4; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(W + 4 * i);
+    float* d = Wl + (i >> 2) * WP + 4 * (i & 3);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  float w0[R], w1[R], wt[32];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    w0[k] = Wl[(2 * lane) * WP + k];
+    w1[k] = Wl[(2 * lane + 1) * WP + k];
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) wt[j] = Wl[(32 * part + j) * WP + kq];
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= E) return;
+  // operands of edge e (requested one trip ahead)
+  int a = id_a[e];
+  float2 g = *reinterpret_cast<const float2*>(g_out + (size_t)a * C + 2 * lane);
+  float2 me = g_rbf ? *reinterpret_cast<const float2*>(m + (size_t)e * C + 2 * lane) : make_float2(0.f, 0.f);
+  for (; e < E; e += stride) {
+    const int64_t en = e + stride;
+    const bool more = en < E;
+    const int64_t ec = more ? en : e;                         // (clamped: the loads below are unconditional)
+    const int an = id_a[ec];
+    const float2 gn = *reinterpret_cast<const float2*>(g_out + (size_t)an * C + 2 * lane);
+    const float2 mn = g_rbf ? *reinterpret_cast<const float2*>(m + (size_t)ec * C + 2 * lane) : make_float2(0.f, 0.f);
+    const float gx = g.x * scale, gy = g.y * scale;
+    if (g_m) {
+      const float* __restrict__ b = rbf + (size_t)e * R;      // uniform address: scalar loads
+      float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < R / 4; ++q) {
+        const float bx = b[4 * q], by = b[4 * q + 1], bz = b[4 * q + 2], bw = b[4 * q + 3];
+        r0 += w0[4 * q] * bx + w0[4 * q + 1] * by + w0[4 * q + 2] * bz + w0[4 * q + 3] * bw;
+        r1 += w1[4 * q] * bx + w1[4 * q + 1] * by + w1[4 * q + 2] * bz + w1[4 * q + 3] * bw;
+      }
+      float2 o = make_float2(gx * r0, gy * r1);
+      if (accum & 1) {
+        const float2 p = *reinterpret_cast<const float2*>(g_m + (size_t)e * C + 2 * lane);
+        o.x += p.x; o.y += p.y;
+      }
+      *reinterpret_cast<float2*>(g_m + (size_t)e * C + 2 * lane) = o;
+    }
+    if (g_rbf) {
+      *reinterpret_cast<float2*>(&tsm[wave][2 * lane]) = make_float2(gx * me.x, gy * me.y);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      float s = 0.f;
+#pragma unroll
+      for (int j4 = 0; j4 < 8; ++j4) {
+        const float4 t = *reinterpret_cast<const float4*>(&tsm[wave][32 * part + 4 * j4]);
+        s += t.x * wt[4 * j4] + t.y * wt[4 * j4 + 1] + t.z * wt[4 * j4 + 2] + t.w * wt[4 * j4 + 3];
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < R) g_rbf[(size_t)e * R + lane] = (accum & 2) ? g_rbf[(size_t)e * R + lane] + s : s;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+    a = an; g = gn; me = mn;
+  }
+}
+
 }  // namespace
 
 extern "C" int gn_rbf_aggregate_fwd_f32(const float* m, const float* rbf, const float* W, const int32_t* perm,
@@ -246,8 +329,13 @@ extern "C" int gn_rbf_aggregate_bwd_f32(const float* g_out, const float* m, cons
   if (C_ != C || R_ != R) return (int)hipErrorInvalidValue;
   if (E <= 0) return 0;
   const int64_t blocks = gn_cdiv(E, 4);
+#ifdef GN_AGG_V2
+  hipLaunchKernelGGL(rbf_aggregate_bwd_kernel_v2, dim3((unsigned)(blocks < GN_AGG_V2 ? blocks : GN_AGG_V2)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale, accum);
+#else
   hipLaunchKernelGGL(rbf_aggregate_bwd_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale, accum);
+#endif
   GN_LAUNCH_CHECK();
   return 0;
 }

@@ -261,7 +261,9 @@ class GraphPlan:
             # (the CSRs of the four atoms of every quadruplet — q_c, q_a, q_b, q_d: four sorts of Q keys, 9 M at B = 32 — are NOT
             #  built here: the force assembly sums per reduce edge / intermediate triplet first (ops._quad_adjoint with the
             #  plan: the only form the model calls); without a plan they are built on first use)
-            out += list(self.quad_geom.values())
+            # likewise the c -> a <- b structures of the intermediate triplets and `reduce_cab` (a sort of Q keys): only the
+            # composite closure's calculate_angles reads them, on the main stream — built on first use there
+            out += [self.quad_geom[k] for k in ("a_of_exp", "b_of_exp", "d_of_exp")]
         return out
 
     def late_indices(self):
