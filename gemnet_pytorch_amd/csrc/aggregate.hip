@@ -149,6 +149,66 @@ __global__ __launch_bounds__(256) GN_AGG_ATTR void rbf_aggregate_fwd_kernel(cons
   }
 }
 
+// Forward, second form (round 5; same arithmetic in the same order: bit-identical): the wave index is made provably uniform,
+// so the edge ids (perm) and the 64-byte rbf rows of a wave's edges are SCALAR loads, and W goes through LDS once per workgroup
+// instead of 8 KB per wave from L2.
+__global__ __launch_bounds__(256) GN_AGG_ATTR void rbf_aggregate_fwd_kernel_v2(const float* __restrict__ m, const float* __restrict__ rbf,
+                                                                   const float* __restrict__ W, const int32_t* __restrict__ perm,
+                                                                   const int32_t* __restrict__ seg_off, float* __restrict__ out,
+                                                                   float scale) {
+  constexpr int WP = R + 1;
+  __shared__ float Wl[C * WP];
+  __shared__ float2 part[4][64];
+  const int a = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int beg = seg_off[a], end = seg_off[a + 1];
+  for (int i = threadIdx.x; i < C * R / 4; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(W + 4 * i);
+    float* d = Wl + (i >> 2) * WP + 4 * (i & 3);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  float w0[R], w1[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    w0[k] = Wl[(2 * lane) * WP + k];
+    w1[k] = Wl[(2 * lane + 1) * WP + k];
+  }
+  float2 acc = make_float2(0.f, 0.f);
+  for (int i = beg + wave; i < end; i += 8) {
+    const bool two = i + 4 < end;
+    const int e0 = perm ? perm[i] : i;
+    const int e1 = two ? (perm ? perm[i + 4] : i + 4) : e0;
+    const float2 m0 = *reinterpret_cast<const float2*>(m + (size_t)e0 * C + 2 * lane);
+    const float2 m1 = *reinterpret_cast<const float2*>(m + (size_t)e1 * C + 2 * lane);
+    const float* __restrict__ b0 = rbf + (size_t)e0 * R;      // uniform addresses: scalar loads
+    const float* __restrict__ b1 = rbf + (size_t)e1 * R;
+    float r0 = 0.f, r1 = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < R / 4; ++q) {
+      r0 += w0[4 * q] * b0[4 * q] + w0[4 * q + 1] * b0[4 * q + 1] + w0[4 * q + 2] * b0[4 * q + 2] + w0[4 * q + 3] * b0[4 * q + 3];
+      r1 += w1[4 * q] * b0[4 * q] + w1[4 * q + 1] * b0[4 * q + 1] + w1[4 * q + 2] * b0[4 * q + 2] + w1[4 * q + 3] * b0[4 * q + 3];
+      s0 += w0[4 * q] * b1[4 * q] + w0[4 * q + 1] * b1[4 * q + 1] + w0[4 * q + 2] * b1[4 * q + 2] + w0[4 * q + 3] * b1[4 * q + 3];
+      s1 += w1[4 * q] * b1[4 * q] + w1[4 * q + 1] * b1[4 * q + 1] + w1[4 * q + 2] * b1[4 * q + 2] + w1[4 * q + 3] * b1[4 * q + 3];
+    }
+    acc.x += m0.x * r0;
+    acc.y += m0.y * r1;
+    if (two) {
+      acc.x += m1.x * s0;
+      acc.y += m1.y * s1;
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    const float2 p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+    float2 o;
+    o.x = ((acc.x + p1.x) + (p2.x + p3.x)) * scale;
+    o.y = ((acc.y + p1.y) + (p2.y + p3.y)) * scale;
+    *reinterpret_cast<float2*>(out + (size_t)a * C + 2 * lane) = o;
+  }
+}
+
 // Adjoint: a wave walks edges e = wave id, + #waves, ...  Per edge
 //   g_m[e][c]   = scale * g_out[a(e)][c] * (W rbf[e])[c]            lane l owns columns 2l, 2l+1 (as in the forward)
 //   g_rbf[e][k] = scale * sum_c g_out[a(e)][c] m[e][c] W[c][k]      a 128 x 16 mat-vec: the products t_c pass through
@@ -317,8 +377,13 @@ extern "C" int gn_rbf_aggregate_fwd_f32(const float* m, const float* rbf, const 
                                         void* stream) {
   if (C_ != C || R_ != R) return (int)hipErrorInvalidValue;
   if (n_atoms <= 0) return 0;
+#ifdef GN_AGG_V1
   hipLaunchKernelGGL(rbf_aggregate_fwd_kernel, dim3((unsigned)n_atoms), dim3(256), 0, static_cast<hipStream_t>(stream), m, rbf,
                      W, perm, seg_off, out, scale);
+#else
+  hipLaunchKernelGGL(rbf_aggregate_fwd_kernel_v2, dim3((unsigned)n_atoms), dim3(256), 0, static_cast<hipStream_t>(stream), m, rbf,
+                     W, perm, seg_off, out, scale);
+#endif
   GN_LAUNCH_CHECK();
   return 0;
 }
@@ -329,11 +394,16 @@ extern "C" int gn_rbf_aggregate_bwd_f32(const float* g_out, const float* m, cons
   if (C_ != C || R_ != R) return (int)hipErrorInvalidValue;
   if (E <= 0) return 0;
   const int64_t blocks = gn_cdiv(E, 4);
-#ifdef GN_AGG_V2
-  hipLaunchKernelGGL(rbf_aggregate_bwd_kernel_v2, dim3((unsigned)(blocks < GN_AGG_V2 ? blocks : GN_AGG_V2)), dim3(256), 0,
+#ifdef GN_AGG_V1      // the round-2 form (A/B: tools/exp/agg_v2_bench.py)
+  hipLaunchKernelGGL(rbf_aggregate_bwd_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale, accum);
 #else
-  hipLaunchKernelGGL(rbf_aggregate_bwd_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
+  // one resident round: 4 workgroups of 4 waves per CU on 256 CUs (measured on MI355X, profiles/r5_agg_v2.txt: grid 512 / 1024 /
+  // 2048 -> 10.6 / 8.5 / 10.6 us at E = 18 122 against 16.7 us for the round-2 form)
+#ifndef GN_AGG_GRID
+#define GN_AGG_GRID 1024
+#endif
+  hipLaunchKernelGGL(rbf_aggregate_bwd_kernel_v2, dim3((unsigned)(blocks < GN_AGG_GRID ? blocks : GN_AGG_GRID)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g_out, m, rbf, W, id_a, g_m, g_rbf, E, scale, accum);
 #endif
   GN_LAUNCH_CHECK();

@@ -1,6 +1,7 @@
-"""A/B of the aggregation adjoint (gn_rbf_aggregate_bwd_f32): the product library against libraries built with -DGN_AGG_V2=<grid>
-(tools/exp/bin/libgemnet_hip_aggv2_<grid>.so): bitwise comparison + stand-alone time at the headline shapes, and inside a
-two-branch graph next to chain programs (the situation of the replayed step).   PYTHONPATH=. python tools/exp/agg_v2_bench.py"""
+"""A/B of the fused edge -> atom aggregation (gn_rbf_aggregate_fwd/bwd_f32): the product library (round-5 kernels: scalar loads of
+the wave-uniform operands, W through LDS, one resident round + next-edge prefetch in the adjoint) against a library built with
+-DGN_AGG_V1 (the round-2 kernels; tools/exp/bin/libgemnet_hip_aggv1.so, or any libgemnet_hip_agg*.so there): bitwise comparison
++ stand-alone time at the headline shapes.   PYTHONPATH=. python tools/exp/agg_v2_bench.py   (-> profiles/r5_agg_v2.txt)"""
 import ctypes
 import glob
 import os
@@ -25,7 +26,7 @@ m, rbf, W = (torch.randn(E, 128, device=dev, generator=g), torch.randn(E, 16, de
 go = torch.randn(A, 128, device=dev, generator=g)
 ida = plan.id_a.idx32
 libs = {"product": _lib.LIB_PATH}
-for p in sorted(glob.glob(os.path.join(ROOT, "tools", "exp", "bin", "libgemnet_hip_aggv2_*.so"))):
+for p in sorted(glob.glob(os.path.join(ROOT, "tools", "exp", "bin", "libgemnet_hip_agg*.so"))):
     libs[os.path.basename(p)[len("libgemnet_hip_"):-3]] = p
 vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -66,5 +67,21 @@ for name, path in libs.items():
     t_both = timeit(call)
     t_m = timeit(lambda: call(gm, None))
     t_acc = timeit(lambda: call(run, gr, 1))
-    print(f"{name:14s}: bit-identical to the product kernel: {same};  g_m + g_rbf {t_both:6.1f} us, g_m only {t_m:6.1f} us, "
-          f"accumulate m {t_acc:6.1f} us")
+    ff = lib.gn_rbf_aggregate_fwd_f32
+    ff.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, cf, vp]
+    ff.restype = ci
+    perm, seg = plan.id_a.csr
+    fo = torch.empty(A, 128, device=dev)
+
+    def fwd():
+        rc = ff(m.data_ptr(), rbf.data_ptr(), W.data_ptr(), perm.data_ptr() if perm is not None else None, seg.data_ptr(),
+                fo.data_ptr(), A, 128, 16, 0.5, st)
+        assert rc == 0, rc
+    fwd()
+    torch.cuda.synchronize()
+    if name == "product":
+        ref_f = fo.clone()
+    same_f = torch.equal(fo, ref_f)
+    t_f = timeit(fwd)
+    print(f"{name:14s}: adjoint bit-identical to the product kernel: {same}, forward: {same_f};  forward {t_f:6.1f} us;  adjoint g_m + "
+          f"g_rbf {t_both:6.1f} us, g_m only {t_m:6.1f} us, accumulate m {t_acc:6.1f} us")
