@@ -17,7 +17,10 @@ GN_HD Env3 envelope(double x, int p, double inv_c) {
   Env3 r = {0.0, 0.0, 0.0};
   if (x < 1.0) {
     const double a = -(p + 1) * (p + 2) / 2.0, b = (double)p * (p + 2), c = -p * (p + 1) / 2.0;
-    const double xp2 = pow(x, (double)(p - 2));  // p >= 2 in all GemNet configs (p = 5)
+    // x^(p-2) by repeated multiplication (p >= 2 in all GemNet configs, p = 5): the f64 pow() was ~200 instructions of every
+    // one of the 49 work items per edge of the basis kernels
+    double xp2 = 1.0;
+    for (int i = 0; i < p - 2; ++i) xp2 *= x;
     const double xp1 = xp2 * x, xp = xp1 * x, xq = xp * x, xr = xq * x;
     r.u = 1.0 + a * xp + b * xq + c * xr;
     r.u1 = (a * p * xp1 + b * (p + 1) * xp + c * (p + 2) * xq) * inv_c;
@@ -44,6 +47,7 @@ GN_HD double sph_jl_series(int l, double y) {
   for (int k = 1; k < 30; ++k) {
     term *= q * rcp_small_int(k * (2.0 * l + 2.0 * k + 1.0));
     acc += term;
+    if (fabs(term) < 1e-18 * fabs(acc)) break;   // (y < l <= 7: a dozen terms; the fixed 30 were most of the small-y cost)
   }
   double yl = 1.0;
   for (int i = 0; i < l; ++i) yl *= y;
@@ -62,6 +66,26 @@ GN_HD double sph_jl(int l, double y, double sn, double cs) {
     j = jn;
   }
   return j;
+}
+
+// (j_{l-1}(y), j_l(y)) in ONE pass (l >= 1): the derivative j_l' = j_{l-1} - (l + 1) / y j_l needs both — two separate
+// recurrences (or two series) before
+GN_HD void sph_jl_pair(int l, double y, double sn, double cs, double& jlm1, double& jl) {
+  if (y < (double)l) {                 // series region
+    jl = sph_jl_series(l, y);
+    jlm1 = (l - 1 > 0 && y < (double)(l - 1)) ? sph_jl_series(l - 1, y) : sph_jl(l - 1, y, sn, cs);
+    return;
+  }
+  const double iy = 1.0 / y;
+  double jm = sn * iy;                 // j0
+  double j = sn * iy * iy - cs * iy;   // j1
+  for (int k = 1; k < l; ++k) {
+    const double jn = (2 * k + 1) * iy * j - jm;
+    jm = j;
+    j = jn;
+  }
+  jlm1 = jm;
+  jl = j;
 }
 
 GN_HD double ylm_prefactor(int l, int m) {
@@ -114,13 +138,14 @@ GN_HD double sph_radial_eval(double d, double z, double nrm, int l, double cutof
   const Env3 u = envelope(d * inv_c, p, inv_c);
   double sn, cs;
   sincos(y, &sn, &cs);
-  const double jl = sph_jl(l, y, sn, cs);
   double v;
   if (kd == 0) {
-    v = u.u * jl;
+    v = u.u * sph_jl(l, y, sn, cs);
   } else {
     // j_l' = j_{l-1} - (l+1)/y j_l  (l >= 1);  j_0' = -j_1
-    const double j1 = (l == 0) ? -sph_jl(1, y, sn, cs) : sph_jl(l - 1, y, sn, cs) - (l + 1) / y * jl;
+    double jl, jlm1 = 0.0;
+    if (l == 0) jl = sph_jl(0, y, sn, cs); else sph_jl_pair(l, y, sn, cs, jlm1, jl);
+    const double j1 = (l == 0) ? -sph_jl(1, y, sn, cs) : jlm1 - (l + 1) / y * jl;
     const double J1 = a * j1;
     if (kd == 1) {
       v = u.u1 * jl + u.u * J1;

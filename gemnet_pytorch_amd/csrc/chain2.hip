@@ -531,6 +531,7 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, 
             gn_ssilu_pair(v[t].z, v[t].z, d.z); gn_ssilu_pair(v[t].w, v[t].w, d.w);
             if (ok[t]) *reinterpret_cast<float4*>(pre_out + off[t]) = d;)
         } else if (act) GN2_EACH(v[t].x = gn_ssilu(v[t].x); v[t].y = gn_ssilu(v[t].y); v[t].z = gn_ssilu(v[t].z); v[t].w = gn_ssilu(v[t].w);)
+        GN2_STAMP(5);      // (trace build) epilogue: gathered adds, pre-activation store and activation done
         const bool want2 = ADJ && (y2_slot >= 0 || out2);
         // second output = v * alpha2 * phi2(Z2), written straight from the current value of v (no copy is kept):
         // before the `mul` stage when y2_src = 1, after the last stage otherwise
@@ -599,9 +600,11 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, 
           GN2_EACH(if (ok[t]) { GN2_RES(q[t], beta2) })
         }
         if (out) GN2_EACH(if (ok[t]) *reinterpret_cast<float4*>(out + off[t]) = v[t];)
+        GN2_STAMP(6);      // mul / alpha / residual stages and the global store done
         if (ADJ && y_slot == 2) GN2_EACH(park[ADJ ? t : 0] = v[t];)
         else if (y_slot >= 0) GN2_EACH(slot_write(y_slot, 16 * t + l15, n0, ok[t] ? (HF ? mul4(v[t], sy[HF ? t : 0]) : v[t]) : make_float4(0.f, 0.f, 0.f, 0.f));)
         if (want2 && !y2_src) emit_y2();
+        GN2_STAMP(7);      // plane split + LDS write (+ second output) issued
 #undef GN2_EACH
 #undef GN2_ADD
 #undef GN2_MUL

@@ -12,31 +12,33 @@
 
 namespace {
 
-// D[e] = |R[a]-R[c]|; rbf[e,n]; rad[e,l,n]
+// D[e] = |R[a]-R[c]|; rbf[e,n]; rad[e,l,n].  16 lanes per edge (round 5; was one work item per basis value: 49 threads
+// per edge each fetching the edge's two atoms again): lane `sub` evaluates the functions sub, sub + 16, sub + 32 of the
+// NR + S NR (= 48) and lane 0 writes the distance — same values as before.
 __global__ void edge_basis_fwd_kernel(const float* __restrict__ R, const int32_t* __restrict__ id_c,
                                       const int32_t* __restrict__ id_a, const float* __restrict__ freq,
                                       const float* __restrict__ z, const double* __restrict__ nrm,
                                       float* __restrict__ D, float* __restrict__ V, float* __restrict__ rbf,
                                       float* __restrict__ rad, int64_t E, int NR, int S, double cutoff, int p) {
-  const int per = 1 + NR + S * NR;  // work items per edge: distance, rbf, radial
-  const int64_t n = E * per;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = i / per;
-    const int j = (int)(i - e * per);
+  const int sub = threadIdx.x & 15;
+  const int nfun = NR + S * NR;
+  for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4; e < E; e += ((int64_t)gridDim.x * blockDim.x) >> 4) {
     const float* Ra = R + 3 * (int64_t)id_a[e];
     const float* Rc = R + 3 * (int64_t)id_c[e];
     // same f32 arithmetic as the reference: V = Rt - Rs; D = sqrt(sum(V^2))
     const float vx = Ra[0] - Rc[0], vy = Ra[1] - Rc[1], vz = Ra[2] - Rc[2];
     const float d = sqrtf(vx * vx + vy * vy + vz * vz);
-    if (j == 0) {
+    if (sub == 0) {
       D[e] = d;
       if (V) { V[3 * e] = vx / d; V[3 * e + 1] = vy / d; V[3 * e + 2] = vz / d; }
-    } else if (j <= NR) {
-      rbf[e * NR + (j - 1)] = (float)bessel_rbf_eval((double)d, (double)freq[j - 1], cutoff, p, 0, 0);
-    } else {
-      const int lr = j - 1 - NR;
-      rad[e * S * NR + lr] = (float)sph_radial_eval((double)d, (double)z[lr], nrm[lr], lr / NR, cutoff, p, 0);
+    }
+    for (int j = sub; j < nfun; j += 16) {
+      if (j < NR) {
+        rbf[e * NR + j] = (float)bessel_rbf_eval((double)d, (double)freq[j], cutoff, p, 0, 0);
+      } else {
+        const int lr = j - NR;
+        rad[e * S * NR + lr] = (float)sph_radial_eval((double)d, (double)z[lr], nrm[lr], lr / NR, cutoff, p, 0);
+      }
     }
   }
 }
@@ -346,7 +348,7 @@ extern "C" int gn_edge_basis_fwd_f32(const float* R, const int32_t* id_c, const 
                                      void* stream) {
   if (E <= 0) return 0;
   if (p < 2 || S > 8) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(edge_basis_fwd_kernel, dim3(grid_for(E * (1 + NR + S * NR))), dim3(256), 0,
+  hipLaunchKernelGGL(edge_basis_fwd_kernel, dim3(grid_for(E * 16)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), R, id_c, id_a, freq, z, nrm, D, V, rbf, rad, E, NR, S,
                      (double)cutoff, p);
   GN_LAUNCH_CHECK();

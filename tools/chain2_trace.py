@@ -61,4 +61,6 @@ for mode in (MODES[0] if MODES else (("split6",) if QUICK else ("split6", "bf16"
                 if b == 1:
                     t0 = buf[0].astype(np.int64)
                     d.append(("vs wave0 at stamps", [int(t[oi, i] - t0[oi, i]) for i in range(5)]))
-                print(f"   wave{b*7} op{oi}: gap {gap:6d}  {d}  total {int(t[oi,4]-t[oi,0])}")
+                sub = [int(t[oi, 5] - t[oi, 2]), int(t[oi, 6] - t[oi, 5]), int(t[oi, 7] - t[oi, 6]), int(t[oi, 3] - t[oi, 7])]
+                print(f"   wave{b*7} op{oi}: gap {gap:6d}  {d}  total {int(t[oi,4]-t[oi,0])}   epilogue = [to act done, mul/res/store, "
+                      f"split + LDS write, row scales] {sub}")
