@@ -664,6 +664,7 @@ class GradSink:
         self.cross = False  # consumers on several streams take part (events order their writes, see enter / leave)
         self.buf_stream = self.buf_event = None
         self.task = None    # id of the backward pass (autograd graph task) the running state belongs to
+        self.home = None    # HIP stream the shared tensor was produced on (= the stream its producer's backward runs on)
 
     def arrive(self):
         """Called once per consumer backward; returns True for the last consumer of this pass."""
@@ -730,7 +731,33 @@ def share_gradient(t):
     """Mark tensor `t` (a non-leaf that requires grad) as shared between fused bilinear layers of one forward."""
     if t.requires_grad and _FUSED:
         t._gn_sink = GradSink()
+        if t.is_cuda:
+            t._gn_sink.home = torch.cuda.current_stream(t.device)
     return t
+
+
+# The combined Y gradient of all consumers of a shared basis (bil_dy_multi: 75 us at the headline shape) is launched by the
+# LAST consumer's backward, in front of the rest of that block's adjoint, although only the basis' own backward needs it.
+# When the basis was produced on another stream than the consumers run on (the forked head of GemNet.forward: autograd
+# replays the producer's backward on that stream), the launch goes to THAT stream: ordered in front of its consumer by
+# stream order, beside the block's remaining adjoint kernels instead of in front of them.
+USE_LATE_DY = os.environ.get("GEMNET_LATE_DY", "0") == "1"   # measured: profiles/r5_late_dy_ab.txt (no gain: off)
+
+
+def _on_home_stream(sink, inputs, fn):
+    home = sink.home
+    t0 = inputs[0]
+    if not (USE_LATE_DY and home is not None and t0.is_cuda):
+        return fn()
+    cur = torch.cuda.current_stream(t0.device)
+    if home.cuda_stream == cur.cuda_stream:
+        return fn()
+    home.wait_stream(cur)
+    with torch.cuda.stream(home):
+        out = fn()
+    for t in inputs:
+        t.record_stream(home)
+    return out
 
 
 USE_GRAD_ACC = os.environ.get("GEMNET_GRAD_ACC", "1") == "1"
@@ -838,8 +865,8 @@ class _FusedBilinear(torch.autograd.Function):
             sink.pending.append((dSm, x))
             gsph = None
             if last:
-                gsph = K.bil_dy_multi([d for d, _ in sink.pending], [xx for _, xx in sink.pending], sp,
-                                      ang=sph if ctx.ang else None)
+                ds, xs = [d for d, _ in sink.pending], [xx for _, xx in sink.pending]
+                gsph = _on_home_stream(sink, ds + xs + [sph], lambda: K.bil_dy_multi(ds, xs, sp, ang=sph if ctx.ang else None))
                 sink.pending = []
         elif sink is not None and need[1]:
             # the Y gradient is summed across the consumers of `sph` inside the kernel (see GradSink)

@@ -77,8 +77,9 @@ def test_rigid_motion_invariance(setup):
     dF = float((F2.double().cpu() - F_rot).abs().mean())
     dE = float((E2 - setup["E"]).abs().max())
     print(f"{setup['kind']} {B}x{n}: rotated+shifted: force MAE {dF:.3e} eV/A, energy diff {dE:.3e}")
-    # the rotated positions are re-rounded to fp32 (1e-7 relative in R): allow 10x the parity bar
-    assert dF <= 1e-4 and dE <= 1e-3 * max(1.0, float(setup["E"].abs().max()))
+    # the rotated positions are re-rounded to fp32 (1e-7 relative in R).  Measured over rounds 4-5: GemNet-T 0.9-1.5e-6,
+    # GemNet-Q 1.25-1.54e-5 eV/A (the dihedral angles amplify the re-rounding); the bars sit 3-7 x above that
+    assert dF <= (1e-5 if setup["cfg"]["triplets_only"] else 4e-5) and dE <= 1e-3 * max(1.0, float(setup["E"].abs().max()))
 
 
 def test_molecule_permutation_and_additivity(setup):

@@ -187,7 +187,7 @@ def test_training_gradients_parity(golden_model, golden_model2, tag):
         if key in g:
             gr = named[n].grad.cpu().numpy()
             worst_el = max(worst_el, float(np.abs(gr - g[key]).max() / np.abs(g[key]).max()))
-            np.testing.assert_allclose(gr, g[key], rtol=5e-3, atol=(2e-2 if tag == "q4s" else 2e-4) * float(np.abs(g[key]).max()))
+            np.testing.assert_allclose(gr, g[key], rtol=5e-3, atol=(4e-3 if tag == "q4s" else 2e-4) * float(np.abs(g[key]).max()))   # measured worst: q4s 1.5e-3, t4s 1.4e-4
     print(f"{tag}: worst elementwise |g - g_ref| / max|g_ref| over the stored gradients = {worst_el:.2e}")
 
 

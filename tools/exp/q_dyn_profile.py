@@ -56,3 +56,27 @@ for i in range(steps):
     runner.build_and_run(builders[b], data[b]["R"], Z=data[b]["Z"], positions_ready=True)
 torch.cuda.synchronize()
 print(f"build_and_run loop: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step")
+# the same loop with the HOST time of each part (no synchronisation added)
+h = dict(build=0.0, fill=0.0, replay=0.0)
+main = torch.cuda.current_stream()
+bs = runner._bstream
+t0 = time.perf_counter()
+for i in range(steps):
+    b = i % nb
+    t1 = time.perf_counter()
+    with torch.cuda.stream(bs):
+        idx = builders[b](data[b]["R"], dtype=runner.index_dtype)
+    main.wait_stream(bs)
+    for v in idx.values():
+        v.record_stream(main)
+    t2 = time.perf_counter()
+    runner._fill(data[b]["R"], idx, data[b]["Z"])
+    t3 = time.perf_counter()
+    runner.graph.replay()
+    t4 = time.perf_counter()
+    h["build"] += t2 - t1
+    h["fill"] += t3 - t2
+    h["replay"] += t4 - t3
+torch.cuda.synchronize()
+print(f"host time per part in the free-running loop ({(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step): "
+      + ", ".join(f"{k} {v / steps * 1e3:.3f} ms" for k, v in h.items()))
