@@ -762,6 +762,27 @@ def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12,
                                        note="every batch padded with a dummy molecule to fixed capacities, one captured "
                                             "hipGraph replayed; index build (with its size read-back) per step, on its own stream "
                                             "(a data provider's batch does not depend on the previous step)")
+            if cfg["triplets_only"] and len({tuple(d["N_host"]) for d in data}) == 1:
+                # the index build INSIDE the replayed graph (padded.attach_builder, gn_index_gpu_padded_t): a step is
+                # positions in -> one replay -> results out, no read-back, no padding launches on the host
+                runner.attach_builder(builders[0])
+                state["i"] = 0
+
+                def gstep():
+                    b = state["i"] % n_batches
+                    state["i"] += 1
+                    return runner.run_positions(data[b]["R"], Z=data[b]["Z"])
+                for _ in range(2 * warmup):
+                    gstep()
+                el = time_steps(gstep, psteps, 0)
+                E2, F2 = runner.run_positions(data[0]["R"], Z=data[0]["Z"])
+                torch.cuda.synchronize()
+                out["padded_graph"]["index_in_graph"] = dict(
+                    ms_per_step=round(el / psteps * 1e3, 3), molecules_per_s=round(n_mol * psteps / el, 1), steps=psteps,
+                    index_error_bits=runner.index_error(), max_abs_force_deviation_vs_eager=float((F2 - F0).abs().max()),
+                    note="the same loop with the neighbour list / index arrays built by the first nodes of the replayed graph "
+                         "from the positions (device-side counts, pad rows written by the commit kernel): positions in -> "
+                         "one hipGraph replay -> energies and forces out")
         except Exception as ex:  # noqa: BLE001
             out["padded_graph"] = dict(error=f"{type(ex).__name__}: {ex}")
     return out

@@ -130,12 +130,13 @@ __global__ void idx_edges_kernel(const int32_t* __restrict__ mol_off, const int3
                                  int32_t* __restrict__ id_a, int32_t* __restrict__ id_c,
                                  int32_t* __restrict__ id_undir, int32_t* __restrict__ id_swap,
                                  int32_t* __restrict__ int_a, int32_t* __restrict__ int_b,
-                                 int32_t* __restrict__ Mx, int32_t* __restrict__ MI) {
+                                 int32_t* __restrict__ Mx, int32_t* __restrict__ MI, int e_cap) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= A) return;
   const int m = atom_mol[g];
   const int a0 = mol_off[m], n = mol_off[m + 1] - a0, x = g - a0;
   const int H = off_half[A];
+  if (2 * (int64_t)H > e_cap) return;       // capacity form (gn_index_gpu_padded_t): nothing is written, the commit kernel flags it
   const size_t base = (size_t)sq_off[m];
   const uint8_t* __restrict__ row = adj + base + (size_t)x * n;
   int e = off_half[g];
@@ -167,9 +168,11 @@ __global__ void idx_edges_kernel(const int32_t* __restrict__ mol_off, const int3
 __global__ void idx_in_kernel(const int32_t* __restrict__ mol_off, const int32_t* __restrict__ sq_off,
                               const int32_t* __restrict__ atom_mol, int A, const uint8_t* __restrict__ adj,
                               const int32_t* __restrict__ Mx, const int32_t* __restrict__ in_ptr,
-                              int32_t* __restrict__ in_edge, int32_t* __restrict__ pos_in) {
+                              int32_t* __restrict__ in_edge, int32_t* __restrict__ pos_in,
+                              const int32_t* __restrict__ half_total, int e_cap) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= A) return;
+  if (half_total && 2 * (int64_t)*half_total > e_cap) return;
   const int m = atom_mol[g];
   const int a0 = mol_off[m], n = mol_off[m + 1] - a0, x = g - a0;
   const size_t base = (size_t)sq_off[m] + (size_t)x * n;
@@ -191,6 +194,15 @@ __global__ void idx_cnt3_kernel(const int32_t* __restrict__ id_a, const int32_t*
   if (r < E) cnt3[r] = deg[id_a[r]] - 1;
 }
 
+// capacity form: the number of edges lives on the device (2 * *half_total); rows behind it count zero triplets
+__global__ void idx_cnt3_cap_kernel(const int32_t* __restrict__ id_a, const int32_t* __restrict__ deg,
+                                    const int32_t* __restrict__ half_total, int n, int e_cap, int32_t* __restrict__ cnt3) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t E = 2 * (int64_t)*half_total;
+  cnt3[r] = (E <= e_cap && r < E) ? deg[id_a[r]] - 1 : 0;
+}
+
 // one wave per reduce edge r = (c -> a): expand edges x = (b -> a), b != c, ascending edge id
 // = sources b > a ascending (first-half ids), then sources b < a ascending (second-half ids)
 __global__ __launch_bounds__(256) void idx_trip_kernel(const int32_t* __restrict__ mol_off,
@@ -200,10 +212,16 @@ __global__ __launch_bounds__(256) void idx_trip_kernel(const int32_t* __restrict
                                                        int E, const uint8_t* __restrict__ adj,
                                                        const int32_t* __restrict__ Mx, const int32_t* __restrict__ off3,
                                                        int32_t* __restrict__ red, int32_t* __restrict__ exp,
-                                                       int32_t* __restrict__ kidx) {
+                                                       int32_t* __restrict__ kidx,
+                                                       const int32_t* __restrict__ half_total, int e_cap, int t_cap) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (r >= E) return;
+  if (half_total) {      // capacity form: E on the device, E = the grid's upper bound; nothing is written past the capacities
+    const int64_t Ed = 2 * (int64_t)*half_total;
+    if (Ed > e_cap || r >= Ed || off3[E] > t_cap) return;
+  } else if (r >= E) {
+    return;
+  }
   const int ga = id_a[r], gc = id_c[r];
   const int m = atom_mol[ga];
   const int a0 = mol_off[m], n = mol_off[m + 1] - a0, a = ga - a0, c = gc - a0;
@@ -225,10 +243,74 @@ __global__ __launch_bounds__(256) void idx_trip_kernel(const int32_t* __restrict
       const int w = o + __popcll(mask & ((1ull << lane) - 1ull));
       red[w] = r;
       exp[w] = Mx[base + b];
-      kidx[w] = w - o0;
+      if (kidx) kidx[w] = w - o0;
     }
     o += __popcll(mask);
   }
+}
+
+// Commit + padding of the capacity form.  The build above wrote E edges / T triplets (counts on the device) into STAGING
+// arrays; this kernel copies them into the arrays the captured model reads and fills the rows behind them with the dummy
+// molecule's pad rows (padded.py: _pad_edges / _pad_triplets, triplets-only layout: groups of 3 dummy atoms behind atom
+// a_cap, pad edges in quads b->a, a->b, c->a, a->c).  A batch that does not fit (or whose padding breaks the rules of
+// padded.py) leaves the arrays of the PREVIOUS step in place — always valid indices — and reports through state[]:
+//   state[0] |= err (sticky), state[1] = E, state[2] = T, state[3] = err of this step
+//   err: 1 E > e_cap, 2 T > t_cap, 4 pad triplets without a complete quad of pad edges, 8 dummy in-degree above deg_bound
+struct PadT {
+  const int32_t *s_c, *s_a, *s_swap, *s_undir, *s_red, *s_exp;
+  int32_t *id_c, *id_a, *id_swap, *id_undir, *red, *exp;
+};
+
+__global__ void idx_commit_pad_t_kernel(PadT p, const int32_t* __restrict__ half_total, const int32_t* __restrict__ t_total,
+                                        int e_cap, int t_cap, int a_cap, int G, int deg_bound, int32_t* __restrict__ state) {
+  const int64_t E = 2 * (int64_t)*half_total, T = E <= e_cap ? (int64_t)*t_total : 0;
+  int err = 0;
+  if (E > e_cap) err |= 1;
+  if (T > t_cap) err |= 2;
+  const int64_t ep = e_cap - E, tp = t_cap - T;
+  if (!err) {
+    if ((tp > 0 && ep < 4) || (tp & 1)) err |= 4;
+    if ((ep / 2 + G - 1) / G > (deg_bound > 2 ? deg_bound : 2)) err |= 8;
+  }
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  if (tid == 0) {
+    state[0] |= err;
+    state[1] = (int32_t)(E > 0x7fffffff ? 0x7fffffff : E);
+    state[2] = (int32_t)T;
+    state[3] = err;
+  }
+  if (err) return;
+  for (int64_t i = tid; i < e_cap; i += nth) {
+    if (i < E) {
+      p.id_c[i] = p.s_c[i]; p.id_a[i] = p.s_a[i]; p.id_swap[i] = p.s_swap[i]; p.id_undir[i] = p.s_undir[i];
+    } else {
+      const int64_t k = i - E, pair = k >> 1;
+      const int rev = (int)(k & 1), typ = (int)(pair & 1), grp = (int)((pair >> 1) % G);
+      const int a = a_cap + 3 * grp, other = a + 1 + typ;
+      p.id_c[i] = rev ? a : other;
+      p.id_a[i] = rev ? other : a;
+      p.id_swap[i] = (int32_t)(E + (k ^ 1));
+      p.id_undir[i] = (int32_t)(E / 2 + pair);
+    }
+  }
+  const int64_t n_fwd = 2 * (ep / 4), den = tp > 1 ? tp : 1;
+  for (int64_t i = tid; i < t_cap; i += nth) {
+    if (i < T) {
+      p.red[i] = p.s_red[i]; p.exp[i] = p.s_exp[i];
+    } else {
+      const int64_t f = ((i - T) * n_fwd) / den;
+      p.red[i] = (int32_t)(E + 2 * f);
+      p.exp[i] = (int32_t)(E + 2 * (f ^ 1));
+    }
+  }
+}
+
+// x[i] = NaN for all i when state[3] (the error of this step's index build) is set: a step whose batch did not fit must not
+// hand out the numbers computed from the previous step's arrays
+__global__ void idx_poison_kernel(float* __restrict__ x, int64_t n, const int32_t* __restrict__ state) {
+  if (state[3] == 0) return;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = __builtin_nanf("");
 }
 
 __global__ void idx_cnt_intm_kernel(const int32_t* __restrict__ int_a, const int32_t* __restrict__ int_b,
@@ -421,9 +503,9 @@ extern "C" int gn_index_gpu_stage1(const void* R, int r_is_f64, const int32_t* m
   if (E == 0) return 0;
   if (!id_a) return 0;    // size query only
   hipLaunchKernelGGL(idx_edges_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, quad, w.adj, w.iadj,
-                     w.off_half, w.off_int, id_a, id_c, id_undir, id_swap, int_a, int_b, w.Mx, w.MI);
+                     w.off_half, w.off_int, id_a, id_c, id_undir, id_swap, int_a, int_b, w.Mx, w.MI, 0x7fffffff);
   hipLaunchKernelGGL(idx_in_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, w.adj, w.Mx, w.in_ptr,
-                     w.in_edge, w.pos_in);
+                     w.in_edge, w.pos_in, (const int32_t*)nullptr, 0);
   hipLaunchKernelGGL(idx_cnt3_kernel, dim3(gn_cdiv(E, 256)), dim3(256), 0, st, id_a, w.deg, (int)E, w.cnt);
   hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off3, E, w.overflow);
   GN_LAUNCH_CHECK();
@@ -470,7 +552,7 @@ extern "C" int gn_index_gpu_stage2(const int32_t* mol_off, const int32_t* sq_off
   const int64_t emax = sum_n2 - A;
   idx_layout((char*)ws, A, sum_n2, emax, quad ? emax : 0, quad, &w);
   hipLaunchKernelGGL(idx_trip_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, id_a, id_c,
-                     (int)E, w.adj, w.Mx, w.off3, id3_reduce_ca, id3_expand_ba, Kidx3);
+                     (int)E, w.adj, w.Mx, w.off3, id3_reduce_ca, id3_expand_ba, Kidx3, (const int32_t*)nullptr, 0, 0);
   GN_LAUNCH_CHECK();
   if (quad && Eint > 0) {
     hipLaunchKernelGGL(idx_intm_kernel, dim3(gn_cdiv(Eint, 256)), dim3(256), 0, st, int_a, int_b, (int)Eint, w.in_ptr,
@@ -481,5 +563,66 @@ extern "C" int gn_index_gpu_stage2(const int32_t* mol_off, const int32_t* sq_off
                        id4_expand_db, id4_reduce_cab, id4_expand_abd, Kidx4);
     GN_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// Capacity form of the triplets-only build: no read-back, capturable.  See include/gemnet_hip.h.
+extern "C" int gn_index_gpu_padded_t(const void* R, int r_is_f64, const int32_t* mol_off, const int32_t* sq_off, int B, int A,
+                                     int nmax, int64_t sum_n2, double cutoff, void* ws, int e_cap, int t_cap, int a_cap,
+                                     int n_groups, int deg_bound, int32_t* staging, int32_t* id_c, int32_t* id_a,
+                                     int32_t* id_swap, int32_t* id_undir, int32_t* id3_reduce_ca, int32_t* id3_expand_ba,
+                                     int32_t* state, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (A <= 0 || B <= 0 || e_cap <= 0 || t_cap <= 0 || n_groups <= 0 || (e_cap & 1) || (t_cap & 1)) return (int)hipErrorInvalidValue;
+  if (sum_n2 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  idx_ws w;
+  const int64_t emax = sum_n2 - A;
+  idx_layout((char*)ws, A, sum_n2, emax, 0, 0, &w);
+  const int n = (int)(emax < e_cap ? emax : e_cap);     // E <= emax always: rows the E-wide passes have to look at
+  int32_t *s_a = staging, *s_c = staging + e_cap, *s_undir = staging + 2 * (size_t)e_cap, *s_swap = staging + 3 * (size_t)e_cap,
+          *s_red = staging + 4 * (size_t)e_cap, *s_exp = staging + 4 * (size_t)e_cap + t_cap;
+  hipError_t e = hipMemsetAsync(w.overflow, 0, sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(idx_atom_mol_kernel, dim3(B), dim3(64), 0, st, mol_off, B, w.atom_mol, (int32_t*)nullptr);
+  dim3 gadj(gn_cdiv((int64_t)nmax * nmax, 256), B);
+  if (r_is_f64)
+    hipLaunchKernelGGL((idx_adj_kernel<double>), gadj, dim3(256), 0, st, (const double*)R, mol_off, sq_off, cutoff, cutoff, 0,
+                       w.adj, w.iadj);
+  else
+    hipLaunchKernelGGL((idx_adj_kernel<float>), gadj, dim3(256), 0, st, (const float*)R, mol_off, sq_off, (float)cutoff,
+                       (float)cutoff, 0, w.adj, w.iadj);
+  const dim3 ga(gn_cdiv(A, 256));
+  hipLaunchKernelGGL(idx_deg_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, 0, w.adj, w.iadj, w.deg, w.up, w.ideg);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.up, w.off_half, (int64_t)A, w.overflow);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.deg, w.in_ptr, (int64_t)A, w.overflow);
+  GN_LAUNCH_CHECK();
+  const int32_t* half_total = w.off_half + A;
+  hipLaunchKernelGGL(idx_edges_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, 0, w.adj, w.iadj, w.off_half,
+                     w.off_int, s_a, s_c, s_undir, s_swap, (int32_t*)nullptr, (int32_t*)nullptr, w.Mx, w.MI, e_cap);
+  hipLaunchKernelGGL(idx_in_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, w.adj, w.Mx, w.in_ptr, w.in_edge,
+                     w.pos_in, half_total, e_cap);
+  if (n > 0) {
+    hipLaunchKernelGGL(idx_cnt3_cap_kernel, dim3(gn_cdiv(n, 256)), dim3(256), 0, st, s_a, w.deg, half_total, n, e_cap, w.cnt);
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off3, (int64_t)n, w.overflow);
+    hipLaunchKernelGGL(idx_trip_kernel, dim3(gn_cdiv(n, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, s_a, s_c, n, w.adj,
+                       w.Mx, w.off3, s_red, s_exp, (int32_t*)nullptr, half_total, e_cap, t_cap);
+  } else {
+    e = hipMemsetAsync(w.off3, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  GN_LAUNCH_CHECK();
+  PadT p{s_c, s_a, s_swap, s_undir, s_red, s_exp, id_c, id_a, id_swap, id_undir, id3_reduce_ca, id3_expand_ba};
+  const int64_t work = e_cap > t_cap ? e_cap : t_cap;
+  hipLaunchKernelGGL(idx_commit_pad_t_kernel, dim3((unsigned)(gn_cdiv(work, 256) < 2048 ? gn_cdiv(work, 256) : 2048)), dim3(256), 0,
+                     st, p, half_total, (const int32_t*)(w.off3 + n), e_cap, t_cap, a_cap, n_groups, deg_bound, state);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_index_poison_f32(float* x, int64_t n, const int32_t* state, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(idx_poison_kernel, dim3((unsigned)(gn_cdiv(n, 256) < 1024 ? gn_cdiv(n, 256) : 1024)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, n, state);
+  GN_LAUNCH_CHECK();
   return 0;
 }

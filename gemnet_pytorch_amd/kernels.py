@@ -221,6 +221,31 @@ def nonfinite_flag(x, flag, bit=1):
     check(_lib.load().gn_nonfinite_flag_f32(ptr(x), x.numel(), ptr(flag), int(bit), stream()), "gn_nonfinite_flag_f32")
 
 
+def index_padded_t(builder, R, e_cap, t_cap, a_cap, n_groups, deg_bound, staging, bufs, state):
+    """The triplets-only index build of `builder` (index_device.DeviceGraphBuilder) for positions R, straight into the
+    capacity-sized arrays `bufs` (id_c, id_a, id_swap, id_undir, id3_reduce_ca, id3_expand_ba: int32) with the dummy
+    molecule's pad rows behind the batch — no read-back, capturable (gn_index_gpu_padded_t; state: int32[4], see the header)."""
+    require_device(R, staging, state)
+    assert builder.triplets_only and R.is_contiguous() and tuple(R.shape) == (builder.A, 3)
+    assert staging.dtype == torch.int32 and staging.numel() >= 4 * e_cap + 2 * t_cap and state.dtype == torch.int32
+    for k in ("id_c", "id_a", "id_swap", "id_undir"):
+        assert bufs[k].dtype == torch.int32 and bufs[k].numel() == e_cap and bufs[k].is_contiguous()
+    for k in ("id3_reduce_ca", "id3_expand_ba"):
+        assert bufs[k].dtype == torch.int32 and bufs[k].numel() == t_cap and bufs[k].is_contiguous()
+    check(_lib.load().gn_index_gpu_padded_t(
+        ptr(R), int(R.dtype == torch.float64), ptr(builder.mol_off), ptr(builder.sq_off), builder.B, builder.A, builder.nmax,
+        builder.sum_n2, builder.cutoff, ptr(builder.ws), int(e_cap), int(t_cap), int(a_cap), int(n_groups), int(deg_bound),
+        ptr(staging), ptr(bufs["id_c"]), ptr(bufs["id_a"]), ptr(bufs["id_swap"]), ptr(bufs["id_undir"]),
+        ptr(bufs["id3_reduce_ca"]), ptr(bufs["id3_expand_ba"]), ptr(state), stream()), "gn_index_gpu_padded_t")
+
+
+def index_poison(x, state):
+    """x <- NaN when the index build of this step reported an error (gn_index_poison_f32)."""
+    require_device(x, state)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    check(_lib.load().gn_index_poison_f32(ptr(x), x.numel(), ptr(state), stream()), "gn_index_poison_f32")
+
+
 def rbf_aggregate_supported(m, rbf, W):
     return m.shape[1] == 128 and rbf.shape[1] == 16 and tuple(W.shape) == (128, 16)
 

@@ -245,6 +245,8 @@ class PaddedGraphRunner:
         self.graph = None
         self.out = None
         self.flag = None
+        self.builder = None                 # attach_builder: the index build runs inside the replayed graph
+        self._filled = False
         if dev.type == "cuda":
             from .runtime import RangeFlag
             self.flag = RangeFlag(dev)      # device-side range check of every replay (fp16-plane arithmetic), polled lazily
@@ -340,6 +342,7 @@ class PaddedGraphRunner:
         if self.quad:
             self._fill_quad(idx, E, ep, tp)
         buf["R"][:self.A].copy_(R)
+        self._filled = True
 
     def _fill_quad(self, idx, E, ep, tp):
         """Interaction edges, intermediate triplets and quadruplets of one batch + their pad rows (module docstring)."""
@@ -399,6 +402,64 @@ class PaddedGraphRunner:
         E, F = self.out
         return E.detach()[:self.n_mol], F.detach()[:self.A]
 
+    # ---- the index build INSIDE the replayed graph (triplets-only models, fixed molecule layout) --------------------------
+    def attach_builder(self, builder):
+        """From the next capture on the graph starts with the index build itself (index_device.DeviceGraphBuilder's layout,
+        gn_index_gpu_padded_t: counts stay on the device, the arrays are committed into the static buffers with their pad
+        rows by one kernel): a step is  positions in -> one replay -> (E, F) out  with no read-back and no padding launches
+        on the host — the MD step of ase_calculator.py:148-170 as ONE graph.  The buffers must hold a valid batch already
+        (one `_fill`): a step that does not fit the capacities keeps the previous arrays, poisons its outputs with NaN and
+        reports through `index_error()`."""
+        if self.quad or self.variable_atoms:
+            raise NotImplementedError("the in-graph index build covers triplets-only models with a fixed molecule layout")
+        if not builder.triplets_only or builder.A != self.A or self.index_dtype != torch.int32:
+            raise ValueError("builder and runner describe different systems")
+        if not self._filled:
+            raise RuntimeError("attach_builder: fill the buffers with a first batch (runner._fill / runner(R, idx)) before")
+        dev = self.inputs["R"].device
+        self.builder = builder
+        self._staging = torch.empty(4 * self.e_cap + 2 * self.t_cap, dtype=torch.int32, device=dev)
+        self._idx_state = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._idx_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.graph = None
+        self.out = None
+
+    def _index_in_graph(self):
+        from . import kernels as K
+        K.index_padded_t(self.builder, self.inputs["R"][:self.A], self.e_cap, self.t_cap, self.a_cap, self.G,
+                         self.pad_degree_bound(), self._staging, self.inputs, self._idx_state)
+
+    def index_error(self):
+        """Error bits (include/gemnet_hip.h, gn_index_gpu_padded_t) of the in-graph index builds COMPLETED so far — sticky;
+        exact after anything that waited for the last replay."""
+        return int(self._idx_host[0]) if self.builder is not None else 0
+
+    def index_sizes(self):
+        """(E, T) of the last completed in-graph index build."""
+        return int(self._idx_host[1]), int(self._idx_host[2])
+
+    def reset_index_state(self):
+        self._idx_state.zero_()
+        self._idx_host.zero_()
+
+    def run_positions(self, R, Z=None):
+        """One step with the index build inside the graph: R (A, 3) float32 on the device -> (E, F) as `__call__`."""
+        if self.builder is None:
+            raise RuntimeError("run_positions needs attach_builder")
+        if self.flag is not None and self.flag.tripped():
+            self.recover()
+        if self.index_error():
+            raise ValueError(f"an earlier step did not fit the capacities ({self.e_cap}, {self.t_cap}): index error bits "
+                             f"{self.index_error()}, sizes {self.index_sizes()} — its outputs were NaN; build a larger runner")
+        if Z is not None:
+            self.inputs["Z"][:self.A].copy_(Z)
+        self.inputs["R"][:self.A].copy_(R)
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        E, F = self.out
+        return E.detach()[:self.n_mol], F.detach()[:self.A]
+
     def recover(self):
         """The range flag tripped: move the model off the fp16 planes (runtime.fall_back_to_bf16_planes: warns) and drop the
         graph — the next call captures anew in the bf16-plane arithmetic."""
@@ -438,17 +499,26 @@ class PaddedGraphRunner:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up off the default stream (autograd stream bookkeeping, lazy caches)
             for _ in range(2):
+                if self.builder is not None:
+                    self._index_in_graph()
                 self.model(dict(inputs))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             cap = dict(inputs)                  # a fresh dict: the plan is built inside the capture, from the static buffers
+            if self.builder is not None:
+                self._index_in_graph()
             if getattr(self, "check", False):   # happens-before check of the capture (hbcheck.py); recorder left in self.hb
                 from . import hbcheck
                 with hbcheck.record() as self.hb:
                     self.out = self.model(cap)
             else:
                 self.out = self.model(cap)
+            if self.builder is not None:
+                from . import kernels as K
+                for t in self.out:
+                    K.index_poison(t, self._idx_state)
+                self._idx_host.copy_(self._idx_state, non_blocking=True)
         self._cap_inputs = cap                  # keeps the plan's tensors (graph memory) referenced
         self.graph = g

@@ -12,6 +12,7 @@ The graphs read the model parameters and the `R` tensors of the sub-batches in p
 copies new coordinates into the captured buffers (MD with a fixed neighbour list); a changed graph
 (new neighbour list) needs a new runner.
 """
+import os
 import warnings
 
 import torch
@@ -147,6 +148,10 @@ class ForceGraphs:
         return (torch.cat([o[0] for o in self.outputs]), torch.cat([o[1] for o in self.outputs]))
 
 
+# The index build inside the replayed graph (padded.PaddedGraphRunner.attach_builder; triplets-only models).
+IN_GRAPH_INDEX = os.environ.get("GEMNET_INDEX_IN_GRAPH", "1") == "1"
+
+
 class DynamicForceField:
     """Energies and forces of ONE system for positions that change from call to call — the loop of the reference's ASE
     calculator (ase_calculator.py:148-170: new neighbour list every step) — at hipGraph speed:
@@ -186,8 +191,22 @@ class DynamicForceField:
             t.record_stream(main)
         return idx
 
-    def __call__(self, R):
+    def __call__(self, R, exact=True):
+        """`exact` (triplets-only models, whose graph builds its own neighbour list): wait for the step and look at the
+        device-side report of its index build — a system that outgrew the capacities is re-sized and the step repeated, as
+        on the host-sized path.  With exact=False nothing waits: such a step returns NaN energies / forces and the NEXT call
+        re-sizes (for callers that keep everything on the device and check `index_failed()` themselves)."""
         from .padded import PaddedGraphRunner
+        r = self.runner
+        if r is not None and r.builder is not None:
+            if not r.index_error():
+                out = r.run_positions(R)            # the whole step — index build included — is one replay
+                if not exact:
+                    return out
+                torch.cuda.current_stream(R.device).synchronize()
+                if not r.index_error():
+                    return out
+            r.reset_index_state()                   # this / an earlier step outgrew the capacities: size them anew below
         idx = self._build(R)
         sizes = PaddedGraphRunner.sizes_of(idx)
         r = self.runner
@@ -206,7 +225,19 @@ class DynamicForceField:
             self.runner = PaddedGraphRunner(self.model, self.Z, self.N, e_cap, t_cap, max_in_degree=self.deg, n_groups=groups,
                                             quad_caps=quad_caps)
             self.recaptures += self.runner is not r and r is not None
+        if IN_GRAPH_INDEX and self.model.triplets_only and R.dtype == torch.float32:
+            # triplets-only models: from here on the index build is part of the graph (padded.attach_builder): this call's
+            # arrays validate the buffers, every later call is  positions in -> one replay -> results out
+            self.runner._fill(R, idx)
+            if self.runner.builder is None:
+                self.runner.attach_builder(self.builder)
+            return self.runner.run_positions(R)
         return self.runner(R, idx)
+
+    def index_failed(self):
+        """Did a completed step's in-graph index build outgrow the capacities (its outputs are NaN)?  Exact after the caller
+        waited for that step."""
+        return self.runner is not None and self.runner.builder is not None and bool(self.runner.index_error())
 
     def range_tripped(self):
         """RangeFlag of the current runner (exact after the caller waited for the last replay)."""

@@ -1,0 +1,122 @@
+"""-m gpu: the index build INSIDE the replayed graph (gn_index_gpu_padded_t, padded.PaddedGraphRunner.attach_builder;
+VERDICT r4 missing 8 / next 7): the MD step of ase_calculator.py:148-170 — neighbour list (:155-158), index arrays
+(data_container.py:244-425), model — as one hipGraph with no read-back.  Checked against the two-stage device builder + the
+host-side padding of padded.py (themselves bit-exact against the reference's arrays: tests/test_gpu_index.py), bit for bit."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import SCALE_FILE
+from gemnet_pytorch_amd.index_device import DeviceGraphBuilder
+from gemnet_pytorch_amd.md import DeviceMolecule
+from gemnet_pytorch_amd.model.gemnet import GemNet
+from gemnet_pytorch_amd.padded import PAD_EDGE_KEYS, PAD_TRIP_KEYS, PaddedGraphRunner
+from gemnet_pytorch_amd.runtime import DynamicForceField
+from gemnet_pytorch_amd.synthetic import make_dataset, make_molecule
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CFG = dict(num_spherical=7, num_radial=6, num_blocks=2, emb_size_atom=128, emb_size_edge=128, emb_size_trip=64,
+           emb_size_quad=32, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=32, emb_size_bil_trip=64,
+           emb_size_bil_quad=32, num_before_skip=1, num_after_skip=1, num_concat=1, num_atom=2, triplets_only=True)
+
+
+def new_model(seed=5):
+    torch.manual_seed(seed)
+    m = GemNet(**CFG, scale_file=SCALE_FILE).to(DEV).eval()
+    m.requires_grad_(False)
+    return m
+
+
+def batches(n_mol=4, n_atoms=24, n=3):
+    out = []
+    for b in range(n):
+        ds = make_dataset(n_mol, n_atoms, config=2, first=40 * (b + 1))
+        out.append((ds, torch.tensor(ds["R"], device=DEV, dtype=torch.float32), torch.tensor(ds["Z"], device=DEV).long(),
+                    torch.tensor(ds["N"], device=DEV).long()))
+    return out
+
+
+def test_in_graph_index_equals_two_stage_build_plus_host_padding():
+    data = batches()
+    builder = DeviceGraphBuilder(data[0][0]["N"], 5.0, 10.0, True, device=DEV)
+    idxs = [builder(R, dtype=torch.int32) for _, R, _, _ in data]
+    sizes = [PaddedGraphRunner.sizes_of(i) for i in idxs]
+    assert len(set(sizes)) > 1, "the batches must differ in size"
+    caps = PaddedGraphRunner.suggest_capacities(sizes)
+    model = new_model()
+    ref = PaddedGraphRunner(model, data[0][2], data[0][3], *caps, n_groups=16)
+    run = PaddedGraphRunner(model, data[0][2], data[0][3], *caps, n_groups=16)
+    run._fill(data[0][1], idxs[0], data[0][2])
+    run.attach_builder(builder)
+    for rep in range(2):
+        for (ds, R, Z, N), idx, sz in zip(data, idxs, sizes):
+            E0, F0 = (t.clone() for t in ref(R, idx, Z=Z))
+            ref_bufs = {k: ref.inputs[k].clone() for k in PAD_EDGE_KEYS + PAD_TRIP_KEYS}
+            E1, F1 = run.run_positions(R, Z=Z)
+            torch.cuda.synchronize()
+            assert run.index_error() == 0 and run.index_sizes() == sz[:2]
+            for k, v in ref_bufs.items():
+                assert torch.equal(run.inputs[k], v), k
+            assert torch.equal(E0, E1) and torch.equal(F0, F1)
+            assert bool(torch.isfinite(F1).all())
+
+
+def test_a_step_that_outgrows_the_capacities_keeps_valid_arrays_poisons_its_outputs_and_reports():
+    (ds, R, Z, N), = batches(n=1)
+    builder = DeviceGraphBuilder(ds["N"], 5.0, 10.0, True, device=DEV)
+    idx = builder(R, dtype=torch.int32)
+    E_, T_ = PaddedGraphRunner.sizes_of(idx)
+    model = new_model()
+    run = PaddedGraphRunner(model, Z, N, E_ + 8, T_ + 8)
+    run._fill(R, idx, Z)
+    run.attach_builder(builder)
+    E1, F1 = (t.clone() for t in run.run_positions(R))
+    before = {k: run.inputs[k].clone() for k in PAD_EDGE_KEYS + PAD_TRIP_KEYS}
+    # the same molecules, every one contracted by 15 % around its centre: more neighbours inside the cutoff
+    n = int(ds["N"][0])
+    Rc = R.view(-1, n, 3)
+    Rd = ((Rc - Rc.mean(1, keepdim=True)) * 0.85 + Rc.mean(1, keepdim=True)).reshape(-1, 3).contiguous()
+    big = PaddedGraphRunner.sizes_of(builder(Rd, dtype=torch.int32))
+    assert big[0] > run.e_cap or big[1] > run.t_cap
+    E2, F2 = run.run_positions(Rd)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(E2).all()) and bool(torch.isnan(F2).all())
+    want = (1 if big[0] > run.e_cap else 0) | (2 if big[0] <= run.e_cap and big[1] > run.t_cap else 0)
+    assert run.index_error() == want and run.index_sizes()[0] == big[0]
+    for k, v in before.items():
+        assert torch.equal(run.inputs[k], v), k       # the arrays of the last step that fitted: valid indices
+    with pytest.raises(ValueError, match="did not fit"):
+        run.run_positions(R)
+    run.reset_index_state()
+    E3, F3 = run.run_positions(R)
+    torch.cuda.synchronize()
+    assert torch.equal(E3, E1) and torch.equal(F3, F1) and run.index_error() == 0
+
+
+def test_force_field_and_predict_resize_when_the_system_contracts():
+    """`GNNCalculator.calculate` -> `model.predict(molecule.get())` (ase_calculator.py:148-170) reads its results on the
+    host: a step whose neighbour list outgrows the graph's capacities is repeated with new capacities, not returned as NaN."""
+    mol = make_molecule(24, 7)
+    R0, Z = mol["R"].astype(np.float32), mol["Z"]
+    model = new_model()
+    dm = DeviceMolecule(R0, Z, 5.0, 10.0, triplets_only=True)
+    dm.to(DEV)
+    E0, F0 = model.predict(dm.get())
+    ff = next(iter(model._md_fields.values()))
+    assert ff.runner.builder is not None, "triplets-only MD runs its index build inside the graph"
+    c = R0.mean(0, keepdims=True)
+    traj = [R0 + 0.01, (R0 - c) * 0.95 + c, (R0 - c) * 0.7 + c, (R0 - c) * 0.72 + c, R0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for Rn in traj:
+            dm.update(Rn.astype(np.float32))
+            E, F = model.predict(dm.get())
+            assert bool(torch.isfinite(E).all()) and bool(torch.isfinite(F).all())
+            b = DeviceGraphBuilder(np.array([len(Z)]), 5.0, 10.0, True, device=DEV)
+            Rt = torch.tensor(Rn, device=DEV, dtype=torch.float32)
+            Er, Fr = model(dict(Z=torch.tensor(Z, device=DEV).long(), R=Rt.clone(), N=torch.tensor([len(Z)], device=DEV), **b(Rt)))
+            assert torch.equal(E, Er.detach().cpu()) and torch.equal(F, Fr.detach().cpu())
+    assert ff.recaptures >= 1, "the contracted geometry must have outgrown the first capacities"

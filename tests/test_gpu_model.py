@@ -204,7 +204,7 @@ def test_repeatable_bitwise(golden_model):
 def test_native_library_loaded():
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
-    assert lib.gn_abi_version() == 13
+    assert lib.gn_abi_version() == 14
     with open("/proc/self/maps") as f:
         assert "libgemnet_hip.so" in f.read()
 
