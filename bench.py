@@ -292,7 +292,7 @@ class LaunchTimer:
 
 PEAK_SPLIT6_TFLOPS = 2500.0 / 6   # fp32-equivalent ceiling of six bf16 products on the 2.5 PF dense bf16 pipe
 PEAK_BF16_TFLOPS = 2500.0
-PROFILE_ROUND = "r4"
+PROFILE_ROUND = "r5"
 
 
 def _profile_json(name):

@@ -1,4 +1,4 @@
-"""Per-kernel HBM-side traffic and MFMA-busy figures from the rocprofv3 PMC passes of tools/gpu_artifacts3.sh (runs
+"""Per-kernel HBM-side traffic and MFMA-busy figures from the rocprofv3 PMC passes of tools/gpu_artifacts5.sh (runs
 anywhere: pandas only).
 
     python tools/pmc_summary.py gpurun_out/<tag> <mode: T|Q|train> [r3]
@@ -27,7 +27,8 @@ def short(name):
     return name.split("(")[0][:64]
 
 
-FAMILIES = {"chain": ("chain_kernel", "chain_split_kernel"), "gemm": ("gemm_nt", "gemm_generic", "gemm_smallk", "gemm_n1"),
+FAMILIES = {"bil_reduce_project_tan": ("bil_reduce_project_ang_tan",), "bil_reduce_t_tan": ("bil_expand_ang_tan",),
+            "chain": ("chain_kernel", "chain_split_kernel"), "gemm": ("gemm_nt", "gemm_generic", "gemm_smallk", "gemm_n1"),
             "gemm_tn": ("gemm_tn",), "bil_fused_fwd": ("bil_fused_fwd",), "bil_fused_bwd": ("bil_fused_bwd",),
             "bil_project_bwd": ("bil_project_bwd",), "bil_dy_multi": ("bil_dy_multi",),
             "bil_reduce_t": ("bil_reduce_t", "bil_expand"), "bil_reduce_project": ("bil_reduce_project",),
@@ -64,7 +65,7 @@ if len(tab) == 2:
     t["total"] = t["bytes_per_launch"] * t["n"]
     t = t.sort_values("total", ascending=False).drop(columns="total")
     head = f"""# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domains) on the {mode} workload of bench.py
-# (tools/gpu_artifacts3.sh, summarised by tools/pmc_summary.py), MI355X.  Raw counter values are KB per dispatch (mean over n).
+# (tools/gpu_artifacts5.sh, summarised by tools/pmc_summary.py), MI355X.  Raw counter values are KB per dispatch (mean over n).
 # gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-reports wide coalesced reads by 2x ->
 # bytes_per_launch = (2 * fetch_kb + write_kb) * 1024.  WRITE_SIZE is uncalibrated for 4-byte strided stores (face value).
 # The working set of this batch is Infinity-Cache resident: these are L2 memory-side requests, not DRAM bytes.
@@ -93,7 +94,7 @@ if df is not None:
     df["dur_ns"] = df["End_Timestamp"] - df["Start_Timestamp"]
     # kernel durations of the UNINSTRUMENTED run of the same workload (rocprofv3 --kernel-trace --stats, hipGraph replay),
     # when it is there: counter collection serialises and stretches the dispatches (chain: 46 vs 30 us)
-    sdir = {"T": "prof", "train": "prof_train", "Q": "prof_Q"}[mode]
+    sdir = {"T": "prof", "train": "prof_train", "Q": "prof_Q", "Qtrain": "prof_Qtrain"}[mode]
     sf = glob.glob(os.path.join(tag, sdir, "**", "*kernel_stats.csv"), recursive=True)
     if sf:
         ks = pd.read_csv(sf[0])
