@@ -6,7 +6,8 @@ call, so a captured forward+force cannot be replayed and the eager path is bound
 2.7 ms of kernels).  Here every batch is PADDED to fixed capacities with a dummy molecule and the one graph captured for
 those capacities is replayed:
 
-  * `A_pad = 3 G` dummy atoms in G groups (a, b, c) with a valid geometry of their own (1 A bonds, 90 degrees), far from
+  * `A_pad = 3 G` dummy atoms in G groups (a, b, c) with a valid geometry of their own (bonds of 0.9 x the cutoff, where
+    the envelope has almost closed: `dummy_positions`; 90 degrees), far from
     every real atom and assigned to an extra molecule whose energy and forces are dropped;
   * pad edges come in quads  b->a, a->b, c->a, a->c  cycling over the groups (id_swap = the neighbour in the pair,
     id_undir continues the numbering), pad triplets are the two orderings (c->a, b->a), (b->a, c->a) of the quads' forward
@@ -159,15 +160,29 @@ def pad_indices(idx, n_atoms, e_cap, t_cap, n_groups, dtype=torch.int64, quad_ca
     return out
 
 
-def dummy_positions(n_groups, like, offset=1.0e3, quad=False):
-    """(3 G, 3) positions: group g = atoms a, b, c with |ab| = |ac| = 1 A and a right angle, 10 A between groups, `offset`
-    away from the origin (real molecules of a batch sit near it).  `quad`: (4 G, 3) — a fourth atom d bonded to b, out of the
-    plane: the angles c-a-b, a-b-d and the dihedral c-a-b-d are all 90 degrees."""
+def dummy_positions(n_groups, like, offset=1.0e3, quad=False, bond=1.0):
+    """(3 G, 3) positions: group g = atoms a, b, c with |ab| = |ac| = `bond` and a right angle, 10 bond lengths between
+    groups, `offset` away from the origin (real molecules of a batch sit near it).  `quad`: (4 G, 3) — a fourth atom d bonded
+    to b, out of the plane: the angles c-a-b, a-b-d and the dihedral c-a-b-d are all 90 degrees.
+    The runner uses bond = 0.9 x the embedding cutoff: the envelope of every radial basis is 0.04 there, so the pad rows'
+    messages are ~1e-3 of a real row's.  With 1 A bonds the few pad edges that carry ALL pad triplets (24-45 identical
+    ones each, summed coherently where a real edge sums ~18 different ones) reached 7e4 in the bilinear layer's output at the
+    32 x 32 batch — beyond the fp16 planes of the default Dense arithmetic: harmless in inference (the dummy molecule's rows
+    are dropped) but in force TRAINING their zero cotangents times inf made every weight gradient NaN (found by the range
+    flag of round 5; round 4's padded training step had it silently)."""
     g = torch.arange(n_groups, device=like.device, dtype=like.dtype)
-    base = torch.stack([offset + 10.0 * g, torch.full_like(g, offset), torch.full_like(g, offset)], dim=1)
+    base = torch.stack([offset + 10.0 * bond * g, torch.full_like(g, offset), torch.full_like(g, offset)], dim=1)
     rows = [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]] + ([[1.0, 0.0, 1.0]] if quad else [])
-    d = torch.tensor(rows, device=like.device, dtype=like.dtype)
+    d = bond * torch.tensor(rows, device=like.device, dtype=like.dtype)
     return (base[:, None, :] + d[None, :, :]).reshape(-1, 3)
+
+
+def dummy_bond(model):
+    """Bond length of the dummy molecule for `model`: 0.9 x its embedding cutoff (1 A when the model does not tell)."""
+    try:
+        return 0.9 * float(model.cbf_basis3.cutoff)
+    except (AttributeError, TypeError, ValueError):
+        return 1.0
 
 
 class PaddedGraphRunner:
@@ -217,7 +232,7 @@ class PaddedGraphRunner:
         fill = torch.arange(self.a_cap, device=dev, dtype=self.inputs["R"].dtype)
         self._R_fill = torch.stack([-1.0e3 - 10.0 * fill, torch.full_like(fill, -1.0e3), torch.full_like(fill, -1.0e3)], dim=1)
         self.inputs["R"][:self.a_cap] = self._R_fill
-        self.inputs["R"][self.a_cap:] = dummy_positions(self.G, self.inputs["R"], quad=self.quad)
+        self.inputs["R"][self.a_cap:] = dummy_positions(self.G, self.inputs["R"], quad=self.quad, bond=dummy_bond(model))
         # The edge / triplet arrays live in `index_dtype` (int32: what the kernels read — the plan built inside the replayed
         # graph then has no conversion launches, and the device index builder hands its int32 arrays over as they are;
         # batches given as int64 are converted by the copy into the buffers).  Values stay far below 2^31 (checked).

@@ -318,3 +318,30 @@ def test_padded_quadruplet_replay_equals_eager_on_changing_batches():
     E, F = runner.build_and_run(int32_idx, batches[1][1], Z=batches[1][0])
     torch.cuda.synchronize()
     assert torch.equal(E, ref[1][0]) and torch.equal(F, ref[1][1])
+
+
+def test_padded_training_step_at_the_headline_batch_keeps_finite_gradients_in_the_fp16_plane_arithmetic(monkeypatch):
+    """The dummy molecule must stay inside the fp16 planes of the default arithmetic.  With 1 A dummy bonds the pad edges that
+    carry all pad triplets (24-45 identical ones each) reached 7e4 in the bilinear layer's output at this batch size; their
+    zero cotangents times inf made every weight gradient of the padded training step NaN (found by the range flag in round 5).
+    The dummy bonds now sit at 0.9 x the cutoff (`padded.dummy_positions`)."""
+    from gemnet_pytorch_amd import kernels as K
+    from gemnet_pytorch_amd.training.ddp import PaddedTrainStep
+    monkeypatch.setattr(K, "DEFAULT_CHAIN_MODE", "h3")
+    cfg = dict(FULL, triplets_only=True)
+    g = torch.Generator().manual_seed(1)
+    ds = make_dataset(32, 32, config=2, first=32)
+    R = torch.tensor(ds["R"], device=DEV, dtype=torch.float32)
+    idx = DeviceGraphBuilder(ds["N"], 5.0, 10.0, True, device=DEV)(R)
+    Z, N = torch.tensor(ds["Z"], device=DEV).long(), torch.tensor(ds["N"], device=DEV).long()
+    Et, Ft = torch.randn(32, 1, generator=g).to(DEV), torch.randn(1024, 3, generator=g).to(DEV)
+    sizes = [(int(idx["id_c"].shape[0]), int(idx["id3_reduce_ca"].shape[0]))]
+    torch.manual_seed(1234)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV)
+    ts = PaddedTrainStep(model, Z, N, *PaddedGraphRunner.suggest_capacities(sizes), fused_optimizer=True)
+    for _ in range(3):
+        loss = ts.step(R, idx, Et, Ft, Z=Z)
+        torch.cuda.synchronize()
+        assert ts.flag.tripped() == 0 and model.matmul_precision is None
+        assert bool(torch.isfinite(loss)) and bool(torch.isfinite(ts.fused.flat_p).all())
+    assert bool(torch.isfinite(ts.buf.flat).all())
