@@ -948,7 +948,8 @@ def main():
     extra = {}
     if args.mode == "train":   # explicit request: the training step IS the timed region
         tr = extra_train_step(cfg, 1234, inputs, targets, world, args.batch, steps=args.steps, warmup=args.warmup,
-                              want_roofline=not args.no_roofline and rank == 0, graph=not args.no_graph)
+                              want_roofline=not args.no_roofline and rank == 0, graph=not args.no_graph,
+                              roof_mode="Qtrain" if args.model == "Q" else "train")
         elapsed = tr["ms_per_step"] * 1e-3 * args.steps
         graph, roof = tr["hipgraph"], tr.pop("roofline", None)
         extra["train_step"] = tr
@@ -974,7 +975,7 @@ def main():
         elapsed = time_steps(graph.replay if graph is not None else step, args.steps, args.warmup, world)
         roof = None
         if not args.no_roofline and rank == 0:
-            roof, fam = family_roofline(step)
+            roof, fam = family_roofline(step, mode=args.model)      # (the committed counter passes are per workload: T | Q)
             log_families("forward+force", fam)
             # the WHOLE step against the same roof: algorithmic flops of every launcher family of one step / the timed step
             step_flops = sum(v["flops"] for v in fam.values())

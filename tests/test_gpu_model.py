@@ -347,22 +347,22 @@ def test_grouped_weight_gradients_match_autograd_accumulation(golden_model):
 
 
 def test_model_matmul_precision_flag(golden_model2):
-    """GemNet.matmul_precision selects the Dense-stack arithmetic per model: "bf16" differs from the default by the
-    bf16 rounding of the operands, "f32" and the default (six split products) agree to fp32 rounding."""
+    """GemNet.matmul_precision selects the Dense-stack arithmetic per model: the three fp32-equivalent forms agree to fp32
+    rounding; reduced-precision operand modes ("bf16": removed in round 5) and unknown names raise."""
     g = golden_model2
     cfg, params, inputs = load_case(g, "t2s")
     model = build(cfg, params).eval()
     dev = to_dev(inputs)
     F = {}
-    for mode in (None, "f32", "bf16"):
+    for mode in (None, "f32", "split6", "h3"):
         model.matmul_precision = mode
         F[mode] = model(dict(dev))[1].detach()
-    assert float((F[None] - F["f32"]).abs().mean()) <= 1e-5
-    d = float((F[None] - F["bf16"]).abs().mean())
-    assert 1e-4 < d < 0.2, d
-    with pytest.raises(ValueError):
-        model.matmul_precision = "fp8"
-        model(dict(dev))
+    for mode in ("f32", "split6", "h3"):
+        assert float((F[None] - F[mode]).abs().mean()) <= 1e-5, mode
+    for bad in ("bf16", "fp8"):
+        model.matmul_precision = bad
+        with pytest.raises(ValueError):
+            model(dict(dev))
 
 
 def test_force_graphs_runtime(golden_model2):
