@@ -545,25 +545,48 @@ void launch(const gn_gemm_args& p, bool fast, int vecA, int vecB, hipStream_t st
 // tile kernel stages both operands through LDS dword by dword (42 us for the (18 k, 6) x (6, 128) edge embedding
 // against 9 MB of output).  Here the B tile (K x 128) sits in LDS, a thread owns one row and 4 columns 32 apart
 // (row-contiguous 128-byte stores), the row of A is a broadcast load, and the usual fused epilogue applies.
+template <bool NARROW>
 __global__ __launch_bounds__(256) void gemm_smallk(const gn_gemm_args p) {
-  extern __shared__ float Bs[];   // [K][128]
+  // NARROW (N <= 32: the radial projections onto 16 columns — 9 of the 10 launches of a forward+force step): a thread owns
+  // ONE column and four rows 8 apart, the B tile is (K, 32) — a quarter of the LDS reads and products of the wide form,
+  // which computed 128 columns whatever N was (round 5).  Same order of products per output: bit-identical.
+  constexpr int TN = NARROW ? 32 : 128;
+  extern __shared__ float Bs[];   // [K][TN]
   const int K = p.K, N = p.N, M = p.M;
   const int tid = threadIdx.x;
-  const int col0 = blockIdx.y * 128, row0 = blockIdx.x * 32;
+  const int col0 = blockIdx.y * TN, row0 = blockIdx.x * 32;
   const float* __restrict__ const B = p.B;
   if (p.trans_b) {   // B is (K,N)
-    for (int i = tid; i < K * 128; i += 256) {
-      const int k = i >> 7, n = i & 127;
+    for (int i = tid; i < K * TN; i += 256) {
+      const int k = i / TN, n = i % TN;
       Bs[i] = col0 + n < N ? B[(size_t)k * p.ldb + col0 + n] : 0.f;
     }
   } else {           // B is (N,K): walk it in memory order
-    for (int i = tid; i < K * 128; i += 256) {
+    for (int i = tid; i < K * TN; i += 256) {
       const int n = i / K, k = i - n * K;
-      Bs[k * 128 + n] = col0 + n < N ? B[(size_t)(col0 + n) * p.ldb + k] : 0.f;
+      Bs[k * TN + n] = col0 + n < N ? B[(size_t)(col0 + n) * p.ldb + k] : 0.f;
     }
   }
   __syncthreads();
   const int l32 = tid & 31, rg = tid >> 5;
+  if (NARROW) {
+    const float* a[4];
+    int row[4], col[4];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      row[n] = row0 + rg + 8 * n;
+      col[n] = col0 + l32;
+      a[n] = p.A + (size_t)(row[n] < M ? row[n] : M - 1) * p.lda;     // (rows behind M: loads clamped, stores masked)
+    }
+    for (int k = 0; k < K; ++k) {
+      const float b = Bs[k * 32 + l32];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) v[n] = fmaf(a[n][k], b, v[n]);
+    }
+    epilogue_vals<4, false>(p, v, row, col);
+    return;
+  }
   const bool full = col0 + 128 <= N;
   for (int rr = rg; rr < 32; rr += 8) {
     const int r = row0 + rr;
@@ -627,8 +650,15 @@ extern "C" int gn_gemm_f32_cfg(const gn_gemm_args* args, int cfg, void* stream) 
     return 0;
   }
   if (cfg < 0 && !p.trans_a && !p.a_dact_pre && p.splitk <= 1 && p.K >= 1 && p.K <= 64 && (p.K % 4 != 0 || p.K < 8)) {
-    hipLaunchKernelGGL(gemm_smallk, dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(256), (size_t)p.K * 128 * sizeof(float),
-                       st, p);
+#ifdef GN_SMALLK_WIDE_ONLY      // (A/B builds: the round-1..4 form for every N)
+    if (false)
+#else
+    if (p.N <= 32)
+#endif
+      hipLaunchKernelGGL(gemm_smallk<true>, dim3(gn_cdiv(p.M, 32), 1), dim3(256), (size_t)p.K * 32 * sizeof(float), st, p);
+    else
+      hipLaunchKernelGGL(gemm_smallk<false>, dim3(gn_cdiv(p.M, 32), gn_cdiv(p.N, 128)), dim3(256),
+                         (size_t)p.K * 128 * sizeof(float), st, p);
     GN_LAUNCH_CHECK();
     return 0;
   }

@@ -72,10 +72,12 @@ def test_gemm_fused_epilogue_and_prologue():
     close(y, ref_y, atol=5e-5)
 
 
-@pytest.mark.parametrize("Kd,N,tb", [(6, 128, False), (6, 100, True), (42, 112, True), (1, 128, False)])
+@pytest.mark.parametrize("Kd,N,tb", [(6, 128, False), (6, 100, True), (42, 112, True), (1, 128, False),
+                                     (6, 16, False), (6, 16, True), (42, 32, True), (6, 32, False), (7, 20, True), (2, 1, True)])
 def test_gemm_small_k_row_kernel_with_fused_epilogue(Kd, N, tb):
     """K <= 64 and tiny / not a multiple of 4 (edge embedding: 6 radial functions + two gathered atom rows + ScaledSiLU;
-    the 42-column circular basis; K = 1 outer products) run the row kernel gemm_smallk with the same epilogue stages."""
+    the 42-column circular basis; K = 1 outer products) run the row kernel gemm_smallk with the same epilogue stages; N <= 32
+    (the radial projections onto 16 columns) its one-column-per-thread form."""
     g = torch.Generator().manual_seed(Kd * N)
     M, A_rows = 1037, 60
     A = rnd(g, M, Kd)
