@@ -303,8 +303,16 @@ __global__ __launch_bounds__(256) void quad_angles_bwd_kernel(const float4* __re
     g_ab = g_ab - g_ba;
     const V3 gc = g_ac, gd = g_bd, gb = g_ab - g_bd;
     Gc[ldc * q] = gc.x; Gc[ldc * q + 1] = gc.y; Gc[ldc * q + 2] = gc.z;
-    Gb[ldb * q] = gb.x; Gb[ldb * q + 1] = gb.y; Gb[ldb * q + 2] = gb.z;
-    Gd[ldd * q] = gd.x; Gd[ldd * q + 1] = gd.y; Gd[ldd * q + 2] = gd.z;
+    if (ldb == 8 && ldd == 8 && Gd == Gb + 4) {
+      // packed rows [Gb xyz, 0, Gd xyz, 0] (the two-level force reduction of ops._quad_adjoint): two 16-byte stores, the pad
+      // lanes written here (round 5: the caller used to zero-fill the 288 MB buffer first)
+      float4* __restrict__ row = reinterpret_cast<float4*>(Gb + 8 * q);
+      row[0] = make_float4(gb.x, gb.y, gb.z, 0.f);
+      row[1] = make_float4(gd.x, gd.y, gd.z, 0.f);
+    } else {
+      Gb[ldb * q] = gb.x; Gb[ldb * q + 1] = gb.y; Gb[ldb * q + 2] = gb.z;
+      Gd[ldd * q] = gd.x; Gd[ldd * q + 1] = gd.y; Gd[ldd * q + 2] = gd.z;
+    }
   }
 }
 

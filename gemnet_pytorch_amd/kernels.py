@@ -1160,7 +1160,7 @@ def quad_angles_bwd(g_ang, R, qc, qa, qb, qd, packed=False):
     Q = qc.shape[0]
     Gc = torch.empty((Q, 3), device=R.device, dtype=torch.float32)
     if packed:
-        Gbd = torch.zeros((Q, 8), device=R.device, dtype=torch.float32)
+        Gbd = torch.empty((Q, 8), device=R.device, dtype=torch.float32)      # (the kernel writes the two pad lanes itself)
         base = addr(Gbd)
         check(_lib.load().gn_quad_angles_bwd_ld_f32(ptr(g_ang), ptr(R), ptr(qc), ptr(qa), ptr(qb), ptr(qd), ptr(Gc), 3,
                                                     base, 8, base + 16, 8, Q, stream()), "gn_quad_angles_bwd_ld_f32")

@@ -310,7 +310,7 @@ class GemNet(torch.nn.Module):
 
         if not T:
             rbf4 = ops.accumulate_gradient(self.mlp_rbf4(rbf))
-            cbf4 = self.mlp_cbf4(cbf4)
+            cbf4 = ops.accumulate_gradient(self.mlp_cbf4(cbf4))     # (one consumer per block: no engine-side (I,16) adds)
             sbf4 = (ops.accumulate_gradient(self.mlp_sbf4(sbf4[0])), sbf4[1])
         else:
             rbf4 = cbf4 = sbf4 = None

@@ -9,11 +9,11 @@ ge.build()
 from gemnet_pytorch_amd.graph import GraphPlan
 from gemnet_pytorch_amd.model.gemnet import GemNet
 dev = torch.device("cuda", 0)
-cfg = dict(B.GEMNET_T)
+cfg = dict(B.GEMNET_T, triplets_only=(len(sys.argv) < 2 or sys.argv[1] != "Q"))
 torch.manual_seed(1234)
 model = GemNet(**cfg, scale_file=B.SCALE_FILE).to(dev)
 inputs, _ = B.make_batch(cfg, 32, 32, first=0, device=dev)
-GraphPlan.from_inputs(inputs, True).warm()
+GraphPlan.from_inputs(inputs, cfg["triplets_only"]).warm()
 model.eval(); model.requires_grad_(False)
 for _ in range(2): model(inputs)
 torch.cuda.synchronize()
