@@ -130,13 +130,14 @@ __global__ void idx_edges_kernel(const int32_t* __restrict__ mol_off, const int3
                                  int32_t* __restrict__ id_a, int32_t* __restrict__ id_c,
                                  int32_t* __restrict__ id_undir, int32_t* __restrict__ id_swap,
                                  int32_t* __restrict__ int_a, int32_t* __restrict__ int_b,
-                                 int32_t* __restrict__ Mx, int32_t* __restrict__ MI, int e_cap) {
+                                 int32_t* __restrict__ Mx, int32_t* __restrict__ MI, int e_cap, int eint_cap) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= A) return;
   const int m = atom_mol[g];
   const int a0 = mol_off[m], n = mol_off[m + 1] - a0, x = g - a0;
   const int H = off_half[A];
-  if (2 * (int64_t)H > e_cap) return;       // capacity form (gn_index_gpu_padded_t): nothing is written, the commit kernel flags it
+  if (2 * (int64_t)H > e_cap) return;       // capacity forms (gn_index_gpu_padded_*): nothing is written, the step is flagged
+  if (quad && off_int[A] > eint_cap) return;
   const size_t base = (size_t)sq_off[m];
   const uint8_t* __restrict__ row = adj + base + (size_t)x * n;
   int e = off_half[g];
@@ -213,9 +214,11 @@ __global__ __launch_bounds__(256) void idx_trip_kernel(const int32_t* __restrict
                                                        const int32_t* __restrict__ Mx, const int32_t* __restrict__ off3,
                                                        int32_t* __restrict__ red, int32_t* __restrict__ exp,
                                                        int32_t* __restrict__ kidx,
-                                                       const int32_t* __restrict__ half_total, int e_cap, int t_cap) {
+                                                       const int32_t* __restrict__ half_total, int e_cap, int t_cap,
+                                                       const int32_t* __restrict__ skip) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  if (skip && skip[3]) return;       // (the decide kernel of gn_index_gpu_padded_q found that this batch does not fit)
   if (half_total) {      // capacity form: E on the device, E = the grid's upper bound; nothing is written past the capacities
     const int64_t Ed = 2 * (int64_t)*half_total;
     if (Ed > e_cap || r >= Ed || off3[E] > t_cap) return;
@@ -305,6 +308,123 @@ __global__ void idx_commit_pad_t_kernel(PadT p, const int32_t* __restrict__ half
   }
 }
 
+// ---- capacity form for quadruplet models (gn_index_gpu_padded_q) ------------------------------------------------------------
+// All five counts are known on the device before any of the large arrays is written: `idx_decide_q_kernel` (one thread)
+// compares them with the capacities and the rules of the padding scheme (padded.py: _fill / _check_quad_padding /
+// pad_in_degree, quadruplet layout) and writes the verdict into state[3]; the triplet / intermediate-triplet / quadruplet
+// writers then go STRAIGHT into the arrays the model reads (they return at once when the verdict is bad, so those arrays
+// keep the previous step's valid contents), and the commit kernel copies the two small staged families and writes every
+// family's pad rows.   state (int32[8]): [0] |= err (sticky)  [1] E  [2] T  [3] err of this call  [4] Eint  [5] I  [6] Q
+//   err bits: 1 E, 2 T, 16 Eint, 32 I, 64 Q over capacity; 4 pad rows without the pad rows they refer to; 8 dummy in-degree;
+//   128 the two intermediate-triplet lists differ in length (cannot happen for symmetric interaction lists)
+struct QCounts { const int32_t *half_total, *t_total, *eint_total, *ica_total, *idb_total, *q_total; };
+struct QCaps { int e, t, eint, i, q, a, G, deg_bound; };
+
+__device__ __forceinline__ int q_decide(const QCounts& c, const QCaps& k, int64_t* n) {
+  const int64_t E = 2 * (int64_t)*c.half_total, T = *c.t_total, Ei = *c.eint_total, Ica = *c.ica_total, Idb = *c.idb_total,
+                Q = *c.q_total;
+  n[0] = E; n[1] = T; n[2] = Ei; n[3] = Ica; n[4] = Q;
+  int err = 0;
+  if (E > k.e) err |= 1;
+  if (Ei > k.eint) err |= 16;
+  if (err) return err;                 // (the counts below were taken from rows that were not written)
+  if (T > k.t) err |= 2;
+  if (Ica > k.i) err |= 32;
+  if (Q > k.q) err |= 64;
+  if (Ica != Idb) err |= 128;
+  if (err) return err;
+  const int64_t ep = k.e - E, tp = k.t - T, eintp = k.eint - Ei, ip = k.i - Ica, qp = k.q - Q;
+  if ((tp & 1) || ((tp || ip || qp) && ep < 6) || (ip && eintp < 1) || (qp && ip < 1)) err |= 4;
+  const int64_t units = (ep + 5) / 6;
+  if (2 * ((units + k.G - 1) / k.G) > (k.deg_bound > 2 ? k.deg_bound : 2)) err |= 8;
+  return err;
+}
+
+__global__ void idx_decide_q_kernel(QCounts c, QCaps k, int32_t* __restrict__ state) {
+  if (blockIdx.x || threadIdx.x) return;
+  int64_t n[5];
+  const int err = q_decide(c, k, n);
+  auto clip = [](int64_t v) { return (int32_t)(v > 0x7fffffff ? 0x7fffffff : v); };
+  state[0] |= err;
+  state[1] = clip(n[0]); state[2] = clip(n[1]); state[3] = err; state[4] = clip(n[2]); state[5] = clip(n[3]); state[6] = clip(n[4]);
+}
+
+struct PadQ {
+  const int32_t *s_c, *s_a, *s_swap, *s_undir, *s_int_a, *s_int_b;
+  int32_t *id_c, *id_a, *id_swap, *id_undir, *red3, *exp3, *int_a, *int_b, *intm_ca, *intm_db, *intm_red_ab, *intm_exp_ab,
+      *q_red_ca, *q_exp_db, *q_red_cab, *q_exp_abd;
+};
+
+__global__ void idx_commit_pad_q_kernel(PadQ p, QCaps k, const int32_t* __restrict__ state) {
+  if (state[3]) return;
+  const int64_t E = state[1], T = state[2], Ei = state[4], I = state[5], Q = state[6];
+  const int64_t ep = k.e - E, tp = k.t - T, eintp = k.eint - Ei, ip = k.i - I, qp = k.q - Q;
+  const int G = k.G;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  // edges: copy + pad (units of six: b->a, a->b, c->a, a->c, d->b, b->d over groups of four dummy atoms)
+  for (int64_t i = tid; i < k.e; i += nth) {
+    if (i < E) {
+      p.id_c[i] = p.s_c[i]; p.id_a[i] = p.s_a[i]; p.id_swap[i] = p.s_swap[i]; p.id_undir[i] = p.s_undir[i];
+    } else {
+      const int64_t kk = i - E, pair = kk >> 1;
+      const int rev = (int)(kk & 1), typ = (int)(pair % 3), grp = (int)((pair / 3) % G);
+      const int a = k.a + 4 * grp;
+      const int src = typ == 2 ? a + 3 : a + 1 + typ, dst = typ == 2 ? a + 1 : a;
+      p.id_c[i] = rev ? dst : src;
+      p.id_a[i] = rev ? src : dst;
+      p.id_swap[i] = (int32_t)(E + (kk ^ 1));
+      p.id_undir[i] = (int32_t)(E / 2 + pair);
+    }
+  }
+  // pad triplets: the forward edges b->a, c->a (offsets 0 and 2) of the complete units
+  {
+    const int64_t nf = 2 * (ep / 6), den = tp > 1 ? tp : 1;
+    for (int64_t j = tid; j < tp; j += nth) {
+      const int64_t sidx = (j * nf) / den, u = sidx >> 1, w = sidx & 1;
+      p.red3[T + j] = (int32_t)(E + 6 * u + 2 * w);
+      p.exp3[T + j] = (int32_t)(E + 6 * u + 2 * (1 - w));
+    }
+  }
+  // interaction edges: copy + pad (pairs b->a, a->b cycling over the groups)
+  for (int64_t i = tid; i < k.eint; i += nth) {
+    if (i < Ei) {
+      p.int_a[i] = p.s_int_a[i]; p.int_b[i] = p.s_int_b[i];
+    } else {
+      const int64_t kk = i - Ei, pr = kk >> 1;
+      const int rev = (int)(kk & 1), a = k.a + 4 * (int)(pr % G);
+      p.int_b[i] = rev ? a : a + 1;
+      p.int_a[i] = rev ? a + 1 : a;
+    }
+  }
+  // pad intermediate triplets / quadruplets
+  const int64_t n_ab = (eintp + 1) / 2, n_units = ep / 6 > 1 ? ep / 6 : 1, iden = ip > 1 ? ip : 1;
+  auto intm_unit = [&](int64_t i, int64_t& pp) {     // unit of pad intermediate triplet i, and its interaction-edge pair
+    pp = (i * n_ab) / iden;
+    const int64_t g = pp % G;
+    return g < n_units ? g : pp % n_units;
+  };
+  for (int64_t i = tid; i < ip; i += nth) {
+    int64_t pp;
+    const int64_t u = intm_unit(i, pp);
+    p.intm_ca[I + i] = (int32_t)(E + 6 * u + 2);
+    p.intm_db[I + i] = (int32_t)(E + 6 * u + 4);
+    p.intm_red_ab[I + i] = (int32_t)(Ei + 2 * pp);
+    p.intm_exp_ab[I + i] = (int32_t)(Ei + 2 * pp);
+  }
+  {
+    const int64_t qden = qp > 1 ? qp : 1, imod = ip > 1 ? ip : 1;
+    for (int64_t q = tid; q < qp; q += nth) {
+      const int64_t u = (q * n_units) / qden, im = q % imod;
+      int64_t pp;
+      const int64_t ui = intm_unit(im, pp);
+      p.q_red_ca[Q + q] = (int32_t)(E + 6 * u + 2);
+      p.q_exp_abd[Q + q] = (int32_t)(I + im);
+      p.q_red_cab[Q + q] = (int32_t)(I + im);
+      p.q_exp_db[Q + q] = (int32_t)(E + 6 * ui + 4);
+    }
+  }
+}
+
 // x[i] = NaN for all i when state[3] (the error of this step's index build) is set: a step whose batch did not fit must not
 // hand out the numbers computed from the previous step's arrays
 __global__ void idx_poison_kernel(float* __restrict__ x, int64_t n, const int32_t* __restrict__ state) {
@@ -323,12 +443,28 @@ __global__ void idx_cnt_intm_kernel(const int32_t* __restrict__ int_a, const int
   }
 }
 
+// capacity form: the number of interaction edges lives on the device; rows behind it count zero intermediate triplets
+__global__ void idx_cnt_intm_cap_kernel(const int32_t* __restrict__ int_a, const int32_t* __restrict__ int_b,
+                                        const int32_t* __restrict__ deg, const int32_t* __restrict__ eint_total, int n,
+                                        int eint_cap, const int32_t* __restrict__ half_total, int e_cap,
+                                        int32_t* __restrict__ cnt_ca, int32_t* __restrict__ cnt_db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int Ei = *eint_total;
+  const bool ok = Ei <= eint_cap && 2 * (int64_t)*half_total <= e_cap && i < Ei;   // (the edge kernel wrote its staging arrays)
+  cnt_ca[i] = ok ? deg[int_a[i]] : 0;
+  cnt_db[i] = ok ? deg[int_b[i]] : 0;
+}
+
 __global__ void idx_intm_kernel(const int32_t* __restrict__ int_a, const int32_t* __restrict__ int_b, int Eint,
                                 const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
                                 const int32_t* __restrict__ off_ca, const int32_t* __restrict__ off_db,
                                 int32_t* __restrict__ red_intm_ca, int32_t* __restrict__ red_intm_ab,
-                                int32_t* __restrict__ exp_intm_db, int32_t* __restrict__ exp_intm_ab) {
+                                int32_t* __restrict__ exp_intm_db, int32_t* __restrict__ exp_intm_ab,
+                                const int32_t* __restrict__ eint_total, const int32_t* __restrict__ skip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (skip && skip[3]) return;
+  if (eint_total) Eint = *eint_total;
   if (i >= Eint) return;
   const int a = int_a[i], b = int_b[i];
   int p = in_ptr[a], q = off_ca[i];
@@ -342,9 +478,13 @@ __global__ void idx_cnt4_kernel(const int32_t* __restrict__ mol_off, const int32
                                 const int32_t* __restrict__ atom_mol, const int32_t* __restrict__ id_a,
                                 const int32_t* __restrict__ id_c, int E, const uint8_t* __restrict__ adj,
                                 const uint8_t* __restrict__ iadj, const int32_t* __restrict__ deg,
-                                int32_t* __restrict__ cnt4) {
+                                int32_t* __restrict__ cnt4, const int32_t* __restrict__ half_total, int e_cap) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= E) return;
+  if (half_total) {       // capacity form: E = rows to write, the edge count on the device; rows behind it count zero
+    const int64_t Ed = 2 * (int64_t)*half_total;
+    if (Ed > e_cap || r >= Ed) { cnt4[r] = 0; return; }
+  }
   const int ga = id_a[r], gc = id_c[r];
   const int m = atom_mol[ga];
   const int a0 = mol_off[m], n = mol_off[m + 1] - a0, a = ga - a0, c = gc - a0;
@@ -364,10 +504,12 @@ __global__ __launch_bounds__(256) void idx_quad_kernel(
     const uint8_t* __restrict__ iadj, const int32_t* __restrict__ Mx, const int32_t* __restrict__ MI,
     const int32_t* __restrict__ pos_in, const int32_t* __restrict__ off_ca, const int32_t* __restrict__ off_db,
     const int32_t* __restrict__ off4, int32_t* __restrict__ red_ca, int32_t* __restrict__ exp_db,
-    int32_t* __restrict__ red_cab, int32_t* __restrict__ exp_abd, int32_t* __restrict__ kidx) {
+    int32_t* __restrict__ red_cab, int32_t* __restrict__ exp_abd, int32_t* __restrict__ kidx,
+    const int32_t* __restrict__ half_total, const int32_t* __restrict__ skip) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (r >= E) return;
+  if (skip && skip[3]) return;
+  if (r >= E || (half_total && r >= 2 * (int64_t)*half_total)) return;
   const int ga = id_a[r], gc = id_c[r];
   const int m = atom_mol[ga];
   const int a0 = mol_off[m], n = mol_off[m + 1] - a0, a = ga - a0, c = gc - a0;
@@ -398,7 +540,7 @@ __global__ __launch_bounds__(256) void idx_quad_kernel(
         exp_db[w] = x;
         red_cab[w] = off_ca[i] + pr;
         exp_abd[w] = off_db[i] + pos_in[x];
-        kidx[w] = w - o0;
+        if (kidx) kidx[w] = w - o0;
       }
       o += __popcll(mask);
     }
@@ -503,7 +645,7 @@ extern "C" int gn_index_gpu_stage1(const void* R, int r_is_f64, const int32_t* m
   if (E == 0) return 0;
   if (!id_a) return 0;    // size query only
   hipLaunchKernelGGL(idx_edges_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, quad, w.adj, w.iadj,
-                     w.off_half, w.off_int, id_a, id_c, id_undir, id_swap, int_a, int_b, w.Mx, w.MI, 0x7fffffff);
+                     w.off_half, w.off_int, id_a, id_c, id_undir, id_swap, int_a, int_b, w.Mx, w.MI, 0x7fffffff, 0x7fffffff);
   hipLaunchKernelGGL(idx_in_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, w.adj, w.Mx, w.in_ptr,
                      w.in_edge, w.pos_in, (const int32_t*)nullptr, 0);
   hipLaunchKernelGGL(idx_cnt3_kernel, dim3(gn_cdiv(E, 256)), dim3(256), 0, st, id_a, w.deg, (int)E, w.cnt);
@@ -518,7 +660,7 @@ extern "C" int gn_index_gpu_stage1(const void* R, int r_is_f64, const int32_t* m
     hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off_ca, Eint, w.overflow);
     hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt2, w.off_db, Eint, w.overflow);
     hipLaunchKernelGGL(idx_cnt4_kernel, dim3(gn_cdiv(E, 256)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, id_a,
-                       id_c, (int)E, w.adj, w.iadj, w.deg, w.cnt);
+                       id_c, (int)E, w.adj, w.iadj, w.deg, w.cnt, (const int32_t*)nullptr, 0);
     hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off4, E, w.overflow);
     GN_LAUNCH_CHECK();
     if (e == hipSuccess) e = hipMemcpyAsync(&tca, w.off_ca + Eint, 4, hipMemcpyDeviceToHost, st);
@@ -552,15 +694,15 @@ extern "C" int gn_index_gpu_stage2(const int32_t* mol_off, const int32_t* sq_off
   const int64_t emax = sum_n2 - A;
   idx_layout((char*)ws, A, sum_n2, emax, quad ? emax : 0, quad, &w);
   hipLaunchKernelGGL(idx_trip_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, id_a, id_c,
-                     (int)E, w.adj, w.Mx, w.off3, id3_reduce_ca, id3_expand_ba, Kidx3, (const int32_t*)nullptr, 0, 0);
+                     (int)E, w.adj, w.Mx, w.off3, id3_reduce_ca, id3_expand_ba, Kidx3, (const int32_t*)nullptr, 0, 0, (const int32_t*)nullptr);
   GN_LAUNCH_CHECK();
   if (quad && Eint > 0) {
     hipLaunchKernelGGL(idx_intm_kernel, dim3(gn_cdiv(Eint, 256)), dim3(256), 0, st, int_a, int_b, (int)Eint, w.in_ptr,
                        w.in_edge, w.off_ca, w.off_db, id4_reduce_intm_ca, id4_reduce_intm_ab, id4_expand_intm_db,
-                       id4_expand_intm_ab);
+                       id4_expand_intm_ab, (const int32_t*)nullptr, (const int32_t*)nullptr);
     hipLaunchKernelGGL(idx_quad_kernel, dim3(gn_cdiv(E, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, id_a, id_c,
                        (int)E, w.adj, w.iadj, w.Mx, w.MI, w.pos_in, w.off_ca, w.off_db, w.off4, id4_reduce_ca,
-                       id4_expand_db, id4_reduce_cab, id4_expand_abd, Kidx4);
+                       id4_expand_db, id4_reduce_cab, id4_expand_abd, Kidx4, (const int32_t*)nullptr, (const int32_t*)nullptr);
     GN_LAUNCH_CHECK();
   }
   return 0;
@@ -598,14 +740,14 @@ extern "C" int gn_index_gpu_padded_t(const void* R, int r_is_f64, const int32_t*
   GN_LAUNCH_CHECK();
   const int32_t* half_total = w.off_half + A;
   hipLaunchKernelGGL(idx_edges_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, 0, w.adj, w.iadj, w.off_half,
-                     w.off_int, s_a, s_c, s_undir, s_swap, (int32_t*)nullptr, (int32_t*)nullptr, w.Mx, w.MI, e_cap);
+                     w.off_int, s_a, s_c, s_undir, s_swap, (int32_t*)nullptr, (int32_t*)nullptr, w.Mx, w.MI, e_cap, 0);
   hipLaunchKernelGGL(idx_in_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, w.adj, w.Mx, w.in_ptr, w.in_edge,
                      w.pos_in, half_total, e_cap);
   if (n > 0) {
     hipLaunchKernelGGL(idx_cnt3_cap_kernel, dim3(gn_cdiv(n, 256)), dim3(256), 0, st, s_a, w.deg, half_total, n, e_cap, w.cnt);
     hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off3, (int64_t)n, w.overflow);
     hipLaunchKernelGGL(idx_trip_kernel, dim3(gn_cdiv(n, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, s_a, s_c, n, w.adj,
-                       w.Mx, w.off3, s_red, s_exp, (int32_t*)nullptr, half_total, e_cap, t_cap);
+                       w.Mx, w.off3, s_red, s_exp, (int32_t*)nullptr, half_total, e_cap, t_cap, (const int32_t*)nullptr);
   } else {
     e = hipMemsetAsync(w.off3, 0, sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
@@ -623,6 +765,75 @@ extern "C" int gn_index_poison_f32(float* x, int64_t n, const int32_t* state, vo
   if (n <= 0) return 0;
   hipLaunchKernelGGL(idx_poison_kernel, dim3((unsigned)(gn_cdiv(n, 256) < 1024 ? gn_cdiv(n, 256) : 1024)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, n, state);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Capacity form of the quadruplet build: no read-back, capturable.  See include/gemnet_hip.h.
+extern "C" int gn_index_gpu_padded_q(const void* R, int r_is_f64, const int32_t* mol_off, const int32_t* sq_off, int B, int A,
+                                     int nmax, int64_t sum_n2, double cutoff, double int_cutoff, void* ws, const int32_t* caps,
+                                     int a_cap, int n_groups, int deg_bound, int32_t* staging, int32_t* const* arrays,
+                                     int32_t* state, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int e_cap = caps[0], t_cap = caps[1], eint_cap = caps[2], i_cap = caps[3], q_cap = caps[4];
+  if (A <= 0 || B <= 0 || n_groups <= 0 || e_cap <= 0 || t_cap <= 0 || eint_cap <= 0 || i_cap <= 0 || q_cap <= 0 ||
+      (e_cap & 1) || (t_cap & 1) || sum_n2 > 0x7fffffffLL)
+    return (int)hipErrorInvalidValue;
+  idx_ws w;
+  const int64_t emax = sum_n2 - A;
+  idx_layout((char*)ws, A, sum_n2, emax, emax, 1, &w);
+  const int n = (int)(emax < e_cap ? emax : e_cap), ni = (int)(emax < eint_cap ? emax : eint_cap);
+  int32_t *s_a = staging, *s_c = staging + e_cap, *s_undir = staging + 2 * (size_t)e_cap, *s_swap = staging + 3 * (size_t)e_cap,
+          *s_int_a = staging + 4 * (size_t)e_cap, *s_int_b = staging + 4 * (size_t)e_cap + eint_cap;
+  // arrays: id_c, id_a, id_swap, id_undir, id3_reduce_ca, id3_expand_ba, id4_int_a, id4_int_b, id4_reduce_intm_ca,
+  //         id4_expand_intm_db, id4_reduce_intm_ab, id4_expand_intm_ab, id4_reduce_ca, id4_expand_db, id4_reduce_cab, id4_expand_abd
+  hipError_t e = hipMemsetAsync(w.overflow, 0, sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(idx_atom_mol_kernel, dim3(B), dim3(64), 0, st, mol_off, B, w.atom_mol, (int32_t*)nullptr);
+  dim3 gadj(gn_cdiv((int64_t)nmax * nmax, 256), B);
+  if (r_is_f64)
+    hipLaunchKernelGGL((idx_adj_kernel<double>), gadj, dim3(256), 0, st, (const double*)R, mol_off, sq_off, cutoff, int_cutoff,
+                       1, w.adj, w.iadj);
+  else
+    hipLaunchKernelGGL((idx_adj_kernel<float>), gadj, dim3(256), 0, st, (const float*)R, mol_off, sq_off, (float)cutoff,
+                       (float)int_cutoff, 1, w.adj, w.iadj);
+  const dim3 ga(gn_cdiv(A, 256));
+  hipLaunchKernelGGL(idx_deg_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, 1, w.adj, w.iadj, w.deg, w.up, w.ideg);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.up, w.off_half, (int64_t)A, w.overflow);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.deg, w.in_ptr, (int64_t)A, w.overflow);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.ideg, w.off_int, (int64_t)A, w.overflow);
+  GN_LAUNCH_CHECK();
+  const int32_t *half_total = w.off_half + A, *eint_total = w.off_int + A;
+  hipLaunchKernelGGL(idx_edges_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, 1, w.adj, w.iadj, w.off_half,
+                     w.off_int, s_a, s_c, s_undir, s_swap, s_int_a, s_int_b, w.Mx, w.MI, e_cap, eint_cap);
+  hipLaunchKernelGGL(idx_in_kernel, ga, dim3(256), 0, st, mol_off, sq_off, w.atom_mol, A, w.adj, w.Mx, w.in_ptr, w.in_edge,
+                     w.pos_in, half_total, e_cap);
+  if (n <= 0 || ni <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(idx_cnt3_cap_kernel, dim3(gn_cdiv(n, 256)), dim3(256), 0, st, s_a, w.deg, half_total, n, e_cap, w.cnt);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off3, (int64_t)n, w.overflow);
+  hipLaunchKernelGGL(idx_cnt_intm_cap_kernel, dim3(gn_cdiv(ni, 256)), dim3(256), 0, st, s_int_a, s_int_b, w.deg, eint_total, ni,
+                     eint_cap, half_total, e_cap, w.cnt, w.cnt2);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off_ca, (int64_t)ni, w.overflow);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt2, w.off_db, (int64_t)ni, w.overflow);
+  hipLaunchKernelGGL(idx_cnt4_kernel, dim3(gn_cdiv(n, 256)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, s_a, s_c, n, w.adj,
+                     w.iadj, w.deg, w.cnt, half_total, e_cap);
+  hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, w.cnt, w.off4, (int64_t)n, w.overflow);
+  GN_LAUNCH_CHECK();
+  const QCounts c{half_total, w.off3 + n, eint_total, w.off_ca + ni, w.off_db + ni, w.off4 + n};
+  const QCaps k{e_cap, t_cap, eint_cap, i_cap, q_cap, a_cap, n_groups, deg_bound};
+  hipLaunchKernelGGL(idx_decide_q_kernel, dim3(1), dim3(64), 0, st, c, k, state);
+  // the writers of the large families: straight into the model's arrays, or nothing at all
+  hipLaunchKernelGGL(idx_trip_kernel, dim3(gn_cdiv(n, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, s_a, s_c, n, w.adj,
+                     w.Mx, w.off3, arrays[4], arrays[5], (int32_t*)nullptr, half_total, e_cap, t_cap, (const int32_t*)state);
+  hipLaunchKernelGGL(idx_intm_kernel, dim3(gn_cdiv(ni, 256)), dim3(256), 0, st, s_int_a, s_int_b, ni, w.in_ptr, w.in_edge,
+                     w.off_ca, w.off_db, arrays[8], arrays[10], arrays[9], arrays[11], eint_total, (const int32_t*)state);
+  hipLaunchKernelGGL(idx_quad_kernel, dim3(gn_cdiv(n, 4)), dim3(256), 0, st, mol_off, sq_off, w.atom_mol, s_a, s_c, n, w.adj,
+                     w.iadj, w.Mx, w.MI, w.pos_in, w.off_ca, w.off_db, w.off4, arrays[12], arrays[13], arrays[14], arrays[15],
+                     (int32_t*)nullptr, half_total, (const int32_t*)state);
+  GN_LAUNCH_CHECK();
+  PadQ p{s_c, s_a, s_swap, s_undir, s_int_a, s_int_b, arrays[0], arrays[1], arrays[2], arrays[3], arrays[4], arrays[5],
+         arrays[6], arrays[7], arrays[8], arrays[9], arrays[10], arrays[11], arrays[12], arrays[13], arrays[14], arrays[15]};
+  hipLaunchKernelGGL(idx_commit_pad_q_kernel, dim3(2048), dim3(256), 0, st, p, k, (const int32_t*)state);
   GN_LAUNCH_CHECK();
   return 0;
 }

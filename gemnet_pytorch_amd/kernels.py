@@ -239,6 +239,32 @@ def index_padded_t(builder, R, e_cap, t_cap, a_cap, n_groups, deg_bound, staging
         ptr(bufs["id3_reduce_ca"]), ptr(bufs["id3_expand_ba"]), ptr(state), stream()), "gn_index_gpu_padded_t")
 
 
+PADDED_Q_KEYS = ("id_c", "id_a", "id_swap", "id_undir", "id3_reduce_ca", "id3_expand_ba", "id4_int_a", "id4_int_b",
+                 "id4_reduce_intm_ca", "id4_expand_intm_db", "id4_reduce_intm_ab", "id4_expand_intm_ab",
+                 "id4_reduce_ca", "id4_expand_db", "id4_reduce_cab", "id4_expand_abd")
+
+
+def index_padded_q(builder, R, caps, a_cap, n_groups, deg_bound, staging, bufs, state):
+    """The quadruplet index build of `builder` for positions R straight into the capacity-sized arrays `bufs` (the sixteen
+    arrays PADDED_Q_KEYS, int32) with the dummy molecule's pad rows — no read-back, capturable (gn_index_gpu_padded_q;
+    caps = (e_cap, t_cap, eint_cap, i_cap, q_cap); state: int32[8])."""
+    require_device(R, staging, state)
+    assert not builder.triplets_only and R.is_contiguous() and tuple(R.shape) == (builder.A, 3)
+    e_cap, t_cap, eint_cap, i_cap, q_cap = (int(c) for c in caps)
+    assert staging.dtype == torch.int32 and staging.numel() >= 4 * e_cap + 2 * eint_cap
+    assert state.dtype == torch.int32 and state.numel() >= 8
+    want = dict(zip(PADDED_Q_KEYS, (e_cap,) * 4 + (t_cap,) * 2 + (eint_cap,) * 2 + (i_cap,) * 4 + (q_cap,) * 4))
+    for k, n in want.items():
+        assert bufs[k].dtype == torch.int32 and bufs[k].numel() == n and bufs[k].is_contiguous(), k
+    c_caps = (ctypes.c_int32 * 5)(e_cap, t_cap, eint_cap, i_cap, q_cap)
+    c_arr = (ctypes.c_void_p * 16)(*[addr(bufs[k]) for k in PADDED_Q_KEYS])
+    check(_lib.load().gn_index_gpu_padded_q(
+        ptr(R), int(R.dtype == torch.float64), ptr(builder.mol_off), ptr(builder.sq_off), builder.B, builder.A, builder.nmax,
+        builder.sum_n2, builder.cutoff, builder.int_cutoff, ptr(builder.ws), ctypes.cast(c_caps, ctypes.c_void_p), int(a_cap),
+        int(n_groups), int(deg_bound), ptr(staging), ctypes.cast(c_arr, ctypes.c_void_p), ptr(state), stream()),
+        "gn_index_gpu_padded_q")
+
+
 def index_poison(x, state):
     """x <- NaN when the index build of this step reported an error (gn_index_poison_f32)."""
     require_device(x, state)

@@ -425,24 +425,29 @@ class PaddedGraphRunner:
         on the host — the MD step of ase_calculator.py:148-170 as ONE graph.  The buffers must hold a valid batch already
         (one `_fill`): a step that does not fit the capacities keeps the previous arrays, poisons its outputs with NaN and
         reports through `index_error()`."""
-        if self.quad or self.variable_atoms:
-            raise NotImplementedError("the in-graph index build covers triplets-only models with a fixed molecule layout")
-        if not builder.triplets_only or builder.A != self.A or self.index_dtype != torch.int32:
+        if self.variable_atoms:
+            raise NotImplementedError("the in-graph index build needs a fixed molecule layout (no a_cap)")
+        if builder.triplets_only == self.quad or builder.A != self.A or self.index_dtype != torch.int32:
             raise ValueError("builder and runner describe different systems")
         if not self._filled:
             raise RuntimeError("attach_builder: fill the buffers with a first batch (runner._fill / runner(R, idx)) before")
         dev = self.inputs["R"].device
         self.builder = builder
-        self._staging = torch.empty(4 * self.e_cap + 2 * self.t_cap, dtype=torch.int32, device=dev)
-        self._idx_state = torch.zeros(4, dtype=torch.int32, device=dev)
-        self._idx_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        n_stage = 4 * self.e_cap + 2 * (self.quad_caps[0] if self.quad else self.t_cap)
+        self._staging = torch.empty(n_stage, dtype=torch.int32, device=dev)
+        self._idx_state = torch.zeros(8, dtype=torch.int32, device=dev)
+        self._idx_host = torch.zeros(8, dtype=torch.int32).pin_memory()
         self.graph = None
         self.out = None
 
     def _index_in_graph(self):
         from . import kernels as K
-        K.index_padded_t(self.builder, self.inputs["R"][:self.A], self.e_cap, self.t_cap, self.a_cap, self.G,
-                         self.pad_degree_bound(), self._staging, self.inputs, self._idx_state)
+        if self.quad:
+            K.index_padded_q(self.builder, self.inputs["R"][:self.A], (self.e_cap, self.t_cap) + self.quad_caps, self.a_cap,
+                             self.G, self.pad_degree_bound(), self._staging, self.inputs, self._idx_state)
+        else:
+            K.index_padded_t(self.builder, self.inputs["R"][:self.A], self.e_cap, self.t_cap, self.a_cap, self.G,
+                             self.pad_degree_bound(), self._staging, self.inputs, self._idx_state)
 
     def index_error(self):
         """Error bits (include/gemnet_hip.h, gn_index_gpu_padded_t) of the in-graph index builds COMPLETED so far — sticky;
@@ -450,8 +455,9 @@ class PaddedGraphRunner:
         return int(self._idx_host[0]) if self.builder is not None else 0
 
     def index_sizes(self):
-        """(E, T) of the last completed in-graph index build."""
-        return int(self._idx_host[1]), int(self._idx_host[2])
+        """(E, T[, Eint, I, Q]) of the last completed in-graph index build."""
+        h = self._idx_host
+        return (int(h[1]), int(h[2])) + ((int(h[4]), int(h[5]), int(h[6])) if self.quad else ())
 
     def reset_index_state(self):
         self._idx_state.zero_()
@@ -464,7 +470,7 @@ class PaddedGraphRunner:
         if self.flag is not None and self.flag.tripped():
             self.recover()
         if self.index_error():
-            raise ValueError(f"an earlier step did not fit the capacities ({self.e_cap}, {self.t_cap}): index error bits "
+            raise ValueError(f"an earlier step did not fit the capacities ({self.e_cap}, {self.t_cap}, {self.quad_caps}): index error bits "
                              f"{self.index_error()}, sizes {self.index_sizes()} — its outputs were NaN; build a larger runner")
         if Z is not None:
             self.inputs["Z"][:self.A].copy_(Z)

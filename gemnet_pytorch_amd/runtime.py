@@ -148,7 +148,7 @@ class ForceGraphs:
         return (torch.cat([o[0] for o in self.outputs]), torch.cat([o[1] for o in self.outputs]))
 
 
-# The index build inside the replayed graph (padded.PaddedGraphRunner.attach_builder; triplets-only models).
+# The index build inside the replayed graph (padded.PaddedGraphRunner.attach_builder: GemNet-T and GemNet-Q).
 IN_GRAPH_INDEX = os.environ.get("GEMNET_INDEX_IN_GRAPH", "1") == "1"
 
 
@@ -192,7 +192,7 @@ class DynamicForceField:
         return idx
 
     def __call__(self, R, exact=True):
-        """`exact` (triplets-only models, whose graph builds its own neighbour list): wait for the step and look at the
+        """`exact` (the graph builds its own neighbour list): wait for the step and look at the
         device-side report of its index build — a system that outgrew the capacities is re-sized and the step repeated, as
         on the host-sized path.  With exact=False nothing waits: such a step returns NaN energies / forces and the NEXT call
         re-sizes (for callers that keep everything on the device and check `index_failed()` themselves)."""
@@ -225,8 +225,8 @@ class DynamicForceField:
             self.runner = PaddedGraphRunner(self.model, self.Z, self.N, e_cap, t_cap, max_in_degree=self.deg, n_groups=groups,
                                             quad_caps=quad_caps)
             self.recaptures += self.runner is not r and r is not None
-        if IN_GRAPH_INDEX and self.model.triplets_only and R.dtype == torch.float32:
-            # triplets-only models: from here on the index build is part of the graph (padded.attach_builder): this call's
+        if IN_GRAPH_INDEX and R.dtype == torch.float32:
+            # from here on the index build is part of the graph (padded.attach_builder): this call's
             # arrays validate the buffers, every later call is  positions in -> one replay -> results out
             self.runner._fill(R, idx)
             if self.runner.builder is None:

@@ -12,7 +12,8 @@ from conftest import SCALE_FILE
 from gemnet_pytorch_amd.index_device import DeviceGraphBuilder
 from gemnet_pytorch_amd.md import DeviceMolecule
 from gemnet_pytorch_amd.model.gemnet import GemNet
-from gemnet_pytorch_amd.padded import PAD_EDGE_KEYS, PAD_TRIP_KEYS, PaddedGraphRunner
+from gemnet_pytorch_amd.padded import (PAD_EDGE_KEYS, PAD_INT_KEYS, PAD_INTM_KEYS, PAD_QUAD_KEYS, PAD_TRIP_KEYS,
+                                       PaddedGraphRunner)
 from gemnet_pytorch_amd.runtime import DynamicForceField
 from gemnet_pytorch_amd.synthetic import make_dataset, make_molecule
 
@@ -23,9 +24,9 @@ CFG = dict(num_spherical=7, num_radial=6, num_blocks=2, emb_size_atom=128, emb_s
            emb_size_bil_quad=32, num_before_skip=1, num_after_skip=1, num_concat=1, num_atom=2, triplets_only=True)
 
 
-def new_model(seed=5):
+def new_model(seed=5, quad=False):
     torch.manual_seed(seed)
-    m = GemNet(**CFG, scale_file=SCALE_FILE).to(DEV).eval()
+    m = GemNet(**dict(CFG, triplets_only=not quad), scale_file=SCALE_FILE).to(DEV).eval()
     m.requires_grad_(False)
     return m
 
@@ -120,3 +121,59 @@ def test_force_field_and_predict_resize_when_the_system_contracts():
             Er, Fr = model(dict(Z=torch.tensor(Z, device=DEV).long(), R=Rt.clone(), N=torch.tensor([len(Z)], device=DEV), **b(Rt)))
             assert torch.equal(E, Er.detach().cpu()) and torch.equal(F, Fr.detach().cpu())
     assert ff.recaptures >= 1, "the contracted geometry must have outgrown the first capacities"
+
+
+ALL_Q_KEYS = PAD_EDGE_KEYS + PAD_TRIP_KEYS + PAD_INT_KEYS + PAD_INTM_KEYS + PAD_QUAD_KEYS
+
+
+def test_in_graph_quadruplet_index_equals_two_stage_build_plus_host_padding():
+    """GemNet-Q (the model of the reference's MD example): all sixteen arrays of the capacity build — real rows and pad rows —
+    equal the two-stage builder's arrays padded on the host, for batches of different sizes; energies and forces bit-identical."""
+    data = batches(n_mol=3, n_atoms=20)
+    builder = DeviceGraphBuilder(data[0][0]["N"], 5.0, 10.0, False, device=DEV)
+    idxs = [builder(R, dtype=torch.int32) for _, R, _, _ in data]
+    sizes = [PaddedGraphRunner.sizes_of(i) for i in idxs]
+    assert len(set(sizes)) > 1 and len(sizes[0]) == 5
+    caps = PaddedGraphRunner.suggest_capacities(sizes)
+    model = new_model(quad=True)
+    mk = lambda: PaddedGraphRunner(model, data[0][2], data[0][3], caps[0], caps[1], quad_caps=caps[2], n_groups=16)   # noqa: E731
+    ref, run = mk(), mk()
+    run._fill(data[0][1], idxs[0], data[0][2])
+    run.attach_builder(builder)
+    for rep in range(2):
+        for (ds, R, Z, N), idx, sz in zip(data, idxs, sizes):
+            E0, F0 = (t.clone() for t in ref(R, idx, Z=Z))
+            ref_bufs = {k: ref.inputs[k].clone() for k in ALL_Q_KEYS}
+            E1, F1 = run.run_positions(R, Z=Z)
+            torch.cuda.synchronize()
+            assert run.index_error() == 0 and run.index_sizes() == sz, (run.index_error(), run.index_sizes(), sz)
+            for k, v in ref_bufs.items():
+                assert torch.equal(run.inputs[k], v), (k, int((run.inputs[k] != v).sum()))
+            assert torch.equal(E0, E1) and torch.equal(F0, F1)
+
+
+def test_quadruplet_step_that_outgrows_the_capacities_is_reported_and_leaves_the_arrays_alone():
+    (ds, R, Z, N), = batches(n_mol=3, n_atoms=20, n=1)
+    builder = DeviceGraphBuilder(ds["N"], 5.0, 10.0, False, device=DEV)
+    idx = builder(R, dtype=torch.int32)
+    sz = PaddedGraphRunner.sizes_of(idx)
+    model = new_model(quad=True)
+    run = PaddedGraphRunner(model, Z, N, sz[0] + 12, sz[1] + 8, quad_caps=(sz[2] + 4, sz[3] + 4, sz[4] + 4), n_groups=16)
+    run._fill(R, idx, Z)
+    run.attach_builder(builder)
+    E1, F1 = (t.clone() for t in run.run_positions(R))
+    before = {k: run.inputs[k].clone() for k in ALL_Q_KEYS}
+    n = int(ds["N"][0])
+    Rc = R.view(-1, n, 3)
+    Rd = ((Rc - Rc.mean(1, keepdim=True)) * 0.8 + Rc.mean(1, keepdim=True)).reshape(-1, 3).contiguous()
+    big = PaddedGraphRunner.sizes_of(builder(Rd, dtype=torch.int32))
+    assert big[4] > run.quad_caps[2]
+    E2, F2 = run.run_positions(Rd)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(E2).all()) and bool(torch.isnan(F2).all()) and run.index_error() != 0
+    for k, v in before.items():
+        assert torch.equal(run.inputs[k], v), k
+    run.reset_index_state()
+    E3, F3 = run.run_positions(R)
+    torch.cuda.synchronize()
+    assert torch.equal(E3, E1) and torch.equal(F3, F1) and run.index_error() == 0
