@@ -762,7 +762,7 @@ def extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=4, steps=12,
                                        note="every batch padded with a dummy molecule to fixed capacities, one captured "
                                             "hipGraph replayed; index build (with its size read-back) per step, on its own stream "
                                             "(a data provider's batch does not depend on the previous step)")
-            if cfg["triplets_only"] and len({tuple(d["N_host"]) for d in data}) == 1:
+            if len({tuple(d["N_host"]) for d in data}) == 1:
                 # the index build INSIDE the replayed graph (padded.attach_builder, gn_index_gpu_padded_t): a step is
                 # positions in -> one replay -> results out, no read-back, no padding launches on the host
                 runner.attach_builder(builders[0])
