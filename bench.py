@@ -207,6 +207,9 @@ class LaunchTimer:
                 by += E * (S * I + I * C) * f32
             return fl, by
         numel = sum(a.numel() for a in args if torch.is_tensor(a))
+        # tensor keyword operands are READ as well (the running sums an accumulate-into launch adds to: acc_m / acc_rbf of the
+        # aggregation adjoint — 9 of its 9 launches per forward+force step carry one)
+        numel += sum(v.numel() for v in kwargs.values() if torch.is_tensor(v))
         outs = out if isinstance(out, tuple) else (out,)
         return 0.0, (numel + sum(o.numel() for o in outs if torch.is_tensor(o))) * f32
 
