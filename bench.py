@@ -622,7 +622,9 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
         out["dynamic_shape"] = extra_dynamic_shape(cfg, model, n_mol, n_atoms, rank, n_batches=3, steps=6, warmup=2)
     except Exception as ex:  # noqa: BLE001
         out["dynamic_shape"] = dict(error=f"{type(ex).__name__}: {ex}"[:300])
-    del graph, model
+    del graph, model, step, plan, fam
+    import gc
+    gc.collect()
     # The GemNet-Q TRAINING step (trainer.py:325-360 on configs[2]): every layer on the fused sweeps of ops_train.py — since
     # round 5 also the quadruplet geometry and the quadruplet bilinear layer with its tensor basis in ANGLE form
     # (ops_train._QuadAngles2 / _BilinearAng2: tangent rows rebuilt in-kernel by dual numbers, no (Q, 49) array in any of the
@@ -631,8 +633,12 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
         try:
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats(dev)
+            held = torch.cuda.memory_allocated(dev)      # what the EARLIER extras of this process still hold (graphs, batches)
             ts_out = extra_train_step(cfg, 1234, inputs, targets, 1, n_mol, steps=5, warmup=2, want_roofline=True, graph=True,
                                       roof_mode="Qtrain")
+            if "peak_memory_gib" in ts_out:
+                ts_out["peak_memory_gib_incl_other_extras"] = ts_out["peak_memory_gib"]
+                ts_out["peak_memory_gib"] = round(ts_out["peak_memory_gib"] - held / 2**30, 1)
             ts_out["note"] = ("forward + force + loss.backward() through the force + fused optimizer; quadruplet interaction on the "
                               "fused angle-form twins (round 4: composite closure over the (Q, 49) harmonics, eager, 112-150 ms); "
                               "roofline = dominant LIBRARY launcher family of one step")

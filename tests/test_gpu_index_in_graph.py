@@ -52,6 +52,7 @@ def test_in_graph_index_equals_two_stage_build_plus_host_padding():
     run = PaddedGraphRunner(model, data[0][2], data[0][3], *caps, n_groups=16)
     run._fill(data[0][1], idxs[0], data[0][2])
     run.attach_builder(builder)
+    run.check = True        # the capture (index build + plan + model, three streams) under the happens-before checker
     for rep in range(2):
         for (ds, R, Z, N), idx, sz in zip(data, idxs, sizes):
             E0, F0 = (t.clone() for t in ref(R, idx, Z=Z))
@@ -63,6 +64,9 @@ def test_in_graph_index_equals_two_stage_build_plus_host_padding():
                 assert torch.equal(run.inputs[k], v), k
             assert torch.equal(E0, E1) and torch.equal(F0, F1)
             assert bool(torch.isfinite(F1).all())
+    races, summary = run.hb.races(), run.hb.summary()
+    print(run.hb.format(races))
+    assert not races and summary["unrecorded_nodes"] == 0 and summary["unresolved_pointers"] == 0, summary
 
 
 def test_a_step_that_outgrows_the_capacities_keeps_valid_arrays_poisons_its_outputs_and_reports():
