@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void bil_reduce_project_ang_kernel(
 template <bool F16>
 __global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __restrict__ ang, const float* __restrict__ dSm,
                                                              const int32_t* __restrict__ seg_off, float* __restrict__ dxt,
-                                                             int64_t E) {
+                                                             int64_t E, const int32_t* __restrict__ row_pos) {
+  // row_pos (optional): row of dxt that receives quadruplet q's result — the position of q in the order of its EXPAND row
+  // (round 5: the segmented sum that follows then reads contiguous rows instead of gathering 128-byte rows through a permutation)
   constexpr int TQ = 32;
   __shared__ float ysm[4][TQ * LDY];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __res
         for (int r = 0; r < 4; ++r) {
           const int q = sub + 4 * lg + r;
           if (q < nq) {
-            float* __restrict__ o = dxt + (int64_t)(tb + q) * C + l15;
+            float* __restrict__ o = dxt + (int64_t)(row_pos ? row_pos[tb + q] : tb + q) * C + l15;
             o[0] = c0[r];
             o[16] = c1[r];
           }
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void bil_expand_ang_kernel(const float4* __res
       for (int r = 0; r < 4; ++r) {
         const int q = sub + 4 * lg + r;
         if (q < nq) {
-          float* __restrict__ o = dxt + (int64_t)(tb + q) * C + l15;
+          float* __restrict__ o = dxt + (int64_t)(row_pos ? row_pos[tb + q] : tb + q) * C + l15;
           o[0] = c0[r];
           o[16] = c1[r];
         }
@@ -849,15 +851,15 @@ extern "C" int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, c
 }
 
 extern "C" int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S_,
-                                     int C_, int arith, void* stream) {
+                                     int C_, int arith, const int32_t* row_pos, void* stream) {
   if (E <= 0) return 0;
   if (S_ != S || C_ != C || !aligned16(ang) || (arith & ~1)) return (int)hipErrorInvalidValue;
   if (arith & 1)
     hipLaunchKernelGGL(bil_expand_ang_kernel<true>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
+                       reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E, row_pos);
   else
     hipLaunchKernelGGL(bil_expand_ang_kernel<false>, dim3(gn_cdiv(E, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E);
+                       reinterpret_cast<const float4*>(ang), dSm, seg_off, dxt, E, row_pos);
   GN_LAUNCH_CHECK();
   return 0;
 }

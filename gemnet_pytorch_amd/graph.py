@@ -108,6 +108,16 @@ class SegmentPlan:
         self.n_expand = int(n_expand)
 
     @property
+    def expand_pos(self):
+        """Inverse of the expand CSR's permutation (int32): position of item t in the order of its expand row."""
+        if getattr(self, "_expand_pos", None) is None:
+            perm, _ = self.expand.csr
+            pos = torch.empty_like(perm)
+            pos[perm.long()] = torch.arange(perm.shape[0], device=perm.device, dtype=perm.dtype)
+            self._expand_pos = pos
+        return self._expand_pos
+
+    @property
     def seg_off(self):
         return self.reduce.csr[1]
 

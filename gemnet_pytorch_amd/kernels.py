@@ -374,6 +374,12 @@ GN_ANG_F16 = 1
 ANG_F16_MASK = int(os.environ.get("GEMNET_ANG_F16", "7")) & 7
 
 
+# GemNet-Q x-adjoint: GEMNET_EXPAND_POS=1 writes the per-quadruplet rows in DESTINATION order (SegmentPlan.expand_pos) so that
+# the segmented sum reads them contiguously.  Measured (profiles/r5_expand_pos_ab.txt): 11.58-11.64 ms against 11.42-11.44 —
+# the scattered 128-byte row writes cost more than the contiguous reads save.  Off.
+USE_EXPAND_POS = os.environ.get("GEMNET_EXPAND_POS", "0") == "1"
+
+
 def bil_reduce_t(Y, D, sp):
     """dx[j,c] = sum_{t: g(t)=j} sum_s Y[t,s] D[r(t),s,c]."""
     require_device(Y, D)
@@ -391,9 +397,11 @@ def bil_reduce_t(Y, D, sp):
                                                           stream()), "gn_bil_expand_atoms_ang_f32")
             return dx
         dxt = torch.empty((sp.size, C), device=Y.device, dtype=torch.float32)
+        pos = sp.expand_pos if USE_EXPAND_POS and permT is not None else None
         check(_lib.load().gn_bil_expand_ang_f32(ptr(Y), ptr(D), ptr(sp.seg_off), ptr(dxt), sp.n_reduce, S, C,
-                                                GN_ANG_F16 if ANG_F16_MASK & 4 else 0, stream()), "gn_bil_expand_ang_f32")
-        return segsum(dxt, permT, segT, sp.n_expand)
+                                                GN_ANG_F16 if ANG_F16_MASK & 4 else 0, ptr(pos), stream()), "gn_bil_expand_ang_f32")
+        # rows written in the order of their expand row: the sum reads them contiguously (same rows, same order of addition)
+        return segsum(dxt, None if pos is not None else permT, segT, sp.n_expand)
     if S > 8:
         # tensor basis: per-quadruplet rows grouped by reduce edge (dSm[e] read once per edge), then one CSR sum
         dxt = torch.empty((sp.size, C), device=Y.device, dtype=torch.float32)

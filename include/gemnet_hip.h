@@ -253,9 +253,11 @@ int gn_quad_angles_bwd_ld_f32(const float* g_ang, const float* R, const int32_t*
 int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_t* expand_idx, const int32_t* seg_off,
                                   const float* B, float* Sm, float* P, int64_t E, int S, int C, int I, int arith,
                                   void* stream);
-/* per-quadruplet x-adjoint rows as gn_bil_expand_f32, Y given as angles */
+/* per-quadruplet x-adjoint rows as gn_bil_expand_f32, Y given as angles.  row_pos (optional, ABI 14): dxt row that receives
+ * quadruplet q — its position in the order of the EXPAND rows, so that gn_segsum_rows_f32 reads contiguous rows (perm = NULL)
+ * instead of gathering 128-byte rows through the permutation; the same rows are summed in the same order. */
 int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,
-                          int arith, void* stream);
+                          int arith, const int32_t* row_pos, void* stream);
 /* Second-order sweeps of GemNet-Q force training (trainer.py:338-346: loss.backward() through dE/dR) in angle form (ABI 13).
  * tang (Q,4) = (dPhi_cab, dTheta_cabd, 0, 0): the tangents of the two angles along the position tangent u = dL/dF
  * (gn_quad_angles_jvp_f32: the double backward of gn_quad_angles_bwd_ld_f32); the kernels rebuild
