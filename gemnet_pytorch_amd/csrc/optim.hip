@@ -95,6 +95,52 @@ extern "C" int gn_nonfinite_flag_f32(const float* x, int64_t n, int32_t* flag, i
   return 0;
 }
 
+// ---- the training loss and its cotangents in one launch ---------------------------------------------------------------------
+// loss = w_e sum |E - Et| + w_f sum_a m_a |F_a - Ft_a|_2   (trainer.py:330-343: (1 - rho) MAE(E) + rho mean L2(F), the weights
+// carry rho and the global counts); gE = w_e sign(E - Et), gF_a = w_f m_a (F_a - Ft_a) / |F_a - Ft_a| (0 where the norm is 0,
+// as ATen's norm backward).  One workgroup, fixed order of addition: bit-reproducible.  The composite form was 16 ATen launches
+// in the forward of the loss and as many in its backward, each a 4 us node of the captured step.
+__global__ __launch_bounds__(1024) void force_loss_kernel(const float* __restrict__ E, const float* __restrict__ Et, int64_t nE,
+                                                          const float* __restrict__ F, const float* __restrict__ Ft, int64_t A,
+                                                          const float* __restrict__ mask, float w_e, float w_f,
+                                                          const float* __restrict__ w_f_dev, float* __restrict__ loss,
+                                                          float* __restrict__ gE, float* __restrict__ gF) {
+  __shared__ double red[1024];
+  const int tid = threadIdx.x;
+  if (w_f_dev) w_f *= *w_f_dev;
+  double acc = 0.0;
+  for (int64_t i = tid; i < nE; i += 1024) {
+    const float d = E[i] - Et[i];
+    acc += (double)w_e * fabsf(d);
+    gE[i] = d > 0.f ? w_e : (d < 0.f ? -w_e : 0.f);
+  }
+  for (int64_t a = tid; a < A; a += 1024) {
+    const float m = mask ? mask[a] : 1.f;
+    const float dx = F[3 * a] - Ft[3 * a], dy = F[3 * a + 1] - Ft[3 * a + 1], dz = F[3 * a + 2] - Ft[3 * a + 2];
+    const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float s = (m != 0.f && n > 0.f) ? w_f * m / n : 0.f;
+    if (m != 0.f) acc += (double)w_f * m * n;
+    gF[3 * a] = s * dx; gF[3 * a + 1] = s * dy; gF[3 * a + 2] = s * dz;
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) *loss = (float)red[0];
+}
+
+extern "C" int gn_force_loss_f32(const float* E, const float* Et, int64_t nE, const float* F, const float* Ft, int64_t A,
+                                 const float* mask, float w_e, float w_f, const float* w_f_dev, float* loss, float* gE, float* gF,
+                                 void* stream) {
+  if (nE < 0 || A < 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(force_loss_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), E, Et, nE, F, Ft, A, mask, w_e,
+                     w_f, w_f_dev, loss, gE, gF);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gn_optim_blocks(int64_t n) {
   int64_t b = (n + OPT_NT * 8 - 1) / (OPT_NT * 8);
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));

@@ -265,6 +265,22 @@ def index_padded_q(builder, R, caps, a_cap, n_groups, deg_bound, staging, bufs, 
         "gn_index_gpu_padded_q")
 
 
+def force_loss(E, Et, F, Ft, w_e, w_f, mask=None, w_f_dev=None):
+    """-> (loss (), gE like E, gF like F): loss = w_e sum|E - Et| + w_f [* w_f_dev] sum_a mask_a |F_a - Ft_a|_2 and its
+    cotangents in one launch (gn_force_loss_f32)."""
+    require_device(E, Et, F, Ft)
+    E, Et, F, Ft = _f32c(E), _f32c(Et), _f32c(F), _f32c(Ft)
+    assert E.shape == Et.shape and F.shape == Ft.shape and F.dim() == 2 and F.shape[1] == 3
+    if mask is not None:
+        mask = _f32c(mask)
+        assert mask.numel() == F.shape[0]
+    loss = torch.empty((), device=E.device, dtype=torch.float32)
+    gE, gF = torch.empty_like(E), torch.empty_like(F)
+    check(_lib.load().gn_force_loss_f32(ptr(E), ptr(Et), E.numel(), ptr(F), ptr(Ft), F.shape[0], ptr(mask), float(w_e), float(w_f),
+                                        ptr(w_f_dev), ptr(loss), ptr(gE), ptr(gF), stream()), "gn_force_loss_f32")
+    return loss, gE, gF
+
+
 def index_poison(x, state):
     """x <- NaN when the index build of this step reported an error (gn_index_poison_f32)."""
     require_device(x, state)

@@ -16,6 +16,8 @@ collective over xGMI, issued after `loss.backward()` and before the shared-gradi
 gradients exactly like the single-process trainer.
 """
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -81,6 +83,29 @@ def make_optimizer(model, learning_rate=1e-3, weight_decay=2e-6):
         lr=learning_rate, eps=1e-7, amsgrad=True)
 
 
+# The loss (trainer.py:330-343) and its cotangents as ONE launch on the device; GEMNET_FUSED_LOSS=0: the ATen composite.
+USE_FUSED_LOSS = os.environ.get("GEMNET_FUSED_LOSS", "1") == "1"
+
+
+class _ForceLoss(torch.autograd.Function):
+    """loss = w_e sum|E - Et| + w_f [* w_f_dev] sum_a mask_a |F_a - Ft_a|_2 (kernels.force_loss); the weights carry rho and the
+    global molecule / atom counts.  First-order backward only: the training step differentiates the loss once (its second
+    order is the force's, inside the model)."""
+
+    @staticmethod
+    def forward(ctx, E, F, Et, Ft, w_e, w_f, mask, w_f_dev):
+        from .. import kernels as K
+        loss, gE, gF = K.force_loss(E, Et, F, Ft, w_e, w_f, mask=mask, w_f_dev=w_f_dev)
+        ctx.save_for_backward(gE, gF)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gE, gF = ctx.saved_tensors
+        return gE * g, gF * g, None, None, None, None, None, None
+
+
 class TrainStep:
     """fwd + force + loss + backward + (all-reduce) + shared-grad rescale + clip + optimizer step."""
 
@@ -136,6 +161,9 @@ class TrainStep:
 
     def loss(self, E, F, targets):
         B, A = self._counts(E.shape[0], F.shape[0], E.device)
+        if USE_FUSED_LOSS and E.is_cuda and E.dtype == torch.float32:
+            # one launch for the loss and its cotangents (csrc/optim.hip: force_loss_kernel) instead of 16 + 16 ATen nodes
+            return _ForceLoss.apply(E, F, targets["E"], targets["F"], (1 - self.rho) / (B * E.shape[1]), self.rho / A, None, None)
         e_term = (E - targets["E"]).abs().sum() / (B * E.shape[1])
         f_term = torch.norm(F - targets["F"], p=2, dim=1).sum() / A
         return (1 - self.rho) * e_term + self.rho * f_term
@@ -316,6 +344,9 @@ class PaddedTrainStep(TrainStep):
 
     def loss(self, E, F, targets):
         B = float(self.pad.n_mol * max(self.world_size, 1))
+        if USE_FUSED_LOSS and E.is_cuda and E.dtype == torch.float32:
+            return _ForceLoss.apply(E, F, targets["E"], targets["F"], (1 - self.rho) / (B * E.shape[1]), self.rho, self.mask,
+                                    self.inv_atoms)
         e_term = (E - targets["E"]).abs().sum() / (B * E.shape[1])
         m = self.mask
         # masked rows get a constant difference: the norm of an exact zero has no gradient (0 * nan), and they have no share

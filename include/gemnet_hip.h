@@ -579,6 +579,14 @@ int gn_adamw_ema_step_f32(float* p, const float* g, const float* gscale, const f
  * and the host polls that copy without synchronising (runtime.RangeFlag).  The word is sticky until the host clears it. */
 int gn_nonfinite_flag_f32(const float* x, int64_t n, int32_t* flag, int bit, void* stream);
 
+/* ---- the training loss with its cotangents (ABI 14) -----------------------------------------------------------------------
+ * trainer.py:330-343: loss = (1 - rho) MAE(E) + rho mean_a |F_a - Ft_a|_2, here with the weights folded by the caller:
+ *   loss = w_e sum_i |E_i - Et_i| + w_f sum_a m_a |F_a - Ft_a|_2,  w_f *= *w_f_dev when given (a device scalar: 1 / atoms of a
+ *   padded step), m = mask (A) or all ones;  gE = dloss/dE, gF = dloss/dF (0 where the norm is 0, as ATen's norm backward).
+ * E, Et, gE: nE values; F, Ft, gF: (A,3).  One workgroup, fixed order of addition. */
+int gn_force_loss_f32(const float* E, const float* Et, int64_t nE, const float* F, const float* Ft, int64_t A, const float* mask,
+                      float w_e, float w_f, const float* w_f_dev, float* loss, float* gE, float* gF, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

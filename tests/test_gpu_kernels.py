@@ -1236,3 +1236,32 @@ def test_twice_differentiable_geometry_kernels():
     assert torch.isfinite(Hc).all() and torch.isfinite(Hb).all() and torch.isfinite(thd).all()
     t2, none_c, none_b = K.angle_jvp(f32(R), f32(tR), None, d(tc), d(ta), d(tb), want_H=False)
     assert none_c is None and none_b is None and torch.equal(t2, thd)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_force_loss_and_its_cotangents_in_one_launch(masked):
+    """gn_force_loss_f32 against the ATen composite of trainer.py:330-343 ((1 - rho) MAE(E) + rho mean L2(F)) and its
+    autograd gradients; a row with F = Ft (zero norm) gets a zero gradient, masked rows (padded training step) no share."""
+    g = torch.Generator().manual_seed(7 + masked)
+    n_mol, A, rho = 37, 1501, 0.999
+    E, Et = (torch.randn(n_mol, 1, generator=g, dtype=torch.float64) for _ in range(2))
+    F, Ft = (torch.randn(A, 3, generator=g, dtype=torch.float64) for _ in range(2))
+    Ft[5] = F[5].float().double()
+    F[5] = Ft[5]
+    mask = (torch.rand(A, generator=g) > 0.3).double() if masked else None
+    n_at = float(mask.sum()) if masked else float(A)
+    E64, F64 = E.clone().requires_grad_(True), F.clone().requires_grad_(True)
+    m = mask if masked else torch.ones(A, dtype=torch.float64)
+    d = torch.where(m[:, None] > 0, F64 - Ft, torch.ones_like(F64))
+    ref = (1 - rho) * (E64 - Et).abs().sum() / n_mol + rho * (torch.norm(d, p=2, dim=1) * m).sum() / n_at
+    ref.backward()
+    inv = torch.tensor(1.0 / n_at, device=DEV, dtype=torch.float32)
+    loss, gE, gF = K.force_loss(f32(E), f32(Et), f32(F), f32(Ft), (1 - rho) / n_mol, rho if masked else rho / n_at,
+                                mask=f32(mask) if masked else None, w_f_dev=inv if masked else None)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    close(gE, E64.grad, atol=1e-9)
+    close(gF, F64.grad, atol=2e-7 * float(F64.grad.abs().max()))
+    assert float(gF[5].abs().max()) == 0.0
+    loss2, gE2, gF2 = K.force_loss(f32(E), f32(Et), f32(F), f32(Ft), (1 - rho) / n_mol, rho if masked else rho / n_at,
+                                   mask=f32(mask) if masked else None, w_f_dev=inv if masked else None)
+    assert torch.equal(loss, loss2) and torch.equal(gF, gF2)
