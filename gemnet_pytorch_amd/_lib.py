@@ -84,8 +84,8 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp],
     "gn_index_poison_f32": [_vp, _i64, _vp, _vp],
     "gn_force_loss_f32": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
-    "gn_index_gpu_padded_q": [_vp, _i, _vp, _vp, _i, _i, _i, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp, _i, _i, _i, _vp,
-                              _vp, _vp, _vp],
+    "gn_index_gpu_padded_q": [_vp, _i, _vp, _vp, _i, _i, _i, _i64, ctypes.c_double, ctypes.c_double, _vp, _i, _i, _i, _i, _i,
+                              _i, _i, _i, _vp, _vp, _vp, _vp],
     "gn_index_gpu_stage2": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_pm_f32": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i64, _vp],

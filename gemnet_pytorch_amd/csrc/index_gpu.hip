@@ -771,11 +771,10 @@ extern "C" int gn_index_poison_f32(float* x, int64_t n, const int32_t* state, vo
 
 // Capacity form of the quadruplet build: no read-back, capturable.  See include/gemnet_hip.h.
 extern "C" int gn_index_gpu_padded_q(const void* R, int r_is_f64, const int32_t* mol_off, const int32_t* sq_off, int B, int A,
-                                     int nmax, int64_t sum_n2, double cutoff, double int_cutoff, void* ws, const int32_t* caps,
-                                     int a_cap, int n_groups, int deg_bound, int32_t* staging, int32_t* const* arrays,
-                                     int32_t* state, void* stream) {
+                                     int nmax, int64_t sum_n2, double cutoff, double int_cutoff, void* ws, int e_cap, int t_cap,
+                                     int eint_cap, int i_cap, int q_cap, int a_cap, int n_groups, int deg_bound,
+                                     int32_t* staging, int32_t* const* arrays, int32_t* state, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int e_cap = caps[0], t_cap = caps[1], eint_cap = caps[2], i_cap = caps[3], q_cap = caps[4];
   if (A <= 0 || B <= 0 || n_groups <= 0 || e_cap <= 0 || t_cap <= 0 || eint_cap <= 0 || i_cap <= 0 || q_cap <= 0 ||
       (e_cap & 1) || (t_cap & 1) || sum_n2 > 0x7fffffffLL)
     return (int)hipErrorInvalidValue;

@@ -256,12 +256,11 @@ def index_padded_q(builder, R, caps, a_cap, n_groups, deg_bound, staging, bufs, 
     want = dict(zip(PADDED_Q_KEYS, (e_cap,) * 4 + (t_cap,) * 2 + (eint_cap,) * 2 + (i_cap,) * 4 + (q_cap,) * 4))
     for k, n in want.items():
         assert bufs[k].dtype == torch.int32 and bufs[k].numel() == n and bufs[k].is_contiguous(), k
-    c_caps = (ctypes.c_int32 * 5)(e_cap, t_cap, eint_cap, i_cap, q_cap)
     c_arr = (ctypes.c_void_p * 16)(*[addr(bufs[k]) for k in PADDED_Q_KEYS])
     check(_lib.load().gn_index_gpu_padded_q(
         ptr(R), int(R.dtype == torch.float64), ptr(builder.mol_off), ptr(builder.sq_off), builder.B, builder.A, builder.nmax,
-        builder.sum_n2, builder.cutoff, builder.int_cutoff, ptr(builder.ws), ctypes.cast(c_caps, ctypes.c_void_p), int(a_cap),
-        int(n_groups), int(deg_bound), ptr(staging), ctypes.cast(c_arr, ctypes.c_void_p), ptr(state), stream()),
+        builder.sum_n2, builder.cutoff, builder.int_cutoff, ptr(builder.ws), e_cap, t_cap, eint_cap, i_cap, q_cap, int(a_cap),
+        int(n_groups), int(deg_bound), ptr(staging), c_arr, ptr(state), stream()),
         "gn_index_gpu_padded_q")
 
 

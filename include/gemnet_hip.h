@@ -339,8 +339,8 @@ int gn_index_gpu_padded_t(const void* R, int r_is_f64, const int32_t* mol_off, c
                           int deg_bound, int32_t* staging, int32_t* id_c, int32_t* id_a, int32_t* id_swap, int32_t* id_undir,
                           int32_t* id3_reduce_ca, int32_t* id3_expand_ba, int32_t* state, void* stream);
 int gn_index_poison_f32(float* x, int64_t n, const int32_t* state, void* stream);
-/* The same for quadruplet models (data_container.py:427-489 as well): five families.  caps (host int32[5]) = {e_cap, t_cap,
- * eint_cap, i_cap, q_cap}; arrays (host array of 16 device pointers) = id_c, id_a, id_swap, id_undir, id3_reduce_ca,
+/* The same for quadruplet models (data_container.py:427-489 as well): five families with their capacities e_cap, t_cap,
+ * eint_cap, i_cap, q_cap; arrays (host array of 16 device pointers) = id_c, id_a, id_swap, id_undir, id3_reduce_ca,
  * id3_expand_ba, id4_int_a, id4_int_b, id4_reduce_intm_ca, id4_expand_intm_db, id4_reduce_intm_ab, id4_expand_intm_ab,
  * id4_reduce_ca, id4_expand_db, id4_reduce_cab, id4_expand_abd — each of its family's capacity; staging: 4 e_cap + 2 eint_cap
  * int32 (the two small families; the three large ones are written straight into `arrays` once a one-thread kernel has
@@ -349,8 +349,9 @@ int gn_index_poison_f32(float* x, int64_t n, const int32_t* state, void* stream)
  *   err bits as above plus 16 Eint > eint_cap, 32 I > i_cap, 64 Q > q_cap, 128 inconsistent intermediate-triplet lists
  * ws: gn_index_gpu_ws_bytes(A, sum_n2, triplets_only = 0). */
 int gn_index_gpu_padded_q(const void* R, int r_is_f64, const int32_t* mol_off, const int32_t* sq_off, int B, int A, int nmax,
-                          int64_t sum_n2, double cutoff, double int_cutoff, void* ws, const int32_t* caps, int a_cap,
-                          int n_groups, int deg_bound, int32_t* staging, int32_t* const* arrays, int32_t* state, void* stream);
+                          int64_t sum_n2, double cutoff, double int_cutoff, void* ws, int e_cap, int t_cap, int eint_cap,
+                          int i_cap, int q_cap, int a_cap, int n_groups, int deg_bound, int32_t* staging, int32_t* const* arrays,
+                          int32_t* state, void* stream);
 
 /* ---- row gather / segmented sum (P2/P3/P10: `x[id3_expand_ba]` interaction_block.py:678,
  *      `x[id4_expand_*]` :543,:548, `x_ac[id_swap]` :693, h[id] embedding_block.py:70-71 and

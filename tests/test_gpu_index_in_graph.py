@@ -144,6 +144,7 @@ def test_in_graph_quadruplet_index_equals_two_stage_build_plus_host_padding():
     ref, run = mk(), mk()
     run._fill(data[0][1], idxs[0], data[0][2])
     run.attach_builder(builder)
+    run.check = True        # the capture under the happens-before checker
     for rep in range(2):
         for (ds, R, Z, N), idx, sz in zip(data, idxs, sizes):
             E0, F0 = (t.clone() for t in ref(R, idx, Z=Z))
@@ -154,6 +155,9 @@ def test_in_graph_quadruplet_index_equals_two_stage_build_plus_host_padding():
             for k, v in ref_bufs.items():
                 assert torch.equal(run.inputs[k], v), (k, int((run.inputs[k] != v).sum()))
             assert torch.equal(E0, E1) and torch.equal(F0, F1)
+    races, summary = run.hb.races(), run.hb.summary()
+    print(run.hb.format(races))
+    assert not races and summary["unrecorded_nodes"] == 0 and summary["unresolved_pointers"] == 0, summary
 
 
 def test_quadruplet_step_that_outgrows_the_capacities_is_reported_and_leaves_the_arrays_alone():
