@@ -264,6 +264,36 @@ def index_padded_q(builder, R, caps, a_cap, n_groups, deg_bound, staging, bufs, 
         "gn_index_gpu_padded_q")
 
 
+def cbf_project_supported(rad, y, W):
+    return rad.dim() == 3 and rad.shape[1] * rad.shape[2] <= 64 and W.shape[0] <= 16 and W.shape[1] == rad.shape[1] * rad.shape[2] \
+        and y.shape[1] == rad.shape[1]
+
+
+def cbf_project_fwd(rad, ie32, y, W):
+    """out[i, n] = sum_{l, r} rad[ie[i], l, r] y[i, l] W[n, l R + r] (gn_cbf_project_fwd_f32)."""
+    require_device(rad, ie32, y, W)
+    rad, y, W = _f32c(rad), _f32c(y), _f32c(W)
+    I, S, R, N = int(y.shape[0]), int(rad.shape[1]), int(rad.shape[2]), int(W.shape[0])
+    out = torch.empty((I, N), device=y.device, dtype=torch.float32)
+    check(_lib.load().gn_cbf_project_fwd_f32(ptr(rad), ptr(ie32), ptr(y), ptr(W), ptr(out), I, S, R, N, stream()),
+          "gn_cbf_project_fwd_f32")
+    return out
+
+
+def cbf_project_bwd(g, rad, seg_off, y, W):
+    """-> (g_rad like rad, g_y like y): the adjoint of cbf_project_fwd for a frozen W (gn_cbf_project_bwd_f32)."""
+    require_device(g, rad, seg_off, y, W)
+    g, rad, y, W = _f32c(g), _f32c(rad), _f32c(y), _f32c(W)
+    E, S, R, N = int(rad.shape[0]), int(rad.shape[1]), int(rad.shape[2]), int(W.shape[0])
+    if seg_off.dtype != torch.int32:
+        seg_off = seg_off.to(torch.int32)
+    assert seg_off.numel() == E + 1
+    g_rad, g_y = torch.empty_like(rad), torch.empty_like(y)
+    check(_lib.load().gn_cbf_project_bwd_f32(ptr(g), ptr(rad), ptr(seg_off), ptr(y), ptr(W), ptr(g_rad), ptr(g_y), E, S, R, N,
+                                             stream()), "gn_cbf_project_bwd_f32")
+    return g_rad, g_y
+
+
 def force_loss(E, Et, F, Ft, w_e, w_f, mask=None, w_f_dev=None):
     """-> (loss (), gE like E, gF like F): loss = w_e sum|E - Et| + w_f [* w_f_dev] sum_a mask_a |F_a - Ft_a|_2 and its
     cotangents in one launch (gn_force_loss_f32)."""

@@ -265,6 +265,7 @@ class GemNet(torch.nn.Module):
             D_ca, V_ca = self.calculate_interatomic_vectors(R, plan.id_c, plan.id_a)
             rbf = self.rbf_basis(D_ca)
             rad3, sph3 = b3(D_ca, self.calculate_angles3(R, plan))
+        cbf4_done = False       # (the fused branch below may project the circular basis through mlp_cbf4 itself)
         if not T and ops.is_fused():
             b4, qg = self.cbf_basis, plan.quad_geom
             # interaction-edge radial basis (cutoff = int_cutoff), a-b<-d angles and the quadruplet
@@ -273,7 +274,13 @@ class GemNet(torch.nn.Module):
                                            want_rbf=False)
             y_abd = ops.trip_basis(R, qg["a_of_exp"], qg["b_of_exp"], qg["d_of_exp"], self.num_spherical)
             S, NR = self.num_spherical, b4.num_radial
-            cbf4 = (ops.gather_rows(rad4, plan.intm_ab) * y_abd[:, :, None]).reshape(-1, S * NR)
+            cbf4 = None
+            if self.mlp_cbf4.bias is None and not self.mlp_cbf4.act:
+                # gather + Hadamard with Y_l0 + mlp_cbf4 in one pass (csrc/cbf.hip); the projected basis is marked below
+                cbf4 = ops.cbf_project(rad4, plan.intm_ab, y_abd, self.mlp_cbf4.weight)
+            cbf4_done = cbf4 is not None
+            if not cbf4_done:
+                cbf4 = (ops.gather_rows(rad4, plan.intm_ab) * y_abd[:, :, None]).reshape(-1, S * NR)
             # (angle form for the published quadruplet widths: the bilinear kernels rebuild Y_lm from 16 B per quadruplet)
             ang = self.int_blocks[0].quad_interaction.mlp_sbf.weight.shape[:2] == (32, 32)
             sbf4 = (rad3, ops.share_gradient(ops.quad_basis(R, plan.q_c, plan.q_a, plan.q_b, plan.q_d, S, plan=plan,
@@ -310,7 +317,9 @@ class GemNet(torch.nn.Module):
 
         if not T:
             rbf4 = ops.accumulate_gradient(self.mlp_rbf4(rbf))
-            cbf4 = ops.accumulate_gradient(self.mlp_cbf4(cbf4))     # (one consumer per block: no engine-side (I,16) adds)
+            if not cbf4_done:
+                cbf4 = self.mlp_cbf4(cbf4)
+            cbf4 = ops.accumulate_gradient(cbf4)     # (one consumer per block: no engine-side (I,16) adds)
             sbf4 = (ops.accumulate_gradient(self.mlp_sbf4(sbf4[0])), sbf4[1])
         else:
             rbf4 = cbf4 = sbf4 = None

@@ -107,6 +107,47 @@ class _SegSum(torch.autograd.Function):
         return _Gather.apply(g, ctx.ri), None
 
 
+class _CbfProject(torch.autograd.Function):
+    """out = Dense_W((rad[ri] * y[:, :, None]).reshape(I, S R)) in one pass (csrc/cbf.hip); W frozen, first-order backward."""
+
+    @staticmethod
+    def forward(ctx, rad, y, W, ri):
+        out = K.cbf_project_fwd(rad, ri.idx32, y, W)
+        ctx.save_for_backward(rad, y, W)
+        ctx.ri = ri
+        ctx.acc = _acc_join(rad)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        rad, y, W = ctx.saved_tensors
+        perm, seg = ctx.ri.csr
+        assert perm is None, "cbf_project: the interaction-edge index of the intermediate triplets is sorted"
+        g_rad, g_y = K.cbf_project_bwd(g.contiguous(), rad, seg, y, W)
+        acc = ctx.acc
+        if acc is not None:      # (rad has one consumer today; kept for symmetry with the other radial tables)
+            prev, last = acc.enter()
+            if prev is not None:
+                g_rad = prev.add_(g_rad)
+            acc.leave(g_rad, last)
+            if not last:
+                g_rad = None
+        return g_rad, g_y, None, None
+
+
+USE_CBF_PROJECT = os.environ.get("GEMNET_CBF_PROJECT", "1") == "1"
+
+
+def cbf_project(rad, ri, y, W):
+    """Circular basis of GemNet-Q's intermediate triplets through mlp_cbf4 (basis_layers.py:119-131 + a bias-free Dense), fused
+    when the weight is frozen (forward+force inference) and the index is sorted by interaction edge; None otherwise (the caller
+    keeps the composite form)."""
+    if not (USE_CBF_PROJECT and constant_weights() and ri.is_sorted and K.cbf_project_supported(rad, y, W)):
+        return None
+    return _CbfProject.apply(rad, y, contiguous_weight(W), ri)
+
+
 def gather_rows(x, ri):
     """y[t] = x[ri.idx[t]]   (interaction_block.py:543,548,678,693; embedding_block.py:70-71)."""
     return _Gather.apply(x, ri)

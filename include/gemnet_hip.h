@@ -580,6 +580,16 @@ int gn_adamw_ema_step_f32(float* p, const float* g, const float* gscale, const f
  * and the host polls that copy without synchronising (runtime.RangeFlag).  The word is sticky until the host clears it. */
 int gn_nonfinite_flag_f32(const float* x, int64_t n, int32_t* flag, int bit, void* stream);
 
+/* ---- circular basis of GemNet-Q's intermediate triplets, projected (ABI 14) --------------------------------------------------
+ * basis_layers.py:119-131 (rbf_env[id4_expand_intm_ab] * Y_l0) followed by mlp_cbf4 (gemnet.py): one pass, no (I, S R) array:
+ *   out[i, n] = sum_{l, r} rad[ie[i], l, r] y[i, l] W[n, l R + r]         rad (Eint, S, R), ie (I) int32, y (I, S), W (N, S R)
+ * adjoint (W frozen): g_rad (Eint, S, R) and g_y (I, S) from g (I, N); the rows of an interaction edge are contiguous (ie is
+ * sorted: seg_off (Eint + 1) = its segment offsets), one wave per edge sums them in order.  S R <= 64, N <= 16. */
+int gn_cbf_project_fwd_f32(const float* rad, const int32_t* ie, const float* y, const float* W, float* out, int64_t I, int S, int R,
+                           int N, void* stream);
+int gn_cbf_project_bwd_f32(const float* g, const float* rad, const int32_t* seg_off, const float* y, const float* W, float* g_rad,
+                           float* g_y, int64_t E, int S, int R, int N, void* stream);
+
 /* ---- the training loss with its cotangents (ABI 14) -----------------------------------------------------------------------
  * trainer.py:330-343: loss = (1 - rho) MAE(E) + rho mean_a |F_a - Ft_a|_2, here with the weights folded by the caller:
  *   loss = w_e sum_i |E_i - Et_i| + w_f sum_a m_a |F_a - Ft_a|_2,  w_f *= *w_f_dev when given (a device scalar: 1 / atoms of a

@@ -594,7 +594,25 @@ def rbf_aggregate_bwd(g_out, m, rbf, W, id_a32, scale, want_m=True, want_rbf=Tru
     return g_m, g_rbf
 
 
-_NAMES = ["quad_angles_jvp", "bil_reduce_project_tan", "bil_reduce_t_tan", "bil_ang_train_supported", "dist_fwd", "dist_bwd", "dist_jvp", "angle_fwd", "angle_bwd", "angle_jvp", "bil_train_supported", "gather_mul", "bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
+def cbf_project_supported(rad, y, W):
+    return rad.dim() == 3 and rad.shape[1] * rad.shape[2] <= 64 and W.shape[0] <= 16
+
+
+def cbf_project_fwd(rad, ie32, y, W):
+    return (rad[ie32.long()] * y[:, :, None]).reshape(y.shape[0], -1) @ W.t()
+
+
+def cbf_project_bwd(g, rad, seg_off, y, W):
+    E, S, R = rad.shape
+    t = (g @ W).reshape(-1, S, R)
+    counts = (seg_off[1:] - seg_off[:-1]).long()
+    e_of = torch.repeat_interleave(torch.arange(E), counts)
+    g_y = (t * rad[e_of]).sum(dim=2)
+    g_rad = torch.zeros_like(rad).index_add(0, e_of, t * y[:, :, None])
+    return g_rad, g_y
+
+
+_NAMES = ["cbf_project_supported", "cbf_project_fwd", "cbf_project_bwd", "quad_angles_jvp", "bil_reduce_project_tan", "bil_reduce_t_tan", "bil_ang_train_supported", "dist_fwd", "dist_bwd", "dist_jvp", "angle_fwd", "angle_bwd", "angle_jvp", "bil_train_supported", "gather_mul", "bil_fused_bwd", "bil_fused_bwd_supported", "segsum_multi", "is_angle_form", "quad_angles_fwd", "quad_angles_bwd", "rbf_aggregate_fwd", "rbf_aggregate_bwd", "bil_fused_fwd", "quad_basis_fwd", "quad_basis_bwd", "quad_basis_bwd_packed", "bil_reduce_project", "bil_project_bwd", "bil_dy_multi", "chain", "edge_basis_fwd", "edge_basis_bwd", "trip_basis_fwd", "trip_basis_bwd", "gemm", "dact_mul", "gather", "segsum", "bmm", "ssilu", "pm", "bil_reduce", "bil_reduce_t", "bil_dot",
           "bessel_rbf", "sph_radial", "ylm0", "ylm"]
 
 

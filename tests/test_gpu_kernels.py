@@ -1265,3 +1265,30 @@ def test_force_loss_and_its_cotangents_in_one_launch(masked):
     loss2, gE2, gF2 = K.force_loss(f32(E), f32(Et), f32(F), f32(Ft), (1 - rho) / n_mol, rho if masked else rho / n_at,
                                    mask=f32(mask) if masked else None, w_f_dev=inv if masked else None)
     assert torch.equal(loss, loss2) and torch.equal(gF, gF2)
+
+
+@pytest.mark.parametrize("S,R,N", [(7, 6, 16), (7, 6, 9), (3, 4, 16)])
+def test_cbf_project_forward_and_adjoint_against_the_composite(S, R, N):
+    """gn_cbf_project_{fwd,bwd}_f32 against basis_layers.py:119-131 + a bias-free Dense in float64: rad[ie] * Y_l0 -> (I, S R)
+    -> @ W^T, and the autograd gradients w.r.t. rad and y; rows sorted by interaction edge, some edges without rows; twice:
+    bitwise."""
+    g = torch.Generator().manual_seed(S * 100 + N)
+    E = 301
+    counts = torch.randint(0, 9, (E,), generator=g)
+    counts[17] = 0
+    counts[E - 1] = 0
+    ie = torch.repeat_interleave(torch.arange(E), counts)
+    I = int(ie.shape[0])
+    seg = torch.zeros(E + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    rad, y, W = rnd(g, E, S, R).requires_grad_(True), rnd(g, I, S).requires_grad_(True), rnd(g, N, S * R)
+    ref = (rad[ie] * y[:, :, None]).reshape(I, S * R) @ W.t()
+    go = rnd(g, I, N)
+    ref.backward(go)
+    out = K.cbf_project_fwd(f32(rad.detach()), ie.to(torch.int32).to(DEV), f32(y.detach()), f32(W))
+    close(out, ref.detach(), atol=2e-5)
+    g_rad, g_y = K.cbf_project_bwd(f32(go), f32(rad.detach()), seg.to(DEV), f32(y.detach()), f32(W))
+    close(g_rad, rad.grad, atol=5e-5)
+    close(g_y, y.grad, atol=5e-5)
+    g_rad2, g_y2 = K.cbf_project_bwd(f32(go), f32(rad.detach()), seg.to(DEV), f32(y.detach()), f32(W))
+    assert torch.equal(g_rad, g_rad2) and torch.equal(g_y, g_y2)
