@@ -336,3 +336,32 @@ def test_quadruplet_runner_fill_equals_pad_indices(golden_model2):
         got = runner.padded_inputs()
         for k, v in ref.items():
             assert torch.equal(got[k].to(torch.int64), v), k
+
+
+def test_dummy_molecule_geometry_scales_with_the_bond_length():
+    """The dummy molecule's bonds sit at 0.9 x the embedding cutoff (padded.dummy_bond: the radial envelopes have almost closed
+    there, so the pad rows' messages stay ~1e-3 of a real row's — DESIGN.md section 14, "A silent NaN"); angles and the dihedral
+    stay 90 degrees at any bond length, groups never overlap."""
+    from gemnet_pytorch_amd.padded import dummy_bond
+
+    class _M:
+        class cbf_basis3:
+            cutoff = 5.0
+    assert abs(dummy_bond(_M()) - 4.5) < 1e-12 and dummy_bond(object()) == 1.0
+    like = torch.zeros(1, dtype=torch.float64)
+    for bond in (1.0, 4.5):
+        for quad in (False, True):
+            P = dummy_positions(3, like, offset=100.0, quad=quad, bond=bond).reshape(3, 4 if quad else 3, 3)
+            a, b, c = P[:, 0], P[:, 1], P[:, 2]
+            assert torch.allclose((b - a).norm(dim=1), torch.full((3,), bond, dtype=torch.float64))
+            assert torch.allclose((c - a).norm(dim=1), torch.full((3,), bond, dtype=torch.float64))
+            assert float(((b - a) * (c - a)).sum(dim=1).abs().max()) < 1e-9          # angle c-a-b = 90 degrees
+            if quad:
+                d = P[:, 3]
+                assert torch.allclose((d - b).norm(dim=1), torch.full((3,), bond, dtype=torch.float64))
+                assert float(((a - b) * (d - b)).sum(dim=1).abs().max()) < 1e-9      # angle a-b-d
+                n1, n2 = torch.cross(c - a, b - a, dim=1), torch.cross(a - b, d - b, dim=1)
+                assert float((n1 * n2).sum(dim=1).abs().max()) < 1e-9                 # dihedral c-a-b-d
+            flat = P.reshape(-1, 3)
+            dist = (flat[:, None] - flat[None]).norm(dim=2) + torch.eye(flat.shape[0], dtype=torch.float64) * 1e9
+            assert float(dist.min()) >= 0.99 * bond
