@@ -38,11 +38,28 @@ inline unsigned key_bits(int64_t n_rows) {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// rocPRIM's default switches to a MERGE sort below 2^20 items: ~21 launches of 5-6 us.  Measured (profiles/r5_csr_onesweep_ab.txt):
+// for the 100 k .. 600 k keys of a batch's triplet / intermediate-triplet groupings Onesweep over the <= 20 significant bits (a
+// histogram + two or three passes) is faster (GemNet-Q new-batch replay 16.30 -> 16.07 ms), for the few thousand keys of a single
+// molecule's plan it is slower (MD step 2.40 -> 2.56 ms): the choice is made per call by size.
+//   GN_CSR_ONESWEEP_FROM: smallest item count sorted by Onesweep (A/B builds: 1048577 = rocPRIM's default everywhere).
+#ifndef GN_CSR_ONESWEEP_FROM
+#define GN_CSR_ONESWEEP_FROM 100000
+#endif
+using cfg_onesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)4096>;
+using cfg_default = rocprim::default_config;
+
+template <class Cfg>
+inline hipError_t sort_pairs(void* temp, size_t& bytes, const int32_t* keys, int32_t* sorted, int32_t* perm, int64_t n, unsigned bits,
+                             hipStream_t st) {
+  return rocprim::radix_sort_pairs<Cfg>(temp, bytes, keys, sorted, rocprim::counting_iterator<int32_t>(0), perm, (size_t)n, 0u, bits, st);
+}
+inline bool use_onesweep(int64_t n) { return n >= (int64_t)GN_CSR_ONESWEEP_FROM; }
+
 inline size_t sort_temp_bytes(int64_t n, unsigned bits) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                                  rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), (size_t)n, 0u, bits,
-                                  static_cast<hipStream_t>(nullptr));
+  if (use_onesweep(n)) (void)sort_pairs<cfg_onesweep>(nullptr, bytes, nullptr, nullptr, nullptr, n, bits, nullptr);
+  else (void)sort_pairs<cfg_default>(nullptr, bytes, nullptr, nullptr, nullptr, n, bits, nullptr);
   return bytes;
 }
 
@@ -74,8 +91,8 @@ extern "C" int gn_csr_build_i32(const int32_t* keys, int64_t n, int64_t n_rows, 
   char* temp = static_cast<char*>(ws) + align256((size_t)n * sizeof(int32_t));
   size_t temp_bytes = (size_t)ws_bytes - align256((size_t)n * sizeof(int32_t));
   // stable: equal keys keep their input order — the permutation of torch.argsort(keys, stable=True)
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted, rocprim::counting_iterator<int32_t>(0), perm, (size_t)n, 0u,
-                                           bits, st);
+  const hipError_t e = use_onesweep(n) ? sort_pairs<cfg_onesweep>(temp, temp_bytes, keys, sorted, perm, n, bits, st)
+                                       : sort_pairs<cfg_default>(temp, temp_bytes, keys, sorted, perm, n, bits, st);
   if (e != hipSuccess) return (int)e;
   return gn_seg_offsets_i32(sorted, n, n_rows, seg_off, stream);
 }

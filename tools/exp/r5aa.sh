@@ -1,0 +1,18 @@
+#!/bin/bash
+O=gpurun_out/r5aa; mkdir -p $O
+export PYTHONPATH=$PWD:$PWD/tests
+timeout 600 python -m pytest tests/test_gpu_index.py tests/test_gpu_padded.py tests/test_gpu_index_in_graph.py -q -x -p no:cacheprovider 2>&1 | grep -E "passed|failed|Error" | tail -3 | tee $O/ab.txt
+for v in default csrmerge; do L=""; [ $v != default ] && L=$PWD/tools/exp/bin/libgemnet_hip_$v.so
+GEMNET_HIP_LIB=$L timeout 600 python - <<PY 2>/dev/null | tee -a $O/ab.txt
+import json, torch, bench
+from gemnet_pytorch_amd.model.gemnet import GemNet
+for tri in (True, False):
+    cfg = dict(bench.GEMNET_T, triplets_only=tri)
+    torch.manual_seed(1234)
+    model = GemNet(**cfg, scale_file=bench.SCALE_FILE).to("cuda").eval(); model.requires_grad_(False)
+    d = bench.extra_dynamic_shape(cfg, model, 32, 32, 0, n_batches=3, steps=6 if not tri else 12, warmup=2)
+    p = d.get("padded_graph", {})
+    print("$v", "T" if tri else "Q", "dynamic:", p.get("ms_per_step"), "ms padded;", p.get("index_in_graph", {}).get("ms_per_step"), "in-graph index", p.get("error"))
+PY
+GEMNET_HIP_LIB=$L timeout 300 python tools/exp/md_bench.py 48 40 2>&1 | grep "GemNet-" | cut -c1-60 | sed "s/^/$v /" | tee -a $O/ab.txt
+done
