@@ -83,6 +83,7 @@ SIGNATURES = {
     "gn_index_gpu_padded_t": [_vp, _i, _vp, _vp, _i, _i, _i, _i64, ctypes.c_double, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp],
     "gn_index_poison_f32": [_vp, _i64, _vp, _vp],
+    "gn_expanded_csr_i32": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "gn_cbf_project_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_cbf_project_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_force_loss_f32": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],

@@ -63,7 +63,74 @@ inline size_t sort_temp_bytes(int64_t n, unsigned bits) {
   return bytes;
 }
 
+// ---- CSR of items grouped by edge, by the row of their edge, without sorting the item keys -----------------------------------
+// The triplets are sorted by their reduce edge (item range of edge e: so[e] .. so[e+1]); their CSR by the ATOM of that edge is
+// the edge CSR (perm_e, seg_e: E keys) expanded into item ranges: slot i of the edge CSR owns the items so[order[i]] .. and
+// lands at off[i] = sum of the item counts of the slots before it — the permutation of the stable sort of the T item keys.
+// (graph.expanded_csr did this with ~13 ATen launches per grouping, two groupings per plan, inside every dynamic replay.)
+__global__ __launch_bounds__(1024) void expanded_scan_kernel(const int32_t* __restrict__ perm_e, const int32_t* __restrict__ so,
+                                                             int64_t E, int32_t* __restrict__ off) {
+  __shared__ int64_t wsum[16];
+  __shared__ int64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < E; base += 1024) {
+    const int64_t i = base + tid;
+    int64_t v = 0;
+    if (i < E) {
+      const int64_t e = perm_e ? perm_e[i] : i;
+      v = (int64_t)so[e + 1] - so[e];
+    }
+    int64_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t t = __shfl_up(s, o, 64);
+      if (lane >= o) s += t;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int64_t carry = carry_s;
+    if (i < E) off[i] = (int32_t)(carry + woff + s - v);
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + s;
+    __syncthreads();
+  }
+  if (tid == 0) off[E] = (int32_t)carry_s;
+}
+
+// 16 lanes per slot of the edge CSR write its item range; the first n_rows + 1 threads also write the row offsets
+__global__ __launch_bounds__(256) void expanded_fill_kernel(const int32_t* __restrict__ perm_e, const int32_t* __restrict__ seg_e,
+                                                            const int32_t* __restrict__ so, const int32_t* __restrict__ off,
+                                                            int64_t E, int64_t n_rows, int32_t* __restrict__ perm,
+                                                            int32_t* __restrict__ seg_out) {
+  const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  for (int64_t r = gid; r <= n_rows; r += nth) seg_out[r] = off[seg_e[r]];
+  const int sub = threadIdx.x & 15;
+  for (int64_t i = gid >> 4; i < E; i += nth >> 4) {
+    const int64_t e = perm_e ? perm_e[i] : i;
+    const int32_t first = so[e], cnt = so[e + 1] - first, o = off[i];
+    for (int32_t j = sub; j < cnt; j += 16) perm[o + j] = first + j;
+  }
+}
+
 }  // namespace
+
+extern "C" int gn_expanded_csr_i32(const int32_t* perm_e, const int32_t* seg_e, int64_t n_rows, const int32_t* seg_off_of_edge,
+                                   int64_t E, int32_t* perm, int32_t* seg_out, int32_t* ws, void* stream) {
+  if (E < 0 || n_rows < 0 || !ws) return (int)hipErrorInvalidValue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(expanded_scan_kernel, dim3(1), dim3(1024), 0, st, perm_e, seg_off_of_edge, E, ws);
+  int64_t nb = (E * 16 + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(expanded_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, perm_e, seg_e, seg_off_of_edge, (const int32_t*)ws, E,
+                     n_rows, perm, seg_out);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int64_t gn_csr_ws_bytes(int64_t n, int64_t n_rows) {
   if (n <= 0) return 256;

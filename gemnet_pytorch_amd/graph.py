@@ -75,6 +75,10 @@ def expanded_csr(row_of_edge: RowIndex, seg_off_of_edge: torch.Tensor, n_items: 
     E keys) expanded into item ranges — the same permutation as the stable sort of the T item keys (edges of a row in
     increasing order, the items of an edge in increasing order), without sorting T keys."""
     perm_e, seg_e = row_of_edge.csr
+    if seg_e.is_cuda and _native_csr() and seg_e.dtype == torch.int32 and seg_off_of_edge.dtype == torch.int32:
+        from . import kernels as _K
+        if _K.USE_NATIVE_EXPANDED:
+            return _K.expanded_csr(perm_e, seg_e, seg_off_of_edge, n_items)
     so = seg_off_of_edge.to(torch.int64)
     cnt = so[1:] - so[:-1]
     order = perm_e.to(torch.int64) if perm_e is not None else torch.arange(cnt.shape[0], device=cnt.device)

@@ -184,6 +184,22 @@ def segsum_multi(terms, n_rows):
 
 
 USE_NATIVE_CSR = os.environ.get("GEMNET_NATIVE_CSR", "1") == "1"
+USE_NATIVE_EXPANDED = os.environ.get("GEMNET_NATIVE_EXPANDED", "1") == "1"     # graph.expanded_csr through gn_expanded_csr_i32
+
+
+def expanded_csr(perm_e, seg_e, seg_off_of_edge, n_items):
+    """(perm int32 (n_items), seg_off int32 (n_rows + 1)) of items sorted by edge, grouped by the row of their edge, from the edge
+    CSR (perm_e or None, seg_e) — gn_expanded_csr_i32 (two launches; graph.expanded_csr's torch form was ~13)."""
+    require_device(seg_e, seg_off_of_edge)
+    assert seg_e.dtype == torch.int32 and seg_off_of_edge.dtype == torch.int32 and (perm_e is None or perm_e.dtype == torch.int32)
+    E, n_rows = int(seg_off_of_edge.shape[0]) - 1, int(seg_e.shape[0]) - 1
+    dev = seg_e.device
+    perm = torch.empty(int(n_items), dtype=torch.int32, device=dev)
+    seg = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    ws = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    check(_lib.load().gn_expanded_csr_i32(ptr(perm_e), ptr(seg_e), n_rows, ptr(seg_off_of_edge), E, ptr(perm), ptr(seg), ptr(ws),
+                                          stream()), "gn_expanded_csr_i32")
+    return perm, seg
 
 
 def csr_build(idx32, n_rows):

@@ -383,6 +383,12 @@ int64_t gn_csr_ws_bytes(int64_t n, int64_t n_rows);
 int gn_csr_build_i32(const int32_t* keys, int64_t n, int64_t n_rows, int32_t* perm, int32_t* seg_off, void* ws,
                      int64_t ws_bytes, void* stream);
 int gn_seg_offsets_i32(const int32_t* sorted_keys, int64_t n, int64_t n_rows, int32_t* seg_off, void* stream);
+/* CSR (perm (T), seg_out (n_rows + 1)) of T items that are sorted by their EDGE (item range of edge e: seg_off_of_edge[e] ..
+ * seg_off_of_edge[e+1]) by the ROW of that edge, from the edge CSR (perm_e (E) or NULL = identity, seg_e (n_rows + 1)): the
+ * edge lists expanded into item ranges — the permutation of the stable sort of the T item keys, without sorting them.
+ * ws: E + 1 int32 (device).  Two launches, capturable. (ABI 14) */
+int gn_expanded_csr_i32(const int32_t* perm_e, const int32_t* seg_e, int64_t n_rows, const int32_t* seg_off_of_edge, int64_t E,
+                        int32_t* perm, int32_t* seg_out, int32_t* ws, void* stream);
 
 /* ---- bilinear aggregation, CSR-segmented (P4: efficient.py:159-189 without the zero-padded
  *      (E,Kmax,C) tensors; SURVEY.md Appendix D kernels K1 and its two adjoints) -----------

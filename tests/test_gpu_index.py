@@ -102,3 +102,33 @@ def test_native_csr_build_equals_the_stable_sort(n, n_rows):
     assert torch.equal(perm.long(), ref_perm) and torch.equal(seg.long(), ref_seg)
     srt = dev[ref_perm].to(torch.int32)
     assert torch.equal(K.seg_offsets(srt, n_rows).long(), ref_seg)
+
+
+def test_expanded_csr_equals_the_stable_sort_of_the_item_keys():
+    """gn_expanded_csr_i32: items sorted by edge, grouped by the row (atom) of their edge, from the edge CSR — against the
+    stable argsort of the item keys and the lower bounds of the sorted keys; edges without items, rows without edges, sorted
+    (perm_e = None) and unsorted edge keys."""
+    from gemnet_pytorch_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    for E, n_rows, sorted_keys in ((5000, 257, False), (5000, 257, True), (1, 3, False), (40000, 1200, False)):
+        row_of_edge = torch.randint(0, n_rows, (E,), generator=g, dtype=torch.int32)
+        if n_rows > 4:
+            row_of_edge[row_of_edge == 2] = 3                      # a row without edges
+        if sorted_keys:
+            row_of_edge = torch.sort(row_of_edge).values
+        cnt = torch.randint(0, 30, (E,), generator=g, dtype=torch.int32)
+        cnt[::7] = 0                                               # edges without items
+        so = torch.zeros(E + 1, dtype=torch.int32)
+        so[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+        T = int(so[-1])
+        item_key = torch.repeat_interleave(row_of_edge.long(), cnt.long())
+        want_perm = torch.argsort(item_key, stable=True).to(torch.int32)
+        want_seg = torch.searchsorted(item_key[want_perm.long()].contiguous(), torch.arange(n_rows + 1)).to(torch.int32)
+        rk = row_of_edge.to("cuda")
+        if sorted_keys:
+            perm_e, seg_e = None, K.seg_offsets(rk, n_rows)
+        else:
+            perm_e, seg_e = K.csr_build(rk, n_rows)
+        perm, seg = K.expanded_csr(perm_e, seg_e, so.to("cuda"), T)
+        torch.cuda.synchronize()
+        assert torch.equal(perm.cpu(), want_perm) and torch.equal(seg.cpu(), want_seg), (E, n_rows, sorted_keys)
