@@ -467,6 +467,11 @@ class PaddedGraphRunner:
         """One step with the index build inside the graph: R (A, 3) float32 on the device -> (E, F) as `__call__`."""
         if self.builder is None:
             raise RuntimeError("run_positions needs attach_builder")
+        if R.dtype != self.inputs["R"].dtype or tuple(R.shape) != (self.A, 3):
+            # the neighbour list is built from the graph's own (fp32) position buffer: positions in another precision would
+            # give other neighbours near the cutoff than the caller's own index build
+            raise TypeError(f"run_positions: positions must be {self.inputs['R'].dtype} of shape ({self.A}, 3); got "
+                            f"{R.dtype} {tuple(R.shape)}")
         if self.flag is not None and self.flag.tripped():
             self.recover()
         if self.index_error():
