@@ -277,3 +277,28 @@ def test_accumulate_gradient_recovers_after_an_aborted_pass():
         x1, ys1 = _shared_consumer_graph(False)
         ref, = torch.autograd.grad(sum((y ** 2).sum() for y in ys1), x1)
         torch.testing.assert_close(g, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_plan_groupings_expanded_csr_and_expand_positions():
+    """graph.expanded_csr (the triplets grouped by the atoms of their reduce edge WITHOUT sorting T keys; its device form is
+    gn_expanded_csr_i32) equals the stable sort of the item keys, and SegmentPlan.expand_pos is the inverse of the expand CSR's
+    permutation."""
+    from gemnet_pytorch_amd.graph import RowIndex, SegmentPlan, expanded_csr
+    g = torch.Generator().manual_seed(3)
+    E, n_rows = 500, 41
+    row_of_edge = torch.randint(0, n_rows, (E,), generator=g)
+    cnt = torch.randint(0, 9, (E,), generator=g)
+    so = torch.zeros(E + 1, dtype=torch.int64)
+    so[1:] = torch.cumsum(cnt, 0)
+    T = int(so[-1])
+    perm, seg = expanded_csr(RowIndex(row_of_edge, n_rows), so, T)
+    item_key = torch.repeat_interleave(row_of_edge, cnt)
+    want = torch.argsort(item_key, stable=True)
+    assert torch.equal(perm.long(), want)
+    assert torch.equal(seg.long(), torch.searchsorted(item_key[want].contiguous(), torch.arange(n_rows + 1)))
+    reduce_idx = torch.repeat_interleave(torch.arange(E), cnt)
+    expand_idx = torch.randint(0, 77, (T,), generator=g)
+    sp = SegmentPlan(reduce_idx, expand_idx, E, 77)
+    p, _ = sp.expand.csr
+    pos = sp.expand_pos
+    assert torch.equal(pos[p.long()].long(), torch.arange(T)) and torch.equal(p[pos.long()].long(), torch.arange(T))
