@@ -85,3 +85,16 @@ class DeviceGraphBuilder:
 
 def build_indices_device(R, N, cutoff, int_cutoff, triplets_only=False, dtype=torch.int64):
     return DeviceGraphBuilder(N, cutoff, int_cutoff, triplets_only, device=R.device)(R, dtype=dtype)
+
+
+def ensure_indices(inputs, cutoff, int_cutoff, triplets_only):
+    """`inputs` as `GemNet.forward` takes them; when the index arrays are missing (a `DataContainer(indices="device")` batch:
+    Z, R, N only) they are built here from the device-resident positions — the same arrays, in the same canonical order, as the
+    host builder's (tests/test_gpu_index.py).  One small read-back (the molecule sizes) + the builder's own size read-backs."""
+    if "id_c" in inputs:
+        return inputs
+    R = inputs["R"]
+    require_device(R)      # (no CPU fallback: on the host the arrays come from training.data_container.build_indices)
+    N_host = inputs["N"].detach().cpu().numpy()
+    idx = build_indices_device(R.detach(), N_host, cutoff, int_cutoff, triplets_only, dtype=torch.int32)
+    return dict(inputs, **idx)

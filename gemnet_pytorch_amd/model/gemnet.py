@@ -402,8 +402,22 @@ class GemNet(torch.nn.Module):
         repeats the pass.  (One host read-back per eager forward.  A hipGraph cannot read back: a runner hands its
         `runtime.RangeFlag` in as `inputs["_range_flag"]`, the captured pass ends with the device-side check of the same rows,
         and the runner polls the flag — PaddedGraphRunner, DynamicForceField, ForceGraphs, TrainStep.)"""
+        inputs = self.with_indices(inputs)
         with ops.exclusive():
             return self._forward_guarded(inputs)
+
+    def with_indices(self, inputs):
+        """`inputs` with the index arrays: as given when it has them, else (a `DataContainer(indices="device")` batch: Z, R, N
+        on the device) a new dict with the arrays built on the GPU (index_device.ensure_indices).  Callers that CAPTURE a step
+        call this first: the build reads sizes back, which a stream capture does not allow."""
+        if "id_c" in inputs:
+            return inputs
+        from ..index_device import ensure_indices
+        self._check_inputs(inputs["R"])
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("inputs without index arrays inside a stream capture: call model.with_indices(inputs) first")
+        return ensure_indices(inputs, self.cbf_basis3.cutoff, getattr(getattr(self, "cbf_basis", None), "cutoff", 10.0),
+                              self.triplets_only)
 
     def _forward_guarded(self, inputs):
         out = self._forward(inputs)

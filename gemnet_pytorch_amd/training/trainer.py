@@ -291,6 +291,7 @@ class Trainer:
         self.model.train()
         inputs, targets = next(dataset_iter)
         inputs, targets = self.dict2device(inputs), self.dict2device(targets)
+        inputs = self.model.with_indices(inputs)      # (DataContainer(indices="device"): the index arrays are built here, on the GPU)
         ps = self._padded_step_for(inputs)
         if ps is not None:
             return self._train_on_batch_padded(ps, inputs, targets, metrics)

@@ -113,3 +113,30 @@ def test_rccl_one_rank_all_reduce_inside_train_step():
             dist.destroy_process_group()
     assert got[0] == ref[0]
     assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+
+
+@pytest.mark.parametrize("tag", ["rmse", "quad"])
+def test_loader_batches_without_index_arrays_train_like_batches_with_them(tag):
+    """`DataContainer(indices="device")`: the batches carry Z, R, N and the targets only; `Trainer.train_on_batch` builds the
+    index arrays on the GPU (model.with_indices -> csrc/index_gpu.hip: the same arrays in the same canonical order as the host
+    builder of data_container.py:244-489).  Same reports and the same parameters after three steps as with host-built arrays."""
+    import copy
+    g = np.load(os.path.join(GOLDEN, "trainer.npz"))
+    cfg, kw = ast.literal_eval(str(g[f"{tag}.cfg"])), ast.literal_eval(str(g[f"{tag}.kw"]))
+    data = dict(N=g[f"{tag}.N"], Z=g[f"{tag}.Z"], R=g[f"{tag}.R"], E=g[f"{tag}.Et"], F=g[f"{tag}.Ft"])
+    batches = [[int(i) for i in str(b).split(",")] for b in g[f"{tag}.batches"]]
+    params = GO.make_params(cfg, int(g[f"{tag}.seed"]), GO.load_scale_factors(SCALE_FILE))
+    base = GemNet(**cfg, scale_file=SCALE_FILE)
+    base.load_state_dict(GO.expand_to_reference_state_dict({k: v.float() for k, v in params.items()}), strict=True)
+    out = {}
+    for mode in ("host", "device"):
+        dc = DataContainer.from_arrays(data, 5.0, 10.0, triplets_only=cfg["triplets_only"], indices=mode)
+        b0 = dc[batches[0]]
+        assert ("id_c" in b0) == (mode == "host") and {"Z", "R", "N", "E", "F"} <= set(b0)
+        model = copy.deepcopy(base).to("cuda")
+        trainer = Trainer(model, **kw)
+        it, metrics = stream(dc, batches), Metrics("train", trainer.tracked_metrics)
+        out[mode] = ([float(trainer.train_on_batch(it, metrics)) for _ in range(3)],
+                     torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+    assert out["host"][0] == out["device"][0], (out["host"][0], out["device"][0])
+    assert torch.equal(out["host"][1], out["device"][1])

@@ -207,3 +207,26 @@ def test_ema_checkpoint_layout_matches_reference():
     assert torch.equal(b.shadow, ema.shadow) and b.shadow.data_ptr() != ema.shadow.data_ptr() and b.backup is None
     with pytest.raises(ValueError):
         a.load_state_dict(dict(ref_fmt, shadow_params=ref_fmt["shadow_params"][:1]))
+
+
+def test_data_container_can_leave_the_index_arrays_to_the_device():
+    """`DataContainer(indices="device")` (not in the reference): batches without the index arrays, everything else as before;
+    the model refuses such a batch on the host (no CPU fallback) instead of guessing."""
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    from gemnet_pytorch_amd.training.data_container import DataContainer
+    ds = make_dataset(3, 6, config=1)
+    host = DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=True)
+    dev = DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=True, indices="device")
+    a, b = host[[0, 2]], dev[[0, 2]]
+    assert set(b) == {"E", "N", "Z", "R", "F"} and set(a) > set(b)
+    for k in b:
+        assert torch.equal(a[k], b[k]) and a[k].dtype == b[k].dtype
+    with pytest.raises(ValueError):
+        DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=True, indices="gpu")
+    cfg = dict(num_spherical=7, num_radial=6, num_blocks=1, emb_size_atom=16, emb_size_edge=16, emb_size_trip=16,
+               emb_size_quad=16, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=16, emb_size_bil_quad=16, emb_size_bil_trip=16,
+               num_before_skip=1, num_after_skip=1, num_concat=1, num_atom=1, triplets_only=True)
+    from conftest import SCALE_FILE
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        GemNet(**cfg, scale_file=SCALE_FILE)({k: v for k, v in b.items() if k not in ("E", "F")})
