@@ -141,7 +141,7 @@ class DataContainer:
         data["F"] = self.F[rows].astype(np.float32)
         # cutoff membership is decided in the dtype the positions are stored in (float32 for the
         # npz datasets, float64 when an ASE caller assigns float64 positions to .R)
-        if self.indices == "host":
+        if getattr(self, "indices", "host") == "host":      # (subclasses with their own __init__: ase_calculator.Molecule)
             data.update(build_indices(R, data["N"], self.cutoff, self.int_cutoff, self.triplets_only))
         return self.convert_to_tensor(data)
 
