@@ -629,8 +629,80 @@ def golden_tfnames():
         json.dump(out, f, indent=1)
 
 
+# ------------------------------------------------------- G7: BASELINE-size fixtures (round 6)
+def _index_digest(idx, triplets_only):
+    """sizes + SHA-256 (int32 little-endian bytes) of the canonicalised reference index arrays."""
+    import hashlib
+    from oracle import index_oracle as IO
+    can = IO.canonicalize({k: np.asarray(v) for k, v in idx.items()}, triplets_only)
+    return {k: dict(n=int(np.asarray(v).shape[0]),
+                    sha256=hashlib.sha256(np.ascontiguousarray(np.asarray(v).astype("<i4")).tobytes()).hexdigest())
+            for k, v in sorted(can.items())}
+
+
+def run_fullsize(cfg, seed, ds, tag, out, digests):
+    """Reference forward+force in float64 on a generated dataset `ds` (all its molecules in ONE batch); the output
+    heads rescaled to mean|F| = 1 eV/A.  Only E, F, the head scale and the (seeded, regenerable) positions are stored;
+    the reference's index arrays go into `digests` as sizes + SHA-256 of their canonical form."""
+    import time
+    to = cfg["triplets_only"]
+    t0 = time.time()
+    dc = _MemContainer(dict(ds), 5.0, 10.0, to)
+    batch = dc[list(range(len(ds["N"])))]
+    t_idx = time.time() - t0
+    digests[tag] = _index_digest({k: batch[k].numpy() for k in dc.index_keys}, to)
+    sf = GO.load_scale_factors(SCALE_FILE)
+    params = GO.make_params(cfg, seed, sf, dtype=torch.float64)
+    inputs = {k: v for k, v in batch.items() if k not in ("E", "F")}
+    inputs["R"] = inputs["R"].double()
+    model = GemNet(**cfg, scale_file=SCALE_FILE).double()
+    model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
+    model.train()
+    t0 = time.time()
+    _, F0 = model(dict(inputs))
+    t_fwd = time.time() - t0
+    scale = 1.0 / float(F0.detach().abs().mean())
+    del F0
+    model.load_state_dict(GO.expand_to_reference_state_dict(scale_heads(params, scale)), strict=True)
+    E, F = model(dict(inputs))
+    out[f"{tag}.seed"], out[f"{tag}.cfg"], out[f"{tag}.out_scale"] = np.array(seed), np.array(repr(cfg)), np.array(scale)
+    out[f"{tag}.N"], out[f"{tag}.Z"], out[f"{tag}.R"] = ds["N"], ds["Z"], ds["R"]
+    out[f"{tag}.E"], out[f"{tag}.F"] = E.detach().numpy(), F.detach().numpy()
+    print(tag, "E", E.detach().numpy().ravel()[:3], "mean|F|", float(F.detach().abs().mean()), "out_scale", scale,
+          {k: int(batch[k].shape[0]) for k in ("id_a", "id3_reduce_ca") + (() if to else ("id4_reduce_ca",))},
+          f"index {t_idx:.1f} s, reference forward+force {t_fwd:.1f} s (float64)", flush=True)
+
+
+def golden_fullsize():
+    """-> fullsize.npz + fullsize_index.json: the workloads BASELINE.json names, run by the REFERENCE in float64 with
+    the published 4-block configurations (gemnet/model/gemnet.py:453-615, training/data_container.py:244-489):
+      t64s / q64s   one 64-atom molecule (configs[4]'s molecule size), GemNet-T and GemNet-Q
+      tB32          the 32 x 32-atom GemNet-T batch of configs[1] (bench.py's rank-0 workload: make_dataset(32, 32, config=2))
+      qB4           a 4 x 32-atom GemNet-Q batch (configs[2]'s per-molecule workload, batched)
+    and index digests (sizes + SHA-256 of the canonical arrays) at 32 atoms, 64 atoms and for the B = 32 batch, T and Q."""
+    import json
+    out, digests = {}, {}
+    m64 = make_molecule(64, 4000)
+    one64 = dict(N=np.array([64], np.int32), Z=m64["Z"], R=m64["R"], E=np.zeros(1, np.float32), F=np.zeros_like(m64["R"]))
+    run_fullsize(cfg_full(True, 4), 7, one64, "t64s", out, digests)
+    run_fullsize(cfg_full(False, 4), 8, one64, "q64s", out, digests)
+    run_fullsize(cfg_full(True, 4), 5, make_dataset(32, 32, config=2), "tB32", out, digests)
+    run_fullsize(cfg_full(False, 4), 6, make_dataset(4, 32, config=2), "qB4", out, digests)
+    # index-only digests: one 32-atom molecule (T and Q), the B = 32 batch as GemNet-Q sees it
+    for tag, ds, to in (("idx32.T", make_dataset(1, 32, config=2), True), ("idx32.Q", make_dataset(1, 32, config=2), False),
+                        ("idxB32.Q", make_dataset(32, 32, config=2), False)):
+        dc = _MemContainer(dict(ds), 5.0, 10.0, to)
+        batch = dc[list(range(len(ds["N"])))]
+        digests[tag] = _index_digest({k: batch[k].numpy() for k in dc.index_keys}, to)
+        print(tag, {k: v["n"] for k, v in digests[tag].items()}, flush=True)
+    np.savez_compressed(os.path.join(HERE, "fullsize.npz"), **out)
+    with open(os.path.join(HERE, "fullsize_index.json"), "w") as f:
+        json.dump(digests, f, indent=1)
+    print("fullsize.npz", len(out), "arrays; fullsize_index.json", len(digests), "digests")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["basis", "indices", "models", "models2", "keys", "trainer", "scaling", "tfnames"]
+    which = sys.argv[1:] or ["basis", "indices", "models", "models2", "keys", "trainer", "scaling", "tfnames", "fullsize"]
     if "tfnames" in which:
         golden_tfnames()
     if "scaling" in which:
@@ -647,3 +719,5 @@ if __name__ == "__main__":
         golden_models2()
     if "keys" in which:
         golden_keys()
+    if "fullsize" in which:
+        golden_fullsize()

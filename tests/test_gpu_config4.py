@@ -3,8 +3,8 @@
 products: fp32-equivalent; the config's "bf16" operand mode was measured slower and 4e-2 eV/A off and is no longer a model
 option) — through the size-independent properties of tests/test_gpu_fullsize.py (the float64 reference does not finish 126 M quadruplets):
   * sum of forces = 0 per molecule,
-  * batch additivity against per-molecule runs (the 64-atom single-molecule size is the golden-covered one: q4s/q2s are
-    single molecules of the same published configuration),
+  * batch additivity against per-molecule runs (the single 64-atom molecule of this configuration is pinned to the REFERENCE
+    directly: fixture q64s of tests/test_gpu_fullsize_golden.py, 2.04 M quadruplets, float64),
   * hipGraph replay == eager, bit for bit.
 The index arrays come from the device builder (csrc/index_gpu.hip, bit-exact vs the reference goldens in
 tests/test_gpu_index.py); the per-molecule runs use the host builder, so the two builders are cross-checked too."""

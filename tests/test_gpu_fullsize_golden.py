@@ -1,0 +1,70 @@
+"""-m gpu: the HIP path against REFERENCE-run float64 goldens at the sizes BASELINE.json names (tests/golden/fullsize.npz,
+written by make_golden.py::golden_fullsize from gemnet/model/gemnet.py:453-615 with the published 4-block configurations, heads
+rescaled to mean|F| = 1 eV/A so that the north-star bar — force MAE <= 1e-5 eV/A — is asserted literally):
+  t64s / q64s  one 64-atom molecule (configs[4]'s molecule size; 2.04 M quadruplets), GemNet-T / GemNet-Q
+  tB32         the 32 x 32-atom GemNet-T batch of configs[1] — the headline workload of bench.py, rank 0
+  qB4          a 4 x 32-atom GemNet-Q batch (configs[2])
+Inputs come from the seeded generator through the product's own DataContainer (host index builder) AND through the device
+index builder (csrc/index_gpu.hip); both builders are also checked bit-exactly against the reference's index arrays
+(sizes + SHA-256 of the canonical form, tests/golden/fullsize_index.json; training/data_container.py:244-489)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SCALE_FILE
+from fullsize_common import dataset, digest, load_digests, load_fullsize, params_of, triplets_only
+from oracle import gemnet_oracle as GO
+from gemnet_pytorch_amd.model.gemnet import GemNet
+from gemnet_pytorch_amd.training.data_container import DataContainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FORCE_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def g():
+    return load_fullsize()
+
+
+def _inputs(tag, builder):
+    ds, to = dataset(tag), triplets_only(tag)
+    if builder == "host":
+        dc = DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=to)
+        batch = dc[list(range(len(ds["N"])))]
+        return {k: v.to(DEV) for k, v in batch.items() if k not in ("E", "F")}
+    from gemnet_pytorch_amd.index_device import DeviceGraphBuilder
+    R = torch.tensor(ds["R"], device=DEV)
+    idx = DeviceGraphBuilder(ds["N"], 5.0, 10.0, to, device=DEV)(R)
+    return dict(Z=torch.tensor(ds["Z"], device=DEV).long(), R=R, N=torch.tensor(ds["N"], device=DEV).long(), **idx)
+
+
+@pytest.mark.parametrize("builder", ["host", "device"])
+@pytest.mark.parametrize("tag", ["t64s", "q64s", "tB32", "qB4"])
+def test_energy_force_parity_at_baseline_sizes(g, tag, builder):
+    cfg, params = params_of(g, tag)
+    model = GemNet(**cfg, scale_file=SCALE_FILE)
+    model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
+    model = model.to(DEV).eval()
+    E, F = model(_inputs(tag, builder))
+    Eref, Fref = g[f"{tag}.E"], g[f"{tag}.F"]
+    assert tuple(F.shape) == Fref.shape and abs(float(np.abs(Fref).mean()) - 1.0) < 1e-9
+    f_mae = float(np.abs(F.detach().cpu().numpy() - Fref).mean())
+    f_max = float(np.abs(F.detach().cpu().numpy() - Fref).max())
+    e_err = float(np.abs(E.detach().cpu().numpy().reshape(Eref.shape) - Eref).max())
+    print(f"{tag} [{builder} indices]: force MAE {f_mae:.3e} eV/A (max {f_max:.3e}) at mean|F_ref| = 1, energy err {e_err:.3e} "
+          f"(max|E_ref| {float(np.abs(Eref).max()):.3f})")
+    assert f_mae <= FORCE_TOL
+    assert e_err <= 2e-5 * max(1.0, float(np.abs(Eref).max()))
+
+
+@pytest.mark.parametrize("tag", ["t64s", "q64s", "tB32", "qB4", "idx32.T", "idx32.Q", "idxB32.Q"])
+def test_device_index_builder_matches_reference_digest(tag):
+    from gemnet_pytorch_amd.index_device import build_indices_device
+    ds, to = dataset(tag), triplets_only(tag)
+    out = build_indices_device(torch.tensor(ds["R"], device=DEV), ds["N"], 5.0, 10.0, to)
+    got = digest({k: v.cpu().numpy() for k, v in out.items()}, to)
+    ref = load_digests()[tag]
+    assert sorted(got) == sorted(ref)
+    for k in ref:
+        assert got[k] == ref[k], (tag, k, got[k]["n"], ref[k]["n"])
