@@ -217,5 +217,5 @@ extern "C" int gn_pm_f32(const float* z, int k, const float* a, const float* b, 
   return 0;
 }
 
-extern "C" int gn_abi_version(void) { return 14; }
+extern "C" int gn_abi_version(void) { return 15; }
 extern "C" const char* gn_error_string(int code) { return hipGetErrorString((hipError_t)code); }

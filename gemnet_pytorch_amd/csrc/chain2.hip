@@ -485,7 +485,10 @@ __global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, 
         }
       }
 #undef GN2_ACC
-      wload_op(bcur, gord);   // next GEMM's fragments (no-op after the last one): in flight under the epilogue
+      // next GEMM's fragments (no-op after the last one): in flight under the epilogue.  (Requested behind the epilogue's
+      // global stores instead — so that the in-order vmcnt wait of the next op never covers a store — measured round 6:
+      // no change, 1 082 vs 1 088 us per step of chain launches.)
+      wload_op(bcur, gord);
 #ifdef GN_CHAIN_TRACE
       if (active) { float sink = 0.f; for (int t = 0; t < RT; ++t) sink += v[t].x; if (sink == 1.2345e30f) smem[0] = 1; }
 #endif
@@ -673,9 +676,16 @@ int dispatch_adj(const gn_chain_args* args, bool adj, hipStream_t st) {
   return adj ? dispatch_rt<NPL, true, HF>(args, st) : dispatch_rt<NPL, false, HF>(args, st);
 }
 
-// eight consecutive k of one weight row -> the planes of (tile, chunk) unit tc: fmt 0 three bf16 planes, 1 two fp16 planes
+// K index of element i (0..7) that lane group g (= lane / 16) supplies to k-chunk c of an MFMA: the natural order, or
+// (GN_SPLIT_F16X2_ROW, csrc/chain4.hip) the order in which the accumulators of the PREVIOUS layer hold a row's columns —
+// lane group g owns columns 16 j + 4 g .. + 3 of every column tile j, chunk c takes tiles 2 c and 2 c + 1
+__device__ __forceinline__ int pack_k(int fmt, int c, int g, int i) {
+  return fmt == GN_SPLIT_F16X2_ROW ? 16 * (2 * c + (i >> 2)) + 4 * g + (i & 3) : c * 32 + (g << 3) + i;
+}
+
+// eight k of one weight row -> the planes of (tile, chunk) unit tc: fmt 0 three bf16 planes, 1 two fp16 planes
 __device__ __forceinline__ void pack_unit(const float (&x)[8], uint4* __restrict__ out, int tc, int lane, int fmt) {
-  if (fmt == GN_SPLIT_F16X2) {
+  if (fmt == GN_SPLIT_F16X2 || fmt == GN_SPLIT_F16X2_ROW) {
     uint2 H0, L0, H1, L1;
     split4h(make_float4(x[0], x[1], x[2], x[3]), H0, L0);
     split4h(make_float4(x[4], x[5], x[6], x[7]), H1, L1);
@@ -701,11 +711,11 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ W, int N, int
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (tile, chunk, lane)
   if (idx >= n_tiles * kc * 64) return;
   const int lane = idx & 63, tc = idx >> 6, c = tc % kc, tile = tc / kc;
-  const int n = tile * 16 + (lane & 15), k0 = c * 32 + ((lane >> 4) << 3);
+  const int n = tile * 16 + (lane & 15);
   float x[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int k = k0 + i;
+    const int k = pack_k(fmt, c, lane >> 4, i);
     x[i] = (n < N && k < K) ? (trans ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k]) : 0.f;
   }
   pack_unit(x, out, tc, lane, fmt);
@@ -725,11 +735,11 @@ __global__ void pack_weight_split_grouped_kernel(const gn_pack_job* __restrict__
   const int u = idx - j.unit_begin;
   const int kc = (j.K + 31) >> 5;
   const int lane = u & 63, tc = u >> 6, c = tc % kc, tile = tc / kc;
-  const int n = tile * 16 + (lane & 15), k0 = c * 32 + ((lane >> 4) << 3);
+  const int n = tile * 16 + (lane & 15);
   float x[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int k = k0 + i;
+    const int k = pack_k(j.fmt, c, lane >> 4, i);
     x[i] = (n < j.N && k < j.K) ? (j.trans ? j.W[(size_t)k * j.ldw + n] : j.W[(size_t)n * j.ldw + k]) : 0.f;
   }
   pack_unit(x, static_cast<uint4*>(j.out), tc, lane, j.fmt);
@@ -757,7 +767,7 @@ extern "C" int64_t gn_pack_weight_split_bytes(int N, int K) {
 
 extern "C" int gn_pack_weight_split_fmt(const float* W, int N, int K, int ldw, int trans, int fmt, void* out, void* stream) {
   if (N <= 0 || K <= 0) return 0;
-  if (fmt != GN_SPLIT_BF16X3 && fmt != GN_SPLIT_F16X2) return (int)hipErrorInvalidValue;
+  if (fmt != GN_SPLIT_BF16X3 && fmt != GN_SPLIT_F16X2 && fmt != GN_SPLIT_F16X2_ROW) return (int)hipErrorInvalidValue;
   const int n_tiles = gn_cdiv(N, 16), kc = gn_cdiv(K, 32);
   const int total = n_tiles * kc * 64;
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3(gn_cdiv(total, 256)), dim3(256), 0,
@@ -776,6 +786,8 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
   if (args->M > (1 << 24)) return (int)hipErrorInvalidValue;
   // wide layout: tile height (GN_CHAIN_WIDE_ROWS) and start-up stagger (GN_CHAIN_WIDE_STAGGER) ride in the upper bits of `nprod`
   // — per call, no library state (ABI 13)
+  const bool row = nprod == (GN_CHAIN_F16X2 | GN_CHAIN_ROW);
+  if (row) nprod = GN_CHAIN_F16X2;
   const bool wide = (nprod & 0xfff) == (GN_CHAIN_F16X2 | GN_CHAIN_WIDE);
   const int wide_rows = ((nprod >> 12) & 0xf) * 8, wide_stagger = (nprod >> 16) & 0xffff;
   if (!wide && (nprod & ~0xfff)) return (int)hipErrorInvalidValue;
@@ -817,6 +829,7 @@ extern "C" int gn_chain_split_f32(const gn_chain_args* args, int nprod, void* st
       adj = adj || o.slot == 2 || (o.kind == GN_OP_LOAD && o.y2_slot >= 0) || o.src_stage != 0;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (row) return gn_chain_row_dispatch(args, adj, st);     // chain4.hip (its weights: GN_SPLIT_F16X2_ROW)
   if (wide) {      // chain3.hip: 4 waves x 32 columns, two workgroups per CU — it has no parking slot
     bool park = false;
     for (int i = 0; i < args->n_ops; ++i) {

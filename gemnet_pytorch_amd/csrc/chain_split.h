@@ -12,6 +12,8 @@ typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 
 // chain3.hip: the wide layout of the two-plane fp16 arithmetic (argument checks are done by the caller, gn_chain_split_f32)
 int gn_chain_wide_dispatch(const gn_chain_args* args, bool adj, int forced_tile_rows, int stagger, hipStream_t st);
+// chain4.hip: the row-resident layout (a wave owns 16 rows and all columns; weights packed with GN_SPLIT_F16X2_ROW)
+int gn_chain_row_dispatch(const gn_chain_args* args, bool adj, hipStream_t st);
 
 namespace gn_split {
 

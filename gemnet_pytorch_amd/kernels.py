@@ -863,8 +863,16 @@ def use_mode(mode):
 # the edge-row programs take the same time in both (a wave of either layout does the same amount of work per op, and two
 # co-resident workgroups neither help nor disturb each other), the atom-row programs are 25-35 % slower in the wide one —
 # "tall" stays the default; programs that use the parking slot always take it (the library decides).
+# "row" (round 6) = csrc/chain4.hip: a wave owns 16 ROWS and all columns, the slots are fp32 register arrays, the fp16 planes of
+# every GEMM operand are formed under a fresh row scale (no fp16 range limit on activations, no `h3_hazards`), only the weights
+# pass through LDS (GN_CHAIN_ROW; weights packed with GN_SPLIT_F16X2_ROW = 2).  Same arithmetic ("h3": two fp16 planes, three
+# products) to fp32 rounding.  Measured slower than "tall" on the batch sizes of BASELINE.json (profiles/r6_chain4_*.txt: 1 133
+# row blocks on 1 024 SIMDs put two 16-row waves on one SIMD of every CU, and a wave's ds_read_b128 stream of weight fragments
+# runs at ~28 B/clk) — selectable, not the default.
 CHAIN_LAYOUT = os.environ.get("GEMNET_CHAIN_LAYOUT", "tall")
 GN_CHAIN_WIDE = 0x100
+GN_CHAIN_ROW = 0x200
+GN_SPLIT_F16X2_ROW = 2
 # per-launch tuning of the wide layout (GN_CHAIN_WIDE_ROWS / GN_CHAIN_WIDE_STAGGER bits of `nprod`; 0 = automatic / none)
 WIDE_TILE_ROWS = int(os.environ.get("GN_CHAIN_TILE_ROWS", "0"))
 WIDE_STAGGER = int(os.environ.get("GN_CHAIN_STAGGER", "0"))
@@ -881,8 +889,9 @@ def linear_mode(mode):
 
 
 def split_format(mode=None):
-    """Packed-weight format (GN_SPLIT_*) of a chain mode; None for the f32 kernel."""
-    return SPLIT_FORMAT.get(mode or current_mode())
+    """Packed-weight format (GN_SPLIT_*) of a chain mode in the current kernel layout; None for the f32 kernel."""
+    fmt = SPLIT_FORMAT.get(mode or current_mode())
+    return GN_SPLIT_F16X2_ROW if (fmt == 1 and CHAIN_LAYOUT == "row") else fmt
 
 
 def pack_weight_split(W, trans=False, fmt=None):
@@ -939,6 +948,26 @@ def chain_split_supported(prog):
                 return False
         elif o["slot"] > 1 or o.get("y2", -1) > 1:
             return False
+    return True
+
+
+def chain_row_supported(prog):
+    """What the row-resident layout (csrc/chain4.hip) takes on top of chain_split_supported: K and every width a multiple of 16."""
+    for o in prog.ops:
+        if o["kind"] == "gemm":
+            if o["W"].shape[1] % 16:
+                return False
+        elif o["kind"] == "load":
+            if o["src"].shape[1] % 16:
+                return False
+        elif o["kind"] == "store":
+            if o["out"].shape[1] % 16:
+                return False
+        else:
+            Z, out = o["Z"], o["out"]
+            w = o["width"] or (Z.shape[1] if Z is not None else out.shape[1])
+            if w % 16:
+                return False
     return True
 
 
@@ -1033,7 +1062,13 @@ def chain(prog, mode=None):
     if nprod and not chain_split_supported(prog):
         nprod = 0
     fmt = SPLIT_FORMAT.get(mode, 0)
-    if nprod == CHAIN_MODES["h3"] and h3_hazards(prog):
+    row = nprod == CHAIN_MODES["h3"] and CHAIN_LAYOUT == "row"
+    if row and not chain_row_supported(prog):
+        raise RuntimeError("chain: the row-resident layout needs K and every width to be a multiple of 16 "
+                           "(GEMNET_CHAIN_LAYOUT=tall runs other shapes)")
+    if row:
+        fmt = GN_SPLIT_F16X2_ROW
+    if nprod == CHAIN_MODES["h3"] and not row and h3_hazards(prog):
         raise RuntimeError("chain: this linear program adds a global tensor into an LDS-resident value "
                            f"(ops {h3_hazards(prog)}): not representable in the row-scaled fp16 form 'h3' — "
                            "launch it in kernels.linear_mode('h3')")
@@ -1156,7 +1191,9 @@ def chain(prog, mode=None):
         raise RuntimeError("chain programs with second-order source terms run on the split-operand kernel only "
                            "(CHAIN_MODE f32 / an unsupported shape): use the composite training path")
     cbuf = (ctypes.c_char * args_size).from_buffer(buf)
-    if nprod == CHAIN_MODES["h3"] and CHAIN_LAYOUT == "wide":
+    if row:
+        nprod |= GN_CHAIN_ROW
+    elif nprod == CHAIN_MODES["h3"] and CHAIN_LAYOUT == "wide":
         if WIDE_TILE_ROWS and (WIDE_TILE_ROWS % 8 or not 8 <= WIDE_TILE_ROWS <= 48):
             raise ValueError("GN_CHAIN_TILE_ROWS: a multiple of 8 in 8..48")
         nprod |= GN_CHAIN_WIDE | ((WIDE_TILE_ROWS // 8) << 12) | ((max(WIDE_STAGGER, 0) & 0xffff) << 16)

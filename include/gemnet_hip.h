@@ -162,6 +162,13 @@ int gn_chain_f32(const gn_chain_args* args, void* stream);
 /* Per-launch tuning of the wide layout, OR-ed into `nprod` (ABI 13: until ABI 12 two process-global setters):
  * GN_CHAIN_WIDE_ROWS(r), r a multiple of 8 in 8..48, fixes the tile height (0 = gn_chain_wide_tile_rows(M));
  * GN_CHAIN_WIDE_STAGGER(u) starts the second workgroup of a CU u x 64 cycles late (0 = none). */
+/* nprod = GN_CHAIN_F16X2 | GN_CHAIN_ROW (ABI 15; csrc/chain4.hip): the same programs with a wave owning 16 ROWS and all
+ * columns — the slots are fp32 register arrays (exact residual stream), the fp16 planes of a GEMM's operand are formed per
+ * GEMM under a fresh power-of-two row scale (no range limit on activations, no restriction on programs that add global
+ * tensors into resident values), only the weights pass through LDS (one loader wave per workgroup, double-buffered).
+ * `W` must have been packed with fmt = GN_SPLIT_F16X2_ROW; additionally K % 16 == 0 and width % 16 == 0.
+ * Same results as GN_CHAIN_F16X2 to fp32 rounding (not bit for bit: the K order inside a dot product differs). */
+#define GN_CHAIN_ROW 0x200
 #define GN_CHAIN_WIDE_ROWS(r) ((((r) / 8) & 0xf) << 12)
 #define GN_CHAIN_WIDE_STAGGER(u) (((u) & 0xffff) << 16)
 /* A program must start with a GN_OP_LOAD (the kernel's prologue relies on that op's barrier); else hipErrorInvalidValue. */
@@ -175,6 +182,9 @@ int gn_pack_weight_split(const float* W, int N, int K, int ldw, int trans, void*
  * thirds of the same buffer size). */
 #define GN_SPLIT_BF16X3 0
 #define GN_SPLIT_F16X2 1
+/* GN_SPLIT_F16X2_ROW (ABI 15): two fp16 planes as GN_SPLIT_F16X2 with the K order of the row-resident layout
+ * (nprod = GN_CHAIN_F16X2 | GN_CHAIN_ROW): element i of lane group g in k-chunk c is k = 16 (2 c + i / 4) + 4 g + i % 4. */
+#define GN_SPLIT_F16X2_ROW 2
 int gn_pack_weight_split_fmt(const float* W, int N, int K, int ldw, int trans, int fmt, void* out, void* stream);
 int64_t gn_pack_weight_split_bytes(int N, int K);
 /* The same for ALL weights of a training step in one launch (the weights change every optimizer step,

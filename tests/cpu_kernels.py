@@ -236,7 +236,7 @@ def chain(prog, mode=None):
     """Interpret a ChainProgram on whole matrices (slots = (M, 128) tensors).  Exact arithmetic; the launch rules of the
     mode still apply (a program the device kernel would refuse must not pass on the emulation)."""
     from gemnet_pytorch_amd import kernels as _K
-    if (mode or _K.current_mode()) == "h3" and _K.h3_hazards(prog):
+    if (mode or _K.current_mode()) == "h3" and _K.CHAIN_LAYOUT != "row" and _K.h3_hazards(prog):
         raise RuntimeError(f"chain: ops {_K.h3_hazards(prog)} are not representable in mode 'h3'")
     M = prog.M
     dt = None

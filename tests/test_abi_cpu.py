@@ -34,7 +34,7 @@ def test_header_declares_the_bound_functions():
 def test_library_exports_every_declared_symbol(lib):
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/gemnet_hip.h but not exported"
-    assert lib.gn_abi_version() == 14
+    assert lib.gn_abi_version() == 15
 
 
 def test_gemm_args_struct_matches_header():

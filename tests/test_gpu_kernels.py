@@ -425,11 +425,18 @@ def _source_programs(M, width, g, dev):
 CHAIN_TOL = {"f32": 1e-4, "split6": 1e-4, "h3": 1e-4, "split3": 2e-3, "bf16": 1e-1}
 
 
-@pytest.mark.parametrize("mode", ["f32", "split6", "h3", "split3", "bf16"])
-@pytest.mark.parametrize("M,width", [(1000, 128), (33, 64), (18122, 128), (5000, 128), (9000, 64), (13000, 128)])
-def test_chain_kernel_vs_interpreter(M, width, mode):
+@pytest.mark.parametrize("mode", ["f32", "split6", "h3", "h3/row", "split3", "bf16"])
+@pytest.mark.parametrize("M,width", [(1000, 128), (33, 64), (18122, 128), (5000, 128), (9000, 64), (13000, 128), (120000, 128)])
+def test_chain_kernel_vs_interpreter(M, width, mode, monkeypatch):
     """Every op kind, aliasing slots, slot / register / global operands, all five tile heights (RT = 1..5), on the f32
-    MFMA kernel and on the split-operand bf16 kernel (packed weights), against the float64 interpreter."""
+    MFMA kernel, on the split-operand bf16 kernel (packed weights) and on both layouts of the two-plane fp16 arithmetic
+    ("h3" = csrc/chain2.hip, the default; "h3/row" = the row-resident csrc/chain4.hip, 1 .. 7 compute waves per workgroup,
+    which also takes the programs chain2's row-scaled form refuses), against the float64 interpreter."""
+    if "/" in mode:
+        mode, layout = mode.split("/")
+        monkeypatch.setattr(K, "CHAIN_LAYOUT", layout)
+    if M > 20000 and K.CHAIN_LAYOUT != "row":
+        pytest.skip("the 7-wave workgroups of the row-resident layout only")
     tol = CHAIN_TOL[mode]
     worst = 0.0
     import functools
@@ -439,7 +446,7 @@ def test_chain_kernel_vs_interpreter(M, width, mode):
         build = maker(M, width, g, DEV)
         p_ref, o_ref = build(lambda t: t.clone(), lambda i: i)
         p_dev, o_dev = build(lambda t: f32(t), lambda i: i.to(DEV))
-        if mode == "h3" and K.h3_hazards(p_dev):
+        if mode == "h3" and K.CHAIN_LAYOUT != "row" and K.h3_hazards(p_dev):
             # second-order source terms / gathered adds into LDS-resident rows: refused, never computed out of range
             with pytest.raises(RuntimeError):
                 K.chain(p_dev, mode=mode)

@@ -200,7 +200,7 @@ def test_repeatable_bitwise(golden_model):
 def test_native_library_loaded():
     from gemnet_pytorch_amd import _lib
     lib = _lib.load()
-    assert lib.gn_abi_version() == 14
+    assert lib.gn_abi_version() == 15
     with open("/proc/self/maps") as f:
         assert "libgemnet_hip.so" in f.read()
 
