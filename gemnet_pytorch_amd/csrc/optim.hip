@@ -49,7 +49,9 @@ __global__ __launch_bounds__(OPT_NT) void adamw_ema_kernel(
     const bool bad = flag != nullptr && !(fabsf(norm) <= 3.4028234e38f);
     clip_s = bad ? -1.0f : (coef < 1.0f ? coef : 1.0f);
     if (blockIdx.x == 0 && norm_out) *norm_out = norm;
-    if (blockIdx.x == 0 && bad) atomicOr(flag, flag_bit);
+    // bits 0-7 of the word: the flags; bits 8+: the number of skipped steps since the last reset (the host corrects Adam's
+    // bias-correction counter by exactly that many: a poll may come one or two calls late and cover several skipped steps)
+    if (blockIdx.x == 0 && bad) { atomicOr(flag, flag_bit); atomicAdd(flag, 256); }
   }
   __syncthreads();
   const float clip = clip_s;

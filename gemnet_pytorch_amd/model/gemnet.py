@@ -416,8 +416,11 @@ class GemNet(torch.nn.Module):
         self._check_inputs(inputs["R"])
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("inputs without index arrays inside a stream capture: call model.with_indices(inputs) first")
-        return ensure_indices(inputs, self.cbf_basis3.cutoff, getattr(getattr(self, "cbf_basis", None), "cutoff", 10.0),
-                              self.triplets_only)
+        cutoff, int_cutoff = self.cbf_basis3.cutoff, getattr(getattr(self, "cbf_basis", None), "cutoff", 10.0)
+        if "cutoffs" in inputs:     # DataContainer(indices="device"): the container's own cutoffs define the graph
+            c = inputs["cutoffs"].detach().cpu().tolist()
+            cutoff, int_cutoff = float(c[0]), float(c[1])
+        return ensure_indices(inputs, cutoff, int_cutoff, self.triplets_only)
 
     def _forward_guarded(self, inputs):
         out = self._forward(inputs)

@@ -434,7 +434,9 @@ class PaddedGraphRunner:
         dev = self.inputs["R"].device
         self.builder = builder
         n_stage = 4 * self.e_cap + 2 * (self.quad_caps[0] if self.quad else self.t_cap)
-        self._staging = torch.empty(n_stage, dtype=torch.int32, device=dev)
+        # (zeros: a build whose interaction-edge count alone exceeds its capacity skips the edge kernel, and the count kernels
+        # behind it must not index with uninitialised staging on the very first build)
+        self._staging = torch.zeros(n_stage, dtype=torch.int32, device=dev)
         self._idx_state = torch.zeros(8, dtype=torch.int32, device=dev)
         self._idx_host = torch.zeros(8, dtype=torch.int32).pin_memory()
         self.graph = None
@@ -493,7 +495,7 @@ class PaddedGraphRunner:
         torch.cuda.synchronize()
         self.flag.trips += 1
         self.flag.reset()
-        if fall_back_to_bf16_planes(self.model, "a replayed padded batch (PaddedGraphRunner)"):
+        if fall_back_to_bf16_planes(self.model, "a replayed padded batch (PaddedGraphRunner)", positions=self.inputs["R"]):
             self.graph = None
             self.out = None
 

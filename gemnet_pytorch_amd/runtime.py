@@ -29,7 +29,10 @@ class RangeFlag:
     reads the pinned copy without synchronising (`tripped()`: what the COMPLETED replays left there — exact right after
     anything that waited for the replay, e.g. the `.cpu()` of `GemNet.predict`).  The word is sticky until `reset()`.
     Bits: OUTPUT = non-finite energies / forces of a forward; GRAD = a non-finite gradient norm (the fused optimizer skipped
-    that step, csrc/optim.hip)."""
+    that step, csrc/optim.hip); bits 8+ of the word count the steps the fused optimizer skipped since the last reset.
+    With several ranks (`snapshot` / `poll_lagged`) the word is OR-reduced over the ranks at a fixed point of every step and
+    read from the mirror slot of the step BEFORE the previous one, behind that step's event: every rank then sees the same
+    word at the same call, whatever its host is ahead of its GPU by."""
     OUTPUT, GRAD = 1, 2
 
     def __init__(self, device):
@@ -37,6 +40,8 @@ class RangeFlag:
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(device).type == "cuda" \
             else torch.zeros(1, dtype=torch.int32)
         self.trips = 0
+        self._slots = None          # multi-rank polling: two pinned mirror slots + their events, by step parity
+        self._step = 0
 
     def watch(self, *tensors, bit=OUTPUT):
         """Enqueue (or capture) the check of `tensors` (contiguous fp32) and the mirror copy on the current stream."""
@@ -49,20 +54,63 @@ class RangeFlag:
         self.host.copy_(self.word, non_blocking=True)
 
     def tripped(self):
-        return int(self.host[0])
+        return int(self.host[0]) & 0xff
+
+    def skipped(self):
+        """Steps the fused optimizer skipped on the device since the last reset (as of the last completed mirror copy)."""
+        return int(self.host[0]) >> 8
 
     def reset(self):
         self.word.zero_()
         self.host.zero_()
+        if self._slots is not None:
+            for h, _ in self._slots:
+                h.zero_()
+
+    # ---- several ranks: one decision for all of them -------------------------------------------------------------------
+    def snapshot(self, group=None):
+        """End of a step (every rank, same point): OR the word over the ranks on the device (the collective is enqueued like the
+        gradient all-reduce: no host synchronisation) and mirror it into the pinned slot of this step's parity, behind an event."""
+        import torch.distributed as dist
+        if self._slots is None:
+            cuda = self.word.is_cuda
+            self._slots = [((torch.zeros(1, dtype=torch.int32).pin_memory() if cuda else torch.zeros(1, dtype=torch.int32)),
+                            torch.cuda.Event() if cuda else None) for _ in range(2)]
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.word, op=dist.ReduceOp.BOR, group=group)
+        host, ev = self._slots[self._step & 1]
+        host.copy_(self.word, non_blocking=True)
+        if ev is not None:
+            ev.record()
+        self.host.copy_(self.word, non_blocking=True)
+        self._step += 1
+
+    def poll_lagged(self):
+        """Start of a step: the word as the step before the previous one left it (waits for THAT step's event — free when the
+        host runs at most one step ahead of the device).  The same value on every rank at the same call."""
+        if self._slots is None or self._step < 2:
+            return 0
+        host, ev = self._slots[self._step & 1]          # parity of step - 2
+        if ev is not None:
+            ev.synchronize()
+        return int(host[0])
 
 
-def fall_back_to_bf16_planes(model, what):
+def fall_back_to_bf16_planes(model, what, positions=None):
     """A replayed graph of `model` produced non-finite values in the fp16-plane arithmetic: warn, move THIS model to the
     bf16-plane form ("split6": fp32 exponent range) and drop everything derived from its weights in the old format.  The
     caller captures anew.  False when the model was not on the fp16 planes (the values are non-finite for another reason:
     nothing to fall back to)."""
     from . import kernels as K
     mode = getattr(model, "matmul_precision", None) or K.DEFAULT_CHAIN_MODE
+    if positions is not None:
+        bad = [p for p in (positions if isinstance(positions, (list, tuple)) else [positions])
+               if torch.is_tensor(p) and not bool(torch.isfinite(p).all())]
+        if bad:
+            # NaN / inf handed in by the caller is not an overflow of the arithmetic: the model stays where it is
+            warnings.warn(f"gemnet_pytorch_amd: non-finite values in {what}: the POSITIONS handed in are not finite "
+                          "(the arithmetic is left unchanged)", RuntimeWarning)
+            return False
     if mode != "h3":
         warnings.warn(f"gemnet_pytorch_amd: non-finite values in {what} (arithmetic {mode!r}: no fp16 range limit involved)",
                       RuntimeWarning)
@@ -130,7 +178,8 @@ class ForceGraphs:
             self.flag.trips += 1
             torch.cuda.synchronize()
             self.flag.reset()
-            if fall_back_to_bf16_planes(self.model, "a replayed forward+force graph (ForceGraphs)"):
+            if fall_back_to_bf16_planes(self.model, "a replayed forward+force graph (ForceGraphs)",
+                                        positions=[b["R"] for b in self.batches]):
                 self._capture()
         cur = torch.cuda.current_stream()
         for g, st in zip(self.graphs, self.streams):

@@ -143,7 +143,12 @@ class DataContainer:
         # npz datasets, float64 when an ASE caller assigns float64 positions to .R)
         if getattr(self, "indices", "host") == "host":      # (subclasses with their own __init__: ase_calculator.Molecule)
             data.update(build_indices(R, data["N"], self.cutoff, self.int_cutoff, self.triplets_only))
-        return self.convert_to_tensor(data)
+            return self.convert_to_tensor(data)
+        out = self.convert_to_tensor(data)
+        # a batch without index arrays names the graph it stands for: (cutoff, int_cutoff) — GemNet.with_indices builds the
+        # neighbour lists from THESE (as the host mode and the reference do from the DataContainer's), not from the model's
+        out["cutoffs"] = torch.tensor([float(self.cutoff), float(self.int_cutoff)], dtype=torch.float64)
+        return out
 
     def convert_to_tensor(self, data):
         for key in data:

@@ -175,9 +175,16 @@ class TrainStep:
 
     def _outputs(self, inputs):
         """(E (n_mol, targets), F (n_atoms, 3)) of the batch — a hook for subclasses that run a padded batch."""
-        if self.flag is not None:
+        if self.flag is None:
+            E, F = self.model(inputs)
+        else:
+            # the flag rides in the dict for the duration of the call only: the caller's dict is left without the non-tensor
+            # entry (Trainer.dict2device, torch.save and a later eval forward of the same dict see what they handed in)
             inputs["_range_flag"] = self.flag
-        E, F = self.model(inputs)
+            try:
+                E, F = self.model(inputs)
+            finally:
+                inputs.pop("_range_flag", None)
         if F.dim() == 3:
             F = F[:, 0]
         return E, F
@@ -197,7 +204,7 @@ class TrainStep:
             self.wgrad.flush()
         return loss.detach()
 
-    def capture(self, inputs, targets, check=False):
+    def capture(self, inputs, targets, check=False, _reuse_counts=False):
         """Capture forward + force + loss + double backward (thousands of small launches) into one
         hipGraph for this (static-shape) batch; the collective, clipping and optimizer stay eager.
         The graph reads the parameters in place, so optimizer updates are seen by every replay.
@@ -206,9 +213,11 @@ class TrainStep:
         if "id_c" not in inputs:
             raise ValueError("capture() needs a batch with its index arrays: inputs = model.with_indices(inputs)")
         local = self._local_counts(inputs)
-        self._pinned_counts = None
-        self._use_pinned = False
-        self._pinned_counts = (local, self._counts(*local, inputs["Z"].device))   # no collective inside the graph
+        if not (_reuse_counts and self._pinned_counts is not None and self._pinned_counts[0] == local):
+            # (a recapture after a range fall-back keeps the counts of the same static batch: no collective on that path)
+            self._pinned_counts = None
+            self._use_pinned = False
+            self._pinned_counts = (local, self._counts(*local, inputs["Z"].device))   # no collective inside the graph
         self._use_pinned = True
         try:
             side = torch.cuda.Stream()
@@ -233,19 +242,37 @@ class TrainStep:
         return self
 
     def _range_check(self):
-        """Poll the range flag (no synchronisation: what completed steps left there).  Tripped: the fused optimizer has
-        skipped the non-finite step(s) on the device; warn, move the model off the fp16 planes and capture the step anew."""
-        if self.flag is None or not self.flag.tripped():
+        """Poll the range flag.  Tripped: the fused optimizer has skipped the non-finite step(s) on the device; warn, move the
+        model off the fp16 planes and capture the step anew.  One rank: what the completed steps left in the pinned word (no
+        synchronisation).  Several ranks: the OR of all ranks' words as of the step before the previous one
+        (RangeFlag.snapshot / poll_lagged) — every rank takes this branch at the SAME call, so the recapture (and whatever
+        collectives the steps around it issue) pair up, and no rank runs a step in another arithmetic than its peers."""
+        if self.flag is None:
             return False
+        if self.world_size > 1:
+            word = self.flag.poll_lagged()
+            if not (word & 0xff):
+                return False
+            torch.cuda.synchronize()
+            # the word as it stands now: every rank has enqueued the same steps, each step OR-reduced it over the ranks, and the
+            # flags are sticky / the skip count monotone — a superset of what the lagged poll saw, identical on every rank
+            word = int(self.flag.word.item())
+            bits, skipped = word & 0xff, word >> 8
+        else:
+            if not self.flag.tripped():
+                return False
+            torch.cuda.synchronize()
+            bits, skipped = self.flag.tripped(), self.flag.skipped()
         from ..runtime import fall_back_to_bf16_planes
-        torch.cuda.synchronize()
-        bits = self.flag.tripped()
         self.flag.trips += 1
         self.flag.reset()
         if self.fused is not None and bits & self.flag.GRAD:
-            self.fused.steps = max(0, self.fused.steps - 1)      # (at least one step was skipped on the device)
+            # exactly the steps the device skipped (counted next to the flag, csrc/optim.hip): Adam's bias-correction counter
+            self.fused.steps = max(0, self.fused.steps - max(1, skipped))
+        cap = getattr(self, "_cap_args", None)
         if fall_back_to_bf16_planes(self.model, "a training step (%s)" % ("gradient norm" if bits & self.flag.GRAD else
-                                                                          "energies / forces")):
+                                                                          "energies / forces"),
+                                    positions=cap[0]["R"] if cap is not None else None):
             if getattr(self, "_graph", None) is not None:
                 self._recapture()
             return True
@@ -255,7 +282,7 @@ class TrainStep:
         inputs, targets = self._cap_args
         inputs.pop("_plan", None)
         self._graph = None
-        self.capture(inputs, targets)
+        self.capture(inputs, targets, _reuse_counts=True)
 
     def _eager(self, inputs, targets):
         """Eager forward/backward on a private stream: autograd ties every parameter's AccumulateGrad node to the
@@ -288,9 +315,18 @@ class TrainStep:
                 self.fused.step(flag=self.flag)
         else:
             scale_shared_grads(self.model)
-            torch.nn.utils.clip_grad_norm_(self.buf.params, max_norm=self.clip)
+            norm = torch.nn.utils.clip_grad_norm_(self.buf.params, max_norm=self.clip)
             if step_optimizer:
-                self.opt.step()
+                # an eager optimizer has no device-side skip: the gradient norm is read here (one synchronisation of this —
+                # already host-bound — path) so that a non-finite step never reaches the parameters; the flag's GRAD bit makes
+                # the next call fall back exactly as after a skipped fused step.  (All ranks hold the same reduced gradient.)
+                if self.flag is not None and not bool(torch.isfinite(norm)):
+                    self.flag.word.bitwise_or_(torch.tensor(self.flag.GRAD, dtype=torch.int32, device=self.flag.word.device))
+                    self.flag.mirror()
+                else:
+                    self.opt.step()
+        if self.flag is not None and self.world_size > 1:
+            self.flag.snapshot()         # every rank, every step, at this fixed point: the ranks decide together
         self.last_loss = loss
         return self.last_loss
 

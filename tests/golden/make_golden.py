@@ -668,9 +668,21 @@ def run_fullsize(cfg, seed, ds, tag, out, digests):
     out[f"{tag}.seed"], out[f"{tag}.cfg"], out[f"{tag}.out_scale"] = np.array(seed), np.array(repr(cfg)), np.array(scale)
     out[f"{tag}.N"], out[f"{tag}.Z"], out[f"{tag}.R"] = ds["N"], ds["Z"], ds["R"]
     out[f"{tag}.E"], out[f"{tag}.F"] = E.detach().numpy(), F.detach().numpy()
+    # the reference's OWN float32 path (its default dtype) on the same weights and inputs: what "the reference PyTorch CPU
+    # path" returns, and how far fp32 rounding alone takes it from the float64 result on this fixture
+    model32 = GemNet(**cfg, scale_file=SCALE_FILE)
+    model32.load_state_dict(GO.expand_to_reference_state_dict({k: v.float() for k, v in scale_heads(params, scale).items()}),
+                            strict=True)
+    model32.train()
+    in32 = dict(inputs)
+    in32["R"] = in32["R"].float()
+    E32, F32 = model32(in32)
+    out[f"{tag}.E32"], out[f"{tag}.F32"] = E32.detach().numpy(), F32.detach().numpy()
+    noise = float((F32.detach().double() - F.detach()).abs().mean())
     print(tag, "E", E.detach().numpy().ravel()[:3], "mean|F|", float(F.detach().abs().mean()), "out_scale", scale,
           {k: int(batch[k].shape[0]) for k in ("id_a", "id3_reduce_ca") + (() if to else ("id4_reduce_ca",))},
-          f"index {t_idx:.1f} s, reference forward+force {t_fwd:.1f} s (float64)", flush=True)
+          f"index {t_idx:.1f} s, reference forward+force {t_fwd:.1f} s (float64); reference float32 vs float64 force MAE {noise:.3e}",
+          flush=True)
 
 
 def golden_fullsize():

@@ -48,6 +48,10 @@ def test_fixture_inputs_are_the_generated_ones():
         for k in ("N", "Z", "R"):
             assert np.array_equal(g[f"{tag}.{k}"], ds[k]), (tag, k)
         assert abs(float(np.abs(g[f"{tag}.F"]).mean()) - 1.0) < 1e-9      # unit-force fixtures: the 1e-5 eV/A bar is literal
+        # the reference's own float32 forces ride along (make_golden.py::run_fullsize): its fp32 rounding on the fixture
+        noise = float(np.abs(g[f"{tag}.F32"].astype(np.float64) - g[f"{tag}.F"]).mean())
+        print(f"{tag}: reference float32 vs float64 force MAE {noise:.3e}")
+        assert (noise < 1e-5) == (tag in ("t64s", "tB32"))          # GemNet-T within the bar, GemNet-Q 1.5e-4 .. 2.1e-4
 
 
 @pytest.mark.parametrize("tag", ["t64s", "tB32"])

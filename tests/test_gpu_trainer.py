@@ -140,3 +140,26 @@ def test_loader_batches_without_index_arrays_train_like_batches_with_them(tag):
                      torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
     assert out["host"][0] == out["device"][0], (out["host"][0], out["device"][0])
     assert torch.equal(out["host"][1], out["device"][1])
+
+
+def test_device_mode_batches_use_the_containers_cutoffs_not_the_models():
+    """A `DataContainer(indices="device")` built with cutoffs other than the model's: the graph built on the GPU is the one
+    the host mode (and the reference, data_container.py:244-308) builds from the CONTAINER's cutoffs — same energies / forces."""
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    cfg = dict(num_spherical=7, num_radial=6, num_blocks=1, emb_size_atom=64, emb_size_edge=64, emb_size_trip=32,
+               emb_size_quad=32, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=32, emb_size_bil_quad=32, emb_size_bil_trip=32,
+               num_before_skip=1, num_after_skip=1, num_concat=1, num_atom=2, triplets_only=False)
+    torch.manual_seed(3)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to("cuda").eval()      # model cutoffs: 5 / 10 (the defaults)
+    ds = make_dataset(3, 12, config=1)
+    res = {}
+    for mode in ("host", "device"):
+        dc = DataContainer.from_arrays(ds, 4.0, 7.0, triplets_only=False, indices=mode)
+        b = dc[[0, 1, 2]]
+        inputs = {k: v.to("cuda") for k, v in b.items() if k not in ("E", "F")}
+        full = model.with_indices(inputs)
+        res[mode] = (int(full["id_c"].shape[0]), int(full["id4_reduce_ca"].shape[0]), *[t.detach().cpu() for t in model(inputs)])
+    assert res["host"][:2] == res["device"][:2], (res["host"][:2], res["device"][:2])
+    big = DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=False)[[0, 1, 2]]
+    assert int(big["id_c"].shape[0]) > res["host"][0]          # (the model's own cutoffs would have given a larger graph)
+    assert torch.allclose(res["host"][2], res["device"][2], rtol=0, atol=1e-5) and torch.allclose(res["host"][3], res["device"][3], rtol=0, atol=1e-5)

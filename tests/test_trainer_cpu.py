@@ -219,8 +219,9 @@ def test_data_container_can_leave_the_index_arrays_to_the_device():
     host = DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=True)
     dev = DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=True, indices="device")
     a, b = host[[0, 2]], dev[[0, 2]]
-    assert set(b) == {"E", "N", "Z", "R", "F"} and set(a) > set(b)
-    for k in b:
+    assert set(b) == {"E", "N", "Z", "R", "F", "cutoffs"} and set(a) > set(b) - {"cutoffs"}
+    assert b["cutoffs"].tolist() == [5.0, 10.0]        # the graph the batch stands for travels with it
+    for k in set(b) - {"cutoffs"}:
         assert torch.equal(a[k], b[k]) and a[k].dtype == b[k].dtype
     with pytest.raises(ValueError):
         DataContainer.from_arrays(ds, 5.0, 10.0, triplets_only=True, indices="gpu")
