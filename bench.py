@@ -295,7 +295,7 @@ class LaunchTimer:
 
 PEAK_SPLIT6_TFLOPS = 2500.0 / 6   # fp32-equivalent ceiling of six bf16 products on the 2.5 PF dense bf16 pipe
 PEAK_BF16_TFLOPS = 2500.0
-PROFILE_ROUND = "r5"
+PROFILE_ROUND = "r6"
 
 
 def _profile_json(name):
@@ -376,23 +376,38 @@ def roofline_from(fam, mode="T"):
                 frac=round(ach / PEAK_HBM_GBS, 4), **common)
 
 
-def cpu_baseline(cfg, n_atoms, budget_s=14.0, n_mol=8):
-    """Oracle (CPU restatement, fp32, all host cores) forward+force on a bounded sample."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(cfg, n_atoms, budget_s=14.0, n_mol=8, threads=None):
+    """Oracle (CPU restatement, fp32, host cores) forward+force on a bounded sample.  `threads`: fixed, else the fastest of
+    8 / 16 / 32 / 64 (capped by the host) on one timed step each — torch's CPU kernels on ~1e5-row operands stop scaling
+    well before a 128-thread host is full, and oversubscribing SMT threads hurts."""
     from oracle import gemnet_oracle as GO
     inputs, _ = make_batch(cfg, n_mol, n_atoms, first=0, device="cpu")
     params = GO.make_params(cfg, 0, GO.load_scale_factors(SCALE_FILE), dtype=torch.float32)
-    # pick the faster of two thread counts on this host (oversubscribing 128+ SMT threads hurts torch CPU)
-    best = None
-    for nthr in sorted({min(32, os.cpu_count() or 1), min(64, os.cpu_count() or 1)}):
-        torch.set_num_threads(nthr)
-        GO.forward(cfg, params, inputs)  # warm-up (page faults, thread pools)
-        t1 = time.time()
-        GO.forward(cfg, params, inputs)
-        dt1 = time.time() - t1
-        if best is None or dt1 < best[1]:
-            best = (nthr, dt1)
-    torch.set_num_threads(best[0])
-    cores = best[0]
+    ncpu = os.cpu_count() or 1
+    tried = {}
+    if threads is None:
+        for nthr in sorted({min(t, ncpu) for t in (8, 16, 32, 64)}):
+            torch.set_num_threads(nthr)
+            GO.forward(cfg, params, inputs)  # warm-up (page faults, thread pools)
+            t1 = time.time()
+            GO.forward(cfg, params, inputs)
+            tried[nthr] = round(time.time() - t1, 3)
+        threads = min(tried, key=tried.get)
+    torch.set_num_threads(threads)
+    cores = threads
+    GO.forward(cfg, params, inputs)
     t0 = time.time()
     steps = 0
     while True:
@@ -401,14 +416,16 @@ def cpu_baseline(cfg, n_atoms, budget_s=14.0, n_mol=8):
         if time.time() - t0 > budget_s or steps >= 20:
             break
     dt = time.time() - t0
-    return dict(value=round(n_mol * steps / dt, 3), unit="molecules/s", cores=cores, kind="port",
+    return dict(value=round(n_mol * steps / dt, 3), unit="molecules/s", cores=cores, kind="port", cpu_model=cpu_model_name(),
+                host_logical_cpus=ncpu, seconds_per_step_by_threads=tried or None,
                 sample=f"{steps} steps of forward+force on {n_mol} molecules x {n_atoms} atoms "
                        f"(same generator/config as the GPU workload), torch CPU fp32, {cores} threads",
                 ms_per_step=round(dt / steps * 1e3, 1),
-                calibration="this is the build's own CPU restatement (oracle/, kind 'port').  The REFERENCE itself, imported in "
-                            "the build container (8 threads of an 8-vCPU Xeon, SURVEY.md section 5): forward+force 1.3 s per "
-                            "32-molecule batch = 24.6 molecules/s; the full training step (fwd + force + loss.backward) 3.8 s = "
-                            "8.4 molecules/s")
+                calibration="the build's own CPU restatement (oracle/, kind 'port'; its bilinear layer is the reference's padded "
+                            "batched matmul, efficient.py:159-189).  Side by side in the build container (8 vCPU Intel Xeon @ 2.1 GHz, "
+                            "8 threads, fp32, the 32 x 32-atom batch of configs[1]): the REFERENCE itself 1.3 s per forward+force = "
+                            "24.6 molecules/s (SURVEY.md section 5), this port 1.04 s = 30.7 molecules/s; the reference's full "
+                            "training step (fwd + force + loss.backward) 3.8 s = 8.4 molecules/s")
 
 
 def cpu_baseline_train(cfg, n_atoms, n_mol=8, budget_s=10.0, threads=32):
@@ -490,6 +507,15 @@ def family_roofline(step, mode="T"):
 
 
 def log_families(title, fam):
+    dump = os.environ.get("GEMNET_DUMP_FAMILIES")
+    if dump:
+        # (tools/gpu_artifacts.sh: the algorithmic bytes / flops per launch of every launcher family, merged into
+        # profiles/<round>_traffic_<mode>.json next to the counted bytes by tools/pmc_summary.py)
+        slug = "".join(c if c.isalnum() else "_" for c in title)
+        with open(f"{dump}_{slug}.json", "w") as f:
+            json.dump({k: dict(launches=v["launches"], algorithmic_bytes_per_launch=int(v["bytes"] / max(v["launches"], 1)),
+                               algorithmic_flops_per_launch=int(v["flops"] / max(v["launches"], 1)), ms_per_step=round(v["ms"], 4))
+                       for k, v in fam.items()}, f, indent=1)
     tot = sum(v["ms"] for v in fam.values())
     log(f"[bench] {title}: per-family kernel time of one step's launches, replayed back-to-back:")
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:14]:
@@ -649,10 +675,37 @@ def extra_gemnet_q(n_mol, n_atoms, rank, steps=10, warmup=3, train=True):
     return out
 
 
+def extra_strict_f32(cfg, inputs, ref_out, n_mol, steps=20, warmup=5):
+    """The headline workload with the Dense stacks on the exact f32-input MFMA (`matmul_precision = "f32"`:
+    v_mfma_f32_16x16x4_f32, csrc/chain.hip) instead of the default two-fp16-plane products: what exactness costs, and how far
+    the two arithmetics' forces are apart on this batch (both sit ~2e-6 eV/A from the float64 reference at mean|F| = 1:
+    tests/test_gpu_fullsize_golden.py::tB32 is this batch with golden weights, test_matmul_arithmetic_modes the per-mode bars)."""
+    from gemnet_pytorch_amd.model.gemnet import GemNet
+    dev = inputs["R"].device
+    torch.manual_seed(1234)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(dev).eval()
+    model.requires_grad_(False)
+    model.matmul_precision = "f32"
+    step = lambda: model(inputs)  # noqa: E731
+    for _ in range(2):
+        step()
+    graph, g_out = capture(step)
+    elapsed = time_steps(graph.replay, steps, warmup)
+    E, F = g_out
+    fscale = float(ref_out[1].abs().mean())
+    return dict(ms_per_step=round(elapsed / steps * 1e3, 4), molecules_per_s=round(n_mol * steps / elapsed, 1), steps=steps,
+                warmup=warmup, hipgraph=True, dense_stack_arithmetic="v_mfma_f32_16x16x4_f32 (fp32 operands, exact products)",
+                force_mae_vs_default_arithmetic_rel=round(float((F - ref_out[1]).abs().mean()) / fscale, 9),
+                energy_maxdiff_vs_default_arithmetic=round(float((E - ref_out[0]).abs().max()), 7),
+                note="same weights (seed 1234) and batch as the headline; the difference of the two forces is relative to mean|F| "
+                     "of this random-weight model; each arithmetic's own error against the float64 reference: "
+                     "tests/test_gpu_model.py::test_matmul_arithmetic_modes")
+
+
 def extra_config4_shard(rank, n_mol=64, n_atoms=64, steps=3, warmup=2):
     """BASELINE.json configs[4], ONE GPU's shard: GemNet-Q, 64 molecules x 64 atoms (batch 512 over 8 GPUs), forward+force —
-    126 M quadruplets, ~50 GiB; eager (the launch count is irrelevant at 110 ms per step), in the default (fp32-equivalent)
-    arithmetic, with the roofline of the dominant launcher family.  The config's "bf16" is not run: a single-plane bf16
+    126 M quadruplets, ~50 GiB; one captured hipGraph since round 6 (eager before), in the default (fp32-equivalent)
+    arithmetic, with the roofline of the dominant launcher family (counted traffic: profiles/<round>_traffic_config4.json).  The config's "bf16" is not run: a single-plane bf16
     operand mode was measured SLOWER than the default on this shard (116 vs 109 ms: only the Dense stacks, 4 % of the step,
     take bf16 operands; the quadruplet kernels already run split-fp16 products at fp32 accuracy) and 4e-2 eV/A off, and was
     removed from the model's options in round 5."""
@@ -687,7 +740,20 @@ def extra_config4_shard(rank, n_mol=64, n_atoms=64, steps=3, warmup=2):
     for mode in (None,):
         model.matmul_precision = mode
         step = lambda: model(inputs)  # noqa: E731
-        elapsed = time_steps(step, steps, warmup)
+        run = step
+        try:
+            # one hipGraph for the ~650 launches of the step (round 5 timed it eagerly); the graph's private pool holds the
+            # step's ~50 GiB of intermediates a second time next to the eager warm-up's cached blocks
+            torch.cuda.empty_cache()
+            g4, _ = capture(step, warm=1)
+            run, out["hipgraph"] = g4.replay, True
+        except Exception as ex:  # noqa: BLE001
+            out["hipgraph_error"] = f"{type(ex).__name__}: {ex}"[:200]
+            torch.cuda.synchronize()
+        elapsed = time_steps(run, steps, warmup)
+        if out["hipgraph"]:
+            del g4, run
+            torch.cuda.empty_cache()
         E, F = step()
         res[mode or "default"] = (E.detach().clone(), F.detach().clone())
         out[mode or "default"] = dict(ms_per_step=round(elapsed / steps * 1e3, 2), molecules_per_s=round(n_mol * steps / elapsed, 1))
@@ -1007,6 +1073,9 @@ def main():
             guarded("train_step", lambda: extra_train_step(cfg, 1234, inputs, targets, world, args.batch,
                                                            want_roofline=False))
         elif args.model == "T":
+            if K.DEFAULT_CHAIN_MODE != "f32":
+                ref_out = tuple(t.detach().clone() for t in step())
+                guarded("strict_f32", lambda: extra_strict_f32(cfg, inputs, ref_out, args.batch))
             guarded("train_step", lambda: extra_train_step(cfg, 1234, inputs, targets, 1, args.batch))
             guarded("interaction_block_fwd_bwd", lambda: extra_interaction_block(model, plan))
             guarded("dynamic_shape", lambda: extra_dynamic_shape(cfg, model, args.batch, args.atoms, rank))
@@ -1018,11 +1087,12 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "force":
-        cpu = cpu_baseline(cfg, args.atoms, n_mol=8)
+        # the full configs[1] batch (the workload `value` is quoted on) is the baseline; an 8-molecule sample rides along
+        cpu = cpu_baseline(cfg, args.atoms, budget_s=14.0, n_mol=args.batch)
         try:
-            cpu["full_batch"] = cpu_baseline(cfg, args.atoms, budget_s=8.0, n_mol=args.batch)
+            cpu["sample_8_molecules"] = cpu_baseline(cfg, args.atoms, budget_s=5.0, n_mol=8, threads=cpu["cores"])
         except Exception as ex:  # noqa: BLE001
-            cpu["full_batch"] = {"error": f"{type(ex).__name__}: {ex}"}
+            cpu["sample_8_molecules"] = {"error": f"{type(ex).__name__}: {ex}"}
         try:
             cpu["train_step"] = cpu_baseline_train(cfg, args.atoms, n_mol=4, budget_s=8.0, threads=cpu["cores"])
         except Exception as ex:  # noqa: BLE001

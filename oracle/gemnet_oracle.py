@@ -210,15 +210,36 @@ def edge_embedding(w, h, m_rbf, id_c, id_a):
 
 
 def bilinear(rbfW1, sph, x_t, id_reduce, W, nE):
-    """efficient.py:159-189 without padding:
-    out[e,o] = sum_{t in seg(e)} sum_s sum_i sum_c sph[t,s] rbfW1[e,i,s] x[t,c] W[c,i,o]."""
+    """efficient.py:159-189:  out[e,o] = sum_{t in seg(e)} sum_s sum_i sum_c sph[t,s] rbfW1[e,i,s] x[t,c] W[c,i,o].
+    As the reference does it — the triplets / quadruplets of an edge zero-padded to (E, Kmax, .) by an index_put
+    (efficient.py:173-182, basis_layers.py:153-159) and contracted by a batched matmul — in chunks of edges so that the
+    padded tensors stay bounded (the segments are contiguous: `id_reduce` is sorted, data_container.py:324-328,369-375).
+    (Until round 5 the (T, S, C) outer products were formed and index_add-ed: the same sums at twice the reference's time.)"""
     S = sph.shape[1]
     C = x_t.shape[1]
-    sum_k = torch.zeros((nE, S, C), dtype=x_t.dtype)                     # (E,S,C), accumulated in chunks of triplets
-    step = max(1, (1 << 24) // (S * C))                                  # (a 32-atom GemNet-Q molecule has 3e5 quadruplets)
-    for lo in range(0, sph.shape[0], step):
-        hi = lo + step
-        sum_k = sum_k.index_add(0, id_reduce[lo:hi], sph[lo:hi, :, None] * x_t[lo:hi, None, :])
+    T = sph.shape[0]
+    if T == 0:
+        sum_k = torch.zeros((nE, S, C), dtype=x_t.dtype)
+    else:
+        cnt = torch.bincount(id_reduce, minlength=nE)
+        off = torch.zeros(nE + 1, dtype=torch.long)
+        off[1:] = torch.cumsum(cnt, 0)
+        kidx = torch.arange(T) - off[id_reduce]                          # position inside the segment (Kidx3 / Kidx4)
+        parts = []
+        kmax_all = int(cnt.max())
+        step = max(1, (1 << 26) // (kmax_all * max(S, C)))               # edges per chunk: one padded operand <= 2^26 elements
+        for e0 in range(0, nE, step):
+            e1 = min(nE, e0 + step)
+            lo, hi = int(off[e0]), int(off[e1])
+            kmax = int(cnt[e0:e1].max())
+            if kmax == 0:
+                parts.append(torch.zeros((e1 - e0, S, C), dtype=x_t.dtype))
+                continue
+            rows, cols = id_reduce[lo:hi] - e0, kidx[lo:hi]
+            sph2 = torch.zeros((e1 - e0, kmax, S), dtype=sph.dtype).index_put((rows, cols), sph[lo:hi])
+            m2 = torch.zeros((e1 - e0, kmax, C), dtype=x_t.dtype).index_put((rows, cols), x_t[lo:hi])
+            parts.append(torch.matmul(sph2.transpose(1, 2), m2))         # (e, S, C)
+        sum_k = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
     P = torch.matmul(rbfW1, sum_k)  # (E,I,S)@(E,S,C) -> (E,I,C)
     return torch.einsum("eic,cio->eo", P, W)
 

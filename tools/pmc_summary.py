@@ -1,4 +1,4 @@
-"""Per-kernel HBM-side traffic and MFMA-busy figures from the rocprofv3 PMC passes of tools/gpu_artifacts5.sh (runs
+"""Per-kernel HBM-side traffic and MFMA-busy figures from the rocprofv3 PMC passes of tools/gpu_artifacts.sh (runs
 anywhere: pandas only).
 
     python tools/pmc_summary.py gpurun_out/<tag> <mode: T|Q|train> [r3]
@@ -16,6 +16,13 @@ import pandas as pd
 tag = sys.argv[1]
 mode = sys.argv[2]
 rnd = sys.argv[3] if len(sys.argv) > 3 else "r3"
+# optional: the algorithmic bytes / flops per launch of every launcher family of the same workload (bench.py with
+# GEMNET_DUMP_FAMILIES=<prefix>: <prefix>_<title>.json) — written next to the counted bytes so that the ratio can be formed
+# from ONE file
+alg = {}
+if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+    with open(sys.argv[4]) as f:
+        alg = json.load(f)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLK_HZ, N_SIMD = 2.4e9, 1024
 
@@ -65,7 +72,7 @@ if len(tab) == 2:
     t["total"] = t["bytes_per_launch"] * t["n"]
     t = t.sort_values("total", ascending=False).drop(columns="total")
     head = f"""# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domains) on the {mode} workload of bench.py
-# (tools/gpu_artifacts5.sh, summarised by tools/pmc_summary.py), MI355X.  Raw counter values are KB per dispatch (mean over n).
+# (tools/gpu_artifacts.sh, summarised by tools/pmc_summary.py), MI355X.  Raw counter values are KB per dispatch (mean over n).
 # gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-reports wide coalesced reads by 2x ->
 # bytes_per_launch = (2 * fetch_kb + write_kb) * 1024.  WRITE_SIZE is uncalibrated for 4-byte strided stores (face value).
 # The working set of this batch is Infinity-Cache resident: these are L2 memory-side requests, not DRAM bytes.
@@ -84,6 +91,11 @@ if len(tab) == 2:
                     "write_kb_raw": round(float((sub["write_kb"] * sub["n"]).sum() / n), 1),
                     "bytes_per_launch": int((sub["bytes_per_launch"] * sub["n"]).sum() / n),
                     "source": f"profiles/{rnd}_pmc_traffic_{mode}.txt"}
+        if fam in alg:
+            a = alg[fam]
+            out[fam].update(algorithmic_bytes_per_launch=a["algorithmic_bytes_per_launch"],
+                            algorithmic_flops_per_launch=a["algorithmic_flops_per_launch"], launches_per_step=a["launches"],
+                            counted_over_algorithmic=round(out[fam]["bytes_per_launch"] / max(a["algorithmic_bytes_per_launch"], 1), 3))
     with open(os.path.join(root, "profiles", f"{rnd}_traffic_{mode}.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v["bytes_per_launch"] for k, v in out.items()}))
@@ -94,7 +106,7 @@ if df is not None:
     df["dur_ns"] = df["End_Timestamp"] - df["Start_Timestamp"]
     # kernel durations of the UNINSTRUMENTED run of the same workload (rocprofv3 --kernel-trace --stats, hipGraph replay),
     # when it is there: counter collection serialises and stretches the dispatches (chain: 46 vs 30 us)
-    sdir = {"T": "prof", "train": "prof_train", "Q": "prof_Q", "Qtrain": "prof_Qtrain"}[mode]
+    sdir = {"T": "prof", "train": "prof_train", "Q": "prof_Q", "Qtrain": "prof_Qtrain"}.get(mode, "prof_" + mode)
     sf = glob.glob(os.path.join(tag, sdir, "**", "*kernel_stats.csv"), recursive=True)
     if sf:
         ks = pd.read_csv(sf[0])
