@@ -104,6 +104,7 @@ SIGNATURES = {
     "gn_bil_reduce_project_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
     "gn_bil_expand_ang_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp],
     "gn_bil_expand_atoms_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "gn_bil_expand_rows_ang_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp],
     "gn_bil_dy_multi_ang_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_quad_angles_jvp_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_bil_reduce_project_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],

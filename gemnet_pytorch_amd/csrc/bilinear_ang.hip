@@ -441,6 +441,169 @@ __global__ __launch_bounds__(NW * 64) void bil_expand_atoms_ang_kernel(
   for (int i = threadIdx.x; i < nJ * (C / 4); i += NW * 64) out[i] = reinterpret_cast<const float4*>(dxl)[i];
 }
 
+// ---- x-adjoint, ROW-STATIONARY per target atom: no per-quadruplet rows in memory, no barriers (round 6) -----------------
+// The same sum as bil_expand_atoms_ang_kernel — dx[J_a] (|J_a| x 32) = sum over the edges e into atom a of Y_e (|J_a| x 49) dSm[e]
+// (49 x 32), one GEMM per atom with K = 49 deg(a) — with the loops turned inside out: a WAVE owns 32 of the atom's rows
+// (intermediate triplets a <- b <- d) and walks the atom's edges with the accumulators in registers.  Nothing is shared between
+// waves: no LDS accumulation, no barrier per edge (what made the per-atom workgroup 5-11 % slower than expand + segmented sum),
+// rows written once.  The quadruplet of (edge e, row j) comes from a dense per-atom grid qmap[a][e_local][j_local] (-1: the
+// pair is excluded, c = b or c = d: data_container.py:470-473) built once per batch with the index plan (graph.py).
+// Same order of addition as the two-pass form (edges of an atom in ascending order).
+template <bool F16, int TR>
+__global__ __launch_bounds__(256) void bil_expand_rows_ang_kernel(
+    const float4* __restrict__ ang, const float* __restrict__ dSm, const int32_t* __restrict__ a_perm,
+    const int32_t* __restrict__ a_seg, const int32_t* __restrict__ j_off, const int32_t* __restrict__ qmap,
+    const int32_t* __restrict__ g_off, const int32_t* __restrict__ task_atom, const int32_t* __restrict__ task_row0,
+    int n_tasks, float* __restrict__ dx) {
+  constexpr int NST = TR / 16;
+  __shared__ float ysm[4][TR * LDY];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= n_tasks) return;
+  float* __restrict__ ys = ysm[wave];
+  const int a = task_atom[task], r0 = task_row0[task];
+  const int j0 = j_off[a], nJ = j_off[a + 1] - j0;
+  const int nr = min(TR, nJ - r0);
+  const int e0 = a_seg[a], e1 = a_seg[a + 1];
+  const int32_t* __restrict__ qrow = qmap + g_off[a] + r0 + lane;
+  v4f_a acc[NST][2];
+#pragma unroll
+  for (int st = 0; st < NST; ++st)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[st][nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+  int q = -1;
+  float4 a4 = make_float4(0.f, 1.f, 0.f, 1.f);
+  if (e0 < e1 && lane < nr) {
+    q = qrow[0];
+    if (q >= 0) a4 = ang[q];
+  }
+  for (int ei = e0; ei < e1; ++ei) {
+    const int e = a_perm ? a_perm[ei] : ei;
+    const float* __restrict__ De = dSm + e * (int64_t)S * C;
+    // the next edge's quadruplets and angles are requested now and land under this edge's work
+    int qn = -1;
+    float4 an = make_float4(0.f, 1.f, 0.f, 1.f);
+    if (ei + 1 < e1 && lane < nr) {
+      qn = qrow[(int64_t)(ei + 1 - e0) * nJ];
+      if (qn >= 0) an = ang[qn];
+    }
+    const unsigned long long valid = __ballot(q >= 0);
+    if (q >= 0) ylm7_row_T<float>(a4.x, a4.y, a4.z, a4.w, ys + lane * LDY);
+    if constexpr (F16) {
+      // B operand: dSm[e][s = 32 kc + 8 lg + i][c = 16 nt + l15] under one exact power-of-two scale per edge (bil_expand_ang_kernel)
+      float bv[2][2][8];
+      float vmax = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int sr = 32 * kc + 8 * lg + i;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float v = De[min(sr, S - 1) * C + 16 * nt + l15];
+            bv[kc][nt][i] = sr < S ? v : 0.f;
+            vmax = fmaxf(vmax, fabsf(bv[kc][nt][i]));
+          }
+        }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+      float sigma = 1.f, inv_sigma = 1.f;
+      {
+        const uint32_t ex = __float_as_uint(vmax) >> 23;
+        const uint32_t ec = ex < 2u ? 2u : (ex > 250u ? 250u : ex);
+        if (vmax > 0.f) {
+          sigma = __uint_as_float((252u - ec) << 23);      // sigma max|dSm[e]| in [0.25, 0.5)
+          inv_sigma = __uint_as_float((2u + ec) << 23);
+        }
+      }
+      h8_a bh[2][2], bl[2][2];
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bv[kc][nt][i] *= sigma;
+          split8s(bv[kc][nt], bh[kc][nt], bl[kc][nt]);
+        }
+      wave_lds_sync();
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const int sub = 16 * st;
+        if (sub < nr) {
+          const bool rv = (valid >> (sub + l15)) & 1ull;      // a row without a quadruplet for this edge contributes nothing
+          const float* __restrict__ yb = ys + (sub + l15) * LDY;
+          v4f_a c0 = (v4f_a){0.f, 0.f, 0.f, 0.f}, c1 = c0, x0 = c0, x1 = c0;
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) {
+            float ya[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int sr = 32 * kc + 8 * lg + i;
+              const float v = yb[min(sr, S - 1)];
+              ya[i] = (sr < S && rv) ? v : 0.f;
+            }
+            h8_a ah, al;
+            split8s(ya, ah, al);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kc][0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kc][1], c1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kc][0], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kc][1], x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kc][0], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kc][1], x1, 0, 0, 0);
+          }
+          acc[st][0] += (c0 + x0 * (1.f / 2048.f)) * inv_sigma;
+          acc[st][1] += (c1 + x1 * (1.f / 2048.f)) * inv_sigma;
+        }
+      }
+    } else {
+      float bd[13][2];   // dSm[4 kk + lg][16 nt + l15]
+#pragma unroll
+      for (int kk = 0; kk < 13; ++kk) {
+        const int sr = 4 * kk + lg;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float v = De[min(sr, S - 1) * C + 16 * nt + l15];
+          bd[kk][nt] = sr < S ? v : 0.f;
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const int sub = 16 * st;
+        if (sub < nr) {
+          const bool rv = (valid >> (sub + l15)) & 1ull;
+          const float* __restrict__ yb = ys + (sub + l15) * LDY + lg;
+          v4f_a c0 = (v4f_a){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+          for (int kk = 0; kk < 13; ++kk) {
+            const float yv = yb[4 * kk];
+            const float av = (rv && (kk < 12 || lg == 0)) ? yv : 0.f;
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bd[kk][0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bd[kk][1], c1, 0, 0, 0);
+          }
+          acc[st][0] += c0;
+          acc[st][1] += c1;
+        }
+      }
+    }
+    wave_lds_sync();
+    q = qn;
+    a4 = an;
+  }
+#pragma unroll
+  for (int st = 0; st < NST; ++st)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * st + 4 * lg + r;
+      if (row < nr) {
+        float* __restrict__ o = dx + (int64_t)(j0 + r0 + row) * C + l15;
+        o[0] = acc[st][0][r];
+        o[16] = acc[st][1][r];
+      }
+    }
+}
+
 // ---- angle gradient of all blocks that share the basis, one pass ------------------------------------------------------
 struct gn_dy_ang_args {
   const float* dS[4];
@@ -883,6 +1046,25 @@ extern "C" int gn_bil_expand_atoms_ang_f32(const float* ang, const float* dSm, c
   hipLaunchKernelGGL((bil_expand_atoms_ang_kernel<NW, TQ>), dim3((unsigned)n_atoms), dim3(NW * 64), lds,
                      static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(ang), dSm, seg_off, expand_idx, a_perm,
                      a_seg, j_off, dx, max_J);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gn_bil_expand_rows_ang_f32(const float* ang, const float* dSm, const int32_t* a_perm, const int32_t* a_seg,
+                                          const int32_t* j_off, const int32_t* qmap, const int32_t* g_off,
+                                          const int32_t* task_atom, const int32_t* task_row0, int64_t n_tasks, float* dx, int S_,
+                                          int C_, int arith, void* stream) {
+  if (n_tasks <= 0) return 0;
+  const int tile = (arith >> 8) & 0xff;       // rows per task the caller built its task table for (0: 32)
+  if (S_ != S || C_ != C || !aligned16(ang) || n_tasks > (1ll << 30) || (tile != 0 && tile != 32 && tile != 64))
+    return (int)hipErrorInvalidValue;
+  const dim3 grid((unsigned)gn_cdiv(n_tasks, 4)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define GN_ROWS_LAUNCH(F, T) hipLaunchKernelGGL((bil_expand_rows_ang_kernel<F, T>), grid, block, 0, st, reinterpret_cast<const float4*>(ang), \
+                                                dSm, a_perm, a_seg, j_off, qmap, g_off, task_atom, task_row0, (int)n_tasks, dx)
+  if (arith & GN_ANG_F16) { if (tile == 64) GN_ROWS_LAUNCH(true, 64); else GN_ROWS_LAUNCH(true, 32); }
+  else { if (tile == 64) GN_ROWS_LAUNCH(false, 64); else GN_ROWS_LAUNCH(false, 32); }
+#undef GN_ROWS_LAUNCH
   GN_LAUNCH_CHECK();
   return 0;
 }

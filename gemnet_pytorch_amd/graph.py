@@ -6,6 +6,8 @@ whose triplet/quadruplet arrays are sorted by reduce edge (:324-328,:369-375); `
 (position inside the segment) exist only to build zero-padded tensors and are not needed here.
 SURVEY.md Appendix D lists the transpose groupings the backward passes need.
 """
+import os
+
 import torch
 
 
@@ -151,6 +153,58 @@ class SegmentPlan:
             self._atom_blocks = (perm, seg.to(torch.int32).contiguous(), j_off.to(torch.int32).contiguous(), max_J)
         return self._atom_blocks
 
+    ROW_TILE = int(os.environ.get("GEMNET_ROW_TILE", "64"))      # expand rows per wave of gn_bil_expand_rows_ang_f32 (32 | 64)
+
+    @property
+    def row_grid(self):
+        """(a_perm | None, a_seg, j_off, qmap, g_off, task_atom, task_row0, n_tasks) for gn_bil_expand_rows_ang_f32 (the x-adjoint
+        of the quadruplet layer without per-quadruplet rows in memory), or None.  qmap: for atom a, starting at g_off[a], the
+        dense grid [reduce edges into a][expand rows of a] of quadruplet numbers, -1 where the pair has none.  Built once per
+        batch with device-side tensor ops; the two sizes are read back (host syncs: `GraphPlan.warm` does this outside of any
+        capture — inside a capture the property answers None and the two-pass form runs)."""
+        src = getattr(self, "_ab_src", None)
+        if src is None:
+            return None
+        if getattr(self, "_row_grid", None) is None:
+            if self.reduce.idx32.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None
+            reduce_atom, expand_atom, A = src
+            dev = expand_atom.device
+            perm, seg = reduce_atom.csr                       # edges grouped by target atom
+            seg64 = seg.to(torch.int64)
+            nE = seg64[1:] - seg64[:-1]
+            nJ = torch.bincount(expand_atom, minlength=A)
+            j_off = torch.zeros(A + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(nJ, 0, out=j_off[1:])
+            g_off = torch.zeros(A + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(nE * nJ, 0, out=g_off[1:])
+            n_edges = int(reduce_atom.idx32.shape[0])
+            e_rank = torch.empty(n_edges, dtype=torch.int64, device=dev)   # position of an edge in its atom's list
+            pos = torch.arange(n_edges, device=dev, dtype=torch.int64)
+            atom_of_pos = torch.repeat_interleave(torch.arange(A, device=dev), nE)
+            atom_of_edge = reduce_atom.idx32.to(torch.int64)
+            if perm is None:
+                e_rank = pos - seg64[atom_of_pos]
+            else:
+                e_rank[perm.to(torch.int64)] = pos - seg64[atom_of_pos]
+            r = self.reduce.idx32.to(torch.int64)
+            a_q = atom_of_edge[r]
+            flat = g_off[a_q] + e_rank[r] * nJ[a_q] + (self.expand.idx32.to(torch.int64) - j_off[a_q])
+            nt = (nJ + self.ROW_TILE - 1) // self.ROW_TILE
+            t_off = torch.zeros(A + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(nt, 0, out=t_off[1:])
+            g_total, n_tasks = (int(v) for v in torch.stack([g_off[-1], t_off[-1]]).tolist())
+            if g_total >= 2 ** 31:
+                self._row_grid = ()
+                return None
+            qmap = torch.full((max(g_total, 1),), -1, dtype=torch.int32, device=dev)
+            qmap[flat] = torch.arange(self.size, device=dev, dtype=torch.int32)
+            task_atom = torch.repeat_interleave(torch.arange(A, device=dev), nt)
+            task_row0 = (torch.arange(n_tasks, device=dev, dtype=torch.int64) - t_off[task_atom]) * self.ROW_TILE
+            i32 = lambda t: t.to(torch.int32).contiguous()   # noqa: E731
+            self._row_grid = (perm, i32(seg), i32(j_off), qmap, i32(g_off), i32(task_atom), i32(task_row0), n_tasks)
+        return self._row_grid or None
+
     def set_row_groups(self, row_group: torch.Tensor, n_groups: int, max_rows=None):
         """Declare that r(t) and g(t) of every entry fall in the same group of rows (`row_group[row]`), as the
         triplets c->a<-b do with the target atom a of both edges (data_container.py:262-300).
@@ -239,7 +293,7 @@ class GraphPlan:
             # (only the fused per-atom x-adjoint reads it — kernels.USE_ATOM_BLOCKS, off by default: no gather / bincount /
             #  host read-back per batch for a structure nobody consumes)
             from . import kernels as _K
-            if _K.USE_ATOM_BLOCKS:
+            if _K.USE_ATOM_BLOCKS or _K.USE_ROW_GRID:
                 self.quad.set_atom_blocks(self.id_a, i_a[exp_ab], self.n_atoms)
             A = self.n_atoms
             self.quad_geom = {
@@ -312,6 +366,10 @@ class GraphPlan:
                 self.trip.groups
             if not self.triplets_only and _atom_blocks_on():
                 self.quad.atom_blocks
+            if not self.triplets_only:
+                from . import kernels as _K
+                if _K.USE_ROW_GRID:
+                    self.quad.row_grid        # (two size read-backs: here, outside of any capture)
             self._warmed = True
         return self
 

@@ -427,6 +427,10 @@ def bil_reduce(Y, x, sp):
 # walking ~18 edges behind a barrier each cannot hide what 20 independent waves per CU hide in the two-pass kernels.  Off by
 # default; GEMNET_ATOM_BLOCKS=1 selects it.
 USE_ATOM_BLOCKS = os.environ.get("GEMNET_ATOM_BLOCKS", "0") == "1"
+# Round 6: the same sum with the loops turned inside out (gn_bil_expand_rows_ang_f32: a WAVE owns 32 expand rows of one atom and
+# walks the atom's reduce edges with the accumulators in registers — no LDS accumulation, no barrier, rows written once; the
+# quadruplet of (edge, row) from a dense per-atom grid built with the index plan, graph.SegmentPlan.row_grid).
+USE_ROW_GRID = os.environ.get("GEMNET_ROW_GRID", "1") == "1"
 ATOM_BLOCK_MAX_ROWS = 848
 # Which angle-form kernels run their products on the fp16 matrix pipe (`arith` = GN_ANG_F16 of the launch): bit 0 = K1 of
 # bil_reduce_project (only under the "h3" Dense arithmetic: x unscaled), bit 1 = the angle gradient bil_dy_multi, bit 2 = the
@@ -448,6 +452,15 @@ def bil_reduce_t(Y, D, sp):
     S, C = D.shape[1], D.shape[2]
     permT, segT = sp.expand.csr
     if is_angle_form(Y, S):
+        rg = sp.row_grid if (USE_ROW_GRID and C == 32) else None
+        if rg is not None:
+            a_perm, a_seg, j_off, qmap, g_off, task_atom, task_row0, n_tasks = rg
+            dx = torch.empty((sp.n_expand, C), device=Y.device, dtype=torch.float32)     # the tasks partition the rows
+            check(_lib.load().gn_bil_expand_rows_ang_f32(ptr(Y), ptr(D), ptr(a_perm), ptr(a_seg), ptr(j_off), ptr(qmap),
+                                                         ptr(g_off), ptr(task_atom), ptr(task_row0), int(n_tasks), ptr(dx), S, C,
+                                                         (GN_ANG_F16 if ANG_F16_MASK & 4 else 0) | (sp.ROW_TILE << 8), stream()),
+                  "gn_bil_expand_rows_ang_f32")
+            return dx
         ab = sp.atom_blocks if USE_ATOM_BLOCKS else None
         if ab is not None and 0 < ab[3] <= ATOM_BLOCK_MAX_ROWS and C == 32:
             # quadruplets: the rows of one target atom summed in LDS, no per-quadruplet rows in memory

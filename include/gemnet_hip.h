@@ -268,6 +268,16 @@ int gn_bil_reduce_project_ang_f32(const float* ang, const float* x, const int32_
  * instead of gathering 128-byte rows through the permutation; the same rows are summed in the same order. */
 int gn_bil_expand_ang_f32(const float* ang, const float* dSm, const int32_t* seg_off, float* dxt, int64_t E, int S, int C,
                           int arith, const int32_t* row_pos, void* stream);
+/* The x-adjoint of the quadruplet layer WITHOUT per-quadruplet rows in memory (ABI 15; csrc/bilinear_ang.hip,
+ * bil_expand_rows_ang_kernel): dx[j] = sum_{q: g(q) = j} Y[q] dSm[r(q)] (interaction_block.py:517-566, backward through the
+ * gather of x) with a wave owning 32 expand rows of one target atom and walking that atom's reduce edges, accumulators in
+ * registers.  a_perm (or NULL) / a_seg (A+1): the reduce edges grouped by target atom; j_off (A+1): the expand rows of atom a
+ * are [j_off[a], j_off[a+1]); qmap: per atom a dense grid [edges of a][rows of a] of quadruplet numbers (-1: none) starting at
+ * g_off[a]; task t works on rows task_row0[t] .. + tile - 1 of atom task_atom[t], tile = 32 or 64 = bits 8-15 of `arith` (0: 32).
+ * Replaces gn_bil_expand_ang_f32 + the segmented sum. */
+int gn_bil_expand_rows_ang_f32(const float* ang, const float* dSm, const int32_t* a_perm, const int32_t* a_seg,
+                               const int32_t* j_off, const int32_t* qmap, const int32_t* g_off, const int32_t* task_atom,
+                               const int32_t* task_row0, int64_t n_tasks, float* dx, int S, int C, int arith, void* stream);
 /* Second-order sweeps of GemNet-Q force training (trainer.py:338-346: loss.backward() through dE/dR) in angle form (ABI 13).
  * tang (Q,4) = (dPhi_cab, dTheta_cabd, 0, 0): the tangents of the two angles along the position tangent u = dL/dF
  * (gn_quad_angles_jvp_f32: the double backward of gn_quad_angles_bwd_ld_f32); the kernels rebuild

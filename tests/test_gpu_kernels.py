@@ -1117,6 +1117,51 @@ def test_fused_per_atom_x_adjoint_of_the_tensor_basis(n_mol, n_atoms, monkeypatc
           f"two-pass vs float64 {float((two_pass.double().cpu() - ref).abs().max()):.2e}")
 
 
+@pytest.mark.parametrize("arith_f16", [True, False], ids=["fp16-planes", "f32-mfma"])
+@pytest.mark.parametrize("n_mol,n_atoms", [(3, 12), (2, 32), (1, 64), (5, 7)])
+def test_row_stationary_x_adjoint_of_the_tensor_basis(n_mol, n_atoms, arith_f16, monkeypatch):
+    """gn_bil_expand_rows_ang_f32 (round 6; the default form of the quadruplet x-adjoint) — a wave owns 32 expand rows of one
+    target atom and walks the atom's reduce edges with the accumulators in registers; the quadruplet of (edge, row) from the
+    dense per-atom grid of graph.SegmentPlan.row_grid — on the real quadruplet structure of GemNet-Q batches (ragged: 64-atom
+    molecules with > 32-row tiles per atom, 7-atom molecules with a single partial tile) against the float64 restatement on the
+    explicit (Q, 49) harmonics and against the two-pass form (gn_bil_expand_ang_f32 + segmented sum); run twice: bitwise.
+    Cotangent blocks of very different magnitude per edge (1e-6 .. 1e3): the per-edge scale of the fp16 planes."""
+    from gemnet_pytorch_amd.graph import GraphPlan
+    from gemnet_pytorch_amd.synthetic import make_dataset
+    from gemnet_pytorch_amd.training.data_container import DataContainer
+    ds = make_dataset(n_mol, n_atoms, config=2)
+    b = DataContainer.from_arrays(dict(ds), 5.0, 10.0, triplets_only=False)[list(range(n_mol))]
+    inputs = {k: v for k, v in b.items() if k not in ("E", "F")}
+    monkeypatch.setattr(K, "USE_ROW_GRID", True)
+    monkeypatch.setattr(K, "ANG_F16_MASK", 7 if arith_f16 else 0)
+    cpu = GraphPlan.from_inputs(dict(inputs), False).quad
+    dev = GraphPlan.from_inputs({k: v.to(DEV) for k, v in inputs.items()}, False).warm().quad
+    rg = dev.row_grid
+    assert rg is not None
+    a_perm, a_seg, j_off, qmap, g_off, task_atom, task_row0, n_tasks = rg
+    # the grid holds every quadruplet exactly once
+    qm = qmap.cpu()
+    assert int((qm >= 0).sum()) == cpu.size and torch.equal(torch.sort(qm[qm >= 0]).values, torch.arange(cpu.size, dtype=torch.int32))
+    assert int(j_off[-1]) == dev.n_expand and n_tasks == int(task_atom.shape[0]) > 0
+    g = torch.Generator().manual_seed(n_atoms)
+    Q, S, C = cpu.size, 49, 32
+    th, ph = torch.rand(Q, generator=g, dtype=torch.float64) * 3.1, torch.rand(Q, generator=g, dtype=torch.float64) * 3.1
+    ang = torch.stack([torch.sin(th), torch.cos(th), torch.sin(ph), torch.cos(ph)], 1)
+    D = rnd(g, dev.n_reduce, S, C) * (10.0 ** torch.randint(-6, 4, (dev.n_reduce, 1, 1), generator=g).double())
+    ref = CK.bil_reduce_t(ang, D, cpu)
+    got = K.bil_reduce_t(f32(ang), f32(D), dev)
+    # error relative to what a row sums up (its largest contribution sets the rounding level)
+    row_scale = CK.bil_reduce_t(ang.abs() * 0 + ang, D.abs(), cpu).abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    err = float(((got.double().cpu() - ref).abs() / row_scale).max())
+    assert torch.equal(got, K.bil_reduce_t(f32(ang), f32(D), dev))
+    monkeypatch.setattr(K, "USE_ROW_GRID", False)
+    two_pass = K.bil_reduce_t(f32(ang), f32(D), dev)
+    err2 = float(((two_pass.double().cpu() - ref).abs() / row_scale).max())
+    print(f"{n_mol} x {n_atoms} [{'fp16 planes' if arith_f16 else 'f32 MFMA'}]: {Q} quadruplets, {n_tasks} row tiles, grid {int(qmap.shape[0])}; "
+          f"row-stationary vs float64 {err:.2e} of the row scale, two-pass {err2:.2e}")
+    assert err <= 5e-5 and err <= 4 * max(err2, 1e-6)
+
+
 def test_quad_angles_geometry_fwd_bwd():
     """gn_quad_angles_fwd / bwd: (sin, cos) of Phi_cab, Theta_cabd per quadruplet and the force contributions of a
     gradient given w.r.t. the two angles, against autograd on the float64 geometry (gemnet.py:334-418)."""
