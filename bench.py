@@ -708,7 +708,7 @@ def extra_config4_shard(rank, n_mol=64, n_atoms=64, steps=3, warmup=2):
     arithmetic, with the roofline of the dominant launcher family (counted traffic: profiles/<round>_traffic_config4.json).  The config's "bf16" is not run: a single-plane bf16
     operand mode was measured SLOWER than the default on this shard (116 vs 109 ms: only the Dense stacks, 4 % of the step,
     take bf16 operands; the quadruplet kernels already run split-fp16 products at fp32 accuracy) and 4e-2 eV/A off, and was
-    removed from the model's options in round 5."""
+    removed from the model's options in round 5 (docs/HISTORY.md section 14)."""
     from gemnet_pytorch_amd.graph import GraphPlan
     from gemnet_pytorch_amd.index_device import DeviceGraphBuilder
     from gemnet_pytorch_amd.model.gemnet import GemNet

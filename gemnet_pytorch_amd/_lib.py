@@ -109,6 +109,7 @@ SIGNATURES = {
     "gn_quad_angles_jvp_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "gn_bil_reduce_project_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "gn_bil_expand_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "gn_bil_expand_rows_ang_tan_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp],
     "gn_csr_build_i32": [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp],
     "gn_seg_offsets_i32": [_vp, _i64, _i64, _vp, _vp],
     "gn_gather_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],

@@ -81,7 +81,7 @@ extern "C" int gn_agg_selfcheck_read(unsigned int* host, int reset) {
 // inputs, no memory conflict (gemnet_pytorch_amd/hbcheck.py), never in a single-branch graph or alone.  Minimal repro (two
 // kernels, no model): tools/exp/graph_corun.py, 25 / 60 (fp16-plane stacks) and 45 / 60 (bf16-plane stacks) replays wrong;
 // with this attribute 0 / 60 (profiles/r4_corun_*.txt).  This was the mechanism behind the three "hipGraph replay != eager"
-// findings of round 3.  -DGN_AGG_PK restores the packed instructions for the repro.
+// findings of round 3 (docs/HISTORY.md section 11).  -DGN_AGG_PK restores the packed instructions for the repro.
 #if !defined(GN_AGG_PK) && defined(__HIP_DEVICE_COMPILE__)
 #define GN_AGG_ATTR __attribute__((target("no-packed-fp32-ops")))
 #else

@@ -1117,6 +1117,141 @@ extern "C" int gn_bil_reduce_project_ang_tan_f32(const float* ang, const float* 
   return 0;
 }
 
+// ---- x-adjoint of S4 (Y D1 + dY D2), ROW-STATIONARY per target atom (round 6): the tangent counterpart of
+// bil_expand_rows_ang_kernel — a wave owns 64 expand rows of one atom (two halves of 32 share the LDS tiles), walks the atom's
+// reduce edges with the accumulators in registers; no per-quadruplet rows in memory, no segmented sum behind it.  f32 MFMA (the
+// cotangent blocks follow the caller's loss scale), same products and order of addition as gn_bil_expand_ang_tan_f32 + segsum.
+namespace {
+template <bool HAS_D1>
+__global__ __launch_bounds__(256, 2) void bil_expand_rows_ang_tan_kernel(
+    const float4* __restrict__ ang, const float4* __restrict__ tang, const float* __restrict__ D1, const float* __restrict__ D2,
+    const int32_t* __restrict__ a_perm, const int32_t* __restrict__ a_seg, const int32_t* __restrict__ j_off,
+    const int32_t* __restrict__ qmap, const int32_t* __restrict__ g_off, const int32_t* __restrict__ task_atom,
+    const int32_t* __restrict__ task_row0, int n_tasks, float* __restrict__ dx) {
+  constexpr int TR = 64, TH = 32;
+  __shared__ float ysm[4][HAS_D1 ? TH * LDY : 1];
+  __shared__ float ytm[4][TH * LDY];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= n_tasks) return;
+  float* __restrict__ ys = ysm[wave];
+  float* __restrict__ yt = ytm[wave];
+  const int a = task_atom[task], r0 = task_row0[task];
+  const int j0 = j_off[a], nJ = j_off[a + 1] - j0;
+  const int nr = min(TR, nJ - r0);
+  const int e0 = a_seg[a], e1 = a_seg[a + 1];
+  const int32_t* __restrict__ qrow = qmap + g_off[a] + r0 + lane;
+  v4f_a acc[4][2];
+#pragma unroll
+  for (int st = 0; st < 4; ++st)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[st][nt] = (v4f_a){0.f, 0.f, 0.f, 0.f};
+  int q = -1;
+  float4 a4 = make_float4(0.f, 1.f, 0.f, 1.f), t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e0 < e1 && lane < nr) {
+    q = qrow[0];
+    if (q >= 0) { a4 = ang[q]; t4 = tang[q]; }
+  }
+  for (int ei = e0; ei < e1; ++ei) {
+    const int e = a_perm ? a_perm[ei] : ei;
+    int qn = -1;
+    float4 an = make_float4(0.f, 1.f, 0.f, 1.f), tn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ei + 1 < e1 && lane < nr) {
+      qn = qrow[(int64_t)(ei + 1 - e0) * nJ];
+      if (qn >= 0) { an = ang[qn]; tn = tang[qn]; }
+    }
+    const unsigned long long valid = __ballot(q >= 0);
+    float b1[13][2], b2[13][2];   // D1 / D2 [e][4 kk + lg][16 nt + l15]
+#pragma unroll
+    for (int kk = 0; kk < 13; ++kk) {
+      const int sr = 4 * kk + lg;
+      const int64_t off = e * (int64_t)S * C + min(sr, S - 1) * C + l15;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float v2 = D2[off + 16 * nt];
+        b2[kk][nt] = sr < S ? v2 : 0.f;
+        if constexpr (HAS_D1) {
+          const float v1 = D1[off + 16 * nt];
+          b1[kk][nt] = sr < S ? v1 : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (TH * h < nr) {
+        // the 32 lanes that hold this half's rows rebuild their harmonics and tangent rows in the tiles
+        if ((lane >> 5) == h && q >= 0)
+          ylm7_row_tangent(a4.x, a4.y, a4.z, a4.w, t4.x, t4.y, HAS_D1 ? ys + (lane & 31) * LDY : nullptr, yt + (lane & 31) * LDY);
+        wave_lds_sync();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int sub = TH * h + 16 * s2;
+          if (sub < nr) {
+            const bool rv = (valid >> (sub + l15)) & 1ull;
+            const int qr = (16 * s2 + l15) * LDY + lg;
+            v4f_a c0 = (v4f_a){0.f, 0.f, 0.f, 0.f}, c1 = (v4f_a){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 13; ++kk) {
+              const bool s_ok = rv && (kk < 12 || lg == 0);
+              const float tv = yt[qr + (kk < 12 ? 4 * kk : 48 - lg)];
+              const float at = s_ok ? tv : 0.f;
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at, b2[kk][0], c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(at, b2[kk][1], c1, 0, 0, 0);
+              if constexpr (HAS_D1) {
+                const float yv = ys[qr + (kk < 12 ? 4 * kk : 48 - lg)];
+                const float av = s_ok ? yv : 0.f;
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[kk][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[kk][1], c1, 0, 0, 0);
+              }
+            }
+            acc[2 * h + s2][0] += c0;
+            acc[2 * h + s2][1] += c1;
+          }
+        }
+        wave_lds_sync();
+      }
+    }
+    q = qn;
+    a4 = an;
+    t4 = tn;
+  }
+#pragma unroll
+  for (int st = 0; st < 4; ++st)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * st + 4 * lg + r;
+      if (row < nr) {
+        float* __restrict__ o = dx + (int64_t)(j0 + r0 + row) * C + l15;
+        o[0] = acc[st][0][r];
+        o[16] = acc[st][1][r];
+      }
+    }
+}
+}  // namespace
+
+extern "C" int gn_bil_expand_rows_ang_tan_f32(const float* ang, const float* tang, const float* D1, const float* D2,
+                                              const int32_t* a_perm, const int32_t* a_seg, const int32_t* j_off,
+                                              const int32_t* qmap, const int32_t* g_off, const int32_t* task_atom,
+                                              const int32_t* task_row0, int64_t n_tasks, float* dx, int S_, int C_, int tile,
+                                              void* stream) {
+  if (n_tasks <= 0) return 0;
+  if (S_ != S || C_ != C || !aligned16(ang) || !tang || !aligned16(tang) || !D2 || tile != 64 || n_tasks > (1ll << 30))
+    return (int)hipErrorInvalidValue;
+  const dim3 grid((unsigned)gn_cdiv(n_tasks, 4)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (D1)
+    hipLaunchKernelGGL(bil_expand_rows_ang_tan_kernel<true>, grid, block, 0, st, reinterpret_cast<const float4*>(ang),
+                       reinterpret_cast<const float4*>(tang), D1, D2, a_perm, a_seg, j_off, qmap, g_off, task_atom, task_row0,
+                       (int)n_tasks, dx);
+  else
+    hipLaunchKernelGGL(bil_expand_rows_ang_tan_kernel<false>, grid, block, 0, st, reinterpret_cast<const float4*>(ang),
+                       reinterpret_cast<const float4*>(tang), D1, D2, a_perm, a_seg, j_off, qmap, g_off, task_atom, task_row0,
+                       (int)n_tasks, dx);
+  GN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gn_bil_expand_ang_tan_f32(const float* ang, const float* tang, const float* D1, const float* D2,
                                          const int32_t* seg_off, float* dxt, int64_t E, int S_, int C_, void* stream) {
   if (E <= 0) return 0;

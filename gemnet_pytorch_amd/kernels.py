@@ -1355,6 +1355,15 @@ def bil_reduce_t_tan(ang, tang, D1, D2, sp):
     D1 = None if D1 is None else _f32c(D1)
     S, C = D2.shape[1], D2.shape[2]
     assert is_angle_form(ang, S) and tang.shape == ang.shape and (D1 is None or D1.shape == D2.shape)
+    rg = sp.row_grid if (USE_ROW_GRID and C == 32 and sp.ROW_TILE == 64) else None
+    if rg is not None:
+        # one pass, no per-quadruplet rows in memory (csrc/bilinear_ang.hip: bil_expand_rows_ang_tan_kernel)
+        a_perm, a_seg, j_off, qmap, g_off, task_atom, task_row0, n_tasks = rg
+        dx = torch.empty((sp.n_expand, C), device=ang.device, dtype=torch.float32)
+        check(_lib.load().gn_bil_expand_rows_ang_tan_f32(ptr(ang), ptr(tang), ptr(D1), ptr(D2), ptr(a_perm), ptr(a_seg), ptr(j_off),
+                                                         ptr(qmap), ptr(g_off), ptr(task_atom), ptr(task_row0), int(n_tasks),
+                                                         ptr(dx), S, C, sp.ROW_TILE, stream()), "gn_bil_expand_rows_ang_tan_f32")
+        return dx
     dxt = torch.empty((sp.size, C), device=ang.device, dtype=torch.float32)
     check(_lib.load().gn_bil_expand_ang_tan_f32(ptr(ang), ptr(tang), ptr(D1), ptr(D2), ptr(sp.seg_off), ptr(dxt), sp.n_reduce,
                                                 S, C, stream()), "gn_bil_expand_ang_tan_f32")

@@ -38,7 +38,7 @@ _H3_GUARD = os.environ.get("GEMNET_H3_GUARD", "1") == "1"     # see GemNet.forwa
 # Side-stream placement switches.  All three were forced off in round 3 because hipGraph replays stopped matching the eager
 # run with them; round 4 located the cause below the library — packed-FP32 instructions of the fused aggregation adjoint
 # returning wrong lanes when its waves share CUs with the chain kernels of another graph branch (csrc/aggregate.hip,
-# tools/exp/graph_corun.py) — and removed it, so they are on again.  `=0` restores the in-line forms.
+# tools/exp/graph_corun.py, docs/HISTORY.md section 11) — and removed it, so they are on again.  `=0` restores the in-line forms.
 _TRAIN_OVERLAP = os.environ.get("GEMNET_TRAIN_OVERLAP", "1") == "1"  # force training: output blocks on the side stream
 _Q_OVERLAP = os.environ.get("GEMNET_Q_OVERLAP", "1") == "1"          # quadruplet models: output blocks on the side stream
 _RBF_OUT_SIDE = os.environ.get("GEMNET_RBF_OUT_SIDE", "1") == "1"    # output-block radial projection in the forked head
@@ -97,7 +97,7 @@ class GemNet(torch.nn.Module):
         # three products), "split6" = three bf16 planes / six products (fp32 exponent range), "f32" = the f32-input MFMA — all
         # three at fp32 accuracy (force MAE 1e-6 .. 4e-6 eV/A against float64).  Single-plane bf16 / three-product modes exist
         # in the chain KERNEL (kernels.CHAIN_MODES, tests) but are not a model option: measured on the configs[4] shard they are
-        # slower than the default (116 vs 109 ms) at 4e-2 eV/A
+        # slower than the default (116 vs 109 ms) at 4e-2 eV/A (docs/HISTORY.md section 14)
         self.matmul_precision = None
         self.overlap_output_blocks = True
         self._side = None
@@ -460,7 +460,7 @@ class GemNet(torch.nn.Module):
         if self.matmul_precision not in self.PRECISIONS and not getattr(self, "_experimental_precision", False):
             raise ValueError(f"matmul_precision must be one of {self.PRECISIONS}; got {self.matmul_precision!r} (reduced-precision "
                              "operand modes are kernel-level experiments, not a model option: slower AND 4e-2 eV/A off on "
-                             "BASELINE configs[4], DESIGN.md section 14)")
+                             "BASELINE configs[4], docs/HISTORY.md section 14)")
         plan = GraphPlan.from_inputs(inputs, self.triplets_only)
         late = None
         pos_graph = False

@@ -133,7 +133,7 @@ class AtomUpdateBlock(torch.nn.Module):
         self.scale_sum = ScalingFactor(scale_file=scale_file, name=name + "_sum")
         self.layers = self.get_mlp(emb_size_atom, nHidden, activation)
         # one-pass Dense(rbf) (.) m -> atom sum (csrc/aggregate.hip); GEMNET_OUT_FUSE=0 keeps the GEMM + segmented-sum
-        # form in the OutputBlocks (the A/B switch of DESIGN.md section 9)
+        # form in the OutputBlocks (the A/B switch of docs/HISTORY.md section 9)
         self.fuse_aggregate = True
 
     def get_mlp(self, units, nHidden, activation):

@@ -295,6 +295,12 @@ int gn_bil_reduce_project_ang_tan_f32(const float* ang, const float* tang, const
                                       const float* Sm, float* Smd, float* Pd, int64_t E, int S, int C, int I, void* stream);
 int gn_bil_expand_ang_tan_f32(const float* ang, const float* tang, const float* D1, const float* D2, const int32_t* seg_off,
                               float* dxt, int64_t E, int S, int C, void* stream);
+/* gn_bil_expand_ang_tan_f32 + the segmented sum over the expand rows in ONE pass without per-quadruplet rows in memory (ABI 15):
+ * dx[j] = sum_{q: g(q) = j} (Y[q] D1[r(q)] + dY[q] D2[r(q)]), per-atom grid arguments as gn_bil_expand_rows_ang_f32, tile = 64. */
+int gn_bil_expand_rows_ang_tan_f32(const float* ang, const float* tang, const float* D1, const float* D2, const int32_t* a_perm,
+                                   const int32_t* a_seg, const int32_t* j_off, const int32_t* qmap, const int32_t* g_off,
+                                   const int32_t* task_atom, const int32_t* task_row0, int64_t n_tasks, float* dx, int S, int C,
+                                   int tile, void* stream);
 /* The same x-adjoint SUMMED over the expand rows, without the per-quadruplet rows in memory: dx[j] = sum_{q: g(q) = j}
  * Y[q] dSm[r(q)].  Needs the quadruplet structure of GemNet (data_container.py:331-397): reduce edge and expand row of a
  * quadruplet end in the same target atom, and the expand rows (intermediate triplets) are sorted by that atom —

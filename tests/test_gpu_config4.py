@@ -1,7 +1,7 @@
 """-m gpu: BASELINE.json configs[4], ONE GPU's shard at its full size — GemNet-Q (published 4-block configuration),
 64 molecules x 64 atoms (batch 512 over 8 GPUs), forward+force, default arithmetic (two fp16 planes per operand, three
 products: fp32-equivalent; the config's "bf16" operand mode was measured slower and 4e-2 eV/A off and is no longer a model
-option) — through the size-independent properties of tests/test_gpu_fullsize.py (the float64 reference does not finish 126 M quadruplets):
+option, docs/HISTORY.md section 14) — through the size-independent properties of tests/test_gpu_fullsize.py (the float64 reference does not finish 126 M quadruplets):
   * sum of forces = 0 per molecule,
   * batch additivity against per-molecule runs (the single 64-atom molecule of this configuration is pinned to the REFERENCE
     directly: fixture q64s of tests/test_gpu_fullsize_golden.py, 2.04 M quadruplets, float64),
@@ -64,7 +64,7 @@ def test_forces_sum_to_zero_per_molecule(shard, mode):
 def test_reduced_precision_operand_modes_are_not_a_model_option(shard):
     """BASELINE configs[4] names "bf16".  A single-plane bf16 operand mode of the Dense stacks was built and measured on this
     shard in rounds 2-4: slower than the default (116 vs 109 ms per step) and 4.3e-2 eV/A off at unit forces — it is no longer
-    selectable on the model; the kernel-level arithmetic stays under test in tests/test_gpu_kernels.py."""
+    selectable on the model (docs/HISTORY.md section 14); the kernel-level arithmetic stays under test in tests/test_gpu_kernels.py."""
     model = shard["model"]
     model.matmul_precision = "bf16"
     try:

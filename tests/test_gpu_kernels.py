@@ -1160,6 +1160,21 @@ def test_row_stationary_x_adjoint_of_the_tensor_basis(n_mol, n_atoms, arith_f16,
     print(f"{n_mol} x {n_atoms} [{'fp16 planes' if arith_f16 else 'f32 MFMA'}]: {Q} quadruplets, {n_tasks} row tiles, grid {int(qmap.shape[0])}; "
           f"row-stationary vs float64 {err:.2e} of the row scale, two-pass {err2:.2e}")
     assert err <= 5e-5 and err <= 4 * max(err2, 1e-6)
+    if not arith_f16:
+        # the tangent form of the training step's S4 (gn_bil_expand_rows_ang_tan_f32: Y D1 + dY D2 in one pass) on the same grid
+        tang = torch.cat([rnd(g, Q, 2), torch.zeros(Q, 2, dtype=torch.float64)], 1)
+        D1 = rnd(g, dev.n_reduce, S, C)
+        for use_D1 in (True, False):
+            ref_t = CK.bil_reduce_t_tan(ang, tang, D1 if use_D1 else None, D, cpu)
+            monkeypatch.setattr(K, "USE_ROW_GRID", True)
+            got_t = K.bil_reduce_t_tan(f32(ang), f32(tang), f32(D1) if use_D1 else None, f32(D), dev)
+            assert torch.equal(got_t, K.bil_reduce_t_tan(f32(ang), f32(tang), f32(D1) if use_D1 else None, f32(D), dev))
+            monkeypatch.setattr(K, "USE_ROW_GRID", False)
+            two_t = K.bil_reduce_t_tan(f32(ang), f32(tang), f32(D1) if use_D1 else None, f32(D), dev)
+            sc = float(ref_t.abs().max())
+            e1, e2 = float((got_t.double().cpu() - ref_t).abs().max()) / sc, float((two_t.double().cpu() - ref_t).abs().max()) / sc
+            print(f"    tangent form (D1 {'given' if use_D1 else 'absent'}): row-stationary {e1:.2e}, two-pass {e2:.2e} of max|dx|")
+            assert e1 <= 3e-5 and e1 <= 4 * max(e2, 1e-6)
 
 
 def test_quad_angles_geometry_fwd_bwd():

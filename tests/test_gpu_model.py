@@ -99,7 +99,7 @@ def test_relative_precision_on_unscaled_deep_fixtures(golden_model, tag):
 def test_matmul_arithmetic_modes(golden_model2, tag, mode, bar, monkeypatch):
     """The Dense stacks on the f32 MFMA, on the fp16 planes (3 products) and on the bf16 matrix pipe with 6 / 3 split-operand
     products: force MAE of the published 4-block configurations against the float64 reference, every mode with a bar.
-    (Plain bf16 operands — BASELINE configs[4]'s arithmetic — are no model option any more: DESIGN.md section 14.)"""
+    (Plain bf16 operands — BASELINE configs[4]'s arithmetic — are no model option any more: docs/HISTORY.md section 14.)"""
     from gemnet_pytorch_amd import kernels as K
     g = golden_model2
     cfg, params, inputs = load_case(g, tag)
@@ -344,7 +344,7 @@ def test_grouped_weight_gradients_match_autograd_accumulation(golden_model):
 
 def test_model_matmul_precision_flag(golden_model2):
     """GemNet.matmul_precision selects the Dense-stack arithmetic per model: the three fp32-equivalent forms agree to fp32
-    rounding; reduced-precision operand modes ("bf16": removed in round 5) and unknown names raise."""
+    rounding; reduced-precision operand modes ("bf16": removed in round 5, docs/HISTORY.md section 14) and unknown names raise."""
     g = golden_model2
     cfg, params, inputs = load_case(g, "t2s")
     model = build(cfg, params).eval()

@@ -340,7 +340,7 @@ def test_quadruplet_runner_fill_equals_pad_indices(golden_model2):
 
 def test_dummy_molecule_geometry_scales_with_the_bond_length():
     """The dummy molecule's bonds sit at 0.9 x the embedding cutoff (padded.dummy_bond: the radial envelopes have almost closed
-    there, so the pad rows' messages stay ~1e-3 of a real row's — DESIGN.md section 14, "A silent NaN"); angles and the dihedral
+    there, so the pad rows' messages stay ~1e-3 of a real row's — docs/HISTORY.md section 14, "A silent NaN"); angles and the dihedral
     stay 90 degrees at any bond length, groups never overlap."""
     from gemnet_pytorch_amd.padded import dummy_bond
 

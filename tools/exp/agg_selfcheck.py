@@ -1,4 +1,4 @@
-"""Does a kernel of a replayed multi-queue hipGraph see its own registers change?  (round-4 replay finding)
+"""Does a kernel of a replayed multi-queue hipGraph see its own registers change?  (round-4 replay finding, docs/HISTORY.md section 11)
 
 The aggregation adjoint (csrc/aggregate.hip) loads 32 values of a CONSTANT weight per lane at kernel start and keeps them
 in registers.  The -DGN_AGG_SELFCHECK build re-reads the weight (volatile) right after the first load and at every edge,

@@ -1,4 +1,4 @@
-"""Minimal co-run experiment for the round-4 replay finding: NO model, two kernels of the library,
+"""Minimal co-run experiment for the round-4 replay finding (docs/HISTORY.md section 11): NO model, two kernels of the library,
 constant inputs.  A two-branch hipGraph is captured — branch A: a string of Dense-stack chain programs (edge rows),
 branch B: a string of fused aggregation kernels (forward + adjoint), every launch writing its own output buffer — and
 replayed; every output of every replay is compared bit for bit with the eager result of the same launch.

@@ -1,5 +1,5 @@
 // Can ONE wave keep the matrix pipe and the transcendental VALU busy at the same time on gfx950, and do two waves of a SIMD
-// overlap them when they are in different phases?  The question behind "next 1" of DESIGN.md section 14: the chain kernel's op
+// overlap them when they are in different phases?  The question behind "next 1" of docs/HISTORY.md section 14: the chain kernel's op
 // is  MFMA phase (60 x v_mfma_f32_16x16x32_f16 per wave)  then  epilogue (20 elements per lane x (v_exp_f32 + v_rcp_f32) + ~8
 // plain VALU), all eight waves of a workgroup in the same phase.  Variants, 8 waves per workgroup, one workgroup per CU:
 //   A  phases in sequence (what chain2.hip does)                      B  MFMA only          C  epilogue only

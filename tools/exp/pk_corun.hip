@@ -1,4 +1,4 @@
-// Standalone repro of the round-4 packed-FP32 finding: NO torch, NO product library —
+// Standalone repro of the round-4 packed-FP32 finding (docs/HISTORY.md section 11): NO torch, NO product library —
 // this file + three kernel sources of the repo, one hipcc command:
 //
 //   cd tools/exp && sh pk_corun.sh            (builds both variants, dumps the ISA of the victim kernel, runs them on gfx950)

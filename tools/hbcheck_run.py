@@ -1,5 +1,5 @@
 """Happens-before check (gemnet_pytorch_amd/hbcheck.py) of the captured steps, including the three configurations whose
-hipGraph replays did not match the eager run in round 3:
+hipGraph replays did not match the eager run in round 3 (docs/HISTORY.md section 10):
 
    PYTHONPATH=.:tests python tools/hbcheck_run.py [case ...]        # default: all
 
