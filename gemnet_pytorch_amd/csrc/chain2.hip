@@ -53,8 +53,15 @@ using namespace gn_split;
 // HF: the two-plane fp16 format (NPL = 2 there: both planes enter the MFMAs, three products)
 // `meta` (computed by the launcher's pass over the program): bits 0-7 index of the first GEMM op (0xff: none), bit 8 the
 // program is linear (no GEMM applies an activation) — what the prologue needs before the op table exists.
+// GN2_TWO_WG (experiment build only, tools/exp: DESIGN.md section 9): registers capped at 128 (4 waves per SIMD) and row tiles sized
+// for TWO co-resident workgroups per CU
+#ifdef GN2_TWO_WG
+#define GN2_BOUNDS __launch_bounds__(NT, 4)
+#else
+#define GN2_BOUNDS __launch_bounds__(NT)
+#endif
 template <int RT, int NPL, bool ADJ, bool HF>
-__global__ __launch_bounds__(NT) void chain_split_kernel(const gn_chain_args P, const int meta) {
+__global__ GN2_BOUNDS void chain_split_kernel(const gn_chain_args P, const int meta) {
   static_assert(!HF || NPL == 2, "format H has two planes");
   constexpr int BM = 16 * RT;
   constexpr int PLANE = BM * ROWB;          // bytes of one plane
@@ -661,7 +668,11 @@ int launch_chain_split(const gn_chain_args* args, hipStream_t st) {
 
 template <int NPL, bool ADJ, bool HF>
 int dispatch_rt(const gn_chain_args* args, hipStream_t st) {
+#ifdef GN2_TWO_WG
+  const int rt = gn_cdiv(args->M, 512 * 16);
+#else
   const int rt = gn_cdiv(args->M, 256 * 16);
+#endif
   switch (rt <= 1 ? 1 : (rt >= 5 ? 5 : rt)) {
     case 1: return launch_chain_split<1, NPL, ADJ, HF>(args, st);
     case 2: return launch_chain_split<2, NPL, ADJ, HF>(args, st);

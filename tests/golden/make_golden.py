@@ -640,7 +640,7 @@ def _index_digest(idx, triplets_only):
             for k, v in sorted(can.items())}
 
 
-def run_fullsize(cfg, seed, ds, tag, out, digests):
+def run_fullsize(cfg, seed, ds, tag, out, digests, with_grads=False):
     """Reference forward+force in float64 on a generated dataset `ds` (all its molecules in ONE batch); the output
     heads rescaled to mean|F| = 1 eV/A.  Only E, F, the head scale and the (seeded, regenerable) positions are stored;
     the reference's index arrays go into `digests` as sizes + SHA-256 of their canonical form."""
@@ -668,6 +668,17 @@ def run_fullsize(cfg, seed, ds, tag, out, digests):
     out[f"{tag}.seed"], out[f"{tag}.cfg"], out[f"{tag}.out_scale"] = np.array(seed), np.array(repr(cfg)), np.array(scale)
     out[f"{tag}.N"], out[f"{tag}.Z"], out[f"{tag}.R"] = ds["N"], ds["Z"], ds["R"]
     out[f"{tag}.E"], out[f"{tag}.F"] = E.detach().numpy(), F.detach().numpy()
+    if with_grads:
+        # the training step at this size (trainer.py:325-346): loss on the dataset's targets, loss.backward() THROUGH the force;
+        # stored as the loss, every parameter's gradient norm and 4 fixed +-1 probe projections (record_grads)
+        Et = torch.tensor(np.asarray(ds["E"], dtype=np.float64)).reshape(-1, 1)
+        Ft = torch.tensor(np.asarray(ds["F"], dtype=np.float64))
+        loss = GO.training_loss(E[:, :1], F, Et, Ft)
+        out[f"{tag}.loss"] = loss.detach().numpy()
+        loss.backward()
+        record_grads(tag, model, out)
+        out[f"{tag}.Et"], out[f"{tag}.Ft"] = Et.numpy().astype(np.float32), Ft.numpy().astype(np.float32)
+        model.zero_grad(set_to_none=True)
     # the reference's OWN float32 path (its default dtype) on the same weights and inputs: what "the reference PyTorch CPU
     # path" returns, and how far fp32 rounding alone takes it from the float64 result on this fixture
     model32 = GemNet(**cfg, scale_file=SCALE_FILE)
@@ -698,8 +709,8 @@ def golden_fullsize():
     one64 = dict(N=np.array([64], np.int32), Z=m64["Z"], R=m64["R"], E=np.zeros(1, np.float32), F=np.zeros_like(m64["R"]))
     run_fullsize(cfg_full(True, 4), 7, one64, "t64s", out, digests)
     run_fullsize(cfg_full(False, 4), 8, one64, "q64s", out, digests)
-    run_fullsize(cfg_full(True, 4), 5, make_dataset(32, 32, config=2), "tB32", out, digests)
-    run_fullsize(cfg_full(False, 4), 6, make_dataset(4, 32, config=2), "qB4", out, digests)
+    run_fullsize(cfg_full(True, 4), 5, make_dataset(32, 32, config=2), "tB32", out, digests, with_grads=True)
+    run_fullsize(cfg_full(False, 4), 6, make_dataset(4, 32, config=2), "qB4", out, digests, with_grads=True)
     # index-only digests: one 32-atom molecule (T and Q), the B = 32 batch as GemNet-Q sees it
     for tag, ds, to in (("idx32.T", make_dataset(1, 32, config=2), True), ("idx32.Q", make_dataset(1, 32, config=2), False),
                         ("idxB32.Q", make_dataset(32, 32, config=2), False)):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import SCALE_FILE
+from conftest import SCALE_FILE, check_grad_probes
 from fullsize_common import dataset, digest, load_digests, load_fullsize, params_of, triplets_only
 from oracle import gemnet_oracle as GO
 from gemnet_pytorch_amd.model.gemnet import GemNet
@@ -80,3 +80,29 @@ def test_device_index_builder_matches_reference_digest(tag):
     assert sorted(got) == sorted(ref)
     for k in ref:
         assert got[k] == ref[k], (tag, k, got[k]["n"], ref[k]["n"])
+
+
+@pytest.mark.parametrize("tag", ["tB32", "qB4"])
+def test_training_gradients_at_baseline_batch_sizes(g, tag):
+    """The training step of trainer.py:325-346 — loss on the dataset's targets, `loss.backward()` THROUGH the force (second
+    order) — on the 32 x 32 GemNet-T batch of configs[1] and on a 4 x 32 GemNet-Q batch against the reference's float64
+    parameter gradients: the loss, every parameter's gradient norm (2e-3) and 4 fixed +-1 probe projections of every gradient
+    (2e-3 of its norm for GemNet-T; GemNet-Q at the level test_gpu_model.py measures for q4s: fp32 rounding of the 4-block double
+    backward)."""
+    cfg, params = params_of(g, tag)
+    model = GemNet(**cfg, scale_file=SCALE_FILE)
+    model.load_state_dict(GO.expand_to_reference_state_dict(params), strict=True)
+    model = model.to(DEV).train()
+    E, F = model(_inputs(tag, "host"))
+    loss = GO.training_loss(E[:, :1], F, torch.tensor(g[f"{tag}.Et"], device=DEV), torch.tensor(g[f"{tag}.Ft"], device=DEV))
+    np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=2e-5)
+    loss.backward()
+    named = dict(model.named_parameters())
+    names = [str(n) for n in g[f"{tag}.grad_names"]]
+    norms = np.array([0.0 if named[n].grad is None else float(named[n].grad.norm()) for n in names])
+    ref = g[f"{tag}.grad_norms"]
+    rtol = 4e-3 if tag == "qB4" else 2e-3
+    np.testing.assert_allclose(norms, ref, rtol=rtol, atol=1e-6 * float(ref.max()))
+    worst = check_grad_probes(g, tag, {n: named[n].grad for n in names}, rtol=rtol)
+    print(f"{tag}: loss {loss.item():.6f} (reference {float(g[f'{tag}.loss']):.6f}); {len(names)} parameter gradients, worst probe error / "
+          f"({rtol:g} ||g_ref||) = {worst:.3f}")
