@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256) void bil_expand_rows_ang_kernel(
   if (task >= n_tasks) return;
   float* __restrict__ ys = ysm[wave];
   const int a = task_atom[task], r0 = task_row0[task];
+  if (a < 0) return;       // (a slot of a capacity-sized task table beyond the batch's tasks)
   const int j0 = j_off[a], nJ = j_off[a + 1] - j0;
   const int nr = min(TR, nJ - r0);
   const int e0 = a_seg[a], e1 = a_seg[a + 1];
@@ -1138,6 +1139,7 @@ __global__ __launch_bounds__(256, 2) void bil_expand_rows_ang_tan_kernel(
   float* __restrict__ ys = ysm[wave];
   float* __restrict__ yt = ytm[wave];
   const int a = task_atom[task], r0 = task_row0[task];
+  if (a < 0) return;       // (a slot of a capacity-sized task table beyond the batch's tasks)
   const int j0 = j_off[a], nJ = j_off[a + 1] - j0;
   const int nr = min(TR, nJ - r0);
   const int e0 = a_seg[a], e1 = a_seg[a + 1];

@@ -127,13 +127,14 @@ class SegmentPlan:
     def seg_off(self):
         return self.reduce.csr[1]
 
-    def set_atom_blocks(self, reduce_atom: "RowIndex", expand_atom: torch.Tensor, n_atoms: int):
+    def set_atom_blocks(self, reduce_atom: "RowIndex", expand_atom: torch.Tensor, n_atoms: int, max_rows=None):
         """Declare the quadruplet structure of GemNet-Q (data_container.py:331-397): r(t) — a reduce edge c -> a — and g(t)
         — an intermediate triplet a <- b <- d — of every entry end in the same target atom, and the expand rows are sorted by
         that atom.  `reduce_atom`: target atom of every reduce row (a RowIndex: its CSR groups the edges by atom);
         `expand_atom`: target atom of every expand row (non-decreasing).  Enables the fused per-atom x-adjoint
         (gn_bil_expand_atoms_ang_f32: no per-quadruplet rows in memory)."""
         self._ab_src = (reduce_atom, expand_atom, int(n_atoms))
+        self._ab_max_rows = None if max_rows is None else int(max_rows)     # static bound of the reduce edges per atom (padded.py)
         self._atom_blocks = None
 
     @property
@@ -166,42 +167,55 @@ class SegmentPlan:
         if src is None:
             return None
         if getattr(self, "_row_grid", None) is None:
-            if self.reduce.idx32.is_cuda and torch.cuda.is_current_stream_capturing():
+            static = getattr(self, "_ab_max_rows", None)
+            if static is None and self.reduce.idx32.is_cuda and torch.cuda.is_current_stream_capturing():
                 return None
             reduce_atom, expand_atom, A = src
             dev = expand_atom.device
             perm, seg = reduce_atom.csr                       # edges grouped by target atom
             seg64 = seg.to(torch.int64)
             nE = seg64[1:] - seg64[:-1]
-            nJ = torch.bincount(expand_atom, minlength=A)
+            # (no bincount: its output size is data-dependent — a host sync, impossible inside a capture)
+            nJ = torch.zeros(A, dtype=torch.int64, device=dev).index_add_(
+                0, expand_atom.to(torch.int64), torch.ones(expand_atom.shape[0], dtype=torch.int64, device=dev))
             j_off = torch.zeros(A + 1, dtype=torch.int64, device=dev)
             torch.cumsum(nJ, 0, out=j_off[1:])
             g_off = torch.zeros(A + 1, dtype=torch.int64, device=dev)
             torch.cumsum(nE * nJ, 0, out=g_off[1:])
             n_edges = int(reduce_atom.idx32.shape[0])
-            e_rank = torch.empty(n_edges, dtype=torch.int64, device=dev)   # position of an edge in its atom's list
             pos = torch.arange(n_edges, device=dev, dtype=torch.int64)
-            atom_of_pos = torch.repeat_interleave(torch.arange(A, device=dev), nE)
             atom_of_edge = reduce_atom.idx32.to(torch.int64)
             if perm is None:
-                e_rank = pos - seg64[atom_of_pos]
+                inv = pos
             else:
-                e_rank[perm.to(torch.int64)] = pos - seg64[atom_of_pos]
+                inv = torch.empty(n_edges, dtype=torch.int64, device=dev)
+                inv[perm.to(torch.int64)] = pos
+            e_rank = inv - seg64[atom_of_edge]                # position of an edge in its atom's list
             r = self.reduce.idx32.to(torch.int64)
             a_q = atom_of_edge[r]
             flat = g_off[a_q] + e_rank[r] * nJ[a_q] + (self.expand.idx32.to(torch.int64) - j_off[a_q])
             nt = (nJ + self.ROW_TILE - 1) // self.ROW_TILE
             t_off = torch.zeros(A + 1, dtype=torch.int64, device=dev)
             torch.cumsum(nt, 0, out=t_off[1:])
-            g_total, n_tasks = (int(v) for v in torch.stack([g_off[-1], t_off[-1]]).tolist())
+            if static is None:
+                g_total, n_tasks = (int(v) for v in torch.stack([g_off[-1], t_off[-1]]).tolist())
+            else:
+                # static capacities from the sizes of the (capacity-sized) arrays and the in-degree bound: nothing is read back, so
+                # the construction can sit inside a captured graph (padded.py); tasks beyond the real count carry atom -1
+                g_total = static * int(self.n_expand)
+                n_tasks = int(self.n_expand) // self.ROW_TILE + A + 1
             if g_total >= 2 ** 31:
                 self._row_grid = ()
                 return None
             qmap = torch.full((max(g_total, 1),), -1, dtype=torch.int32, device=dev)
             qmap[flat] = torch.arange(self.size, device=dev, dtype=torch.int32)
-            task_atom = torch.repeat_interleave(torch.arange(A, device=dev), nt)
-            task_row0 = (torch.arange(n_tasks, device=dev, dtype=torch.int64) - t_off[task_atom]) * self.ROW_TILE
-            i32 = lambda t: t.to(torch.int32).contiguous()   # noqa: E731
+            t = torch.arange(n_tasks, device=dev, dtype=torch.int64)
+            task_atom = torch.searchsorted(t_off[1:].contiguous(), t, right=True)
+            real = task_atom < A
+            task_atom = torch.where(real, task_atom, torch.zeros_like(task_atom))
+            task_row0 = (t - t_off[task_atom]) * self.ROW_TILE
+            task_atom = torch.where(real, task_atom, torch.full_like(task_atom, -1))
+            i32 = lambda x: x.to(torch.int32).contiguous()   # noqa: E731
             self._row_grid = (perm, i32(seg), i32(j_off), qmap, i32(g_off), i32(task_atom), i32(task_row0), n_tasks)
         return self._row_grid or None
 
@@ -294,7 +308,7 @@ class GraphPlan:
             #  host read-back per batch for a structure nobody consumes)
             from . import kernels as _K
             if _K.USE_ATOM_BLOCKS or _K.USE_ROW_GRID:
-                self.quad.set_atom_blocks(self.id_a, i_a[exp_ab], self.n_atoms)
+                self.quad.set_atom_blocks(self.id_a, i_a[exp_ab], self.n_atoms, max_rows=inputs.get("max_in_degree"))
             A = self.n_atoms
             self.quad_geom = {
                 # a - b <- d per intermediate triplet (gemnet.py:385-388)
