@@ -612,6 +612,8 @@ __global__ __launch_bounds__(1024) void bil_fused_fwd_mfma7_kernel(const float* 
           b[nt] = ok ? v : 0.f;
         }
       };
+      // (requesting the gathers of the whole segment — up to 32 triplets — before the first MFMA was measured in round 6:
+      //  56-58 us against 43-47 us per launch, profiles/r6_bil_fused_prefetch_all.txt; the two-step look-ahead stays)
       float a0 = 0.f, b0[4] = {0.f, 0.f, 0.f, 0.f}, a1, b1[4];
       if (t0 < t1) load(t0, a0, b0);
       for (int t = t0; t < t1; t += 8) {

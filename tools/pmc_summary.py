@@ -34,7 +34,7 @@ def short(name):
     return name.split("(")[0][:64]
 
 
-FAMILIES = {"bil_reduce_project_tan": ("bil_reduce_project_ang_tan",), "bil_reduce_t_tan": ("bil_expand_ang_tan",),
+FAMILIES = {"bil_reduce_project_tan": ("bil_reduce_project_ang_tan",), "bil_reduce_t_tan": ("bil_expand_ang_tan", "bil_expand_rows_ang_tan"),
             "chain": ("chain_kernel", "chain_split_kernel"), "gemm": ("gemm_nt", "gemm_generic", "gemm_smallk", "gemm_n1"),
             "gemm_tn": ("gemm_tn",), "bil_fused_fwd": ("bil_fused_fwd",), "bil_fused_bwd": ("bil_fused_bwd",),
             "bil_project_bwd": ("bil_project_bwd",), "bil_dy_multi": ("bil_dy_multi",),
