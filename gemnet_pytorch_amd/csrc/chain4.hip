@@ -25,7 +25,17 @@
 //   * a workgroup has ceil(row blocks / 256) (<= 7) compute waves: 18 122 rows = 1 133 row blocks = 227 workgroups of 5,
 //     1 024 rows = 64 workgroups of one.
 // Per 128 x 128 layer a wave issues 96 v_mfma_f32_16x16x32_f16 (1.6 k cycles of its SIMD's matrix pipe) behind
-// 64 ds_read_b128 of weight fragments (256 LDS cycles).
+// 64 ds_read_b128 of weight fragments.
+//
+// MEASURED (round 6, tools/chain4_trace.py, profiles/r6_chain4_*.txt): exact, and SLOWER than chain2.hip at
+// the batch sizes of BASELINE.json — 1 675 vs 1 102 us for the 50 chain launches of a forward+force step.  (i) A lone wave's
+// ds_read_b128 stream runs at ~28 B/clk, so the 64 KB of weight fragments of one layer take 3.5 k cycles (with the reads
+// knocked out the phase takes exactly 96 x 17 cycles); (ii) 18 122 rows are 1 133 sixteen-row blocks on 1 024 SIMDs: one SIMD
+// of every CU carries two waves (32 rows, where the column split gives every SIMD 20 rows' worth), in lock step behind the
+// per-op barrier; (iii) ~800 VALU instructions per op and wave (fp16 split, epilogue) at 6-8 cycles each for a lone wave;
+// (iv) the adjoint instance needs 372 VGPRs (96 slot registers + the epilogue's operands): one wave per SIMD, three compute
+// waves per workgroup.  The layout is kept selectable (GEMNET_CHAIN_LAYOUT=row) for what it does better: no fp16 range limit
+// (the 64-atom GemNet-Q fixture q64s needs no fall-back and is most accurate here) and no restriction on programs.
 #include "common.h"
 
 #include <type_traits>

@@ -446,7 +446,10 @@ USE_EXPAND_POS = os.environ.get("GEMNET_EXPAND_POS", "0") == "1"
 
 
 def bil_reduce_t(Y, D, sp):
-    """dx[j,c] = sum_{t: g(t)=j} sum_s Y[t,s] D[r(t),s,c]."""
+    """dx[j,c] = sum_{t: g(t)=j} sum_s Y[t,s] D[r(t),s,c].
+    Angle form (GemNet-Q): the row-stationary kernel when the plan carries the per-atom grid (USE_ROW_GRID, the default: no
+    per-quadruplet rows in memory), else the per-atom workgroup of round 4 (USE_ATOM_BLOCKS), else per-quadruplet rows + a
+    segmented sum.  Spherical basis of the triplets: the atom-grouped kernel; other shapes: the scalar kernels."""
     require_device(Y, D)
     Y, D = _f32c(Y), _f32c(D)
     S, C = D.shape[1], D.shape[2]

@@ -5,6 +5,8 @@ import bench
 from gemnet_pytorch_amd.model.gemnet import GemNet
 from gemnet_pytorch_amd import kernels as K
 cfg = dict(bench.GEMNET_T)
+if "Q" in sys.argv:
+    cfg["triplets_only"] = False
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
 model = GemNet(**cfg, scale_file=bench.SCALE_FILE).to(dev).eval()
