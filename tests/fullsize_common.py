@@ -50,8 +50,10 @@ def params_of(g, tag, dtype=torch.float32):
     return cfg, {k: (v * sc if k.endswith(HEAD_KEYS) else v) for k, v in params.items()}
 
 
-def digest(idx, to):
-    """sizes + SHA-256 of the int32 little-endian bytes of the canonical index arrays (make_golden.py::_index_digest)."""
-    can = IO.canonicalize({k: np.asarray(v) for k, v in idx.items()}, to)
+def digest(idx, to, canonicalize=False):
+    """sizes + SHA-256 of the int32 little-endian bytes of the index arrays (make_golden.py::_index_digest hashes the
+    CANONICAL form of the reference's arrays).  The product builders and the oracle emit the canonical order themselves, so their
+    raw output is hashed as it is (canonicalize=False): a builder that returned another within-segment order would fail here."""
+    can = IO.canonicalize({k: np.asarray(v) for k, v in idx.items()}, to) if canonicalize else {k: np.asarray(v) for k, v in idx.items()}
     return {k: dict(n=int(v.shape[0]), sha256=hashlib.sha256(np.ascontiguousarray(v.astype("<i4")).tobytes()).hexdigest())
             for k, v in sorted(can.items())}
