@@ -241,15 +241,17 @@ class TrainStep:
         self._cap_args = (inputs, targets)
         return self
 
-    def _range_check(self):
+    def _range_check(self, agreed=False):
         """Poll the range flag.  Tripped: the fused optimizer has skipped the non-finite step(s) on the device; warn, move the
         model off the fp16 planes and capture the step anew.  One rank: what the completed steps left in the pinned word (no
         synchronisation).  Several ranks: the OR of all ranks' words as of the step before the previous one
         (RangeFlag.snapshot / poll_lagged) — every rank takes this branch at the SAME call, so the recapture (and whatever
-        collectives the steps around it issue) pair up, and no rank runs a step in another arithmetic than its peers."""
+        collectives the steps around it issue) pair up, and no rank runs a step in another arithmetic than its peers.
+        `agreed`: the caller has already made the decision collective and written it into every rank's pinned word
+        (Trainer._train_on_batch_padded synchronises and exchanges the flag BEFORE its optimizers see the gradients)."""
         if self.flag is None:
             return False
-        if self.world_size > 1:
+        if self.world_size > 1 and not agreed:
             word = self.flag.poll_lagged()
             if not (word & 0xff):
                 return False

@@ -265,7 +265,7 @@ class Trainer:
             torch.cuda.current_stream().synchronize()
             if not self._all_ranks(not ps.flag.tripped()):
                 ps.flag.host.fill_(ps.flag.tripped() | ps.flag.OUTPUT)      # (a rank that did not trip follows the others)
-                if ps._range_check():
+                if ps._range_check(agreed=True):
                     loss = ps.run(inputs, targets)
         report = loss.detach().clone()
         if self._world() > 1:
