@@ -1,6 +1,7 @@
 """-m gpu: batches of changing array sizes replayed from ONE captured hipGraph (gemnet_pytorch_amd/padded.py): the real
 molecules of a batch padded to the capacities get the energies and forces of the plain eager run on the unpadded batch,
 for several batches with different edge / triplet counts in turn, twice around (the second round replays only)."""
+import numpy as np
 import pytest
 import torch
 
@@ -247,6 +248,51 @@ def test_trainer_with_padded_graph_follows_the_plain_trainer():
         assert abs(a - b) <= 2e-3 * abs(b), (lp, le)
     for k in me:
         assert abs(float(mp[k]) - float(me[k])) <= 2e-3 * abs(float(me[k])), (k, float(mp[k]), float(me[k]))
+
+
+def test_trainer_padded_step_overflow_is_caught_before_the_optimizers(monkeypatch):
+    """`Trainer.train_on_batch` on the captured padded step in the fp16-plane arithmetic: an activation driven past 65 504 AFTER
+    the capture (the atom embedding is gathered from the live parameter by every replay) must not reach the optimizers — the
+    Trainer reads the replayed graph's range flag before they see the gradients (`_train_on_batch_padded`, all ranks decide
+    together: `TrainStep._range_check(agreed=True)`), warns, moves the model to the bf16 planes, captures anew and repeats the
+    step: the reported loss is finite and every parameter stays finite."""
+    import warnings
+    from gemnet_pytorch_amd import kernels as K
+    from gemnet_pytorch_amd.training.metrics import Metrics
+    from gemnet_pytorch_amd.training.trainer import Trainer
+    monkeypatch.setattr(K, "DEFAULT_CHAIN_MODE", "h3")
+    cfg = dict(FULL, triplets_only=True, num_blocks=2)
+    torch.manual_seed(13)
+    model = GemNet(**cfg, scale_file=SCALE_FILE).to(DEV)
+    g = torch.Generator().manual_seed(8)
+    batches = [_batch(8, n, 300 * (i + 1), g) for i, n in enumerate((32, 24, 28))]
+
+    def it():
+        i = 0
+        while True:
+            b = batches[i % len(batches)]
+            i += 1
+            yield dict(Z=b["Z"], R=b["R"].clone(), N=b["N"], **b["idx"]), {"E": b["Et"], "F": b["Ft"]}
+    sizes = [(int(b["idx"]["id_c"].shape[0]), int(b["idx"]["id3_reduce_ca"].shape[0])) for b in batches]
+    e_cap, t_cap = PaddedGraphRunner.suggest_capacities(sizes)
+    tr = Trainer(model, learning_rate=1e-3, loss="rmse", rho_force=0.99, grad_clip_max=10.0)
+    tr.dict2device = lambda d, device=None: d
+    tr.enable_padded_graph(a_cap=8 * 32, e_cap=e_cap, t_cap=t_cap, max_in_degree=31, n_groups=max(1, e_cap // 62))
+    m = Metrics("train", tr.tracked_metrics)
+    stream = it()
+    l0 = float(tr.train_on_batch(stream, m))
+    assert np.isfinite(l0) and tr._pstep is not None and tr._pstep._captured and model.matmul_precision is None
+    with torch.no_grad():
+        model.atom_emb.embeddings.weight.mul_(1.0e6)
+    with pytest.warns(RuntimeWarning, match="fp16-plane"):
+        l1 = float(tr.train_on_batch(stream, m))
+    torch.cuda.synchronize()
+    assert model.matmul_precision == "split6" and np.isfinite(l1)
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        l2 = float(tr.train_on_batch(stream, m))          # and stays quiet afterwards
+    assert np.isfinite(l2) and tr._pstep.flag.trips == 1
 
 
 def test_captured_training_step_is_bit_reproducible_and_equals_eager():
